@@ -1,0 +1,205 @@
+/*
+ * noize_hip.h -- C ABI of libnoize_hip.so: the MI355X (gfx950) replacement for the Burst job
+ * structs on noize-job's per-cell terrain path.
+ *
+ * Every entry point replaces one reference *static delegate* (the seam the C# stages call,
+ * SURVEY.md 8b) or one `PipelineStage.Schedule` body.  Conventions:
+ *   - `NativeSlice<float>` / `NativeArray<float>`  ->  `float*` DEVICE pointer (nz_tile_alloc, or any
+ *     hipMalloc'd / torch allocation on the ctx's device); planes are row-major, index z*res + x
+ *     (Pipeline/Tiles/TileData.cs:72-77).
+ *   - `JobHandle dependency` -> `nz_handle dep` (0 = default(JobHandle)); the returned JobHandle ->
+ *     `nz_handle* out` (may be NULL).  Work is enqueued asynchronously on the ctx's HIP stream.
+ *   - exceptions -> negative `int32` status; `nz_last_error()` gives the message.
+ *   - scalar argument order is the delegate's.
+ * One nz_ctx is driven by one host thread at a time (the reference schedules everything from the
+ * Unity main thread, Pipeline/Executable/Pipeline.cs:29-30,154-181).
+ * All citations are relative to /root/reference.
+ */
+#ifndef NOIZE_HIP_H
+#define NOIZE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NZ_VERSION 100
+
+typedef struct nz_ctx nz_ctx;
+typedef uint64_t nz_handle;
+
+enum nz_status {
+    NZ_OK = 0,
+    NZ_ERR_INVALID = -1,     /* bad argument (reference: undefined behaviour or C# exception) */
+    NZ_ERR_UNSUPPORTED = -2, /* enum value outside the hot path (e.g. Sobel3_2D) */
+    NZ_ERR_HIP = -3,         /* HIP runtime error */
+    NZ_ERR_NOMEM = -4,
+    NZ_ERR_NO_DEVICE = -5    /* no gfx950 device / HIP runtime unavailable */
+};
+
+/* NoiseStage.FractalNoise, Noise/NoiseStage.cs:15-24 */
+enum nz_noise_type {
+    NZ_NOISE_SIN = 0, NZ_NOISE_PERLIN, NZ_NOISE_PERIODIC_PERLIN, NZ_NOISE_SIMPLEX,
+    NZ_NOISE_ROTATED_SIMPLEX, NZ_NOISE_CELLULAR, NZ_NOISE_DOMAIN_ROTATED_PERLIN,
+    NZ_NOISE_DOMAIN_ROTATED_SIMPLEX
+};
+
+/* KernelFilterType, Filter/Kernel/KernelJob.cs:79-94 */
+enum nz_kernel_filter_type {
+    NZ_GAUSS9_S1 = 0, NZ_GAUSS7_S1, NZ_GAUSS5_S1, NZ_GAUSS3_S1,
+    NZ_GAUSS9_S2, NZ_GAUSS7_S2, NZ_GAUSS5_S2, NZ_GAUSS3_S2,
+    NZ_SMOOTH3, NZ_SOBEL3_HORIZONTAL, NZ_SOBEL3_VERTICAL, NZ_SOBEL3_2D,
+    NZ_PREWITT3_HORIZONTAL, NZ_PREWITT3_VERTICAL
+};
+
+/* MeshType, Mesh/Stage/MeshTileStage.cs:23-26 */
+enum nz_mesh_type { NZ_MESH_SQUARE_GRID = 0, NZ_MESH_OVERSHOOT_SQUARE_GRID = 1 };
+
+/* Row-stripe view of a (grows x cols) global grid held by one rank (new-framework feature,
+ * SURVEY.md 8e).  The buffer holds `rows` rows of `cols` floats; buffer row b is global row
+ * b + grow0.  Stencil reads clamp to the global border only; rows [own0, own1) are produced, the
+ * others are ghost rows the caller fills by halo exchange.  A single reference tile is
+ * {res, res, 0, res, 0, res, 0}. */
+typedef struct nz_stripe {
+    int32_t cols;  /* cells per row */
+    int32_t rows;  /* rows held in the buffer */
+    int32_t grow0; /* global row of buffer row 0 (negative when ghost rows hang over the top border) */
+    int32_t grows; /* rows of the global grid */
+    int32_t own0;  /* owned rows [own0, own1) in buffer coordinates */
+    int32_t own1;
+    int32_t pitch; /* floats between consecutive rows; 0 = cols */
+} nz_stripe;
+
+/* ---- runtime ---------------------------------------------------------------------------- */
+int32_t nz_version(void);
+const char *nz_last_error(void);
+int32_t nz_device_count(int32_t *count);
+
+/* own stream */
+int32_t nz_ctx_create(int32_t device, nz_ctx **out);
+/* borrow an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL = default) */
+int32_t nz_ctx_create_on_stream(int32_t device, void *hip_stream, nz_ctx **out);
+int32_t nz_ctx_destroy(nz_ctx *ctx);
+int32_t nz_ctx_synchronize(nz_ctx *ctx);
+void *nz_ctx_stream(nz_ctx *ctx);
+
+/* NativeArray<float>(n, Allocator.Persistent, UninitializedMemory) / Dispose() */
+int32_t nz_tile_alloc(nz_ctx *ctx, size_t n_floats, float **out_dev);
+int32_t nz_tile_free(nz_ctx *ctx, float *dev);
+/* host NativeArray interop (async on the ctx stream; host memory must stay valid until `out` completes) */
+int32_t nz_tile_upload(nz_ctx *ctx, float *dev, const float *host, size_t n_floats, nz_handle dep, nz_handle *out);
+int32_t nz_tile_download(nz_ctx *ctx, const float *dev, float *host, size_t n_floats, nz_handle dep, nz_handle *out);
+int32_t nz_bytes_download(nz_ctx *ctx, const void *dev, void *host, size_t n_bytes, nz_handle dep, nz_handle *out);
+
+/* JobHandle: marker recorded on the stream after the last kernel of a call */
+int32_t nz_handle_record(nz_ctx *ctx, nz_handle *out);
+int32_t nz_handle_query(nz_ctx *ctx, nz_handle h, int32_t *is_completed); /* JobHandle.IsCompleted */
+int32_t nz_handle_wait(nz_ctx *ctx, nz_handle h);                          /* JobHandle.Complete() */
+/* GPU time between two handles in ms (hipEventElapsedTime); both must have completed */
+int32_t nz_handle_elapsed_ms(nz_ctx *ctx, nz_handle start, nz_handle stop, float *ms);
+
+/* ---- noise: FractalJobDelegate, Noise/Fractal/Fractal.cs:76-88 ------------------------------ */
+int32_t nz_fractal(nz_ctx *ctx, int32_t noiseType, float *src, int32_t resolution, float hurst,
+                   float startingAmplitude, float stepdown, float detuneRate, int32_t octaves,
+                   int32_t xpos, int32_t zpos, int32_t noiseSize, nz_handle dep, nz_handle *out);
+/* same on the owned rows of a stripe: cell (x, b) is world cell (x + xpos, b + grow0 + zpos) */
+int32_t nz_fractal_stripe(nz_ctx *ctx, int32_t noiseType, float *buf, const nz_stripe *st, float hurst,
+                          float startingAmplitude, float stepdown, float detuneRate, int32_t octaves,
+                          int32_t xpos, int32_t zpos, int32_t noiseSize, nz_handle dep, nz_handle *out);
+
+/* ---- separable kernel filters ------------------------------------------------------------- */
+/* SeperableKernelFilterDelegate, Filter/Kernel/KernelJob.cs:308-314 (one X+Z application) */
+int32_t nz_kernel_filter(nz_ctx *ctx, float *src, float *tmp, int32_t filter, int32_t resolution,
+                         nz_handle dep, nz_handle *out);
+/* GaussFilter.GaussFilterDelegate, Filter/Kernel/Blur/BlurJob.cs:23-30 (sigma = GaussSigma enum 0..15) */
+int32_t nz_gauss_filter(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t sigma,
+                        int32_t resolution, nz_handle dep, nz_handle *out);
+/* SmoothFilter.SmoothFilterDelegate, BlurJob.cs:46-52 */
+int32_t nz_smooth_filter(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t resolution,
+                         nz_handle dep, nz_handle *out);
+/* SeparableKernelFilter.ScheduleSeries, KernelJob.cs:165-185; kernelX/kernelZ are HOST arrays of
+ * kernelSize floats (the NativeArray<float> kernel bodies) */
+int32_t nz_separable_series(nz_ctx *ctx, float *src, float *tmp, int32_t resolution, int32_t kernelSize,
+                            const float *kernelX, const float *kernelZ, float kernelFactor,
+                            nz_handle dep, nz_handle *out);
+/* ErosionKernelJobDelegate, KernelJob.cs:350 (min-X then min-Z, window {-1,0}) */
+int32_t nz_erosion_kernel(nz_ctx *ctx, float *src, int32_t resolution, nz_handle dep, nz_handle *out);
+
+/* Stage bodies: the `iterations` loops of KernelFilterStage.Schedule (Filter/KernelFilterStage.cs:31-43),
+ * StageGaussianBlur.Schedule / StageSmoothBlur.Schedule (Filter/Kernel/Blur/Stage*.cs) fused into
+ * as few launches as halo growth allows.  Result lands in `src`; `tmp` is stage scratch. */
+int32_t nz_kernel_filter_stage(nz_ctx *ctx, float *src, float *tmp, int32_t filter, int32_t iterations,
+                               int32_t resolution, nz_handle dep, nz_handle *out);
+int32_t nz_gauss_blur_stage(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t sigma,
+                            int32_t iterations, int32_t resolution, nz_handle dep, nz_handle *out);
+int32_t nz_smooth_blur_stage(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t iterations,
+                             int32_t resolution, nz_handle dep, nz_handle *out);
+/* ErosionKernelJob applied `iterations` times (the reference has no stage wrapper for it) */
+int32_t nz_erosion_stage(nz_ctx *ctx, float *src, float *tmp, int32_t iterations, int32_t resolution,
+                         nz_handle dep, nz_handle *out);
+
+/* stripe forms: one launch that advances `iterations` applications on rows [own0, own1); needs
+ * nz_*_halo_rows(...) valid ghost rows on each side; reads `src`, writes `dst` (owned rows only). */
+int32_t nz_kernel_filter_halo_rows(int32_t filter, int32_t iterations);
+int32_t nz_kernel_filter_max_fused(int32_t filter);
+int32_t nz_kernel_filter_stripe(nz_ctx *ctx, const float *src, float *dst, const nz_stripe *st,
+                                int32_t filter, int32_t iterations, nz_handle dep, nz_handle *out);
+int32_t nz_erosion_stripe(nz_ctx *ctx, const float *src, float *dst, const nz_stripe *st,
+                          int32_t iterations, nz_handle dep, nz_handle *out);
+
+/* ---- flow map ------------------------------------------------------------------------------ */
+/* FillArrayJobDelegate, Geologic/FlowMap/FlowMapComponents.cs:204 */
+int32_t nz_fill_array(nz_ctx *ctx, float *data, int32_t resolution, float value, nz_handle dep, nz_handle *out);
+/* FlowMapStepComputeFlowDelegate, Geologic/FlowMap/FlowMapJob.cs:82-98 */
+int32_t nz_flowmap_compute_flow(nz_ctx *ctx, const float *src, const float *waterMap, float *flowMapN,
+                                float *flowMapN__buff, float *flowMapS, float *flowMapS__buff,
+                                float *flowMapE, float *flowMapE__buff, float *flowMapW,
+                                float *flowMapW__buff, int32_t resolution, nz_handle dep, nz_handle *out);
+/* FlowMapStepUpdateWaterDelegate, FlowMapJob.cs:154-165 */
+int32_t nz_flowmap_update_water(nz_ctx *ctx, float *waterMap, float *waterMap__buff, const float *flowMapN,
+                                const float *flowMapS, const float *flowMapE, const float *flowMapW,
+                                int32_t resolution, nz_handle dep, nz_handle *out);
+/* FlowMapWriteValuesDelegate, FlowMapJob.cs:220-228 */
+int32_t nz_flowmap_write_values(nz_ctx *ctx, float *src, const float *flowMapN, const float *flowMapS,
+                                const float *flowMapE, const float *flowMapW, int32_t resolution,
+                                nz_handle dep, nz_handle *out);
+/* MapNormalizeValuesDelegate, Filter/NormalizeJob.cs:94-100; args = HOST {min, max, range} */
+int32_t nz_map_normalize_values(nz_ctx *ctx, float *src, float *tmp, const float *args,
+                                int32_t resolution, nz_handle dep, nz_handle *out);
+/* FlowMapStage.Schedule, Geologic/Stage/FlowMapStage.cs:124-214: fill -> iterations x (flow, water)
+ * -> velocity -> normalise, result in `src`.  `work` = stage-owned scratch of
+ * nz_flowmap_stage_work_floats(resolution) floats (the stage's 11 planes; flux is defined as zero
+ * at the start of every run). */
+size_t nz_flowmap_stage_work_floats(int32_t resolution);
+int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
+                         float normMax, int32_t resolution, nz_handle dep, nz_handle *out);
+
+/* stripe forms for sharded runs: state = {water, fN, fS, fE, fW} planes of the stripe's shape. */
+int32_t nz_flow_first_stripe(nz_ctx *ctx, const float *height, float *water, float *fN, float *fS,
+                             float *fE, float *fW, const nz_stripe *st, nz_handle dep, nz_handle *out);
+int32_t nz_flow_iter_stripe(nz_ctx *ctx, const float *height, const float *water_in, const float *fN_in,
+                            const float *fS_in, const float *fE_in, const float *fW_in, float *water_out,
+                            float *fN_out, float *fS_out, float *fE_out, float *fW_out,
+                            const nz_stripe *st, nz_handle dep, nz_handle *out);
+int32_t nz_flow_velocity_stripe(nz_ctx *ctx, float *dst, const float *fN, const float *fS, const float *fE,
+                                const float *fW, const nz_stripe *st, float normMin, float normMax,
+                                nz_handle dep, nz_handle *out);
+
+/* ---- mesh: HeightMapMeshJobScheduleDelegate, Mesh/Job/HeightMapMeshJob.cs:55-65 -------------- */
+/* (Mesh, MeshData) -> device vertex stream of (resolution+1)^2 records
+ * {float3 position; float3 normal; float4 tangent; float2 texCoord0} = 48 B
+ * (PositionStream32.Stream0, Mesh/Streams/PositionStream.cs:77-82) and device index buffer of
+ * 6*resolution^2 uint32 (TriangleUInt32, Mesh/Streams/Triangle.cs:19-27). */
+size_t nz_mesh_vertex_count(int32_t resolution);
+size_t nz_mesh_index_count(int32_t resolution);
+int32_t nz_heightmap_mesh(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_t *indices,
+                          int32_t resolution, int32_t inputResolution, int32_t marginPix,
+                          float tileHeight, float tileSize, const float *heights, nz_handle dep,
+                          nz_handle *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOIZE_HIP_H */

@@ -1,0 +1,15 @@
+"""noize_job_amd -- MI355X-native (gfx950, hand-written HIP) engine for noize-job's per-cell
+terrain path: fractal noise -> separable kernel filters -> flow map -> value erosion -> mesh.
+
+Importing the package loads libnoize_hip.so through the C ABI of include/noize_hip.h and raises if
+it is missing: there is no CPU or PyTorch fallback in the product path.
+"""
+from . import _native
+from ._native import NoizeError, Stripe
+from .runtime import Context, DeviceTile, JobHandle
+from .pipeline import (BasePipeline, BlurHelper, ErosionStage, FlowMapStage, FractalNoise, GaussSigma,
+                       GeneratorData, KernelFilterStage, KernelFilterType, MeshBuffers, MeshStageData,
+                       MeshTileStage, MeshType, NoiseStage, PipelineStage, PipelineWorkItem, StageGaussianBlur,
+                       StageIO, StageSmoothBlur)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

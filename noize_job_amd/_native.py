@@ -1,0 +1,111 @@
+"""ctypes binding of libnoize_hip.so (the C ABI declared in include/noize_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If the shared object is missing
+or cannot be loaded, importing this module raises -- build it with `python -c "import
+__graft_entry__ as g; g.build()"` or `make -C noize_job_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnoize_hip.so")
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+handle_t = C.c_uint64
+handle_p = C.POINTER(C.c_uint64)
+ctx_p = C.c_void_p
+dev_ptr = C.c_void_p  # device addresses travel as plain integers
+
+
+class Stripe(C.Structure):
+    """nz_stripe (include/noize_hip.h)."""
+    _fields_ = [("cols", C.c_int32), ("rows", C.c_int32), ("grow0", C.c_int32), ("grows", C.c_int32),
+                ("own0", C.c_int32), ("own1", C.c_int32), ("pitch", C.c_int32)]
+
+
+stripe_p = C.POINTER(Stripe)
+
+NZ_OK, NZ_ERR_INVALID, NZ_ERR_UNSUPPORTED, NZ_ERR_HIP, NZ_ERR_NOMEM, NZ_ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+
+_i, _f, _sz = C.c_int32, C.c_float, C.c_size_t
+_tail = [handle_t, handle_p]  # (dep, out)
+
+# name -> (restype, argtypes); every symbol include/noize_hip.h declares
+SIGNATURES = {
+    "nz_version": (_i, []),
+    "nz_last_error": (C.c_char_p, []),
+    "nz_device_count": (_i, [C.POINTER(_i)]),
+    "nz_ctx_create": (_i, [_i, C.POINTER(ctx_p)]),
+    "nz_ctx_create_on_stream": (_i, [_i, C.c_void_p, C.POINTER(ctx_p)]),
+    "nz_ctx_destroy": (_i, [ctx_p]),
+    "nz_ctx_synchronize": (_i, [ctx_p]),
+    "nz_ctx_stream": (C.c_void_p, [ctx_p]),
+    "nz_tile_alloc": (_i, [ctx_p, _sz, C.POINTER(dev_ptr)]),
+    "nz_tile_free": (_i, [ctx_p, dev_ptr]),
+    "nz_tile_upload": (_i, [ctx_p, dev_ptr, C.c_void_p, _sz] + _tail),
+    "nz_tile_download": (_i, [ctx_p, dev_ptr, C.c_void_p, _sz] + _tail),
+    "nz_bytes_download": (_i, [ctx_p, dev_ptr, C.c_void_p, _sz] + _tail),
+    "nz_handle_record": (_i, [ctx_p, handle_p]),
+    "nz_handle_query": (_i, [ctx_p, handle_t, C.POINTER(_i)]),
+    "nz_handle_wait": (_i, [ctx_p, handle_t]),
+    "nz_handle_elapsed_ms": (_i, [ctx_p, handle_t, handle_t, C.POINTER(_f)]),
+    "nz_fractal": (_i, [ctx_p, _i, dev_ptr, _i, _f, _f, _f, _f, _i, _i, _i, _i] + _tail),
+    "nz_fractal_stripe": (_i, [ctx_p, _i, dev_ptr, stripe_p, _f, _f, _f, _f, _i, _i, _i, _i] + _tail),
+    "nz_kernel_filter": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
+    "nz_gauss_filter": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
+    "nz_smooth_filter": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
+    "nz_separable_series": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, f32p, f32p, _f] + _tail),
+    "nz_erosion_kernel": (_i, [ctx_p, dev_ptr, _i] + _tail),
+    "nz_kernel_filter_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
+    "nz_gauss_blur_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _i] + _tail),
+    "nz_smooth_blur_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
+    "nz_erosion_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
+    "nz_kernel_filter_halo_rows": (_i, [_i, _i]),
+    "nz_kernel_filter_max_fused": (_i, [_i]),
+    "nz_kernel_filter_stripe": (_i, [ctx_p, dev_ptr, dev_ptr, stripe_p, _i, _i] + _tail),
+    "nz_erosion_stripe": (_i, [ctx_p, dev_ptr, dev_ptr, stripe_p, _i] + _tail),
+    "nz_fill_array": (_i, [ctx_p, dev_ptr, _i, _f] + _tail),
+    "nz_flowmap_compute_flow": (_i, [ctx_p] + [dev_ptr] * 10 + [_i] + _tail),
+    "nz_flowmap_update_water": (_i, [ctx_p] + [dev_ptr] * 6 + [_i] + _tail),
+    "nz_flowmap_write_values": (_i, [ctx_p] + [dev_ptr] * 5 + [_i] + _tail),
+    "nz_map_normalize_values": (_i, [ctx_p, dev_ptr, dev_ptr, f32p, _i] + _tail),
+    "nz_flowmap_stage_work_floats": (_sz, [_i]),
+    "nz_flowmap_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _f, _f, _i] + _tail),
+    "nz_flow_first_stripe": (_i, [ctx_p] + [dev_ptr] * 6 + [stripe_p] + _tail),
+    "nz_flow_iter_stripe": (_i, [ctx_p] + [dev_ptr] * 11 + [stripe_p] + _tail),
+    "nz_flow_velocity_stripe": (_i, [ctx_p] + [dev_ptr] * 5 + [stripe_p, _f, _f] + _tail),
+    "nz_mesh_vertex_count": (_sz, [_i]),
+    "nz_mesh_index_count": (_sz, [_i]),
+    "nz_heightmap_mesh": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _i, _i, _i, _f, _f, dev_ptr] + _tail),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "noize_job_amd: %s is missing -- the HIP extension is not built (run __graft_entry__.build()); "
+            "there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class NoizeError(RuntimeError):
+    """The C# host maps negative statuses to exceptions (error convention)."""
+
+    def __init__(self, status, where):
+        self.status = status
+        msg = lib.nz_last_error()
+        super().__init__("%s failed with status %d: %s" % (where, status, msg.decode() if msg else ""))
+
+
+def check(status, where):
+    if status != NZ_OK:
+        raise NoizeError(status, where)

@@ -1,0 +1,790 @@
+// nz_api.cpp -- runtime (context, device tiles, JobHandle markers) and the extern "C" entry points
+// of libnoize_hip.so.  See include/noize_hip.h for the reference interface each entry replaces.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "nz_internal.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void nz_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *nz_last_error(void) { return g_err; }
+extern "C" int32_t nz_version(void) { return NZ_VERSION; }
+
+extern "C" int32_t nz_device_count(int32_t *count) {
+    NZ_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        nz_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return NZ_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return NZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+static constexpr size_t NZ_EVENT_RING = 4096;
+
+static int32_t build_rgrad_table(nz_ctx *ctx) {
+    // rgrad2 of noise.psrnoise: the hash is an exact integer in
+    // [0, 289], so (cos u, sin u) is tabulated with the same libm the CPU restatement calls.
+    std::vector<float> tab(2 * NZ_RGRAD_N * 2);
+    const float rots[2] = {0.0f, 0.62f};  // PeriodicPerlinGetter / RotatedSimplexGetter, Fractal.cs:184,201
+    for (int t = 0; t < 2; t++) {
+        for (int h = 0; h < NZ_RGRAD_N; h++) {
+            float u = (float)h * 0.0243902439f + rots[t];
+            u = (u - floorf(u)) * 6.28318530718f;
+            tab[(t * NZ_RGRAD_N + h) * 2 + 0] = cosf(u);
+            tab[(t * NZ_RGRAD_N + h) * 2 + 1] = sinf(u);
+        }
+    }
+    NZ_HIP(hipMalloc((void **)&ctx->d_rgrad, tab.size() * sizeof(float)));
+    NZ_HIP(hipMemcpy(ctx->d_rgrad, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return NZ_OK;
+}
+
+static int32_t ctx_create(int32_t device, hipStream_t stream, bool own, nz_ctx **out) {
+    NZ_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        nz_set_error("no HIP device available (%s)", e != hipSuccess ? hipGetErrorString(e) : "count 0");
+        return NZ_ERR_NO_DEVICE;
+    }
+    NZ_REQUIRE(device >= 0 && device < n, "device %d out of range [0,%d)", device, n);
+    NZ_HIP(hipSetDevice(device));
+    nz_ctx *ctx = new nz_ctx();
+    ctx->device = device;
+    if (own) {
+        hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete ctx;
+            nz_set_error("hipStreamCreate: %s", hipGetErrorString(se));
+            return NZ_ERR_HIP;
+        }
+        ctx->owns_stream = true;
+    } else {
+        ctx->stream = stream;
+    }
+    int32_t rc = build_rgrad_table(ctx);
+    if (rc != NZ_OK) {
+        if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_ctx_create(int32_t device, nz_ctx **out) { return ctx_create(device, nullptr, true, out); }
+
+extern "C" int32_t nz_ctx_create_on_stream(int32_t device, void *hip_stream, nz_ctx **out) {
+    return ctx_create(device, (hipStream_t)hip_stream, false, out);
+}
+
+extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
+    if (!ctx) return NZ_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t ev : ctx->events)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->d_rgrad) (void)hipFree(ctx->d_rgrad);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_ctx_synchronize(nz_ctx *ctx) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    NZ_HIP(hipSetDevice(ctx->device));
+    NZ_HIP(hipStreamSynchronize(ctx->stream));
+    return NZ_OK;
+}
+
+extern "C" void *nz_ctx_stream(nz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    NZ_HIP(hipSetDevice(ctx->device));
+    // all work of a ctx is ordered on one stream, so a dependency on one of its own handles is
+    // already satisfied by stream order; anything else is a caller error
+    NZ_REQUIRE(dep <= ctx->last_handle, "dependency handle %llu was not issued by this context",
+               (unsigned long long)dep);
+    return NZ_OK;
+}
+
+int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out) {
+    if (!out) return NZ_OK;
+    if (ctx->events.empty()) ctx->events.assign(NZ_EVENT_RING, nullptr);
+    uint64_t h = ctx->last_handle + 1;
+    hipEvent_t &ev = ctx->events[h % NZ_EVENT_RING];
+    if (!ev) NZ_HIP(hipEventCreate(&ev));
+    NZ_HIP(hipEventRecord(ev, ctx->stream));
+    ctx->last_handle = h;
+    *out = h;
+    return NZ_OK;
+}
+
+int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out) {
+    if (floats > ctx->scratch_floats) {
+        if (ctx->scratch) {
+            NZ_HIP(hipStreamSynchronize(ctx->stream));
+            NZ_HIP(hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_floats = 0;
+        }
+        hipError_t e = hipMalloc((void **)&ctx->scratch, floats * sizeof(float));
+        if (e != hipSuccess) {
+            nz_set_error("hipMalloc(%zu floats): %s", floats, hipGetErrorString(e));
+            return NZ_ERR_NOMEM;
+        }
+        ctx->scratch_floats = floats;
+    }
+    *out = ctx->scratch;
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_handle_record(nz_ctx *ctx, nz_handle *out) {
+    NZ_REQUIRE(ctx && out, "ctx/out is NULL");
+    NZ_HIP(hipSetDevice(ctx->device));
+    return nz_ctx_finish(ctx, out);
+}
+
+static bool handle_live(nz_ctx *ctx, nz_handle h) {
+    return h != 0 && h <= ctx->last_handle && h + NZ_EVENT_RING > ctx->last_handle;
+}
+
+extern "C" int32_t nz_handle_query(nz_ctx *ctx, nz_handle h, int32_t *is_completed) {
+    NZ_REQUIRE(ctx && is_completed, "ctx/is_completed is NULL");
+    NZ_REQUIRE(h <= ctx->last_handle, "unknown handle");
+    NZ_HIP(hipSetDevice(ctx->device));
+    if (h == 0) {
+        *is_completed = 1;  // default(JobHandle).IsCompleted == true
+        return NZ_OK;
+    }
+    hipError_t e = handle_live(ctx, h) ? hipEventQuery(ctx->events[h % NZ_EVENT_RING]) : hipStreamQuery(ctx->stream);
+    if (e == hipSuccess) {
+        *is_completed = 1;
+    } else if (e == hipErrorNotReady) {
+        *is_completed = 0;
+        (void)hipGetLastError();
+    } else {
+        nz_set_error("handle query: %s", hipGetErrorString(e));
+        return NZ_ERR_HIP;
+    }
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_handle_wait(nz_ctx *ctx, nz_handle h) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    NZ_REQUIRE(h <= ctx->last_handle, "unknown handle");
+    NZ_HIP(hipSetDevice(ctx->device));
+    if (h == 0) return NZ_OK;
+    if (handle_live(ctx, h)) {
+        NZ_HIP(hipEventSynchronize(ctx->events[h % NZ_EVENT_RING]));
+    } else {
+        NZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_handle_elapsed_ms(nz_ctx *ctx, nz_handle start, nz_handle stop, float *ms) {
+    NZ_REQUIRE(ctx && ms, "ctx/ms is NULL");
+    NZ_REQUIRE(handle_live(ctx, start) && handle_live(ctx, stop), "handle expired or unknown");
+    NZ_HIP(hipSetDevice(ctx->device));
+    NZ_HIP(hipEventElapsedTime(ms, ctx->events[start % NZ_EVENT_RING], ctx->events[stop % NZ_EVENT_RING]));
+    return NZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tiles
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t nz_tile_alloc(nz_ctx *ctx, size_t n_floats, float **out_dev) {
+    NZ_REQUIRE(ctx && out_dev, "ctx/out is NULL");
+    NZ_HIP(hipSetDevice(ctx->device));
+    *out_dev = nullptr;
+    hipError_t e = hipMalloc((void **)out_dev, (n_floats ? n_floats : 1) * sizeof(float));
+    if (e != hipSuccess) {
+        nz_set_error("hipMalloc(%zu floats): %s", n_floats, hipGetErrorString(e));
+        return NZ_ERR_NOMEM;
+    }
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_tile_free(nz_ctx *ctx, float *dev) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    if (!dev) return NZ_OK;
+    NZ_HIP(hipSetDevice(ctx->device));
+    NZ_HIP(hipStreamSynchronize(ctx->stream));  // Dispose(handle): free after the work that uses it
+    NZ_HIP(hipFree(dev));
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_tile_upload(nz_ctx *ctx, float *dev, const float *host, size_t n_floats, nz_handle dep,
+                                  nz_handle *out) {
+    int32_t rc = nz_ctx_begin(ctx, dep);
+    if (rc) return rc;
+    NZ_REQUIRE(dev && host, "dev/host is NULL");
+    NZ_HIP(hipMemcpyAsync(dev, host, n_floats * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_bytes_download(nz_ctx *ctx, const void *dev, void *host, size_t n_bytes, nz_handle dep,
+                                     nz_handle *out) {
+    int32_t rc = nz_ctx_begin(ctx, dep);
+    if (rc) return rc;
+    NZ_REQUIRE(dev && host, "dev/host is NULL");
+    NZ_HIP(hipMemcpyAsync(host, dev, n_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_tile_download(nz_ctx *ctx, const float *dev, float *host, size_t n_floats, nz_handle dep,
+                                    nz_handle *out) {
+    return nz_bytes_download(ctx, dev, host, n_floats * sizeof(float), dep, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers shared by the stage entry points
+// ---------------------------------------------------------------------------------------------
+int32_t nz_check_stripe(const nz_stripe *st, int halo) {
+    NZ_REQUIRE(st, "stripe is NULL");
+    NZ_REQUIRE(st->cols > 0 && st->rows > 0 && st->grows > 0, "stripe: non-positive extent");
+    NZ_REQUIRE(st->pitch == 0 || st->pitch >= st->cols, "stripe: pitch < cols");
+    NZ_REQUIRE(st->own0 >= 0 && st->own0 <= st->own1 && st->own1 <= st->rows, "stripe: owned rows outside buffer");
+    NZ_REQUIRE(st->own0 + st->grow0 >= 0 && st->own1 + st->grow0 <= st->grows,
+               "stripe: owned rows outside the global grid");
+    // every row within `halo` of the owned rows must be in the buffer unless it is beyond the border
+    int need_lo = st->own0 - halo, need_hi = st->own1 - 1 + halo;
+    int dom_lo = -st->grow0, dom_hi = st->grows - 1 - st->grow0;
+    if (need_lo < dom_lo) need_lo = dom_lo;
+    if (need_hi > dom_hi) need_hi = dom_hi;
+    NZ_REQUIRE(need_lo >= 0 && need_hi <= st->rows - 1, "stripe: %d ghost rows required", halo);
+    return NZ_OK;
+}
+
+static int32_t check_res(int32_t resolution) {
+    NZ_REQUIRE(resolution >= 1 && resolution <= 46340, "resolution %d out of range", resolution);
+    return NZ_OK;
+}
+
+// FractalJob.CalcFractalNormValue, Noise/Fractal/Fractal.cs:31-40 (startingAmplitude is ignored)
+static float calc_fractal_norm(float hurst, int octaves) {
+    float G = exp2f(-hurst);
+    float a = 1.0f, t = 0.0f;
+    for (int i = 0; i < octaves; i++) {
+        t += a * 1.0f;
+        a *= G;
+    }
+    return t;
+}
+
+static int32_t fractal_impl(nz_ctx *ctx, int noiseType, float *dst, int rows, int cols, int pitch, float hurst,
+                            float amp, float stepdown, float detune, int octaves, int xpos, int zpos_first_row,
+                            int noiseSize) {
+    NZ_REQUIRE(dst, "src is NULL");
+    NZ_REQUIRE(noiseType >= 0 && noiseType <= NZ_NOISE_DOMAIN_ROTATED_SIMPLEX, "unknown noise type %d", noiseType);
+    NZ_REQUIRE(octaves >= 0, "octaves < 0");
+    NZ_REQUIRE(noiseSize != 0, "noiseSize == 0");
+    nz_fractal_params p;
+    p.posx = (float)xpos;  // SetPosition, Fractal.cs:109-112
+    p.posz = (float)zpos_first_row;
+    p.noise_size = (float)noiseSize;
+    p.G = exp2f(-hurst);
+    p.amp = amp;
+    p.stepdown = stepdown;
+    p.detune_rate = detune;
+    p.norm = calc_fractal_norm(hurst, octaves);
+    p.octaves = octaves;
+    return nz_launch_fractal(ctx->stream, noiseType, dst, rows, cols, pitch, p, ctx->d_rgrad);
+}
+
+// SeparableKernelFilter tables, Filter/Kernel/KernelJob.cs:97-136.  Gaussian bodies are
+// exp(-i^2/2s^2)/sum in double rounded to fp32, which reproduces the reference literals
+// (tests/golden/gauss_tables.json).
+static void gauss_coeffs(double sigma, int width, float *out) {
+    int o = (width - 1) / 2;
+    double w[NZ_MAX_KSIZE], sum = 0.0;
+    for (int i = 0; i < width; i++) {
+        double d = (double)(i - o);
+        w[i] = exp(-(d * d) / (2.0 * sigma * sigma));
+        sum += w[i];
+    }
+    for (int i = 0; i < width; i++) out[i] = (float)(w[i] / sum);
+}
+
+static int32_t filter_taps(int32_t filter, nz_kernel_taps *t) {
+    memset(t, 0, sizeof *t);
+    auto set3 = [&](float a0, float a1, float a2, float b0, float b1, float b2, float f) {
+        t->kx[0] = a0; t->kx[1] = a1; t->kx[2] = a2;
+        t->kz[0] = b0; t->kz[1] = b1; t->kz[2] = b2;
+        t->factor = f;
+        t->ksize = 3;
+    };
+    switch (filter) {
+        case NZ_GAUSS9_S1: case NZ_GAUSS7_S1: case NZ_GAUSS5_S1: case NZ_GAUSS3_S1:
+        case NZ_GAUSS9_S2: case NZ_GAUSS7_S2: case NZ_GAUSS5_S2: case NZ_GAUSS3_S2: {
+            static const int sizes[4] = {9, 7, 5, 3};
+            int w = sizes[filter & 3];
+            double sigma = filter >= NZ_GAUSS9_S2 ? 2.0 : 1.0;
+            gauss_coeffs(sigma, w, t->kx);
+            gauss_coeffs(sigma, w, t->kz);
+            t->factor = 1.0f;
+            t->ksize = w;
+            return NZ_OK;
+        }
+        case NZ_SMOOTH3: set3(1, 1, 1, 1, 1, 1, 1.0f / 3.0f); return NZ_OK;          // KernelJob.cs:107-108
+        case NZ_SOBEL3_HORIZONTAL: set3(-1, 0, 1, 1, 2, 1, 1.0f); return NZ_OK;       // :110-116
+        case NZ_SOBEL3_VERTICAL: set3(1, 2, 1, 1, 0, -1, 1.0f); return NZ_OK;         // :117-122
+        case NZ_PREWITT3_HORIZONTAL: set3(1, 0, -1, 1, 1, 1, 1.0f); return NZ_OK;     // :124-130
+        case NZ_PREWITT3_VERTICAL: set3(1, 1, 1, -1, 0, 1, 1.0f); return NZ_OK;       // :131-136
+        case NZ_SOBEL3_2D:
+            nz_set_error("Sobel3_2D runs through ScheduleReduce (KernelJob.cs:187-215), outside the hot path");
+            return NZ_ERR_UNSUPPORTED;
+    }
+    nz_set_error("unknown KernelFilterType %d", filter);
+    return NZ_ERR_INVALID;
+}
+
+// BlurHelper.limitWidth, Filter/Kernel/Blur/BlurKernels.cs:29-36
+static int limit_width(int width) {
+    if (width % 2 == 0) width += 1;
+    if (width > 25) width = 25;
+    return width < 3 ? 3 : width;
+}
+
+// GaussFilter.Schedule, Filter/Kernel/Blur/BlurJob.cs:11-21: body of limitWidth(width) taps, pass run
+// with kernelSize = width as given
+static int32_t gauss_taps(int32_t width, int32_t sigma, nz_kernel_taps *t) {
+    memset(t, 0, sizeof *t);
+    NZ_REQUIRE(sigma >= 0 && sigma <= 15, "GaussSigma %d out of range", sigma);
+    int w = limit_width(width);
+    NZ_REQUIRE(width >= 1 && width <= w, "gauss width %d indexes outside its %d-tap kernel", width, w);
+    gauss_coeffs(0.5 * (double)(sigma + 1), w, t->kx);
+    memcpy(t->kz, t->kx, sizeof t->kx);
+    t->factor = 1.0f;
+    t->ksize = width;
+    return NZ_OK;
+}
+
+// SmoothFilter.Schedule BlurJob.cs:34-44; SmoothBlur.GetKernel BlurKernels.cs:39-43
+static int32_t smooth_taps(int32_t width, nz_kernel_taps *t) {
+    memset(t, 0, sizeof *t);
+    NZ_REQUIRE(width >= 1 && width <= NZ_MAX_KSIZE, "smooth width %d out of range [1,25]", width);
+    for (int i = 0; i < width; i++) t->kx[i] = t->kz[i] = 1.0f / (float)width;
+    t->factor = 1.0f;
+    t->ksize = width;
+    return NZ_OK;
+}
+
+static int conv_tcap(int ksize) {
+    int hw = nz_conv_max_fused(ksize);
+    if (hw == 0) return 0;
+    static const char *env = getenv("NZ_CONV_TCAP");
+    int cap;
+    if (env && atoi(env) > 0) {
+        cap = atoi(env);
+    } else {
+        switch (ksize) {  // default fusion depth per launch (tuned on MI355X)
+            case 3: cap = 6; break;
+            case 5: cap = 3; break;
+            case 7: cap = 2; break;
+            default: cap = 2; break;
+        }
+    }
+    return cap < hw ? cap : hw;
+}
+
+// `iterations` applications of (X pass, Z pass) with the result back in `src`: the applications are
+// grouped into an even number of fused launches that ping-pong src <-> tmp.
+static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geom &g, const nz_kernel_taps &t,
+                               int iterations) {
+    NZ_REQUIRE(src && tmp && src != tmp, "src/tmp must be two distinct planes");
+    NZ_REQUIRE(iterations >= 1, "iterations < 1");
+    int cap = (t.ksize & 1) ? conv_tcap(t.ksize) : 0;
+    if (cap == 0 || iterations == 1) {
+        for (int i = 0; i < iterations; i++) {
+            int32_t rc = nz_launch_conv_pass_x(ctx->stream, src, tmp, g, t);
+            if (rc) return rc;
+            rc = nz_launch_conv_pass_z(ctx->stream, tmp, src, g, t);
+            if (rc) return rc;
+        }
+        return NZ_OK;
+    }
+    int L = (iterations + cap - 1) / cap;
+    if (L & 1) L += 1;
+    int base = iterations / L, rem = iterations % L;
+    float *cur = src, *other = tmp;
+    for (int i = 0; i < L; i++) {
+        int T = base + (i < rem ? 1 : 0);
+        int32_t rc = nz_launch_conv_fused(ctx->stream, cur, other, g, t, T);
+        if (rc) return rc;
+        float *s = cur; cur = other; other = s;
+    }
+    return NZ_OK;
+}
+
+static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geom &g, int iterations) {
+    NZ_REQUIRE(src && tmp && src != tmp, "src/tmp must be two distinct planes");
+    NZ_REQUIRE(iterations >= 1, "iterations < 1");
+    if (iterations == 1) {  // ErosionKernelJob.ScheduleSeries KernelJob.cs:318-335: min-X then min-Z, size 3
+        int32_t rc = nz_launch_min_pass(ctx->stream, src, tmp, g, 3, 0);
+        if (rc) return rc;
+        return nz_launch_min_pass(ctx->stream, tmp, src, g, 3, 1);
+    }
+    int cap = nz_erosion_max_fused();
+    int L = (iterations + cap - 1) / cap;
+    if (L < 2) L = 2;
+    if (L & 1) L += 1;
+    int base = iterations / L, rem = iterations % L;
+    float *cur = src, *other = tmp;
+    for (int i = 0; i < L; i++) {
+        int E = base + (i < rem ? 1 : 0);
+        int32_t rc = nz_launch_erosion_fused(ctx->stream, cur, other, g, E);
+        if (rc) return rc;
+        float *s = cur; cur = other; other = s;
+    }
+    return NZ_OK;
+}
+
+#define NZ_BEGIN(ctx, dep)                   \
+    do {                                     \
+        int32_t rc_ = nz_ctx_begin(ctx, dep); \
+        if (rc_) return rc_;                 \
+    } while (0)
+
+#define NZ_TRY(expr)              \
+    do {                          \
+        int32_t rc_ = (expr);     \
+        if (rc_) return rc_;      \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// noise
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t nz_fractal(nz_ctx *ctx, int32_t noiseType, float *src, int32_t resolution, float hurst,
+                              float startingAmplitude, float stepdown, float detuneRate, int32_t octaves,
+                              int32_t xpos, int32_t zpos, int32_t noiseSize, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_TRY(fractal_impl(ctx, noiseType, src, resolution, resolution, resolution, hurst, startingAmplitude, stepdown,
+                        detuneRate, octaves, xpos, zpos, noiseSize));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_fractal_stripe(nz_ctx *ctx, int32_t noiseType, float *buf, const nz_stripe *st, float hurst,
+                                     float startingAmplitude, float stepdown, float detuneRate, int32_t octaves,
+                                     int32_t xpos, int32_t zpos, int32_t noiseSize, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(nz_check_stripe(st, 0));
+    NZ_REQUIRE(buf, "buf is NULL");
+    int pitch = st->pitch > 0 ? st->pitch : st->cols;
+    int rows = st->own1 - st->own0;
+    if (rows > 0) {
+        NZ_TRY(fractal_impl(ctx, noiseType, buf + (size_t)st->own0 * pitch, rows, st->cols, pitch, hurst,
+                            startingAmplitude, stepdown, detuneRate, octaves, xpos, zpos + st->grow0 + st->own0,
+                            noiseSize));
+    }
+    return nz_ctx_finish(ctx, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// separable filters
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t nz_kernel_filter_stage(nz_ctx *ctx, float *src, float *tmp, int32_t filter, int32_t iterations,
+                                          int32_t resolution, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    nz_kernel_taps t;
+    NZ_TRY(filter_taps(filter, &t));
+    NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_tile(resolution), t, iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_kernel_filter(nz_ctx *ctx, float *src, float *tmp, int32_t filter, int32_t resolution,
+                                    nz_handle dep, nz_handle *out) {
+    return nz_kernel_filter_stage(ctx, src, tmp, filter, 1, resolution, dep, out);
+}
+
+extern "C" int32_t nz_gauss_blur_stage(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t sigma,
+                                       int32_t iterations, int32_t resolution, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    nz_kernel_taps t;
+    NZ_TRY(gauss_taps(width, sigma, &t));
+    NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_tile(resolution), t, iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_gauss_filter(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t sigma,
+                                   int32_t resolution, nz_handle dep, nz_handle *out) {
+    return nz_gauss_blur_stage(ctx, src, tmp, width, sigma, 1, resolution, dep, out);
+}
+
+extern "C" int32_t nz_smooth_blur_stage(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t iterations,
+                                        int32_t resolution, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    nz_kernel_taps t;
+    NZ_TRY(smooth_taps(width, &t));
+    NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_tile(resolution), t, iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_smooth_filter(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t resolution,
+                                    nz_handle dep, nz_handle *out) {
+    return nz_smooth_blur_stage(ctx, src, tmp, width, 1, resolution, dep, out);
+}
+
+extern "C" int32_t nz_separable_series(nz_ctx *ctx, float *src, float *tmp, int32_t resolution, int32_t kernelSize,
+                                       const float *kernelX, const float *kernelZ, float kernelFactor,
+                                       nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(kernelX && kernelZ, "kernel body is NULL");
+    NZ_REQUIRE(kernelSize >= 1 && kernelSize <= NZ_MAX_KSIZE, "kernelSize %d out of range [1,25]", kernelSize);
+    nz_kernel_taps t;
+    memset(&t, 0, sizeof t);
+    int used = 2 * ((kernelSize - 1) / 2) + 1;  // taps an odd or even kernelSize actually touches
+    memcpy(t.kx, kernelX, used * sizeof(float));
+    memcpy(t.kz, kernelZ, used * sizeof(float));
+    t.factor = kernelFactor;
+    t.ksize = kernelSize;
+    NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_tile(resolution), t, 1));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_erosion_stage(nz_ctx *ctx, float *src, float *tmp, int32_t iterations, int32_t resolution,
+                                    nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_TRY(erosion_iterations(ctx, src, tmp, nz_geom_tile(resolution), iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_erosion_kernel(nz_ctx *ctx, float *src, int32_t resolution, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    // the reference allocates its own TempJob plane (KernelJob.cs:327); here it is ctx scratch
+    float *tmp = nullptr;
+    NZ_TRY(nz_ctx_scratch(ctx, (size_t)resolution * resolution, &tmp));
+    NZ_TRY(erosion_iterations(ctx, src, tmp, nz_geom_tile(resolution), 1));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_kernel_filter_max_fused(int32_t filter) {
+    nz_kernel_taps t;
+    if (filter_taps(filter, &t) != NZ_OK) return 0;
+    int cap = conv_tcap(t.ksize);
+    return cap < 1 ? 1 : cap;
+}
+
+extern "C" int32_t nz_kernel_filter_halo_rows(int32_t filter, int32_t iterations) {
+    nz_kernel_taps t;
+    if (filter_taps(filter, &t) != NZ_OK) return -1;
+    return iterations * ((t.ksize - 1) / 2);
+}
+
+extern "C" int32_t nz_kernel_filter_stripe(nz_ctx *ctx, const float *src, float *dst, const nz_stripe *st,
+                                           int32_t filter, int32_t iterations, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    nz_kernel_taps t;
+    NZ_TRY(filter_taps(filter, &t));
+    NZ_REQUIRE(src && dst && src != dst, "src/dst must be two distinct planes");
+    NZ_REQUIRE(iterations >= 1 && iterations <= nz_conv_max_fused(t.ksize), "iterations %d cannot be fused",
+               iterations);
+    NZ_TRY(nz_check_stripe(st, iterations * ((t.ksize - 1) / 2)));
+    NZ_TRY(nz_launch_conv_fused(ctx->stream, src, dst, nz_geom_from_stripe(*st), t, iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_erosion_stripe(nz_ctx *ctx, const float *src, float *dst, const nz_stripe *st,
+                                     int32_t iterations, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(src && dst && src != dst, "src/dst must be two distinct planes");
+    NZ_REQUIRE(iterations >= 1 && iterations <= nz_erosion_max_fused(), "iterations %d cannot be fused", iterations);
+    NZ_TRY(nz_check_stripe(st, iterations));
+    NZ_TRY(nz_launch_erosion_fused(ctx->stream, src, dst, nz_geom_from_stripe(*st), iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// flow map
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t nz_fill_array(nz_ctx *ctx, float *data, int32_t resolution, float value, nz_handle dep,
+                                 nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(data, "data is NULL");
+    NZ_TRY(nz_launch_fill(ctx->stream, data, (size_t)resolution * resolution, value));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_flowmap_compute_flow(nz_ctx *ctx, const float *src, const float *waterMap, float *flowMapN,
+                                           float *flowMapN__buff, float *flowMapS, float *flowMapS__buff,
+                                           float *flowMapE, float *flowMapE__buff, float *flowMapW,
+                                           float *flowMapW__buff, int32_t resolution, nz_handle dep,
+                                           nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(src && waterMap && flowMapN && flowMapS && flowMapE && flowMapW, "plane is NULL");
+    // The reference writes the __buff planes and flushes them back (FlowMapJob.cs:70-77).  Each
+    // cell reads only its own flux, so the update is done in place and the buffers stay untouched.
+    (void)flowMapN__buff; (void)flowMapS__buff; (void)flowMapE__buff; (void)flowMapW__buff;
+    NZ_TRY(nz_launch_flow_step(ctx->stream, src, waterMap, flowMapN, flowMapS, flowMapE, flowMapW, flowMapN, flowMapS,
+                               flowMapE, flowMapW, nz_geom_tile(resolution)));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_flowmap_update_water(nz_ctx *ctx, float *waterMap, float *waterMap__buff,
+                                           const float *flowMapN, const float *flowMapS, const float *flowMapE,
+                                           const float *flowMapW, int32_t resolution, nz_handle dep,
+                                           nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(waterMap && flowMapN && flowMapS && flowMapE && flowMapW, "plane is NULL");
+    (void)waterMap__buff;
+    NZ_TRY(nz_launch_water_step(ctx->stream, waterMap, waterMap, flowMapN, flowMapS, flowMapE, flowMapW,
+                                nz_geom_tile(resolution)));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_flowmap_write_values(nz_ctx *ctx, float *src, const float *flowMapN, const float *flowMapS,
+                                           const float *flowMapE, const float *flowMapW, int32_t resolution,
+                                           nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(src && flowMapN && flowMapS && flowMapE && flowMapW, "plane is NULL");
+    NZ_TRY(nz_launch_velocity(ctx->stream, src, flowMapN, flowMapS, flowMapE, flowMapW, nz_geom_tile(resolution), 0,
+                              0.0f, 1.0f));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_map_normalize_values(nz_ctx *ctx, float *src, float *tmp, const float *args,
+                                           int32_t resolution, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(src && args, "src/args is NULL");
+    (void)tmp;  // element-wise: done in place, no flush copy
+    NZ_TRY(nz_launch_normalize(ctx->stream, src, src, (size_t)resolution * resolution, args[0], args[2]));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" size_t nz_flowmap_stage_work_floats(int32_t resolution) {
+    return resolution > 0 ? (size_t)10 * resolution * resolution : 0;
+}
+
+extern "C" int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
+                                    float normMax, int32_t resolution, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(src && work, "src/work is NULL");
+    NZ_REQUIRE(iterations >= 1, "iterations < 1");
+    size_t n = (size_t)resolution * resolution;
+    nz_geom g = nz_geom_tile(resolution);
+    float *A[5], *B[5];  // {water, fN, fS, fE, fW} x {READ, WRITE}, FlowMapStage.cs:52-62
+    for (int i = 0; i < 5; i++) {
+        A[i] = work + (size_t)i * n;
+        B[i] = work + (size_t)(5 + i) * n;
+    }
+    // iteration 1: water == 0.0001 (fillStage, FlowMapStage.cs:129) and flux == 0 (defined) are implied
+    NZ_TRY(nz_launch_flow_iter(ctx->stream, src, nullptr, nullptr, nullptr, nullptr, nullptr, A[0], A[1], A[2], A[3],
+                               A[4], g, 1));
+    float **cur = A, **nxt = B;
+    for (int i = 1; i < iterations; i++) {
+        NZ_TRY(nz_launch_flow_iter(ctx->stream, src, cur[0], cur[1], cur[2], cur[3], cur[4], nxt[0], nxt[1], nxt[2],
+                                   nxt[3], nxt[4], g, 0));
+        float **s = cur; cur = nxt; nxt = s;
+    }
+    // writeStage + normStage, FlowMapStage.cs:179-194; args = {normMin, normMax, normMax - normMin} (:48-51)
+    NZ_TRY(nz_launch_velocity(ctx->stream, src, cur[1], cur[2], cur[3], cur[4], g, 1, normMin, normMax - normMin));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_flow_first_stripe(nz_ctx *ctx, const float *height, float *water, float *fN, float *fS,
+                                        float *fE, float *fW, const nz_stripe *st, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(nz_check_stripe(st, 2));
+    NZ_REQUIRE(height && water && fN && fS && fE && fW, "plane is NULL");
+    NZ_TRY(nz_launch_flow_iter(ctx->stream, height, nullptr, nullptr, nullptr, nullptr, nullptr, water, fN, fS, fE, fW,
+                               nz_geom_from_stripe(*st), 1));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_flow_iter_stripe(nz_ctx *ctx, const float *height, const float *water_in, const float *fN_in,
+                                       const float *fS_in, const float *fE_in, const float *fW_in, float *water_out,
+                                       float *fN_out, float *fS_out, float *fE_out, float *fW_out,
+                                       const nz_stripe *st, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(nz_check_stripe(st, 2));
+    NZ_REQUIRE(height && water_in && fN_in && fS_in && fE_in && fW_in && water_out && fN_out && fS_out && fE_out &&
+                   fW_out,
+               "plane is NULL");
+    NZ_TRY(nz_launch_flow_iter(ctx->stream, height, water_in, fN_in, fS_in, fE_in, fW_in, water_out, fN_out, fS_out,
+                               fE_out, fW_out, nz_geom_from_stripe(*st), 0));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_flow_velocity_stripe(nz_ctx *ctx, float *dst, const float *fN, const float *fS,
+                                           const float *fE, const float *fW, const nz_stripe *st, float normMin,
+                                           float normMax, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(nz_check_stripe(st, 1));
+    NZ_REQUIRE(dst && fN && fS && fE && fW, "plane is NULL");
+    NZ_TRY(nz_launch_velocity(ctx->stream, dst, fN, fS, fE, fW, nz_geom_from_stripe(*st), 1, normMin,
+                              normMax - normMin));
+    return nz_ctx_finish(ctx, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// mesh
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t nz_mesh_vertex_count(int32_t resolution) {  // VertexCount, Overshoot :26
+    return resolution > 0 ? (size_t)(resolution + 1) * (resolution + 1) : 0;
+}
+
+extern "C" size_t nz_mesh_index_count(int32_t resolution) {  // IndexCount, Overshoot :28
+    return resolution > 0 ? (size_t)6 * resolution * resolution : 0;
+}
+
+extern "C" int32_t nz_heightmap_mesh(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_t *indices,
+                                     int32_t resolution, int32_t inputResolution, int32_t marginPix,
+                                     float tileHeight, float tileSize, const float *heights, nz_handle dep,
+                                     nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    (void)marginPix;  // MarginScale is commented out of the vertex path (Overshoot :64)
+    NZ_REQUIRE(vertices && indices && heights, "buffer is NULL");
+    NZ_REQUIRE(resolution >= 1 && resolution <= 26754, "resolution %d out of range", resolution);
+    NZ_REQUIRE(inputResolution >= resolution && inputResolution <= 46340, "inputResolution %d out of range",
+               inputResolution);
+    int off = (inputResolution - resolution) / 2;  // PixOffset, Overshoot :33
+    // shapes for which the reference would index outside the height plane are rejected
+    if (meshType == NZ_MESH_OVERSHOOT_SQUARE_GRID) {
+        int hi = resolution + 1 < resolution + off ? resolution + 1 : resolution + off;
+        NZ_REQUIRE(hi + off <= inputResolution - 1, "overshoot mesh: margin too small for resolution %d / input %d",
+                   resolution, inputResolution);
+    } else if (meshType == NZ_MESH_SQUARE_GRID) {
+        NZ_REQUIRE(resolution + off <= inputResolution - 1, "square mesh: inputResolution must exceed resolution");
+    } else {
+        nz_set_error("unknown MeshType %d", meshType);
+        return NZ_ERR_INVALID;
+    }
+    NZ_TRY(nz_launch_mesh(ctx->stream, meshType, vertices, indices, resolution, inputResolution, tileHeight, tileSize,
+                          heights));
+    return nz_ctx_finish(ctx, out);
+}

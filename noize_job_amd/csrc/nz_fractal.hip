@@ -1,0 +1,434 @@
+// nz_fractal.hip -- fBm octave accumulation over the reference's noise bases (gfx950).
+//
+// Replaces FractalJob<FractalGenerator<N>, WriteTileData> (Noise/Fractal/Fractal.cs:19-74) for the
+// eight N of Noise/NoiseStage.cs:26-35.  The arithmetic below is the oracle's operation sequence
+// (oracle/noize_oracle.c), compiled with -ffp-contract=off: the top octaves
+// multiply coordinates by up to 2^12, so the skew/unskew steps cancel catastrophically and any
+// re-association or FMA contraction moves the result by more than the 1e-5 tolerance.  Every
+// operation is an IEEE-754 binary32 add/mul/div/floor, which makes the result bit-identical to the
+// CPU restatement.  psrnoise's cos/sin come from a 290-entry table built by the host libm
+// (its hash is an exact small integer), so no device trig is involved except for the Sin basis.
+//
+// VALU-bound (~1.1 k fp32 ops per cell for 13 simplex octaves against 4 B written): one thread
+// produces VEC consecutive cells of a row so the octave chains of different cells interleave, and
+// stores them with one 8/16-byte coalesced write.
+#include "nz_internal.hpp"
+
+namespace {
+
+__device__ __forceinline__ float fracf_(float x) { return x - floorf(x); }
+__device__ __forceinline__ float lerpf_(float a, float b, float s) { return a + s * (b - a); }
+__device__ __forceinline__ float stepf_(float y, float x) { return x >= y ? 1.0f : 0.0f; }
+__device__ __forceinline__ float mod289f(float x) { return x - floorf(x * (1.0f / 289.0f)) * 289.0f; }
+__device__ __forceinline__ float mod7f(float x) { return x - floorf(x * (1.0f / 7.0f)) * 7.0f; }
+__device__ __forceinline__ float permutef(float x) { return mod289f((34.0f * x + 1.0f) * x); }
+__device__ __forceinline__ float taylor_inv_sqrt(float r) { return 1.79284291400159f - 0.85373472095314f * r; }
+__device__ __forceinline__ float fadef(float t) { return t * t * t * (t * (t * 6.0f - 15.0f) + 10.0f); }
+__device__ __forceinline__ float rectify(float v) { return (1.0f + v) / 2.0f * 1.0f; }
+
+// noise.cnoise(float2), Appendix A.2
+__device__ __forceinline__ float cnoise2(float Px, float Py) {
+    float flx = floorf(Px), fly = floorf(Py);
+    float frx = Px - flx, fry = Py - fly;
+    float Pi0 = mod289f(flx + 0.0f), Pi1 = mod289f(fly + 0.0f);
+    float Pi2 = mod289f(flx + 1.0f), Pi3 = mod289f(fly + 1.0f);
+    float Pf0 = frx - 0.0f, Pf1 = fry - 0.0f, Pf2 = frx - 1.0f, Pf3 = fry - 1.0f;
+    float ix[4] = {Pi0, Pi2, Pi0, Pi2};
+    float iy[4] = {Pi1, Pi1, Pi3, Pi3};
+    float gx[4], gy[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float i = permutef(permutef(ix[k]) + iy[k]);
+        float g = fracf_(i * (1.0f / 41.0f)) * 2.0f - 1.0f;
+        gy[k] = fabsf(g) - 0.5f;
+        float tx = floorf(g + 0.5f);
+        gx[k] = g - tx;
+    }
+    float g00x = gx[0], g00y = gy[0], g10x = gx[1], g10y = gy[1];
+    float g01x = gx[2], g01y = gy[2], g11x = gx[3], g11y = gy[3];
+    float n0 = taylor_inv_sqrt(g00x * g00x + g00y * g00y);
+    float n1 = taylor_inv_sqrt(g01x * g01x + g01y * g01y);
+    float n2 = taylor_inv_sqrt(g10x * g10x + g10y * g10y);
+    float n3 = taylor_inv_sqrt(g11x * g11x + g11y * g11y);
+    g00x *= n0; g00y *= n0;
+    g01x *= n1; g01y *= n1;
+    g10x *= n2; g10y *= n2;
+    g11x *= n3; g11y *= n3;
+    float n00 = g00x * Pf0 + g00y * Pf1;
+    float n10 = g10x * Pf2 + g10y * Pf1;
+    float n01 = g01x * Pf0 + g01y * Pf3;
+    float n11 = g11x * Pf2 + g11y * Pf3;
+    float fdx = fadef(Pf0), fdy = fadef(Pf1);
+    float nx0 = lerpf_(n00, n10, fdx);
+    float nx1 = lerpf_(n01, n11, fdx);
+    return 2.3f * lerpf_(nx0, nx1, fdy);
+}
+
+// noise.snoise(float2), Appendix A.3
+__device__ __forceinline__ float snoise2(float vx, float vy) {
+    const float Cx = 0.211324865405187f, Cy = 0.366025403784439f;
+    const float Cz = -0.577350269189626f, Cw = 0.024390243902439f;
+    float s = vx * Cy + vy * Cy;
+    float ix = floorf(vx + s), iy = floorf(vy + s);
+    float t = ix * Cx + iy * Cx;
+    float x0x = vx - ix + t, x0y = vy - iy + t;
+    bool gt = x0x > x0y;
+    float i1x = gt ? 1.0f : 0.0f, i1y = gt ? 0.0f : 1.0f;
+    float x12x = x0x + Cx, x12y = x0y + Cx, x12z = x0x + Cz, x12w = x0y + Cz;
+    x12x -= i1x;
+    x12y -= i1y;
+    ix = mod289f(ix);
+    iy = mod289f(iy);
+    float p0 = permutef(permutef(iy + 0.0f) + ix + 0.0f);
+    float p1 = permutef(permutef(iy + i1y) + ix + i1x);
+    float p2 = permutef(permutef(iy + 1.0f) + ix + 1.0f);
+    float m0 = fmaxf(0.5f - (x0x * x0x + x0y * x0y), 0.0f);
+    float m1 = fmaxf(0.5f - (x12x * x12x + x12y * x12y), 0.0f);
+    float m2 = fmaxf(0.5f - (x12z * x12z + x12w * x12w), 0.0f);
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
+    float xa = 2.0f * fracf_(p0 * Cw) - 1.0f;
+    float xb = 2.0f * fracf_(p1 * Cw) - 1.0f;
+    float xc = 2.0f * fracf_(p2 * Cw) - 1.0f;
+    float h0 = fabsf(xa) - 0.5f, h1 = fabsf(xb) - 0.5f, h2 = fabsf(xc) - 0.5f;
+    float a00 = xa - floorf(xa + 0.5f);
+    float a01 = xb - floorf(xb + 0.5f);
+    float a02 = xc - floorf(xc + 0.5f);
+    m0 *= 1.79284291400159f - 0.85373472095314f * (a00 * a00 + h0 * h0);
+    m1 *= 1.79284291400159f - 0.85373472095314f * (a01 * a01 + h1 * h1);
+    m2 *= 1.79284291400159f - 0.85373472095314f * (a02 * a02 + h2 * h2);
+    float g0 = a00 * x0x + h0 * x0y;
+    float g1 = a01 * x12x + h1 * x12y;
+    float g2 = a02 * x12z + h2 * x12w;
+    return 130.0f * (m0 * g0 + m1 * g1 + m2 * g2);
+}
+
+// rgrad2 through the host-built table: hash is an exact integer in [0, 289]
+__device__ __forceinline__ float2 rgrad2_tab(float px, float py, const float2 *tab) {
+    float h = permutef(permutef(px) + py);
+    int idx = (int)h;
+    idx = idx < 0 ? 0 : (idx > NZ_RGRAD_N - 1 ? NZ_RGRAD_N - 1 : idx);
+    return tab[idx];
+}
+
+// noise.psrnoise(float2 pos, float2 per = (1010,102), rot), Appendix A.4
+__device__ __forceinline__ float psrnoise2(float posx, float posy, const float2 *tab) {
+    const float perx = 1010.0f, pery = 102.0f;
+    posy += 0.001f;
+    float uvx = posx + posy * 0.5f, uvy = posy;
+    float i0x = floorf(uvx), i0y = floorf(uvy);
+    float f0x = uvx - i0x, f0y = uvy - i0y;
+    bool gt = f0x > f0y;
+    float i1x = gt ? 1.0f : 0.0f, i1y = gt ? 0.0f : 1.0f;
+    float p0x = i0x - i0y * 0.5f, p0y = i0y;
+    float p1x = p0x + i1x - i1y * 0.5f, p1y = p0y + i1y;
+    float p2x = p0x + 0.5f, p2y = p0y + 1.0f;
+    float d0x = posx - p0x, d0y = posy - p0y;
+    float d1x = posx - p1x, d1y = posy - p1y;
+    float d2x = posx - p2x, d2y = posy - p2y;
+    float xw0 = fmodf(p0x, perx), xw1 = fmodf(p1x, perx), xw2 = fmodf(p2x, perx);
+    float yw0 = fmodf(p0y, pery), yw1 = fmodf(p1y, pery), yw2 = fmodf(p2y, pery);
+    float iu0 = xw0 + 0.5f * yw0, iu1 = xw1 + 0.5f * yw1, iu2 = xw2 + 0.5f * yw2;
+    float2 g0 = rgrad2_tab(iu0, yw0, tab);
+    float2 g1 = rgrad2_tab(iu1, yw1, tab);
+    float2 g2 = rgrad2_tab(iu2, yw2, tab);
+    float w0 = g0.x * d0x + g0.y * d0y;
+    float w1 = g1.x * d1x + g1.y * d1y;
+    float w2 = g2.x * d2x + g2.y * d2y;
+    float t0 = 0.8f - (d0x * d0x + d0y * d0y);
+    float t1 = 0.8f - (d1x * d1x + d1y * d1y);
+    float t2 = 0.8f - (d2x * d2x + d2y * d2y);
+    t0 = fmaxf(t0, 0.0f); t1 = fmaxf(t1, 0.0f); t2 = fmaxf(t2, 0.0f);
+    float t20 = t0 * t0, t21 = t1 * t1, t22 = t2 * t2;
+    float t40 = t20 * t20, t41 = t21 * t21, t42 = t22 * t22;
+    float n = t40 * w0 + t41 * w1 + t42 * w2;
+    return 11.0f * n;
+}
+
+// one column of the 3x3 cellular search, Appendix A.5
+__device__ __forceinline__ void cell_column(float pxc, float Piy, float Pfx_off, float Pfy, float d[3]) {
+    const float K = 0.142857142857f, Ko = 0.428571428571f;
+    const float oi[3] = {-1.0f, 0.0f, 1.0f};
+    const float of[3] = {-0.5f, 0.5f, 1.5f};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float p = permutef(pxc + Piy + oi[k]);
+        float ox = fracf_(p * K) - Ko;
+        float oy = mod7f(floorf(p * K)) * K - Ko;
+        float dx = Pfx_off + 1.0f * ox;
+        float dy = Pfy - of[k] + 1.0f * oy;
+        d[k] = dx * dx + dy * dy;
+    }
+}
+
+__device__ __forceinline__ float cellular_rect(float Px, float Py) {
+    float Pix = mod289f(floorf(Px)), Piy = mod289f(floorf(Py));
+    float Pfx = fracf_(Px), Pfy = fracf_(Py);
+    float px0 = permutef(Pix + -1.0f), px1 = permutef(Pix + 0.0f), px2 = permutef(Pix + 1.0f);
+    float d1[3], d2[3], d3[3], d1a[3];
+    cell_column(px0, Piy, Pfx + 0.5f, Pfy, d1);
+    cell_column(px1, Piy, Pfx - 0.5f, Pfy, d2);
+    cell_column(px2, Piy, Pfx - 1.5f, Pfy, d3);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        d1a[k] = fminf(d1[k], d2[k]);
+        d2[k] = fmaxf(d1[k], d2[k]);
+        d2[k] = fminf(d2[k], d3[k]);
+        d1[k] = fminf(d1a[k], d2[k]);
+        d2[k] = fmaxf(d1a[k], d2[k]);
+    }
+    if (!(d1[0] < d1[1])) { float s = d1[0]; d1[0] = d1[1]; d1[1] = s; }
+    if (!(d1[0] < d1[2])) { float s = d1[0]; d1[0] = d1[2]; d1[2] = s; }
+    d1[1] = fminf(d1[1], d2[1]);
+    d1[2] = fminf(d1[2], d2[2]);
+    d1[1] = fminf(d1[1], d1[2]);
+    d1[1] = fminf(d1[1], d2[0]);
+    float F1 = sqrtf(d1[0]), F2 = sqrtf(d1[1]);
+    return rectify(F1) * rectify(F2);  // CellularGetter.Rectify Fractal.cs:274-277
+}
+
+// noise.cnoise(float3), Appendix A.6
+__device__ __forceinline__ float cnoise3(float Px, float Py, float Pz) {
+    float Pi0[3] = {floorf(Px), floorf(Py), floorf(Pz)};
+    float Pf0[3] = {fracf_(Px), fracf_(Py), fracf_(Pz)};
+    float Pi1[3], Pf1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        Pi1[k] = Pi0[k] + 1.0f;
+        Pi0[k] = mod289f(Pi0[k]);
+        Pi1[k] = mod289f(Pi1[k]);
+        Pf1[k] = Pf0[k] - 1.0f;
+    }
+    float ix[4] = {Pi0[0], Pi1[0], Pi0[0], Pi1[0]};
+    float iy[4] = {Pi0[1], Pi0[1], Pi1[1], Pi1[1]};
+    float n[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float ixy = permutef(permutef(ix[k]) + iy[k]);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            float ixyz = permutef(ixy + (s ? Pi1[2] : Pi0[2]));
+            float gxx = ixyz * (1.0f / 7.0f);
+            float gyy = fracf_(floorf(gxx) * (1.0f / 7.0f)) - 0.5f;
+            gxx = fracf_(gxx);
+            float gzz = 0.5f - fabsf(gxx) - fabsf(gyy);
+            float sz = stepf_(gzz, 0.0f);
+            gxx -= sz * (stepf_(0.0f, gxx) - 0.5f);
+            gyy -= sz * (stepf_(0.0f, gyy) - 0.5f);
+            float nr = taylor_inv_sqrt(gxx * gxx + gyy * gyy + gzz * gzz);
+            float ax = gxx * nr, ay = gyy * nr, az = gzz * nr;
+            float fx = (k & 1) ? Pf1[0] : Pf0[0];
+            float fy = (k & 2) ? Pf1[1] : Pf0[1];
+            float fz = s ? Pf1[2] : Pf0[2];
+            n[s][k] = ax * fx + ay * fy + az * fz;
+        }
+    }
+    float fdx = fadef(Pf0[0]), fdy = fadef(Pf0[1]), fdz = fadef(Pf0[2]);
+    float nz0 = lerpf_(n[0][0], n[1][0], fdz);
+    float nz1 = lerpf_(n[0][1], n[1][1], fdz);
+    float nz2 = lerpf_(n[0][2], n[1][2], fdz);
+    float nz3 = lerpf_(n[0][3], n[1][3], fdz);
+    float nyz0 = lerpf_(nz0, nz2, fdy);
+    float nyz1 = lerpf_(nz1, nz3, fdy);
+    return 2.2f * lerpf_(nyz0, nyz1, fdx);
+}
+
+// noise.snoise(float3), Appendix A.6
+__device__ __forceinline__ float snoise3(float vx, float vy, float vz) {
+    const float Cx = 1.0f / 6.0f, Cy = 1.0f / 3.0f;
+    float v[3] = {vx, vy, vz};
+    float s = vx * Cy + vy * Cy + vz * Cy;
+    float i[3], x0[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) i[k] = floorf(v[k] + s);
+    float t = i[0] * Cx + i[1] * Cx + i[2] * Cx;
+#pragma unroll
+    for (int k = 0; k < 3; k++) x0[k] = v[k] - i[k] + t;
+    float g[3] = {stepf_(x0[1], x0[0]), stepf_(x0[2], x0[1]), stepf_(x0[0], x0[2])};
+    float l[3] = {1.0f - g[0], 1.0f - g[1], 1.0f - g[2]};
+    float lz[3] = {l[2], l[0], l[1]};
+    float i1[3], i2[3], x1[3], x2[3], x3[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        i1[k] = fminf(g[k], lz[k]);
+        i2[k] = fmaxf(g[k], lz[k]);
+        x1[k] = x0[k] - i1[k] + Cx;
+        x2[k] = x0[k] - i2[k] + Cy;
+        x3[k] = x0[k] - 0.5f;
+        i[k] = mod289f(i[k]);
+    }
+    float oz[4] = {0.0f, i1[2], i2[2], 1.0f};
+    float oy[4] = {0.0f, i1[1], i2[1], 1.0f};
+    float ox[4] = {0.0f, i1[0], i2[0], 1.0f};
+    const float n_ = 0.142857142857f;
+    const float nsx = n_ * 2.0f - 0.0f, nsy = n_ * 0.5f - 1.0f, nsz = n_ * 1.0f - 0.0f;
+    float X[4], Y[4], H[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float p = permutef(permutef(permutef(i[2] + oz[k]) + i[1] + oy[k]) + i[0] + ox[k]);
+        float j = p - 49.0f * floorf(p * nsz * nsz);
+        float x_ = floorf(j * nsz);
+        float y_ = floorf(j - 7.0f * x_);
+        X[k] = x_ * nsx + nsy;
+        Y[k] = y_ * nsx + nsy;
+        H[k] = 1.0f - fabsf(X[k]) - fabsf(Y[k]);
+    }
+    float b0[4] = {X[0], X[1], Y[0], Y[1]}, b1[4] = {X[2], X[3], Y[2], Y[3]};
+    float s0[4], s1[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        s0[k] = floorf(b0[k]) * 2.0f + 1.0f;
+        s1[k] = floorf(b1[k]) * 2.0f + 1.0f;
+        sh[k] = -stepf_(H[k], 0.0f);
+    }
+    float a0[4] = {b0[0] + s0[0] * sh[0], b0[2] + s0[2] * sh[0], b0[1] + s0[1] * sh[1],
+                   b0[3] + s0[3] * sh[1]};
+    float a1[4] = {b1[0] + s1[0] * sh[2], b1[2] + s1[2] * sh[2], b1[1] + s1[1] * sh[3],
+                   b1[3] + s1[3] * sh[3]};
+    float P[4][3] = {{a0[0], a0[1], H[0]}, {a0[2], a0[3], H[1]}, {a1[0], a1[1], H[2]},
+                     {a1[2], a1[3], H[3]}};
+    float xs[4][3] = {{x0[0], x0[1], x0[2]}, {x1[0], x1[1], x1[2]}, {x2[0], x2[1], x2[2]},
+                      {x3[0], x3[1], x3[2]}};
+    float m[4], pd[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float nr = taylor_inv_sqrt(P[k][0] * P[k][0] + P[k][1] * P[k][1] + P[k][2] * P[k][2]);
+        float px = P[k][0] * nr, py = P[k][1] * nr, pz = P[k][2] * nr;
+        m[k] = fmaxf(0.6f - (xs[k][0] * xs[k][0] + xs[k][1] * xs[k][1] + xs[k][2] * xs[k][2]), 0.0f);
+        m[k] = m[k] * m[k];
+        pd[k] = px * xs[k][0] + py * xs[k][1] + pz * xs[k][2];
+    }
+    return 42.0f * ((m[0] * m[0]) * pd[0] + (m[1] * m[1]) * pd[1] + (m[2] * m[2]) * pd[2] +
+                    (m[3] * m[3]) * pd[3]);
+}
+
+__device__ __forceinline__ void domain_rotate(float x, float z, float &xr, float &zr, float &yr) {
+    float xz = x + z;
+    float s2 = xz * -0.211324865405187f;
+    xr = x + s2;
+    zr = z + s2;
+    yr = xz * -0.577350269189626f;
+}
+
+// IMakeNoise.NoiseValue of the eight getters, Fractal.cs:141-278
+template <int BASIS>
+__device__ __forceinline__ float noise_value(float x, float z, const float2 *tab) {
+    if constexpr (BASIS == NZ_NOISE_SIN) {
+        float vx = 0.5f + (0.5f * sinf(x));
+        float vy = 0.5f + (0.5f * sinf(z));
+        return vx * vy;
+    } else if constexpr (BASIS == NZ_NOISE_PERLIN) {
+        return rectify(cnoise2(x, z));
+    } else if constexpr (BASIS == NZ_NOISE_PERIODIC_PERLIN || BASIS == NZ_NOISE_ROTATED_SIMPLEX) {
+        return rectify(psrnoise2(x, z, tab));
+    } else if constexpr (BASIS == NZ_NOISE_SIMPLEX) {
+        return rectify(snoise2(x, z));
+    } else if constexpr (BASIS == NZ_NOISE_CELLULAR) {
+        return cellular_rect(x, z);
+    } else if constexpr (BASIS == NZ_NOISE_DOMAIN_ROTATED_PERLIN) {
+        float xr, zr, yr;
+        domain_rotate(x, z, xr, zr, yr);
+        return rectify(cnoise3(xr, zr, yr));
+    } else {
+        float xr, zr, yr;
+        domain_rotate(x, z, xr, zr, yr);
+        return rectify(snoise3(xr, zr, yr));
+    }
+}
+
+constexpr int FR_THREADS = 256;
+
+// FractalGenerator.NoiseValue (Fractal.cs:114-131) for VEC consecutive cells of one row.
+template <int BASIS, int VEC>
+__global__ __launch_bounds__(FR_THREADS) void fractal_kernel(float *__restrict__ dst, int rows, int cols,
+                                                            int pitch, int blocks_per_row,
+                                                            nz_fractal_params p,
+                                                            const float2 *__restrict__ rgrad) {
+    constexpr bool USES_TAB = BASIS == NZ_NOISE_PERIODIC_PERLIN || BASIS == NZ_NOISE_ROTATED_SIMPLEX;
+    __shared__ float2 s_tab[USES_TAB ? NZ_RGRAD_N : 1];
+    if constexpr (USES_TAB) {
+        const float2 *src = rgrad + (BASIS == NZ_NOISE_ROTATED_SIMPLEX ? NZ_RGRAD_N : 0);
+        for (int i = threadIdx.x; i < NZ_RGRAD_N; i += FR_THREADS) s_tab[i] = src[i];
+        __syncthreads();
+    }
+    int z = blockIdx.x / blocks_per_row;
+    int bx = blockIdx.x - z * blocks_per_row;
+    int x0 = (bx * FR_THREADS + threadIdx.x) * VEC;
+    if (z >= rows || x0 >= cols) return;
+
+    float zi = ((float)z + p.posz) / p.noise_size;
+    float xi[VEC], t[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; c++) {
+        xi[c] = ((float)(x0 + c) + p.posx) / p.noise_size;
+        t[c] = 0.0f;
+    }
+    float detune = 0.0f, f = 1.0f, a = p.amp;
+    for (int i = 0; i < p.octaves; i++) {
+        float zV = f * zi;
+#pragma unroll
+        for (int c = 0; c < VEC; c++) {
+            float xV = f * xi[c];
+            t[c] += a * noise_value<BASIS>(xV, zV, s_tab);
+        }
+        detune += p.detune_rate;
+        f *= (p.stepdown - detune);
+        a *= p.G;
+    }
+    float *row = dst + (size_t)z * pitch;
+    float o[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; c++) o[c] = t[c] / p.norm;
+    bool full = x0 + VEC <= cols && ((reinterpret_cast<uintptr_t>(row + x0) & (VEC * 4 - 1)) == 0);
+    if (full) {
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4 *>(row + x0) = make_float4(o[0], o[1], o[2], o[3]);
+        } else if constexpr (VEC == 2) {
+            *reinterpret_cast<float2 *>(row + x0) = make_float2(o[0], o[1]);
+        } else {
+            row[x0] = o[0];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < VEC; c++)
+            if (x0 + c < cols) row[x0 + c] = o[c];
+    }
+}
+
+template <int BASIS, int VEC>
+int32_t launch_basis(hipStream_t s, float *dst, int rows, int cols, int pitch, const nz_fractal_params &p,
+                     const float *d_rgrad) {
+    int per_block = FR_THREADS * VEC;
+    int bpr = (cols + per_block - 1) / per_block;
+    long long blocks = (long long)bpr * rows;
+    if (blocks > 0x7fffffffLL) {
+        nz_set_error("fractal grid too large");
+        return NZ_ERR_INVALID;
+    }
+    hipLaunchKernelGGL((fractal_kernel<BASIS, VEC>), dim3((unsigned)blocks), dim3(FR_THREADS), 0, s, dst, rows,
+                       cols, pitch, bpr, p, reinterpret_cast<const float2 *>(d_rgrad));
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+}  // namespace
+
+int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, int cols, int pitch,
+                          const nz_fractal_params &p, const float *d_rgrad) {
+    switch (noiseType) {
+        case NZ_NOISE_SIN: return launch_basis<NZ_NOISE_SIN, 4>(s, dst, rows, cols, pitch, p, d_rgrad);
+        case NZ_NOISE_PERLIN: return launch_basis<NZ_NOISE_PERLIN, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
+        case NZ_NOISE_PERIODIC_PERLIN:
+            return launch_basis<NZ_NOISE_PERIODIC_PERLIN, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
+        case NZ_NOISE_SIMPLEX: return launch_basis<NZ_NOISE_SIMPLEX, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
+        case NZ_NOISE_ROTATED_SIMPLEX:
+            return launch_basis<NZ_NOISE_ROTATED_SIMPLEX, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
+        case NZ_NOISE_CELLULAR: return launch_basis<NZ_NOISE_CELLULAR, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
+        case NZ_NOISE_DOMAIN_ROTATED_PERLIN:
+            return launch_basis<NZ_NOISE_DOMAIN_ROTATED_PERLIN, 1>(s, dst, rows, cols, pitch, p, d_rgrad);
+        case NZ_NOISE_DOMAIN_ROTATED_SIMPLEX:
+            return launch_basis<NZ_NOISE_DOMAIN_ROTATED_SIMPLEX, 1>(s, dst, rows, cols, pitch, p, d_rgrad);
+    }
+    nz_set_error("unknown noise type %d", noiseType);
+    return NZ_ERR_INVALID;
+}

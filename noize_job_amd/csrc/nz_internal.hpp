@@ -1,0 +1,139 @@
+// nz_internal.hpp -- shared declarations of libnoize_hip (host side + launcher prototypes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/noize_hip.h"
+
+// ---- error plumbing -------------------------------------------------------------------------
+void nz_set_error(const char *fmt, ...);
+
+#define NZ_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            nz_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                       \
+            return NZ_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+#define NZ_REQUIRE(cond, ...)        \
+    do {                             \
+        if (!(cond)) {               \
+            nz_set_error(__VA_ARGS__); \
+            return NZ_ERR_INVALID;   \
+        }                            \
+    } while (0)
+
+// ---- context --------------------------------------------------------------------------------
+struct nz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    // JobHandle ring: handle h lives in events[h % size] while h > last_handle - size
+    std::vector<hipEvent_t> events;
+    uint64_t last_handle = 0;
+    // psrnoise gradient tables (rot 0 and rot 0.62), built with the host libm
+    float *d_rgrad = nullptr;
+    // stage scratch owned by the ctx (grown on demand)
+    float *scratch = nullptr;
+    size_t scratch_floats = 0;
+};
+
+int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep);           // set device, honour `dep`
+int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out);         // record the JobHandle marker
+int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out);
+
+// ---- kernel parameter blocks ----------------------------------------------------------------
+constexpr int NZ_MAX_KSIZE = 25;
+constexpr int NZ_RGRAD_N = 320;  // entries per rotation table (hash values are in [0, 289])
+
+struct nz_kernel_taps {
+    float kx[NZ_MAX_KSIZE];
+    float kz[NZ_MAX_KSIZE];
+    float factor;
+    int ksize;
+};
+
+struct nz_fractal_params {
+    float posx, posz;     // (float)xpos, (float)(zpos + first row)
+    float noise_size;     // (float)NoiseSize
+    float G;              // exp2f(-hurst), host libm
+    float amp;            // StartingAmplitude
+    float stepdown, detune_rate;
+    float norm;           // CalcFractalNormValue
+    int octaves;
+};
+
+// plane geometry handed to every stencil kernel: clamp rows are the global border seen from the
+// buffer, intersected with the buffer itself.
+struct nz_geom {
+    int cols;      // row length
+    int pitch;     // floats between rows
+    int rows;      // rows in the buffer
+    int zc0, zc1;  // inclusive clamp range for row reads (buffer coordinates)
+    int or0, or1;  // rows to produce [or0, or1)
+};
+
+inline nz_geom nz_geom_from_stripe(const nz_stripe &s) {
+    nz_geom g;
+    g.cols = s.cols;
+    g.pitch = s.pitch > 0 ? s.pitch : s.cols;
+    g.rows = s.rows;
+    int lo = -s.grow0, hi = s.grows - 1 - s.grow0;
+    g.zc0 = lo > 0 ? lo : 0;
+    g.zc1 = hi < s.rows - 1 ? hi : s.rows - 1;
+    g.or0 = s.own0;
+    g.or1 = s.own1;
+    return g;
+}
+
+inline nz_geom nz_geom_tile(int res) { return nz_geom{res, res, res, 0, res - 1, 0, res}; }
+
+int32_t nz_check_stripe(const nz_stripe *st, int halo);
+
+// ---- launchers (defined in the .hip files) ---------------------------------------------------
+int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, int cols, int pitch,
+                          const nz_fractal_params &p, const float *d_rgrad);
+
+int nz_conv_max_fused(int ksize);
+// T fused applications of (X pass, Z pass) src -> dst on rows [or0, or1)
+int32_t nz_launch_conv_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g,
+                             const nz_kernel_taps &k, int T);
+// single unfused passes (src -> dst), used when the launch count must be even
+int32_t nz_launch_conv_pass_x(hipStream_t s, const float *src, float *dst, const nz_geom &g,
+                              const nz_kernel_taps &k);
+int32_t nz_launch_conv_pass_z(hipStream_t s, const float *src, float *dst, const nz_geom &g,
+                              const nz_kernel_taps &k);
+// E fused applications of the {-1,0} min window: src -> dst
+int nz_erosion_max_fused();
+int32_t nz_launch_erosion_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g, int E);
+// one reference min pass, window k in [-k_off, k_off), along x (along_z == 0) or z
+int32_t nz_launch_min_pass(hipStream_t s, const float *src, float *dst, const nz_geom &g, int ksize, int along_z);
+
+int32_t nz_launch_fill(hipStream_t s, float *data, size_t n, float value);
+int32_t nz_launch_copy(hipStream_t s, float *dst, const float *src, size_t n);
+// delegate-level flow kernels (single tile semantics, global-memory stencils)
+int32_t nz_launch_flow_step(hipStream_t s, const float *h, const float *w, const float *fN, const float *fS,
+                            const float *fE, const float *fW, float *oN, float *oS, float *oE, float *oW,
+                            const nz_geom &g);
+int32_t nz_launch_water_step(hipStream_t s, const float *w, float *w_out, const float *fN, const float *fS,
+                             const float *fE, const float *fW, const nz_geom &g);
+int32_t nz_launch_velocity(hipStream_t s, float *dst, const float *fN, const float *fS, const float *fE,
+                           const float *fW, const nz_geom &g, int normalize, float nmin, float nrange);
+int32_t nz_launch_normalize(hipStream_t s, const float *src, float *dst, size_t n, float nmin, float nrange);
+// fused flow+water iteration through LDS.  first != 0: water_in == 1e-4 and flux_in == 0 are
+// implied and not read.
+int32_t nz_launch_flow_iter(hipStream_t s, const float *h, const float *w_in, const float *fN_in,
+                            const float *fS_in, const float *fE_in, const float *fW_in, float *w_out,
+                            float *fN_out, float *fS_out, float *fE_out, float *fW_out, const nz_geom &g,
+                            int first);
+
+int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *indices, int res, int in_res,
+                       float tile_height, float tile_size, const float *heights);

@@ -1,0 +1,146 @@
+// nz_mesh.hip -- heightmap -> interleaved vertex stream + uint32 triangle indices (gfx950).
+//
+// Replaces HeightMapMeshJob<{Overshoot,}SquareGridHeightMap, PositionStream32>
+// (Mesh/Job/HeightMapMeshJob.cs:8-52, Mesh/Generators/OvershootSquareGridHeightMap.cs:12-103,
+// Mesh/Generators/SquareGridHeightMap.cs:12-106, Mesh/Streams/PositionStream.cs:75-134,
+// Mesh/Streams/Triangle.cs:19-27).
+//
+// Vertex record = {float3 position; float3 normal; float4 tangent; float2 texCoord0} = 48 B = three
+// 16-byte stores per vertex.  The index buffer has a closed form (vi = (R+1) z + x,
+// ti = 2R(z-1) + 2(x-1)), so it is written as a flat array, one uint4 (16 B) per lane, fully
+// coalesced, without reading anything.  Integer output is bit-exact by construction.
+#include "nz_internal.hpp"
+
+namespace {
+
+constexpr int CT = 256;
+
+struct mesh_params {
+    int res, in_res, off, type;
+    float height, tile_size, normal_strength;
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// getIdx: Overshoot :54-59 / Square :59-64
+__device__ __forceinline__ float mesh_h(const mesh_params &g, const float *__restrict__ heights, int x, int z) {
+    if (g.type == NZ_MESH_OVERSHOOT_SQUARE_GRID) {
+        x = clampi(x, 0 - g.off, g.res + g.off);
+        z = clampi(z, 0 - g.off, g.res + g.off);
+    } else {
+        x = clampi(x, 0, g.res + 1);
+        z = clampi(z, 0, g.res + 1);
+    }
+    return heights[((z + g.off) * g.in_res) + x + g.off];
+}
+
+__device__ __forceinline__ float interpolate_edge(float a, float b) { return a - (b - a); }
+
+__global__ __launch_bounds__(CT) void mesh_vertex_kernel(float4 *__restrict__ vtx, const float *__restrict__ heights,
+                                                        mesh_params g) {
+    const int R = g.res;
+    size_t vi = (size_t)blockIdx.x * CT + threadIdx.x;
+    size_t nv = (size_t)(R + 1) * (R + 1);
+    if (vi >= nv) return;
+    int z = (int)(vi / (R + 1));
+    int x = (int)(vi - (size_t)z * (R + 1));
+    // Execute(): Overshoot :77-102 / Square :84-105
+    float px = x == 0 ? -(0.5f * g.tile_size / (float)R) : (float)x * g.tile_size / (float)R - 0.5f;
+    float pz = (float)z * g.tile_size / (float)R - 0.5f;
+    // SetVertexValues(): Overshoot :62-75 / Square :67-82
+    float t = mesh_h(g, heights, x, z);
+    float py = t * g.height;
+    float l, r, u, d;
+    if (g.type == NZ_MESH_OVERSHOOT_SQUARE_GRID) {
+        l = mesh_h(g, heights, x - 1, z);
+        r = mesh_h(g, heights, x + 1, z);
+        u = mesh_h(g, heights, x, z - 1);
+        d = mesh_h(g, heights, x, z + 1);
+    } else {
+        l = x > 0 ? mesh_h(g, heights, x - 1, z) : interpolate_edge(t, mesh_h(g, heights, x + 1, z));
+        r = x < R - 1 ? mesh_h(g, heights, x + 1, z) : interpolate_edge(t, mesh_h(g, heights, x - 1, z));
+        u = z > 0 ? mesh_h(g, heights, x, z - 1) : interpolate_edge(mesh_h(g, heights, x, z + 1), t);
+        d = z < R - 1 ? mesh_h(g, heights, x, z + 1) : interpolate_edge(mesh_h(g, heights, x, z - 1), t);
+    }
+    float t1x = 4.0f, t1y = (r - l) / 2.0f, t1z = 0.0f;
+    float t2x = 0.0f, t2y = (u - d) / 2.0f, t2z = 4.0f;
+    float tgx = t2y * t1z - t2z * t1y;  // math.cross(t2, t1)
+    float tgy = t2z * t1x - t2x * t1z;
+    float tgz = t2x * t1y - t2y * t1x;
+    float nx = (l - r) / 2.0f * g.normal_strength;
+    float ny = 2.0f / g.height;
+    float nz = (u - d) / 2.0f * g.normal_strength;
+    float rs = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);  // math.normalize = rsqrt(dot) * v
+    float uvx, uvy;
+    if (g.type == NZ_MESH_OVERSHOOT_SQUARE_GRID) {
+        uvx = ((float)x) / (((float)R) - 0.5f);
+        uvy = ((float)z) / (((float)R) - 0.5f);
+    } else {
+        uvx = ((float)x) / ((float)R + 1.0f);
+        uvy = ((float)z) / ((float)R + 1.0f);
+    }
+    float4 *o = vtx + vi * 3;
+    o[0] = make_float4(px, py, pz, rs * nx);
+    o[1] = make_float4(rs * ny, rs * nz, tgx, tgy);
+    o[2] = make_float4(tgz, 0.0f /* tangent.w of `new Vertex()` */, uvx, uvy);
+}
+
+// flat index i -> triangle i/3 (ti), corner i%3.  ti = 2R(z-1) + 2(x-1) + s, s in {0,1}:
+//   s=0: vi + (-R-2, -1, -R-1);  s=1: vi + (-R-1, -1, 0);  vi = (R+1) z + x
+__device__ __forceinline__ uint32_t mesh_index(uint32_t i, uint32_t R) {
+    uint32_t ti = i / 3u, corner = i - ti * 3u;
+    uint32_t quad = ti >> 1, s = ti & 1u;
+    uint32_t zq = quad / R, xq = quad - zq * R;  // z-1, x-1
+    uint32_t vi = (R + 1u) * (zq + 1u) + xq + 1u;
+    uint32_t a = s ? vi - R - 1u : vi - R - 2u;
+    uint32_t b = vi - 1u;
+    uint32_t c = s ? vi : vi - R - 1u;
+    return corner == 0 ? a : (corner == 1 ? b : c);
+}
+
+__global__ __launch_bounds__(CT) void mesh_index_kernel(uint32_t *__restrict__ idx, uint32_t R, size_t n) {
+    size_t i = ((size_t)blockIdx.x * CT + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n && ((reinterpret_cast<uintptr_t>(idx) & 15) == 0)) {
+        uint4 v;
+        v.x = mesh_index((uint32_t)i, R);
+        v.y = mesh_index((uint32_t)i + 1, R);
+        v.z = mesh_index((uint32_t)i + 2, R);
+        v.w = mesh_index((uint32_t)i + 3, R);
+        *reinterpret_cast<uint4 *>(idx + i) = v;
+    } else {
+        for (size_t k = i; k < n && k < i + 4; k++) idx[k] = mesh_index((uint32_t)k, R);
+    }
+}
+
+}  // namespace
+
+int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *indices, int res, int in_res,
+                       float tile_height, float tile_size, const float *heights) {
+    mesh_params g;
+    g.res = res;
+    g.in_res = in_res;
+    g.off = (in_res - res) / 2;  // PixOffset
+    g.type = meshType;
+    g.height = tile_height;
+    g.tile_size = tile_size;
+    g.normal_strength = 8.0f;  // HeightMapMeshJob.cs:41
+    size_t nv = (size_t)(res + 1) * (res + 1);
+    size_t ni = (size_t)6 * res * res;
+    if (ni > 0xffffffffULL) {
+        nz_set_error("mesh index count overflows uint32");
+        return NZ_ERR_INVALID;
+    }
+    if ((reinterpret_cast<uintptr_t>(vertices) & 15) != 0) {
+        nz_set_error("vertex buffer must be 16-byte aligned");
+        return NZ_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(mesh_vertex_kernel, dim3((unsigned)((nv + CT - 1) / CT)), dim3(CT), 0, s,
+                       reinterpret_cast<float4 *>(vertices), heights, g);
+    NZ_HIP(hipGetLastError());
+    size_t nthreads = (ni + 3) / 4;
+    hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT)), dim3(CT), 0, s, indices,
+                       (uint32_t)res, ni);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}

@@ -1,0 +1,460 @@
+"""Host-side mirror of the reference's Pipeline / PipelineStage operator API for the hot path.
+
+Same names, field names, argument meaning and error behaviour as the C# classes, so that stage
+graphs written against the reference (NoiseStage -> KernelFilterStage -> FlowMapStage ->
+MeshTileStage ...) run unchanged; each `Schedule` body calls the C ABI where the reference calls a
+Burst job delegate.  (The C# host in INTEGRATION.md is the same code in the reference's own
+language; no .NET toolchain exists in this image, so the Python mirror is what the tests drive.)
+
+Reference files: Pipeline/Stage/PipelineStage.cs, Pipeline/Stage/StageIO.cs,
+Pipeline/Stage/StageIOTypes/*.cs, Pipeline/Stage/PipelineDefinition.cs,
+Pipeline/Executable/Pipeline.cs, Noise/NoiseStage.cs, Filter/KernelFilterStage.cs,
+Filter/Kernel/Blur/Stage{Gaussian,Smooth}Blur.cs, Geologic/Stage/FlowMapStage.cs,
+Mesh/Stage/MeshTileStage.cs.
+"""
+import collections
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _native as N
+from .runtime import Context, DeviceTile, JobHandle
+
+
+# ---- enums (values are the C# enum values) ----------------------------------------------------
+class FractalNoise(enum.IntEnum):  # Noise/NoiseStage.cs:15-24
+    Sin = 0
+    Perlin = 1
+    PeriodicPerlin = 2
+    Simplex = 3
+    RotatedSimplex = 4
+    Cellular = 5
+    DomainRotatedPerlin = 6
+    DomainRotatedSimplex = 7
+
+
+class KernelFilterType(enum.IntEnum):  # Filter/Kernel/KernelJob.cs:79-94
+    Gauss9_S1 = 0
+    Gauss7_S1 = 1
+    Gauss5_S1 = 2
+    Gauss3_S1 = 3
+    Gauss9_S2 = 4
+    Gauss7_S2 = 5
+    Gauss5_S2 = 6
+    Gauss3_S2 = 7
+    Smooth3 = 8
+    Sobel3Horizontal = 9
+    Sobel3Vertical = 10
+    Sobel3_2D = 11
+    Prewitt3Horizontal = 12
+    Prewitt3Vertical = 13
+
+
+class GaussSigma(enum.IntEnum):  # Filter/Kernel/Blur/BlurKernels.cs:8-25; sigma = 0.5 * (value + 1)
+    s0d50 = 0
+    s1d00 = 1
+    s1d50 = 2
+    s2d00 = 3
+    s2d50 = 4
+    s3d00 = 5
+    s3d50 = 6
+    s4d00 = 7
+    s4d50 = 8
+    s5d00 = 9
+    s5d50 = 10
+    s6d00 = 11
+    s6d50 = 12
+    s7d00 = 13
+    s7d50 = 14
+    s8d00 = 15
+
+
+class MeshType(enum.IntEnum):  # Mesh/Stage/MeshTileStage.cs:23-26
+    SquareGridHeightMap = 0
+    OvershootSquareGridHeightMap = 1
+
+
+class BlurHelper:  # Filter/Kernel/Blur/BlurKernels.cs:27-37
+    max_width = 25
+
+    @staticmethod
+    def limitWidth(width):
+        if width % 2 == 0:
+            width += 1
+        width = min(width, BlurHelper.max_width)
+        return max(3, width)
+
+
+# ---- StageIO payloads ---------------------------------------------------------------------------
+class StageIO:  # Pipeline/Stage/StageIO.cs:8-11
+    def __init__(self, uuid="", data=None):
+        self.uuid = uuid
+        self.data = data  # DeviceTile (the NativeSlice<float>)
+
+
+class GeneratorData(StageIO):  # StageIOTypes/GeneratorData.cs:9-15
+    def __init__(self, uuid="", data=None, resolution=512, xpos=0, zpos=0):
+        super().__init__(uuid, data)
+        self.resolution = resolution
+        self.xpos = xpos
+        self.zpos = zpos
+
+
+class MeshStageData(StageIO):  # StageIOTypes/MeshStageData.cs:9-21
+    def __init__(self, uuid="", data=None, resolution=512, inputResolution=512, marginPix=5, tileSize=512.0,
+                 tileHeight=512.0, xpos=0, zpos=0, mesh=None):
+        super().__init__(uuid, data)
+        self.resolution = resolution
+        self.inputResolution = inputResolution
+        self.marginPix = marginPix
+        self.tileSize = tileSize
+        self.tileHeight = tileHeight
+        self.xpos = xpos
+        self.zpos = zpos
+        self.mesh = mesh  # MeshBuffers, stands in for UnityEngine.Mesh
+
+
+class MeshBuffers:
+    """What Mesh.AllocateWritableMeshData + PositionStream32.Setup provide (Mesh/Streams/
+    PositionStream.cs:90-123): one interleaved 48-byte vertex stream and a uint32 index buffer."""
+    VERTEX_DTYPE = np.dtype([("position", np.float32, 3), ("normal", np.float32, 3), ("tangent", np.float32, 4),
+                             ("texCoord0", np.float32, 2)])
+
+    def __init__(self):
+        self.vertices = None  # DeviceTile, float32 view of the 48-byte records
+        self.indices = None   # DeviceTile, uint32
+        self.vertexCount = 0
+        self.indexCount = 0
+
+    def vertex_array(self):
+        return self.vertices.ToArray().view(self.VERTEX_DTYPE).reshape(-1)
+
+    def index_array(self):
+        return self.indices.ToArray()
+
+
+class PipelineWorkItem:  # Pipeline/Stage/PipelineDefinition.cs:18-25
+    def __init__(self, data, completeAction=None, scheduledAction=None, dependency=None, stageManager=None):
+        self.data = data
+        self.completeAction = completeAction
+        self.scheduledAction = scheduledAction
+        self.dependency = dependency if dependency is not None else JobHandle()
+        self.stageManager = stageManager
+
+
+# ---- PipelineStage ------------------------------------------------------------------------------
+class PipelineStage:  # Pipeline/Stage/PipelineStage.cs:10-62
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.jobHandle = JobHandle()
+        self.OnStageScheduledAction = []  # multicast delegate
+        self.arraysInitialized = False
+        self.dataLength = 0
+
+    def ResizeNativeContainers(self, size):
+        pass
+
+    def IsSchedulable(self, job):
+        return True
+
+    def CheckRequirements(self, io_type, requirements):
+        if isinstance(requirements.data, io_type):
+            d = requirements.data
+            if d.data.Length != self.dataLength:
+                self.dataLength = d.data.Length
+                self.ResizeNativeContainers(d.data.Length)
+        else:
+            raise Exception("Unhandled stageio %s" % type(requirements.data).__name__)
+
+    def Schedule(self, requirements, dependency):
+        pass
+
+    def ReceiveHandledInput(self, requirements, dependency):
+        self.Schedule(requirements, dependency)
+        self.TransformData(requirements)
+        self.OnStageScheduled(requirements, self.jobHandle)
+
+    def Destroy(self):
+        self.OnDestroy()
+
+    def TransformData(self, data):
+        pass
+
+    def OnStageScheduled(self, requirements, dependency):
+        for action in self.OnStageScheduledAction:
+            action(requirements, self.jobHandle)
+
+    def OnStageComplete(self):
+        pass
+
+    def OnDestroy(self):
+        pass
+
+    # helper shared by the stages that own one `tmp` plane (KernelFilterStage.cs:22-29 etc.)
+    def _resize_tmp(self):
+        if getattr(self, "tmp", None) is not None and self.tmp.IsCreated:
+            self.tmp.Dispose()
+        self.tmp = self.ctx.alloc(self.dataLength)
+
+
+class NoiseStage(PipelineStage):  # Noise/NoiseStage.cs:13-61
+    def __init__(self, ctx, noiseType=FractalNoise.Sin, hurst=0.0, startingAmplitude=1.0, octaves=1, stepdown=2.0,
+                 detuneRate=0.0, noiseSize=1000):
+        super().__init__(ctx)
+        self.noiseType = noiseType
+        self.hurst = hurst
+        self.startingAmplitude = startingAmplitude
+        self.octaves = octaves
+        self.stepdown = stepdown
+        self.detuneRate = detuneRate
+        self.noiseSize = noiseSize
+
+    def Schedule(self, requirements, dependency):
+        self.CheckRequirements(GeneratorData, requirements)
+        d = requirements.data
+        # jobs[(int)noiseType](d.data, d.resolution, hurst, startingAmplitude, stepdown, detuneRate, octaves, ...)
+        self.jobHandle = self.ctx.call("nz_fractal", int(self.noiseType), d.data.ptr, d.resolution, self.hurst,
+                                       self.startingAmplitude, self.stepdown, self.detuneRate, self.octaves, d.xpos,
+                                       d.zpos, self.noiseSize, dep=dependency)
+
+
+class KernelFilterStage(PipelineStage):  # Filter/KernelFilterStage.cs:13-51
+    def __init__(self, ctx, filter=KernelFilterType.Gauss9_S1, iterations=1):
+        super().__init__(ctx)
+        self.filter = filter
+        self.iterations = iterations
+        self.tmp = None
+
+    def ResizeNativeContainers(self, size):
+        self._resize_tmp()
+
+    def Schedule(self, requirements, dependency):
+        self.CheckRequirements(GeneratorData, requirements)
+        d = requirements.data
+        # the reference chains `iterations` SeparableKernelFilter.Schedule calls (:35-41); the
+        # library fuses the chain into as few launches as halo growth allows
+        self.jobHandle = self.ctx.call("nz_kernel_filter_stage", d.data.ptr, self.tmp.ptr, int(self.filter),
+                                       self.iterations, d.resolution, dep=dependency)
+
+    def OnDestroy(self):
+        if self.tmp is not None and self.tmp.IsCreated:
+            self.tmp.Dispose()
+
+
+class StageGaussianBlur(PipelineStage):  # Filter/Kernel/Blur/StageGaussianBlur.cs:14-53
+    def __init__(self, ctx, iterations=1, sigma=GaussSigma.s0d50, width=3):
+        super().__init__(ctx)
+        self.iterations = iterations
+        self.sigma = sigma
+        self.width = width
+        self.tmp = None
+
+    def ResizeNativeContainers(self, size):
+        self._resize_tmp()
+
+    def Schedule(self, requirements, dependency):
+        self.CheckRequirements(GeneratorData, requirements)
+        d = requirements.data
+        width_ = BlurHelper.limitWidth(self.width)
+        self.jobHandle = self.ctx.call("nz_gauss_blur_stage", d.data.ptr, self.tmp.ptr, width_, int(self.sigma),
+                                       self.iterations, d.resolution, dep=dependency)
+
+    def OnDestroy(self):
+        if self.tmp is not None and self.tmp.IsCreated:
+            self.tmp.Dispose()
+
+
+class StageSmoothBlur(PipelineStage):  # Filter/Kernel/Blur/StageSmoothBlur.cs:14-52
+    def __init__(self, ctx, iterations=1, width=1):
+        super().__init__(ctx)
+        self.iterations = iterations
+        self.width = width
+        self.tmp = None
+
+    def ResizeNativeContainers(self, size):
+        self._resize_tmp()
+
+    def Schedule(self, requirements, dependency):
+        self.CheckRequirements(GeneratorData, requirements)
+        d = requirements.data
+        width_ = BlurHelper.limitWidth(self.width)
+        self.jobHandle = self.ctx.call("nz_smooth_blur_stage", d.data.ptr, self.tmp.ptr, width_, self.iterations,
+                                       d.resolution, dep=dependency)
+
+    def OnDestroy(self):
+        if self.tmp is not None and self.tmp.IsCreated:
+            self.tmp.Dispose()
+
+
+class ErosionStage(PipelineStage):
+    """ErosionKernelJob (Filter/Kernel/KernelJob.cs:317-350) has no PipelineStage wrapper in the
+    reference; this stage applies its delegate `iterations` times in KernelFilterStage's shape."""
+
+    def __init__(self, ctx, iterations=1):
+        super().__init__(ctx)
+        self.iterations = iterations
+        self.tmp = None
+
+    def ResizeNativeContainers(self, size):
+        self._resize_tmp()
+
+    def Schedule(self, requirements, dependency):
+        self.CheckRequirements(GeneratorData, requirements)
+        d = requirements.data
+        self.jobHandle = self.ctx.call("nz_erosion_stage", d.data.ptr, self.tmp.ptr, self.iterations, d.resolution,
+                                       dep=dependency)
+
+    def OnDestroy(self):
+        if self.tmp is not None and self.tmp.IsCreated:
+            self.tmp.Dispose()
+
+
+class FlowMapStage(PipelineStage):  # Geologic/Stage/FlowMapStage.cs:16-220
+    def __init__(self, ctx, iterations=5, normMin=-0.1, normMax=0.1):
+        super().__init__(ctx)
+        self.iterations = iterations
+        self.normMin = normMin
+        self.normMax = normMax
+        self.resolution = 0
+        self.work = None  # the stage's water/flux READ+WRITE planes (:52-62)
+
+    def DisposeArrays(self):
+        if self.work is not None and self.work.IsCreated:
+            self.work.Dispose()
+        self.work = None
+
+    def ResizeNativeContainers(self, size):
+        self.DisposeArrays()
+        self.work = self.ctx.alloc(N.lib.nz_flowmap_stage_work_floats(self.resolution))
+
+    def Schedule(self, requirements, dependency):
+        d = requirements.data
+        if not isinstance(d, GeneratorData):
+            raise Exception("Unhandled stageio %s" % type(d).__name__)
+        if self.resolution != d.resolution:
+            self.resolution = d.resolution
+        self.CheckRequirements(GeneratorData, requirements)
+        self.jobHandle = self.ctx.call("nz_flowmap_stage", d.data.ptr, self.work.ptr, self.iterations, self.normMin,
+                                       self.normMax, d.resolution, dep=dependency)
+
+    def OnDestroy(self):
+        self.DisposeArrays()
+
+
+class MeshTileStage(PipelineStage):  # Mesh/Stage/MeshTileStage.cs:28-61
+    def __init__(self, ctx, meshType=MeshType.SquareGridHeightMap):
+        super().__init__(ctx)
+        self.meshType = meshType
+        self.currentMesh = None
+
+    def Schedule(self, requirements, dependency):
+        d = requirements.data  # (MeshStageData) cast
+        if not isinstance(d, MeshStageData):
+            raise Exception("Unhandled stageio %s" % type(d).__name__)
+        self.currentMesh = d.mesh if d.mesh is not None else MeshBuffers()
+        d.mesh = self.currentMesh
+        m = self.currentMesh
+        nv, ni = N.lib.nz_mesh_vertex_count(d.resolution), N.lib.nz_mesh_index_count(d.resolution)
+        if m.vertexCount != nv or m.vertices is None:  # Mesh.AllocateWritableMeshData(1)
+            m.vertices = self.ctx.alloc(nv * 12)
+            m.indices = self.ctx.alloc(ni, dtype=np.uint32)
+            m.vertexCount, m.indexCount = nv, ni
+        self.jobHandle = self.ctx.call("nz_heightmap_mesh", int(self.meshType), m.vertices.ptr, m.indices.ptr,
+                                       d.resolution, d.inputResolution, d.marginPix, d.tileHeight, d.tileSize,
+                                       d.data.ptr, dep=dependency)
+
+
+# ---- BasePipeline -------------------------------------------------------------------------------
+class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
+    def __init__(self, stages, alias="Unnamed Pipeline"):
+        self.alias = alias
+        self.queue = collections.deque()  # ConcurrentQueue: deque.append is thread-safe
+        self.dependencyHell = []
+        self.activeItem = None
+        self.pipelineHandle = JobHandle()
+        self.pipelineBeingScheduled = False
+        self.pipelineRunning = False
+        self.stage_instances = list(stages) if stages is not None else None
+        self.Setup()
+        self.pipeLineReady = True
+
+    def Setup(self):  # :130-152
+        if not self.stage_instances:
+            return
+        previous = None
+        for stage in self.stage_instances:
+            if previous is not None:
+                previous.OnStageScheduledAction.append(stage.ReceiveHandledInput)
+            previous = stage
+        self.stage_instances[-1].OnStageScheduledAction.append(self.OnPipelineFullyScheduled)
+
+    def Enqueue(self, input, scheduleAction=None, completeAction=None, dependency=None):  # :76-90
+        self.queue.append(PipelineWorkItem(input, completeAction, scheduleAction, dependency))
+
+    def Schedule(self, input=None, scheduleAction=None, completeAction=None, dependency=None):  # :91-120
+        if isinstance(input, PipelineWorkItem):
+            self.activeItem = input
+        elif input is not None:
+            self.activeItem = PipelineWorkItem(input, completeAction, scheduleAction, dependency)
+        if not self.stage_instances:
+            raise Exception("No stages in pipeline")
+        self.pipelineBeingScheduled = True
+        self.stage_instances[0].ReceiveHandledInput(self.activeItem, self.activeItem.dependency)
+
+    def OnPipelineFullyScheduled(self, res, handle):  # :122-128
+        self.pipelineHandle = handle
+        self.pipelineRunning = True
+        self.pipelineBeingScheduled = False
+        if self.activeItem.scheduledAction:
+            self.activeItem.scheduledAction(res.data, handle)
+
+    def WorkIsSchedulable(self, item):  # :256-265
+        ready = True
+        for stage in self.stage_instances:
+            ready = stage.IsSchedulable(item) and ready
+        return ready
+
+    def GetNextJob(self):  # :183-214
+        for i, job in enumerate(list(self.dependencyHell)):
+            if self.WorkIsSchedulable(job):
+                self.dependencyHell.remove(job)
+                return job
+        while self.queue:
+            wi = self.queue.popleft()
+            if self.WorkIsSchedulable(wi):
+                return wi
+            self.dependencyHell.append(wi)
+        return None
+
+    def Update(self):  # :154-158,224-230
+        if not self.pipelineRunning and not self.pipelineBeingScheduled:
+            job = self.GetNextJob()
+            if job is not None:
+                self.Schedule(job)
+
+    def LateUpdate(self):  # :160-181
+        if self.pipelineRunning and self.pipelineHandle.IsCompleted:
+            self.pipelineHandle.Complete()
+            self.CleanUp()
+            if self.activeItem.completeAction:
+                self.activeItem.completeAction(self.activeItem.data)
+            self.pipelineRunning = False
+            return True
+        return False
+
+    def CleanUp(self):  # :232-242
+        for stage in self.stage_instances:
+            stage.OnStageComplete()
+
+    def RunToCompletion(self):
+        """Drive Update/LateUpdate (Unity's frame loop) until the queue is drained."""
+        while self.queue or self.dependencyHell or self.pipelineRunning:
+            self.Update()
+            if self.pipelineRunning:
+                self.pipelineHandle.Complete()
+                self.LateUpdate()
+
+    def Destroy(self):  # :244-254,267-274
+        for stage in self.stage_instances:
+            stage.OnDestroy()

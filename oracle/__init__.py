@@ -1,0 +1,284 @@
+"""ctypes wrapper around oracle/libnoize_oracle.so -- the CPU restatement of the reference.
+
+TEST INFRASTRUCTURE ONLY (parity unpinned, see noize_oracle.h).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
+package (noize_job_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libnoize_oracle.so")
+_lib = None
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+
+# Noise/NoiseStage.cs:15-24
+SIN, PERLIN, PERIODIC_PERLIN, SIMPLEX, ROTATED_SIMPLEX, CELLULAR, DR_PERLIN, DR_SIMPLEX = range(8)
+# Filter/Kernel/KernelJob.cs:79-94
+(GAUSS9_S1, GAUSS7_S1, GAUSS5_S1, GAUSS3_S1, GAUSS9_S2, GAUSS7_S2, GAUSS5_S2, GAUSS3_S2, SMOOTH3,
+ SOBEL3_H, SOBEL3_V, SOBEL3_2D, PREWITT3_H, PREWITT3_V) = range(14)
+MESH_SQUARE, MESH_OVERSHOOT = 0, 1
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, n) for n in ("noize_oracle.c", "noize_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libnoize_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        L = _lib
+        i, f = C.c_int, C.c_float
+        L.nzo_set_threads.argtypes = [i]
+        L.nzo_get_threads.restype = i
+        for n, a in (("nzo_cnoise2", 2), ("nzo_snoise2", 2), ("nzo_psrnoise2", 5),
+                     ("nzo_cnoise3", 3), ("nzo_snoise3", 3), ("nzo_psr_hash", 2)):
+            fn = getattr(L, n)
+            fn.argtypes = [f] * a
+            fn.restype = f
+        L.nzo_cellular2.argtypes = [f, f, f32p, f32p]
+        L.nzo_noise_value.argtypes = [i, f, f]
+        L.nzo_noise_value.restype = f
+        L.nzo_fractal_norm.argtypes = [f, i, f]
+        L.nzo_fractal_norm.restype = f
+        L.nzo_fractal_cell.argtypes = [i, i, i, f, f, f, f, i, i, i, i]
+        L.nzo_fractal_cell.restype = f
+        L.nzo_fractal.argtypes = [i, f32p, i, i, f, f, f, f, i, i, i, i]
+        L.nzo_pass_sample_x.argtypes = [f32p, f32p, i, i, i, f32p, f]
+        L.nzo_pass_sample_z.argtypes = [f32p, f32p, i, i, i, f32p, f]
+        L.nzo_pass_min_x.argtypes = [f32p, f32p, i, i, i]
+        L.nzo_pass_min_z.argtypes = [f32p, f32p, i, i, i]
+        L.nzo_separable.argtypes = [f32p, f32p, i, i, i, f32p, f32p, f]
+        L.nzo_kernel_filter.argtypes = [f32p, f32p, i, i, i]
+        L.nzo_kernel_filter_table.argtypes = [i, f32p, f32p, f32p, C.POINTER(i)]
+        L.nzo_limit_width.argtypes = [i]
+        L.nzo_gauss_kernel.argtypes = [i, i, f32p]
+        L.nzo_gauss.argtypes = [f32p, f32p, i, i, i, i]
+        L.nzo_smooth.argtypes = [f32p, f32p, i, i, i]
+        L.nzo_erosion_min.argtypes = [f32p, i, i]
+        L.nzo_fill.argtypes = [f32p, i, i, f]
+        L.nzo_flow_step.argtypes = [f32p] * 10 + [i, i]
+        L.nzo_water_step.argtypes = [f32p] * 6 + [i, i]
+        L.nzo_velocity.argtypes = [f32p] * 5 + [i, i]
+        L.nzo_normalize.argtypes = [f32p, f32p, f32p, i, i]
+        L.nzo_flowmap.argtypes = [f32p, i, i, i, f, f]
+        L.nzo_mesh_heightmap.argtypes = [i, f32p, i, i, i, f, f, f32p, u32p]
+        L.nzo_pipeline.argtypes = [f32p, f32p, i, i, i, f, f, f, f, i, i, i, i, i, i, i, f, f, i]
+    return _lib
+
+
+def _p(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(f32p)
+
+
+def _plane(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2
+    return a
+
+
+def set_threads(n):
+    lib().nzo_set_threads(int(n))
+
+
+def get_threads():
+    return lib().nzo_get_threads()
+
+
+# ---- scalar noise probes -------------------------------------------------------------------
+def cnoise2(x, y): return lib().nzo_cnoise2(x, y)
+def snoise2(x, y): return lib().nzo_snoise2(x, y)
+def psrnoise2(x, y, perx=1010.0, pery=102.0, rot=0.0): return lib().nzo_psrnoise2(x, y, perx, pery, rot)
+def cnoise3(x, y, z): return lib().nzo_cnoise3(x, y, z)
+def snoise3(x, y, z): return lib().nzo_snoise3(x, y, z)
+def psr_hash(x, y): return lib().nzo_psr_hash(x, y)
+def noise_value(noise_type, x, z): return lib().nzo_noise_value(noise_type, x, z)
+
+
+def cellular2(x, y):
+    a, b = C.c_float(), C.c_float()
+    lib().nzo_cellular2(x, y, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def fractal_norm(hurst, octaves, amp=1.0):
+    return lib().nzo_fractal_norm(hurst, octaves, amp)
+
+
+def fractal_cell(noise_type, x, z, hurst, amp, stepdown, detune, octaves, xpos, zpos, noise_size):
+    return lib().nzo_fractal_cell(noise_type, x, z, hurst, amp, stepdown, detune, octaves, xpos,
+                                  zpos, noise_size)
+
+
+def fractal(noise_type, rows, cols, hurst=0.0, amp=1.0, stepdown=2.0, detune=0.0, octaves=1,
+            xpos=0, zpos=0, noise_size=1000):
+    out = np.empty((rows, cols), np.float32)
+    rc = lib().nzo_fractal(noise_type, _p(out), rows, cols, hurst, amp, stepdown, detune, octaves,
+                           xpos, zpos, noise_size)
+    if rc:
+        raise ValueError("nzo_fractal rc=%d" % rc)
+    return out
+
+
+# ---- filters (functional: return a new plane) -----------------------------------------------
+def kernel_filter_table(filter_type):
+    kx, kz = np.zeros(9, np.float32), np.zeros(9, np.float32)
+    fac, ks = C.c_float(), C.c_int()
+    rc = lib().nzo_kernel_filter_table(filter_type, _p(kx), _p(kz), C.byref(fac), C.byref(ks))
+    if rc:
+        raise ValueError("unsupported filter %d" % filter_type)
+    return kx[:ks.value].copy(), kz[:ks.value].copy(), fac.value, ks.value
+
+
+def limit_width(w): return lib().nzo_limit_width(w)
+
+
+def gauss_kernel(sigma_enum, width):
+    out = np.zeros(25, np.float32)
+    n = lib().nzo_gauss_kernel(sigma_enum, width, _p(out))
+    if n < 0:
+        raise ValueError("bad sigma enum")
+    return out[:n].copy()
+
+
+def separable(a, ksize, kx, kz, factor):
+    a = _plane(a).copy()
+    tmp = np.empty_like(a)
+    kx = np.ascontiguousarray(kx, np.float32)
+    kz = np.ascontiguousarray(kz, np.float32)
+    lib().nzo_separable(_p(a), _p(tmp), a.shape[0], a.shape[1], ksize, _p(kx), _p(kz), factor)
+    return a
+
+
+def pass_sample_x(a, ksize, k, factor):
+    a = _plane(a).copy(); tmp = np.empty_like(a); k = np.ascontiguousarray(k, np.float32)
+    lib().nzo_pass_sample_x(_p(a), _p(tmp), a.shape[0], a.shape[1], ksize, _p(k), factor)
+    return a
+
+
+def pass_sample_z(a, ksize, k, factor):
+    a = _plane(a).copy(); tmp = np.empty_like(a); k = np.ascontiguousarray(k, np.float32)
+    lib().nzo_pass_sample_z(_p(a), _p(tmp), a.shape[0], a.shape[1], ksize, _p(k), factor)
+    return a
+
+
+def kernel_filter(a, filter_type, iterations=1):
+    a = _plane(a).copy()
+    tmp = np.empty_like(a)
+    for _ in range(iterations):
+        rc = lib().nzo_kernel_filter(_p(a), _p(tmp), filter_type, a.shape[0], a.shape[1])
+        if rc:
+            raise ValueError("unsupported filter %d" % filter_type)
+    return a
+
+
+def gauss(a, width, sigma_enum, iterations=1):
+    a = _plane(a).copy()
+    tmp = np.empty_like(a)
+    for _ in range(iterations):
+        rc = lib().nzo_gauss(_p(a), _p(tmp), width, sigma_enum, a.shape[0], a.shape[1])
+        if rc:
+            raise ValueError("nzo_gauss rc=%d" % rc)
+    return a
+
+
+def smooth(a, width, iterations=1):
+    a = _plane(a).copy()
+    tmp = np.empty_like(a)
+    for _ in range(iterations):
+        rc = lib().nzo_smooth(_p(a), _p(tmp), width, a.shape[0], a.shape[1])
+        if rc:
+            raise ValueError("nzo_smooth rc=%d" % rc)
+    return a
+
+
+def erosion_min(a, iterations=1):
+    a = _plane(a).copy()
+    for _ in range(iterations):
+        rc = lib().nzo_erosion_min(_p(a), a.shape[0], a.shape[1])
+        if rc:
+            raise ValueError("nzo_erosion_min rc=%d" % rc)
+    return a
+
+
+# ---- flow map -------------------------------------------------------------------------------
+def flow_step(height, water, fN, fS, fE, fW):
+    """One ComputeFlowStep; returns new (fN, fS, fE, fW)."""
+    height, water = _plane(height), _plane(water)
+    fl = [_plane(x).copy() for x in (fN, fS, fE, fW)]
+    bufs = [np.empty_like(x) for x in fl]
+    r, c = height.shape
+    lib().nzo_flow_step(_p(height), _p(water), _p(fl[0]), _p(bufs[0]), _p(fl[1]), _p(bufs[1]),
+                        _p(fl[2]), _p(bufs[2]), _p(fl[3]), _p(bufs[3]), r, c)
+    return tuple(fl)
+
+
+def water_step(water, fN, fS, fE, fW):
+    water = _plane(water).copy()
+    buf = np.empty_like(water)
+    fN, fS, fE, fW = (_plane(x) for x in (fN, fS, fE, fW))
+    lib().nzo_water_step(_p(water), _p(buf), _p(fN), _p(fS), _p(fE), _p(fW), *water.shape)
+    return water
+
+
+def velocity(fN, fS, fE, fW):
+    fN, fS, fE, fW = (_plane(x) for x in (fN, fS, fE, fW))
+    out = np.empty_like(fN)
+    lib().nzo_velocity(_p(out), _p(fN), _p(fS), _p(fE), _p(fW), *fN.shape)
+    return out
+
+
+def normalize(a, nmin, nmax):
+    a = _plane(a).copy()
+    tmp = np.empty_like(a)
+    args = np.array([nmin, nmax, np.float32(nmax) - np.float32(nmin)], np.float32)
+    lib().nzo_normalize(_p(a), _p(tmp), _p(args), *a.shape)
+    return a
+
+
+def flowmap(a, iterations=5, norm_min=-0.1, norm_max=0.1):
+    a = _plane(a).copy()
+    rc = lib().nzo_flowmap(_p(a), a.shape[0], a.shape[1], iterations, norm_min, norm_max)
+    if rc:
+        raise ValueError("nzo_flowmap rc=%d" % rc)
+    return a
+
+
+# ---- mesh -----------------------------------------------------------------------------------
+def mesh_heightmap(mesh_type, heights, resolution, margin_pix, tile_height, tile_size):
+    heights = _plane(heights)
+    in_res = heights.shape[0]
+    assert heights.shape[0] == heights.shape[1]
+    vtx = np.zeros(((resolution + 1) ** 2, 12), np.float32)
+    idx = np.zeros(6 * resolution * resolution, np.uint32)
+    rc = lib().nzo_mesh_heightmap(mesh_type, _p(heights), resolution, in_res, margin_pix,
+                                  tile_height, tile_size, _p(vtx), idx.ctypes.data_as(u32p))
+    if rc:
+        raise ValueError("nzo_mesh_heightmap rc=%d" % rc)
+    return vtx, idx
+
+
+def pipeline(rows, cols, noise_type=SIMPLEX, hurst=0.4, amp=1.0, stepdown=2.0, detune=0.0,
+             octaves=13, xpos=0, zpos=0, noise_size=1700, filter_type=GAUSS5_S1, gauss_iterations=17,
+             flow_iterations=5, norm_min=0.0, norm_max=0.005, erosion_iterations=5):
+    data = np.empty((rows, cols), np.float32)
+    tmp = np.empty_like(data)
+    rc = lib().nzo_pipeline(_p(data), _p(tmp), rows, cols, noise_type, hurst, amp, stepdown, detune,
+                            octaves, xpos, zpos, noise_size, filter_type, gauss_iterations,
+                            flow_iterations, norm_min, norm_max, erosion_iterations)
+    if rc:
+        raise ValueError("nzo_pipeline rc=%d" % rc)
+    return data

@@ -1,0 +1,65 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# parity bar of BASELINE.json: 1e-5 relative with an absolute floor of 1e-6;
+# integer outputs (mesh indices) bit-exact
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def assert_parity(got, want, what=""):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (what, got.shape, want.shape)
+    bad = ~(np.abs(got - want) <= RTOL * np.abs(want) + ATOL)
+    if bad.any():
+        i = np.argmax(np.abs(got - want) / (np.abs(want) + ATOL))
+        raise AssertionError("%s: %d/%d cells outside 1e-5 rel; worst got %r want %r" %
+                             (what, int(bad.sum()), bad.size, got.flat[i], want.flat[i]))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def nj():
+    import noize_job_amd
+    return noize_job_amd
+
+
+@pytest.fixture(scope="session")
+def ctx(nj):
+    c = nj.Context(0)  # raises NoizeError (NZ_ERR_NO_DEVICE) when no GPU: gpu tests must not pass silently
+    yield c
+    c.close()
+
+
+def adversarial_tiles(res, rng=None):
+    """Stage-isolated inputs of BASELINE.md section 3."""
+    rng = rng or np.random.default_rng(1234)
+    tiles = {"uniform": rng.random((res, res), dtype=np.float32),
+             "constant": np.full((res, res), 0.5, np.float32)}
+    for name, (z, x) in {"impulse_centre": (res // 2, res // 2), "impulse_corner": (0, 0),
+                         "impulse_edge": (res // 2, res - 1)}.items():
+        t = np.zeros((res, res), np.float32)
+        t[z, x] = 1.0
+        tiles[name] = t
+    ramp = np.arange(res, dtype=np.float32) / np.float32(res)
+    tiles["ramp_x"] = np.tile(ramp, (res, 1))
+    tiles["ramp_z"] = np.tile(ramp[:, None], (1, res))
+    return tiles

@@ -1,0 +1,285 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bar: 1e-5 relative (abs floor 1e-6) for float planes, bit-exact for mesh indices
+(BASELINE.json); where the kernels reproduce the oracle's operation order the planes are
+additionally required to be equal bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import adversarial_tiles, assert_parity
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+BASES = ["Sin", "Perlin", "PeriodicPerlin", "Simplex", "RotatedSimplex", "Cellular", "DomainRotatedPerlin",
+         "DomainRotatedSimplex"]
+
+
+def gen(nj, ctx, res, uuid="t", xpos=0, zpos=0, host=None):
+    data = ctx.alloc(res * res) if host is None else ctx.from_host(host)
+    return nj.GeneratorData(uuid, data, res, xpos, zpos)
+
+
+def run(stage, nj, d):
+    stage.ReceiveHandledInput(nj.PipelineWorkItem(d), nj.JobHandle())
+    stage.jobHandle.Complete()
+    return d.data.ToArray((d.resolution, d.resolution))
+
+
+# ---- noise ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("basis", range(8), ids=BASES)
+def test_fractal_matches_oracle(nj, ctx, oracle, basis):
+    res = 96
+    for (octv, hurst, amp, step, det, ns, xp, zp) in [(8, 0.5, 1.0, 2.0, 0.0, 1000, 0, 0),
+                                                       (13, 0.4, 1.0, 2.0, 0.0, 1700, 12288, 20480),
+                                                       (6, 0.5938, 2.5, 1.9168, 0.0317, 658, 300, 77),
+                                                       (1, 0.0, 1.0, 2.0, 0.0, 5, 0, 0)]:
+        st = nj.NoiseStage(ctx, nj.FractalNoise(basis), hurst, amp, octv, step, det, ns)
+        d = gen(nj, ctx, res, xpos=xp, zpos=zp)
+        got = run(st, nj, d)
+        want = oracle.fractal(basis, res, res, hurst, amp, step, det, octv, xp, zp, ns)
+        assert_parity(got, want, "%s oct=%d" % (BASES[basis], octv))
+        if basis != 0:  # every basis but Sin is op-for-op the oracle's arithmetic (Sin calls device sinf)
+            assert np.array_equal(got, want), "%s oct=%d not bit-equal" % (BASES[basis], octv)
+        d.data.Dispose()
+
+
+def test_fractal_config1_plumbing(nj, ctx, oracle):
+    # BASELINE config 1: 1024^2 Perlin, 8 octaves, hurst 0.5
+    st = nj.NoiseStage(ctx, nj.FractalNoise.Perlin, 0.5, 1.0, 8, 2.0, 0.0, 1000)
+    d = gen(nj, ctx, 1024)
+    got = run(st, nj, d)
+    assert np.array_equal(got, oracle.fractal(oracle.PERLIN, 1024, 1024, 0.5, 1.0, 2.0, 0.0, 8, 0, 0, 1000))
+    d.data.Dispose()
+
+
+def test_fractal_odd_resolution_and_tile_seams(nj, ctx, oracle):
+    # resolutions that are not multiples of the vector width; neighbouring tiles continue each other (B3)
+    for res in (8, 37, 130):
+        st = nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700)
+        a = run(st, nj, gen(nj, ctx, res, xpos=0, zpos=0))
+        b = run(st, nj, gen(nj, ctx, res, xpos=res, zpos=0))
+        mono = oracle.fractal(oracle.SIMPLEX, res, 2 * res, 0.4, 1.0, 2.0, 0.0, 13, 0, 0, 1700)
+        assert np.array_equal(np.hstack([a, b]), mono)
+
+
+# ---- separable filters ----------------------------------------------------------------------------
+@pytest.mark.parametrize("ft", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13])
+def test_kernel_filter_delegate_matches_oracle(nj, ctx, oracle, ft):
+    res = 150
+    for name, t in adversarial_tiles(res).items():
+        d = gen(nj, ctx, res, host=t)
+        got = run(nj.KernelFilterStage(ctx, nj.KernelFilterType(ft), 1), nj, d)
+        assert np.array_equal(got, oracle.kernel_filter(t, ft)), (ft, name)
+        d.data.Dispose()
+
+
+@pytest.mark.parametrize("ft,iters", [(2, 2), (2, 3), (2, 4), (2, 17), (2, 32), (3, 5), (3, 13), (0, 2), (0, 5),
+                                      (1, 3), (6, 7), (8, 6), (12, 2)])
+def test_kernel_filter_stage_iterations(nj, ctx, oracle, ft, iters):
+    # fused launches (T applications per launch, halo T*(K-1)/2) must equal the reference's chain of
+    # single applications, including clamp-to-edge at every pass; resolutions straddle tile sizes
+    for res in (64, 203, 300):
+        tiles = adversarial_tiles(res)
+        for name in ("uniform", "impulse_corner", "ramp_z"):
+            d = gen(nj, ctx, res, host=tiles[name])
+            got = run(nj.KernelFilterStage(ctx, nj.KernelFilterType(ft), iters), nj, d)
+            want = oracle.kernel_filter(tiles[name], ft, iters)
+            assert_parity(got, want, "ft=%d it=%d res=%d %s" % (ft, iters, res, name))
+            assert np.array_equal(got, want), "ft=%d it=%d res=%d %s not bit-equal" % (ft, iters, res, name)
+            d.data.Dispose()
+
+
+def test_sobel_2d_is_rejected(nj, ctx):
+    d = gen(nj, ctx, 16)
+    with pytest.raises(nj.NoizeError) as e:
+        run(nj.KernelFilterStage(ctx, nj.KernelFilterType.Sobel3_2D, 1), nj, d)
+    assert e.value.status == nj._native.NZ_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("sigma,width,iters", [(0, 3, 1), (1, 5, 3), (3, 9, 2), (7, 13, 1), (15, 25, 2), (5, 4, 1),
+                                               (2, 40, 1)])
+def test_gaussian_blur_stage(nj, ctx, oracle, sigma, width, iters):
+    res = 90
+    t = adversarial_tiles(res)["uniform"]
+    d = gen(nj, ctx, res, host=t)
+    got = run(nj.StageGaussianBlur(ctx, iters, nj.GaussSigma(sigma), width), nj, d)
+    want = oracle.gauss(t, oracle.limit_width(width), sigma, iters)  # the stage passes limitWidth(width)
+    assert np.array_equal(got, want)
+
+
+def test_gauss_filter_delegate_even_width_quirk(nj, ctx, oracle):
+    # GaussFilter.Schedule called directly with an even width: 5-tap body, kernelSize 4 (BlurJob.cs:11-21)
+    res = 40
+    t = adversarial_tiles(res)["uniform"]
+    src, tmp = ctx.from_host(t), ctx.alloc(res * res)
+    ctx.call("nz_gauss_filter", src.ptr, tmp.ptr, 4, 3, res).Complete()
+    assert np.array_equal(src.ToArray((res, res)), oracle.gauss(t, 4, 3))
+    with pytest.raises(nj.NoizeError):
+        ctx.call("nz_gauss_filter", src.ptr, tmp.ptr, 40, 3, res)  # indexes outside the 25-tap body
+
+
+@pytest.mark.parametrize("width,iters", [(3, 1), (7, 2), (25, 1)])
+def test_smooth_blur_stage(nj, ctx, oracle, width, iters):
+    res = 77
+    t = adversarial_tiles(res)["uniform"]
+    d = gen(nj, ctx, res, host=t)
+    got = run(nj.StageSmoothBlur(ctx, iters, width), nj, d)
+    assert np.array_equal(got, oracle.smooth(t, width, iters))
+
+
+def test_separable_series_custom_kernels(nj, ctx, oracle):
+    res = 65
+    t = adversarial_tiles(res)["uniform"]
+    kx = np.array([0.1, -0.3, 0.5, 0.2, 0.7], f32)
+    kz = np.array([-1.0, 0.25, 0.5, 0.125, 2.0], f32)
+    src, tmp = ctx.from_host(t), ctx.alloc(res * res)
+    ctx.call("nz_separable_series", src.ptr, tmp.ptr, res, 5, kx.ctypes.data_as(nj._native.f32p),
+             kz.ctypes.data_as(nj._native.f32p), 0.37).Complete()
+    assert np.array_equal(src.ToArray((res, res)), oracle.separable(t, 5, kx, kz, 0.37))
+
+
+@pytest.mark.parametrize("iters", [1, 2, 3, 5, 8, 16, 33])
+def test_erosion_stage(nj, ctx, oracle, iters):
+    for res in (50, 257):
+        for name, t in adversarial_tiles(res).items():
+            if name.startswith("impulse"):
+                t = 1.0 - t  # a low pixel that spreads towards +x, +z (B9)
+            d = gen(nj, ctx, res, host=t)
+            got = run(nj.ErosionStage(ctx, iters), nj, d)
+            assert np.array_equal(got, oracle.erosion_min(t, iters)), (iters, res, name)
+            d.data.Dispose()
+
+
+def test_erosion_delegate(nj, ctx, oracle):
+    res = 100
+    t = adversarial_tiles(res)["uniform"]
+    src = ctx.from_host(t)
+    ctx.call("nz_erosion_kernel", src.ptr, res).Complete()
+    assert np.array_equal(src.ToArray((res, res)), oracle.erosion_min(t))
+
+
+# ---- flow map -------------------------------------------------------------------------------------
+def test_flow_delegates_match_oracle(nj, ctx, oracle):
+    res = 70
+    rng = np.random.default_rng(11)
+    h = rng.random((res, res), dtype=f32)
+    w = (rng.random((res, res), dtype=f32) * f32(0.01)).astype(f32)
+    fl = [(rng.random((res, res), dtype=f32) * f32(0.02)).astype(f32) for _ in range(4)]  # N,S,E,W
+    dh, dw = ctx.from_host(h), ctx.from_host(w)
+    dfl = [ctx.from_host(x) for x in fl]
+    buf = [ctx.alloc(res * res) for _ in range(5)]
+    ctx.call("nz_flowmap_compute_flow", dh.ptr, dw.ptr, dfl[0].ptr, buf[0].ptr, dfl[1].ptr, buf[1].ptr, dfl[2].ptr,
+             buf[2].ptr, dfl[3].ptr, buf[3].ptr, res).Complete()
+    want = oracle.flow_step(h, w, *fl)
+    for g, wv, n in zip(dfl, want, "NSEW"):
+        assert np.array_equal(g.ToArray((res, res)), wv), n
+    ctx.call("nz_flowmap_update_water", dw.ptr, buf[4].ptr, dfl[0].ptr, dfl[1].ptr, dfl[2].ptr, dfl[3].ptr,
+             res).Complete()
+    assert np.array_equal(dw.ToArray((res, res)), oracle.water_step(w, *want))
+    ctx.call("nz_flowmap_write_values", dh.ptr, dfl[0].ptr, dfl[1].ptr, dfl[2].ptr, dfl[3].ptr, res).Complete()
+    v = oracle.velocity(*want)
+    assert np.array_equal(dh.ToArray((res, res)), v)
+    args = np.array([0.0, 0.005, 0.005], f32)
+    ctx.call("nz_map_normalize_values", dh.ptr, buf[0].ptr, args.ctypes.data_as(nj._native.f32p), res).Complete()
+    assert np.array_equal(dh.ToArray((res, res)), oracle.normalize(v, 0.0, 0.005))
+    fill = ctx.alloc(res * res)
+    ctx.call("nz_fill_array", fill.ptr, res, 0.0001).Complete()
+    assert np.array_equal(fill.ToArray(), np.full(res * res, 0.0001, f32))
+
+
+@pytest.mark.parametrize("iters", [1, 2, 5, 9])
+def test_flowmap_stage_matches_oracle(nj, ctx, oracle, iters):
+    for res in (16, 67, 200):
+        h = oracle.kernel_filter(oracle.fractal(oracle.SIMPLEX, res, res, 0.4, 1.0, 2.0, 0.0, 8, 0, 0, 170),
+                                 oracle.GAUSS5_S1, 2)
+        for nmin, nmax in ((0.0, 0.005), (-0.1, 0.1)):
+            d = gen(nj, ctx, res, host=h)
+            got = run(nj.FlowMapStage(ctx, iters, nmin, nmax), nj, d)
+            want = oracle.flowmap(h, iters, nmin, nmax)
+            assert_parity(got, want, "flowmap it=%d res=%d" % (iters, res))
+            assert np.array_equal(got, want)
+            d.data.Dispose()
+
+
+def test_flowmap_flat_and_ramp(nj, ctx, oracle):
+    res = 64
+    flat = np.full((res, res), 0.3, f32)
+    got = run(nj.FlowMapStage(ctx, 5, -0.1, 0.1), nj, gen(nj, ctx, res, host=flat))
+    assert np.array_equal(got, np.full((res, res), 0.5, f32))  # zero velocity -> (0 + 0.1) / 0.2 (B12)
+    ramp = adversarial_tiles(res)["ramp_x"]
+    got = run(nj.FlowMapStage(ctx, 3, 0.0, 0.005), nj, gen(nj, ctx, res, host=ramp))
+    assert np.array_equal(got, oracle.flowmap(ramp, 3, 0.0, 0.005))
+
+
+def test_flowmap_stage_reuses_its_planes_across_work_items(nj, ctx, oracle):
+    # the stage keeps its planes between runs (FlowMapStage.cs:52-62); flux is defined zero per run
+    res = 48
+    st = nj.FlowMapStage(ctx, 3, 0.0, 0.005)
+    for seed in (1, 2):
+        h = np.random.default_rng(seed).random((res, res), dtype=f32)
+        got = run(st, nj, gen(nj, ctx, res, host=h))
+        assert np.array_equal(got, oracle.flowmap(h, 3, 0.0, 0.005))
+
+
+# ---- mesh -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mesh_type", [0, 1], ids=["SquareGrid", "Overshoot"])
+def test_mesh_matches_oracle(nj, ctx, oracle, mesh_type):
+    for in_res, res, margin in ((40, 32, 4), (70, 63, 3), (21, 16, 2)):
+        h = np.random.default_rng(3).random((in_res, in_res), dtype=f32)
+        d = nj.MeshStageData("m", ctx.from_host(h), res, in_res, margin, 500.0, 2000.0)
+        st = nj.MeshTileStage(ctx, nj.MeshType(mesh_type))
+        st.ReceiveHandledInput(nj.PipelineWorkItem(d), nj.JobHandle())
+        st.jobHandle.Complete()
+        vtx, idx = oracle.mesh_heightmap(mesh_type, h, res, margin, 2000.0, 500.0)
+        assert np.array_equal(d.mesh.index_array(), idx)  # bit-exact integer stream
+        got = d.mesh.vertices.ToArray().reshape(-1, 12)
+        assert_parity(got, vtx, "vertices")
+        assert np.array_equal(got, vtx)
+        va = d.mesh.vertex_array()
+        assert va.dtype.itemsize == 48 and np.array_equal(va["tangent"][:, 3], np.zeros(len(va), f32))
+
+
+def test_mesh_rejects_unsafe_margins(nj, ctx):
+    h = ctx.alloc(64)
+    st = nj.MeshTileStage(ctx, nj.MeshType.OvershootSquareGridHeightMap)
+    with pytest.raises(nj.NoizeError):
+        st.ReceiveHandledInput(nj.PipelineWorkItem(nj.MeshStageData("m", h, 8, 8, 0, 1.0, 1.0)), nj.JobHandle())
+
+
+# ---- whole pipeline -------------------------------------------------------------------------------
+def test_metric_pipeline_matches_oracle(nj, ctx, oracle):
+    # README example: simplex 13 oct -> Gauss5 x17 -> FlowMap -> value erosion (README.md:23-32), then mesh
+    res = 512
+    data = ctx.alloc(res * res)
+    stages = [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700),
+              nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17),
+              nj.FlowMapStage(ctx, 5, 0.0, 0.005),
+              nj.ErosionStage(ctx, 5)]
+    pipe = nj.BasePipeline(stages, "metric")
+    done = []
+    pipe.Enqueue(nj.GeneratorData("tile-0", data, res, 4096 * 3, 4096 * 5), completeAction=done.append)
+    pipe.RunToCompletion()
+    assert len(done) == 1 and done[0].uuid == "tile-0"
+    got = data.ToArray((res, res))
+    want = oracle.pipeline(res, res, xpos=4096 * 3, zpos=4096 * 5)
+    assert_parity(got, want, "metric pipeline")
+    assert np.array_equal(got, want)
+    pipe.Destroy()
+
+
+def test_job_handles(nj, ctx):
+    res = 256
+    d = gen(nj, ctx, res)
+    st = nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700)
+    st.ReceiveHandledInput(nj.PipelineWorkItem(d), nj.JobHandle())
+    h = st.jobHandle
+    assert h.id > 0
+    h.Complete()
+    assert h.IsCompleted and nj.JobHandle().IsCompleted
+    with pytest.raises(nj.NoizeError):
+        ctx.call("nz_fill_array", d.data.ptr, res, 0.0, dep=10 ** 12)  # a handle this context never issued
+    a, b = ctx.record(), ctx.record()
+    b.Complete()
+    assert ctx.elapsed_ms(a, b) >= 0.0

@@ -1,0 +1,349 @@
+"""Known-answer and cross-implementation tests of the CPU oracle.
+
+The reference ships no tests, so these are authored: analytic answers, hand-computed small cases,
+and an independent numpy (fp32, same operation order) restatement of each stencil that the C
+oracle must equal bit for bit.
+"""
+import numpy as np
+import pytest
+
+from conftest import adversarial_tiles
+
+f32 = np.float32
+
+
+# ---- independent numpy restatements ---------------------------------------------------------------
+def np_pass_x(a, k, factor):
+    o = (len(k) - 1) // 2
+    p = np.pad(a, ((0, 0), (o, o)), mode="edge")
+    tot = np.zeros_like(a)
+    for kk in range(len(k)):  # k ascending, KernelOperators.cs:34-40
+        tot = tot + p[:, kk:kk + a.shape[1]] * f32(k[kk])
+    return tot * f32(factor)
+
+
+def np_pass_z(a, k, factor):
+    o = (len(k) - 1) // 2
+    p = np.pad(a, ((o, o), (0, 0)), mode="edge")
+    tot = np.zeros_like(a)
+    for kk in range(len(k)):  # k = o - kk descending, Kernel[k_off - k] = k[kk], KernelOperators.cs:59-65
+        off = 2 * o - kk
+        tot = tot + p[off:off + a.shape[0], :] * f32(k[kk])
+    return tot * f32(factor)
+
+
+def np_erosion(a):
+    px = np.pad(a, ((0, 0), (1, 0)), mode="edge")
+    a = np.minimum(px[:, :-1], px[:, 1:])
+    pz = np.pad(a, ((1, 0), (0, 0)), mode="edge")
+    return np.minimum(pz[:-1, :], pz[1:, :])
+
+
+def sh(a, dz, dx):
+    """a sampled at (z+dz, x+dx) with clamp-to-edge."""
+    p = np.pad(a, 1, mode="edge")
+    return p[1 + dz:1 + dz + a.shape[0], 1 + dx:1 + dx + a.shape[1]]
+
+
+def np_flow_step(h, w, fN, fS, fE, fW):
+    tot = w + h
+    dW, dE, dS, dN = tot - sh(tot, 0, -1), tot - sh(tot, 0, 1), tot - sh(tot, -1, 0), tot - sh(tot, 1, 0)
+    z = f32(0)
+    flW, flE, flS, flN = (np.maximum(z, fW + dW), np.maximum(z, fE + dE), np.maximum(z, fS + dS),
+                          np.maximum(z, fN + dN))
+    s = ((flW + flE) + flS) + flN
+    with np.errstate(divide="ignore", invalid="ignore"):
+        K = np.clip(w / (s * f32(0.2)), f32(0), f32(1))
+    pos = s > 0
+    return tuple(np.where(pos, f * K, z).astype(f32) for f in (flN, flS, flE, flW))
+
+
+def np_water_step(w, fN, fS, fE, fW):
+    out = ((fW + fE) + fS) + fN
+    inn = f32(0) + sh(fE, 0, -1)
+    inn = inn + sh(fW, 0, 1)
+    inn = inn + sh(fN, -1, 0)
+    inn = inn + sh(fS, 1, 0)
+    return np.maximum(f32(0), w + (inn - out) * f32(0.2))
+
+
+def np_velocity(fN, fS, fE, fW):
+    dl, dr = sh(fE, 0, -1) - fW, fE - sh(fW, 0, 1)
+    dt, db = sh(fS, 1, 0) - fN, fS - sh(fN, -1, 0)
+    vx, vy = (dl + dr) * f32(0.5), (dt + db) * f32(0.5)
+    return np.sqrt(vx * vx + vy * vy)
+
+
+# ---- fractal --------------------------------------------------------------------------------------
+def test_b1_normalisation_ignores_starting_amplitude(oracle):
+    a1 = oracle.fractal(oracle.SIMPLEX, 16, 16, 0.5, 1.0, 2.0, 0.0, 4, 3, 5, 37)
+    a2 = oracle.fractal(oracle.SIMPLEX, 16, 16, 0.5, 2.0, 2.0, 0.0, 4, 3, 5, 37)
+    assert np.array_equal(a2, a1 * f32(2))  # power-of-two scaling is exact
+    assert oracle.fractal_norm(0.5, 4, 1.0) == oracle.fractal_norm(0.5, 4, 7.0)
+    G = f32(np.exp2(f32(-0.5)))
+    t, a = f32(0), f32(1)
+    for _ in range(4):
+        t = f32(t + a)
+        a = f32(a * G)
+    assert oracle.fractal_norm(0.5, 4) == t
+
+
+def test_b2_detune_applies_before_first_frequency_step(oracle):
+    hurst, amp, step, det, ns = 0.3, 1.5, 2.0, 0.03, 50
+    x, z, xp, zp = 7, 11, 100, 200
+    xi, zi = f32(f32(x) + f32(xp)) / f32(ns), f32(f32(z) + f32(zp)) / f32(ns)
+    G = f32(np.exp2(f32(-hurst)))
+    f1 = f32(f32(step) - f32(det))
+    n0 = f32(oracle.noise_value(oracle.PERLIN, float(xi), float(zi)))
+    n1 = f32(oracle.noise_value(oracle.PERLIN, float(f32(f1 * xi)), float(f32(f1 * zi))))
+    t = f32(f32(0) + f32(f32(amp) * n0))
+    t = f32(t + f32(f32(f32(amp) * G) * n1))
+    want = f32(t / oracle.fractal_norm(hurst, 2))
+    got = oracle.fractal_cell(oracle.PERLIN, x, z, hurst, amp, step, det, 2, xp, zp, ns)
+    assert got == want
+
+
+def test_b3_world_offsets_are_added_cells(oracle):
+    R = 24
+    for basis in (oracle.SIMPLEX, oracle.PERLIN, oracle.CELLULAR, oracle.ROTATED_SIMPLEX):
+        mono = oracle.fractal(basis, R, 2 * R, 0.4, 1.0, 2.0, 0.0, 5, 1000, 2000, 170)
+        right = oracle.fractal(basis, R, R, 0.4, 1.0, 2.0, 0.0, 5, 1000 + R, 2000, 170)
+        below = oracle.fractal(basis, R, R, 0.4, 1.0, 2.0, 0.0, 5, 1000, 2000 + 7, 170)
+        assert np.array_equal(mono[:, R:], right)
+        assert np.array_equal(mono[7:, :R], below[:R - 7])
+
+
+def test_b4_perlin_is_half_on_the_integer_lattice(oracle):
+    a = oracle.fractal(oracle.PERLIN, 8, 8, 0.0, 1.0, 2.0, 0.0, 1, 0, 0, 1)  # xi = x exactly
+    assert np.array_equal(a, np.full((8, 8), 0.5, f32))
+    assert oracle.cnoise2(5.0, 9.0) == 0.0
+
+
+def test_noise_ranges_and_continuity(oracle):
+    rng = np.random.default_rng(7)
+    pts = (rng.random((4000, 2)) * 60).astype(f32)
+    for fn, lo, hi in ((oracle.snoise2, -1.0, 1.0), (oracle.cnoise2, -1.0, 1.0),
+                       (lambda x, y: oracle.psrnoise2(x, y, rot=0.62), -1.01, 1.01)):
+        v = np.array([fn(float(x), float(y)) for x, y in pts])
+        assert lo <= v.min() < -0.8 and 0.8 < v.max() <= hi
+    for basis in range(8):
+        v = np.array([oracle.noise_value(basis, float(x), float(y)) for x, y in pts[:1000]])
+        assert v.min() >= -0.01 and v.max() <= 1.4, basis  # rectified bases live in ~[0,1]
+    xs = np.arange(0, 12, 1e-3, dtype=f32)
+    for basis in (oracle.SIMPLEX, oracle.PERLIN, oracle.ROTATED_SIMPLEX, oracle.CELLULAR, oracle.DR_PERLIN,
+                  oracle.DR_SIMPLEX):
+        v = np.array([oracle.noise_value(basis, float(x), float(f32(0.37) * x + f32(0.11))) for x in xs])
+        assert np.abs(np.diff(v)).max() < 0.01, basis  # no jumps across lattice cells
+
+
+def test_psrnoise_hash_is_a_small_integer(oracle):
+    # the HIP kernel tabulates rgrad2 by this value (nz_fractal.hip); it must be an integer in [0, 289]
+    hs = [oracle.psr_hash(float(x), float(y)) for x in np.arange(-1.0, 1062.0, 0.5) for y in (0.0, 1.0, 57.0, 101.0)]
+    assert min(hs) >= 0.0 and max(hs) <= 289.0 and all(float(h).is_integer() for h in hs)
+
+
+def test_psrnoise_is_periodic_in_y(oracle):
+    for x, y in ((3.25, 7.5), (100.125, 40.75), (555.5, 99.0)):
+        a, b = oracle.psrnoise2(x, y), oracle.psrnoise2(x, y + 102.0)
+        assert abs(a - b) < 2e-3
+
+
+# ---- separable filters ----------------------------------------------------------------------------
+@pytest.mark.parametrize("ft", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13])
+def test_kernel_filter_equals_numpy_restatement(oracle, ft):
+    kx, kz, factor, ks = oracle.kernel_filter_table(ft)
+    for name, t in adversarial_tiles(33).items():
+        want = np_pass_z(np_pass_x(t, kx, factor), kz, factor)
+        got = oracle.kernel_filter(t, ft)
+        assert np.array_equal(got, want), (ft, name)
+
+
+def test_b6_pass_order_x_ascending_z_descending(oracle):
+    ones = np.ones(3, f32)
+    row = np.zeros((3, 3), f32)
+    row[1] = [1e8, -1e8, 1.0]
+    assert oracle.pass_sample_x(row, 3, ones, 1.0)[1, 1] == 1.0        # ((1e8 + -1e8) + 1)
+    assert oracle.pass_sample_z(row.T.copy(), 3, ones, 1.0)[1, 1] == 0.0  # ((1 + -1e8) + 1e8)
+
+
+def test_b7_impulse_response_is_the_outer_product(oracle):
+    R, c = 17, 8
+    imp = np.zeros((R, R), f32)
+    imp[c, c] = 1.0
+    k = oracle.kernel_filter_table(oracle.GAUSS5_S1)[0]
+    got = oracle.kernel_filter(imp, oracle.GAUSS5_S1)
+    assert np.array_equal(got[c - 2:c + 3, c - 2:c + 3], np.outer(k, k).astype(f32))
+    assert got.sum() == pytest.approx(1.0, abs=1e-6)
+    # asymmetric bodies: the X pass correlates, the Z pass indexes Kernel[k_off - k] (flipped)
+    got = oracle.kernel_filter(imp, oracle.SOBEL3_H)   # kx = {-1,0,1}, kz = {1,2,1}
+    assert list(got[c, c - 1:c + 2]) == [2.0, 0.0, -2.0] and list(got[c - 1, c - 1:c + 2]) == [1.0, 0.0, -1.0]
+    got = oracle.kernel_filter(imp, oracle.PREWITT3_V)  # kx = {1,1,1}, kz = {-1,0,1}
+    assert list(got[c - 1:c + 2, c]) == [-1.0, 0.0, 1.0]
+
+
+def test_b5_b8_clamp_to_edge_keeps_constant_tiles_constant(oracle):
+    t = np.full((20, 20), 0.5, f32)
+    for ft in (oracle.GAUSS5_S1, oracle.GAUSS9_S2, oracle.SMOOTH3):
+        out = oracle.kernel_filter(t, ft, iterations=3)
+        assert np.all(out == out[0, 0]) and abs(out[0, 0] - 0.5) < 1e-6
+    # an impulse in the corner keeps more mass than one in the middle (edge taps fold back)
+    imp = np.zeros((9, 9), f32)
+    imp[0, 0] = 1.0
+    k = oracle.kernel_filter_table(oracle.GAUSS5_S1)[0]
+    out = oracle.kernel_filter(imp, oracle.GAUSS5_S1)
+    assert out[0, 0] == f32(f32(f32(k[0] + k[1]) + k[2]) * f32(f32(k[0] + k[1]) + k[2]))
+
+
+def test_gauss_and_smooth_entry_points(oracle):
+    t = adversarial_tiles(40)["uniform"]
+    for sigma in (0, 3, 15):
+        for width in (3, 5, 9, 25):
+            k = oracle.gauss_kernel(sigma, width)
+            assert np.array_equal(oracle.gauss(t, width, sigma), np_pass_z(np_pass_x(t, k, 1.0), k, 1.0))
+    k = np.full(7, f32(1) / f32(7), f32)
+    assert np.array_equal(oracle.smooth(t, 7), np_pass_z(np_pass_x(t, k, 1.0), k, 1.0))
+    # GaussFilter.Schedule with an even width: 5-tap body, kernelSize 4 -> k_off 1 -> taps 0..2 (BlurJob.cs:11-21)
+    k5 = oracle.gauss_kernel(3, 4)
+    assert np.array_equal(oracle.gauss(t, 4, 3), np_pass_z(np_pass_x(t, k5[:3], 1.0), k5[:3], 1.0))
+
+
+def test_b9_min_window_is_minus_one_zero(oracle):
+    t = np.ones((7, 7), f32)
+    t[3, 3] = 0.0
+    out = oracle.erosion_min(t)
+    want = np.ones((7, 7), f32)
+    want[3:5, 3:5] = 0.0
+    assert np.array_equal(out, want)
+    for name, a in adversarial_tiles(21).items():
+        assert np.array_equal(oracle.erosion_min(a), np_erosion(a)), name
+        assert np.array_equal(oracle.erosion_min(a, 3), np_erosion(np_erosion(np_erosion(a)))), name
+
+
+# ---- flow map -------------------------------------------------------------------------------------
+def test_flow_steps_equal_numpy_restatement(oracle):
+    rng = np.random.default_rng(5)
+    R = 19
+    h = rng.random((R, R), dtype=f32)
+    w = (rng.random((R, R), dtype=f32) * f32(0.01)).astype(f32)
+    fl = [(rng.random((R, R), dtype=f32) * f32(0.02)).astype(f32) for _ in range(4)]
+    got = oracle.flow_step(h, w, *fl)
+    want = np_flow_step(h, w, *fl)
+    for g, wv, n in zip(got, want, "NSEW"):
+        assert np.array_equal(g, wv), n
+    assert np.array_equal(oracle.water_step(w, *got), np_water_step(w, *got))
+    assert np.array_equal(oracle.velocity(*got), np_velocity(*got))
+
+
+def test_flowmap_equals_composition(oracle):
+    rng = np.random.default_rng(6)
+    R = 23
+    h = rng.random((R, R), dtype=f32)
+    w = np.full((R, R), 0.0001, f32)
+    fl = [np.zeros((R, R), f32) for _ in range(4)]
+    for _ in range(4):
+        fl = list(np_flow_step(h, w, *fl))
+        w = np_water_step(w, *fl)
+    v = np_velocity(*fl)
+    want = (v - f32(0.0)) / f32(f32(0.005) - f32(0.0))
+    assert np.array_equal(oracle.flowmap(h, 4, 0.0, 0.005), want)
+
+
+def test_b12_flat_terrain_has_zero_velocity(oracle):
+    out = oracle.flowmap(np.full((12, 12), 0.3, f32), 5, -0.1, 0.1)
+    assert np.array_equal(out, np.full((12, 12), (f32(0) - f32(-0.1)) / f32(f32(0.1) - f32(-0.1)), f32))
+
+
+def test_b13_b14_ramp_first_iteration(oracle):
+    R = 8
+    s = f32(1.0 / 64.0)
+    h = np.tile(np.arange(R, dtype=f32) * s, (R, 1))
+    w = np.full((R, R), 0.0001, f32)
+    z = np.zeros((R, R), f32)
+    fN, fS, fE, fW = oracle.flow_step(h, w, z, z, z, z)
+    # water runs downhill to the west: flow = slope * K, K = w / (slope * 0.2)
+    K = f32(f32(0.0001) / f32(s * f32(0.2)))
+    assert np.all(fE == 0) and np.all(fN == 0) and np.all(fS == 0)
+    assert np.all(fW[:, 0] == 0)  # clamped neighbour is the cell itself: no gradient
+    assert np.allclose(fW[:, 1:], s * K, rtol=1e-6)
+    w2 = oracle.water_step(w, fN, fS, fE, fW)
+    assert np.allclose(w2[:, 1:R - 1], 0.0001, rtol=1e-5)       # in == out
+    assert np.allclose(w2[:, R - 1], 0.0001, rtol=1e-5)         # border cell receives its own outflow (B14)
+    assert np.allclose(w2[:, 0], 0.0001 + float(s * K) * 0.2, rtol=1e-5)
+
+
+def test_b15_normalise_divides_even_for_an_empty_range(oracle):
+    a = np.full((4, 4), 0.7, f32)
+    with np.errstate(all="ignore"):
+        out = oracle.normalize(a, 0.2, 0.2)
+    assert np.all(np.isneginf(out))  # v forced to 0, (0 - 0.2) / 0
+    assert np.array_equal(oracle.normalize(a, 0.0, 0.5), (a - f32(0)) / f32(0.5))
+
+
+# ---- mesh -----------------------------------------------------------------------------------------
+def test_b18_index_buffer_closed_form(oracle):
+    R = 3
+    heights = np.zeros((R + 4, R + 4), f32)
+    _, idx = oracle.mesh_heightmap(oracle.MESH_OVERSHOOT, heights, R, 2, 10.0, 30.0)
+    want = []
+    for z in range(1, R + 1):
+        for x in range(1, R + 1):
+            vi = (R + 1) * z + x
+            want += [vi - R - 2, vi - 1, vi - R - 1, vi - R - 1, vi - 1, vi]
+    assert idx.tolist() == want
+    assert idx.max() == (R + 1) ** 2 - 1
+
+
+def test_b16_mesh_vertices_by_hand(oracle):
+    R, IR, H, TS = 2, 6, 10.0, 30.0
+    hts = (np.arange(IR * IR, dtype=f32).reshape(IR, IR) / f32(IR * IR)).astype(f32)
+    vtx, _ = oracle.mesh_heightmap(oracle.MESH_OVERSHOOT, hts, R, 2, H, TS)
+    off = 2
+    assert vtx.shape == (9, 12)
+    # x = 0 special case and the regular positions
+    assert vtx[0, 0] == -(f32(0.5) * f32(TS) / f32(R)) and vtx[1, 0] == f32(1) * f32(TS) / f32(R) - f32(0.5)
+    assert vtx[3, 2] == f32(1) * f32(TS) / f32(R) - f32(0.5)
+    z, x = 1, 2
+    v = vtx[z * (R + 1) + x]
+    t = hts[z + off, x + off]
+    l, r, u, d = hts[z + off, x - 1 + off], hts[z + off, x + 1 + off], hts[z - 1 + off, x + off], hts[z + 1 + off, x + off]
+    assert v[1] == t * f32(H)
+    n = np.array([(l - r) / f32(2) * f32(8), f32(2) / f32(H), (u - d) / f32(2) * f32(8)], f32)
+    n = (f32(1) / np.sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])) * n
+    assert np.array_equal(v[3:6], n)
+    assert v[6] == (u - d) / f32(2) * f32(0) - f32(4) * ((r - l) / f32(2)) and v[7] == 16.0 and v[9] == 0.0
+    assert v[8] == f32(0) * ((r - l) / f32(2)) - (u - d) / f32(2) * f32(4)
+    assert v[10] == f32(x) / (f32(R) - f32(0.5)) and v[11] == f32(z) / (f32(R) - f32(0.5))
+    # SquareGrid: edge-extrapolated neighbours, uv / (R + 1)
+    vs, _ = oracle.mesh_heightmap(oracle.MESH_SQUARE, hts, R, 2, H, TS)
+    v0 = vs[0]
+    t = hts[off, off]
+    l = t - (hts[off, 1 + off] - t)          # InterpolateEdge(t, h(x+1))
+    r = hts[off, 1 + off]                    # x < R - 1
+    u = hts[1 + off, off] - (t - hts[1 + off, off])  # InterpolateEdge(h(z+1), t)
+    d = hts[1 + off, off]
+    n = np.array([(l - r) / f32(2) * f32(8), f32(2) / f32(H), (u - d) / f32(2) * f32(8)], f32)
+    n = (f32(1) / np.sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])) * n
+    assert np.array_equal(v0[3:6], n)
+    assert vs[4, 10] == f32(1) / (f32(R) + f32(1))
+
+
+def test_b17_mesh_rejects_margins_that_index_outside_the_plane(oracle):
+    hts = np.zeros((8, 8), f32)
+    with pytest.raises(ValueError):
+        oracle.mesh_heightmap(oracle.MESH_OVERSHOOT, hts, 8, 0, 1.0, 1.0)   # off = 0, reads column 8
+    with pytest.raises(ValueError):
+        oracle.mesh_heightmap(oracle.MESH_OVERSHOOT, hts, 6, 1, 1.0, 1.0)   # off = 1, reads row 8
+    with pytest.raises(ValueError):
+        oracle.mesh_heightmap(oracle.MESH_SQUARE, hts, 8, 0, 1.0, 1.0)
+    oracle.mesh_heightmap(oracle.MESH_OVERSHOOT, hts, 4, 2, 1.0, 1.0)
+    oracle.mesh_heightmap(oracle.MESH_SQUARE, hts, 7, 0, 1.0, 1.0)
+
+
+def test_pipeline_equals_stage_composition(oracle):
+    R = 48
+    a = oracle.fractal(oracle.SIMPLEX, R, R, 0.4, 1.0, 2.0, 0.0, 13, 0, 0, 1700)
+    a = oracle.kernel_filter(a, oracle.GAUSS5_S1, 3)
+    a = oracle.flowmap(a, 2, 0.0, 0.005)
+    a = oracle.erosion_min(a, 2)
+    b = oracle.pipeline(R, R, gauss_iterations=3, flow_iterations=2, erosion_iterations=2)
+    assert np.array_equal(a, b)
