@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- the BASELINE.json metric on MI355X.
+
+A step = one pass of the metric pipeline (simplex fBm 13 oct -> Gauss5 x17 -> FlowMap x5 -> value
+erosion x5) over one device-resident grid; nothing crosses PCIe inside the timed region.
+  N = 1 : the 4096^2 tile BASELINE.json's metric is quoted on.
+  N > 1 : one process per GPU (torch.distributed, backend nccl = RCCL); the grid is row-stripe
+          sharded, 2048 x 16384 cells per rank (N = 8 is BASELINE config 5, 16384^2), with neighbour
+          halo exchange before every stencil launch -> "scaling": "weak".
+Rank 0 prints ONE JSON line.  `roofline` describes the stage that takes the most GPU time, `stages`
+every stage; both come from HIP events recorded on the kernels' stream inside the timed steps.
+`cpu_baseline` is the CPU oracle (reference-shaped restatement of the Burst jobs) timed on this
+box's host cores on one full 4096^2 pass.
+"""
+import argparse
+import ctypes as C
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GOPS = 78643.2     # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, non-FMA fp32 ops
+
+# algorithmic bytes per cell: fused minimum, one read + one write per plane per application
+G_IT, F_IT, E_IT = 17, 5, 5
+BYTES = {"noise": 4.0, "gauss": 8.0 * G_IT, "flow": 24.0 + 44.0 * (F_IT - 1) + 20.0, "erosion": 8.0 * E_IT}
+KERNEL_OF = {"noise": "fractal_kernel<Simplex>", "gauss": "conv_fused_kernel<5>", "flow": "flow_iter_kernel",
+             "erosion": "erosion_fused_kernel"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--res", type=int, default=4096, help="tile resolution at N=1")
+    ap.add_argument("--stripe-rows", type=int, default=2048, help="rows per rank at N>1")
+    ap.add_argument("--cols", type=int, default=16384, help="grid columns at N>1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-res", type=int, default=4096)
+    return ap.parse_args()
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/*pmc*.json), or None."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if kernel_key in d.get("kernels", {}):
+                best = d["kernels"][kernel_key].get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+    return best
+
+
+def cpu_baseline(res):
+    import oracle as O
+    O.lib()
+    t0 = time.perf_counter()
+    O.pipeline(res, res, O.SIMPLEX, 0.4, 1.0, 2.0, 0.0, 13, 0, 0, 1700, O.GAUSS5_S1, G_IT, F_IT, 0.0, 0.005, E_IT)
+    dt = time.perf_counter() - t0
+    return {"value": res * res / dt / 1e6, "unit": "Mcells/s", "cores": O.get_threads(), "kind": "port",
+            "sample": "1 pass of the full metric pipeline on a %dx%d tile (%.1f s), OpenMP row-parallel passes with "
+                      "the reference's serial flush copies" % (res, res, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import noize_job_amd as nj
+    from noize_job_amd import sharded as sh
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx = nj.Context(local_rank, stream=stream.cuda_stream)
+
+    p = sh.PipelineParams(gaussIterations=G_IT, flowIterations=F_IT, erosionIterations=E_IT)
+    marks = []  # per step: handles at stage boundaries
+
+    if world == 1:
+        res = args.res
+        cells = res * res
+        data = torch.empty(cells, dtype=torch.float32, device="cuda")
+        tile = ctx.wrap(data.data_ptr(), cells)
+        stages = [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, p.hurst, p.startingAmplitude, p.octaves, p.stepdown,
+                                p.detuneRate, p.noiseSize),
+                  nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, G_IT),
+                  nj.FlowMapStage(ctx, F_IT, p.normMin, p.normMax),
+                  nj.ErosionStage(ctx, E_IT)]
+        pipe = nj.BasePipeline(stages, "metric")
+        gd = nj.GeneratorData("bench", tile, res, 0, 0)
+
+        def step(record):
+            if record:
+                hs = [ctx.record()]
+                for st in stages:  # same chain BasePipeline.Schedule builds, with a marker between stages
+                    st.Schedule(nj.PipelineWorkItem(gd), hs[-1])
+                    hs.append(st.jobHandle)
+                marks.append(hs)
+            else:
+                pipe.Schedule(gd)
+                pipe.pipelineRunning = False
+
+        workload = "%dx%d tile: simplex-13oct(h0.4,size1700) -> Gauss5_S1 x%d -> FlowMap x%d (norm 0/0.005) -> " \
+                   "ValueErosion x%d" % (res, res, G_IT, F_IT, E_IT)
+        parallelism = "single tile"
+    else:
+        ops = sh.HipStripeOps(ctx)
+        halo = sh.halo_rows_needed(ops, p)
+        plan = sh.StripePlan(rank, world, args.stripe_rows * world, args.cols, halo)
+        cells = plan.grows * plan.cols
+        bufs = (torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
+                torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
+                torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
+                torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"))
+        comm = sh.TorchComm(dist)
+
+        def step(record):
+            sh.run_pipeline(ops, comm, plan, p, bufs)
+
+        workload = "%dx%d grid as %d row stripes of %dx%d (halo exchange over RCCL): simplex-13oct -> Gauss5_S1 x%d " \
+                   "-> FlowMap x%d -> ValueErosion x%d" % (plan.grows, plan.cols, world, args.stripe_rows, plan.cols,
+                                                            G_IT, F_IT, E_IT)
+        parallelism = "row-stripe dp%d" % world
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(world == 1)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = cells / (dt / args.steps) / 1e6
+        total_bytes = sum(BYTES.values())
+        out = {"metric": "Mcells/s 4096^2 simplex13oct->Gauss5x17->FlowMap->Erosion; %HBM roofline @1/8GPU",
+               "value": round(value, 1), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": workload, "cells": cells, "parallelism": parallelism,
+                          "algorithmic_bytes_per_cell": total_bytes},
+               "pipeline_hbm": {"achieved": round(total_bytes * cells / (dt / args.steps) / 1e9 / world, 1),
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                                "frac": round(total_bytes * cells / (dt / args.steps) / 1e9 / world / HBM_PEAK_GBS, 4)}}
+        if marks:
+            names = ["noise", "gauss", "flow", "erosion"]
+            launches = {"noise": 1, "gauss": None, "flow": F_IT, "erosion": 2}
+            acc = {n: 0.0 for n in names}
+            for hs in marks:
+                for i, n in enumerate(names):
+                    acc[n] += ctx.elapsed_ms(hs[i], hs[i + 1])
+            stages_out = {}
+            for n in names:
+                ms = acc[n] / len(marks)
+                gbs = BYTES[n] * cells / (ms * 1e-3) / 1e9
+                stages_out[n] = {"kernel": KERNEL_OF[n], "ms": round(ms, 4), "algorithmic_GB/s": round(gbs, 1),
+                                 "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+            stages_out["noise"]["valu_Gops/s"] = round(13 * 165.0 * cells / (stages_out["noise"]["ms"] * 1e-3) / 1e9, 1)
+            stages_out["noise"]["frac_valu"] = round(stages_out["noise"]["valu_Gops/s"] / VALU_PEAK_GOPS, 4)
+            stages_out["gauss"]["launches"] = N_gauss = len(sh.split_iterations(G_IT, nj._native.lib.nz_kernel_filter_max_fused(2)))
+            if N_gauss & 1:
+                stages_out["gauss"]["launches"] = N_gauss + 1
+            out["stages"] = stages_out
+            dom = max(names, key=lambda n: stages_out[n]["ms"])
+            n_launch = stages_out["gauss"]["launches"] if dom == "gauss" else (launches[dom] + (1 if dom == "flow" else 0))
+            s = stages_out[dom]
+            out["roofline"] = {"kernel": s["kernel"], "bound": "hbm", "achieved": s["algorithmic_GB/s"],
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s["frac_hbm"],
+                               "traffic": pmc_traffic(dom),
+                               "launches_per_step": n_launch, "avg_launch_ms": round(s["ms"] / n_launch, 4),
+                               "algorithmic_bytes_per_launch": round(BYTES[dom] * cells / n_launch),
+                               "note": ("fBm noise is fp32-VALU-bound, not HBM-bound: %.1f%% of the %.0f Gops/s "
+                                        "non-FMA VALU peak" % (100 * stages_out["noise"]["frac_valu"], VALU_PEAK_GOPS))
+                               if dom == "noise" else "stage time / launches of its dominant kernel"}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_res)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

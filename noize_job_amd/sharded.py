@@ -1,0 +1,191 @@
+"""Row-stripe sharding of one large grid over the GPUs of a node (new-framework feature; the
+reference only has independent clamped tiles, Scripts/MeshTileGenerator.cs:166-192).
+
+Rank r of P owns rows [r*R/P, (r+1)*R/P) x all columns of a (grows x cols) grid.  The
+noise stage needs no communication (world offsets, Noise/Fractal/Fractal.cs:109-116); every other
+stage is a small-radius stencil, so before each launch the ranks exchange the ghost rows that launch
+consumes with their two neighbours (rank-1 / rank+1 only).  Because the kernels compute each cell
+with the same operations wherever it sits, the sharded result equals the single-GPU monolithic
+result bit for bit; the only clamps are at the global border.
+
+The schedule below is host logic shared by two compute back ends:
+  * HipStripeOps  -- the product path: C-ABI stripe entry points on device buffers (torch CUDA tensors
+    used as plain HBM allocations), halo exchange by torch.distributed P2P on the `nccl` backend
+    (= RCCL over xGMI);
+  * any object with the same methods (tests/ supplies one built on the CPU oracle, driven over `gloo`).
+"""
+import ctypes as C
+
+from . import _native as N
+
+
+class StripePlan:
+    """Geometry of one rank's stripe.  Every plane buffer has `halo` ghost rows above and below the
+    owned rows (the ones hanging over the global border are never read)."""
+
+    def __init__(self, rank, world, grows, cols, halo):
+        assert 0 <= rank < world and grows >= world
+        base, rem = divmod(grows, world)
+        self.rank, self.world, self.grows, self.cols, self.halo = rank, world, grows, cols, halo
+        self.g0 = rank * base + min(rank, rem)           # first owned global row
+        self.nown = base + (1 if rank < rem else 0)
+        self.rows = self.nown + 2 * halo                 # rows in every buffer
+        self.own0, self.own1 = halo, halo + self.nown
+        self.grow0 = self.g0 - halo
+        assert self.nown >= halo, "stripe thinner than the halo"
+
+    def stripe(self, pitch=0):
+        return N.Stripe(self.cols, self.rows, self.grow0, self.grows, self.own0, self.own1, pitch)
+
+    @property
+    def up(self):
+        return self.rank - 1 if self.rank > 0 else None
+
+    @property
+    def down(self):
+        return self.rank + 1 if self.rank + 1 < self.world else None
+
+
+def split_iterations(n, cap):
+    """n applications in launches of at most `cap` (any count: stripes ping-pong between two buffers)."""
+    launches = (n + cap - 1) // cap
+    base, rem = divmod(n, launches)
+    return [base + (1 if i < rem else 0) for i in range(launches)]
+
+
+class PipelineParams:
+    """The metric pipeline's stage parameters."""
+
+    def __init__(self, noiseType=3, hurst=0.4, startingAmplitude=1.0, stepdown=2.0, detuneRate=0.0, octaves=13,
+                 xpos=0, zpos=0, noiseSize=1700, filter=2, gaussIterations=17, flowIterations=5, normMin=0.0,
+                 normMax=0.005, erosionIterations=5):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+FLOW_PLANES = 5  # water, fN, fS, fE, fW: state buffers are [5, rows, cols]
+
+
+def halo_rows_needed(ops, p):
+    k_off = ops.kernel_filter_halo_rows(p.filter, 1)
+    cap = max(1, ops.kernel_filter_max_fused(p.filter))
+    g = max(split_iterations(p.gaussIterations, cap)) * k_off if p.gaussIterations > 0 else 0
+    e = min(p.erosionIterations, ops.erosion_max_fused()) if p.erosionIterations > 0 else 0
+    return max(g, 2 if p.flowIterations > 0 else 0, e, 1)
+
+
+def run_pipeline(ops, comm, plan, p, bufs):
+    """One pass of the sharded metric pipeline.  bufs = (A, B, S0, S1): two height planes
+    [plan.rows, cols] and two flow-state buffers [5, plan.rows, cols].  Returns the plane whose owned
+    rows hold the result."""
+    A, B, S0, S1 = bufs
+    cur, nxt = A, B
+    ops.fractal(cur, plan, p)
+    if p.gaussIterations > 0:
+        k_off = ops.kernel_filter_halo_rows(p.filter, 1)
+        cap = max(1, ops.kernel_filter_max_fused(p.filter))
+        for T in split_iterations(p.gaussIterations, cap):
+            comm.exchange([cur], plan, T * k_off, T * k_off)
+            ops.kernel_filter(cur, nxt, plan, p.filter, T)
+            cur, nxt = nxt, cur
+    if p.flowIterations > 0:
+        comm.exchange([cur], plan, 2, 2)               # height, read at +-2 rows by every iteration
+        ops.flow_first(cur, S0, plan)
+        s_cur, s_nxt = S0, S1
+        for _ in range(1, p.flowIterations):
+            # water is read at +-2 rows, the four flux planes at +-1: one grouped exchange
+            comm.exchange([s_cur[i] for i in range(FLOW_PLANES)], plan, 2, 2)
+            ops.flow_iter(cur, s_cur, s_nxt, plan)
+            s_cur, s_nxt = s_nxt, s_cur
+        comm.exchange([s_cur[1], s_cur[2]], plan, 1, 1)  # velocity reads fN(z-1), fS(z+1)
+        ops.flow_velocity(nxt, s_cur, plan, p.normMin, p.normMax)
+        cur, nxt = nxt, cur
+    left = p.erosionIterations
+    while left > 0:
+        E = min(left, ops.erosion_max_fused())
+        comm.exchange([cur], plan, E, 0)               # the min window reaches upwards only
+        ops.erosion(cur, nxt, plan, E)
+        cur, nxt = nxt, cur
+        left -= E
+    return cur
+
+
+class HipStripeOps:
+    """Stripe operations on device memory through the C ABI.  Buffers are objects with `.data_ptr()`
+    (torch CUDA tensors used as plain HBM allocations); state buffers are indexable by plane."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lib = N.lib
+
+    def kernel_filter_halo_rows(self, filter, iterations):
+        return self.lib.nz_kernel_filter_halo_rows(filter, iterations)
+
+    def kernel_filter_max_fused(self, filter):
+        return self.lib.nz_kernel_filter_max_fused(filter)
+
+    def erosion_max_fused(self):
+        return 16
+
+    def _call(self, name, *args):
+        N.check(getattr(self.lib, name)(self.ctx._h, *args, 0, None), name)
+
+    def fractal(self, buf, plan, p):
+        st = plan.stripe()
+        self._call("nz_fractal_stripe", p.noiseType, buf.data_ptr(), C.byref(st), p.hurst, p.startingAmplitude,
+                   p.stepdown, p.detuneRate, p.octaves, p.xpos, p.zpos, p.noiseSize)
+
+    def kernel_filter(self, src, dst, plan, filter, T):
+        st = plan.stripe()
+        self._call("nz_kernel_filter_stripe", src.data_ptr(), dst.data_ptr(), C.byref(st), filter, T)
+
+    def erosion(self, src, dst, plan, E):
+        st = plan.stripe()
+        self._call("nz_erosion_stripe", src.data_ptr(), dst.data_ptr(), C.byref(st), E)
+
+    def flow_first(self, h, S, plan):
+        st = plan.stripe()
+        self._call("nz_flow_first_stripe", h.data_ptr(), *[S[i].data_ptr() for i in range(FLOW_PLANES)], C.byref(st))
+
+    def flow_iter(self, h, S_in, S_out, plan):
+        st = plan.stripe()
+        self._call("nz_flow_iter_stripe", h.data_ptr(), *[S_in[i].data_ptr() for i in range(FLOW_PLANES)],
+                   *[S_out[i].data_ptr() for i in range(FLOW_PLANES)], C.byref(st))
+
+    def flow_velocity(self, dst, S, plan, normMin, normMax):
+        st = plan.stripe()
+        self._call("nz_flow_velocity_stripe", dst.data_ptr(), *[S[i].data_ptr() for i in range(1, FLOW_PLANES)],
+                   C.byref(st), normMin, normMax)
+
+
+class TorchComm:
+    """Neighbour halo exchange with torch.distributed P2P (backend `nccl` = RCCL over xGMI on the GPU
+    box, `gloo` in the CPU tests).  Each exchange is one grouped batch: at most two neighbours."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def exchange(self, planes, plan, up_rows, down_rows):
+        d = self.dist
+        ops = []
+        for t in planes:
+            if up_rows > 0:  # my top ghost rows <- the rows just above, owned by rank-1
+                if plan.down is not None:
+                    ops.append(d.P2POp(d.isend, t[plan.own1 - up_rows:plan.own1], plan.down))
+                if plan.up is not None:
+                    ops.append(d.P2POp(d.irecv, t[plan.own0 - up_rows:plan.own0], plan.up))
+            if down_rows > 0:  # my bottom ghost rows <- the rows just below, owned by rank+1
+                if plan.up is not None:
+                    ops.append(d.P2POp(d.isend, t[plan.own0:plan.own0 + down_rows], plan.up))
+                if plan.down is not None:
+                    ops.append(d.P2POp(d.irecv, t[plan.own1:plan.own1 + down_rows], plan.down))
+        if ops:
+            for req in d.batch_isend_irecv(ops):
+                req.wait()
+
+
+class NoComm:
+    """world == 1: nothing to exchange (clamp-to-edge at both borders)."""
+
+    def exchange(self, planes, plan, up_rows, down_rows):
+        pass

@@ -76,6 +76,12 @@ def lib():
         L.nzo_flowmap.argtypes = [f32p, i, i, i, f, f]
         L.nzo_mesh_heightmap.argtypes = [i, f32p, i, i, i, f, f, f32p, u32p]
         L.nzo_pipeline.argtypes = [f32p, f32p, i, i, i, f, f, f, f, i, i, i, i, i, i, i, f, f, i]
+        # the GPU box grants a CPU share, not the whole host: size the OpenMP team to the affinity mask
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        L.nzo_set_threads(max(1, min(ncpu, int(os.environ.get("NZO_MAX_THREADS", "32")))))
     return _lib
 
 
