@@ -74,10 +74,11 @@ def halo_rows_needed(ops, p):
     return max(g, 2 if p.flowIterations > 0 else 0, e, 1)
 
 
-def run_pipeline(ops, comm, plan, p, bufs):
-    """One pass of the sharded metric pipeline.  bufs = (A, B, S0, S1): two height planes
-    [plan.rows, cols] and two flow-state buffers [5, plan.rows, cols].  Returns the plane whose owned
-    rows hold the result."""
+def pipeline_steps(ops, plan, p, bufs, result):
+    """The sharded metric pipeline as a generator: yields (planes, up_rows, down_rows) wherever the
+    ranks must exchange ghost rows, runs the stripe kernels in between.  bufs = (A, B, S0, S1): two
+    height planes [plan.rows, cols] and two flow-state buffers [5, plan.rows, cols].  The plane whose
+    owned rows hold the result is appended to `result`."""
     A, B, S0, S1 = bufs
     cur, nxt = A, B
     ops.fractal(cur, plan, p)
@@ -85,29 +86,64 @@ def run_pipeline(ops, comm, plan, p, bufs):
         k_off = ops.kernel_filter_halo_rows(p.filter, 1)
         cap = max(1, ops.kernel_filter_max_fused(p.filter))
         for T in split_iterations(p.gaussIterations, cap):
-            comm.exchange([cur], plan, T * k_off, T * k_off)
+            yield [cur], T * k_off, T * k_off
             ops.kernel_filter(cur, nxt, plan, p.filter, T)
             cur, nxt = nxt, cur
     if p.flowIterations > 0:
-        comm.exchange([cur], plan, 2, 2)               # height, read at +-2 rows by every iteration
+        yield [cur], 2, 2                               # height, read at +-2 rows by every iteration
         ops.flow_first(cur, S0, plan)
         s_cur, s_nxt = S0, S1
         for _ in range(1, p.flowIterations):
             # water is read at +-2 rows, the four flux planes at +-1: one grouped exchange
-            comm.exchange([s_cur[i] for i in range(FLOW_PLANES)], plan, 2, 2)
+            yield [s_cur[i] for i in range(FLOW_PLANES)], 2, 2
             ops.flow_iter(cur, s_cur, s_nxt, plan)
             s_cur, s_nxt = s_nxt, s_cur
-        comm.exchange([s_cur[1], s_cur[2]], plan, 1, 1)  # velocity reads fN(z-1), fS(z+1)
+        yield [s_cur[1], s_cur[2]], 1, 1                # velocity reads fN(z-1), fS(z+1)
         ops.flow_velocity(nxt, s_cur, plan, p.normMin, p.normMax)
         cur, nxt = nxt, cur
     left = p.erosionIterations
     while left > 0:
         E = min(left, ops.erosion_max_fused())
-        comm.exchange([cur], plan, E, 0)               # the min window reaches upwards only
+        yield [cur], E, 0                               # the min window reaches upwards only
         ops.erosion(cur, nxt, plan, E)
         cur, nxt = nxt, cur
         left -= E
-    return cur
+    result.append(cur)
+
+
+def run_pipeline(ops, comm, plan, p, bufs):
+    """One pass of the sharded metric pipeline on this rank; returns the plane holding the result."""
+    result = []
+    for planes, up_rows, down_rows in pipeline_steps(ops, plan, p, bufs, result):
+        comm.exchange(planes, plan, up_rows, down_rows)
+    return result[0]
+
+
+def run_pipeline_lockstep(ops_list, plans, p, bufs_list, copy_rows):
+    """All ranks of a grid inside ONE process (tests, single-GPU rehearsal): the per-rank generators
+    advance in lockstep and ghost rows are copied directly, copy_rows(dst_plane, d0, src_plane, s0, n)."""
+    results = [[] for _ in plans]
+    gens = [pipeline_steps(o, pl, p, b, r) for o, pl, b, r in zip(ops_list, plans, bufs_list, results)]
+    while True:
+        reqs = []
+        for g in gens:
+            try:
+                reqs.append(next(g))
+            except StopIteration:
+                reqs.append(None)
+        if all(r is None for r in reqs):
+            break
+        assert all(r is not None for r in reqs), "ranks left the schedule at different points"
+        for r, (planes, up_rows, down_rows) in enumerate(reqs):
+            pl = plans[r]
+            for i, t in enumerate(planes):
+                if up_rows > 0 and pl.up is not None:
+                    q = plans[pl.up]
+                    copy_rows(t, pl.own0 - up_rows, reqs[pl.up][0][i], q.own1 - up_rows, up_rows)
+                if down_rows > 0 and pl.down is not None:
+                    q = plans[pl.down]
+                    copy_rows(t, pl.own1, reqs[pl.down][0][i], q.own0, down_rows)
+    return [r[0] for r in results]
 
 
 class HipStripeOps:

@@ -1,0 +1,96 @@
+"""N > 1 path on CPU: world_size-2 and -3 `gloo` process groups run the row-stripe schedule of
+noize_job_amd.sharded (partition, ghost-row widths, neighbour exchange order) with the oracle as
+compute back end; the gathered stripes must equal the monolithic oracle run bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, grows, cols, pkw, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from noize_job_amd import sharded as sh
+    from oracle_stripe_ops import OracleStripeOps
+    O.set_threads(2)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    ops = OracleStripeOps()
+    p = sh.PipelineParams(**pkw)
+    plan = sh.StripePlan(rank, world, grows, cols, sh.halo_rows_needed(ops, p))
+    bufs = (torch.full((plan.rows, cols), float("nan")), torch.full((plan.rows, cols), float("nan")),
+            torch.full((5, plan.rows, cols), float("nan")), torch.full((5, plan.rows, cols), float("nan")))
+    res = sh.run_pipeline(ops, sh.TorchComm(dist), plan, p, bufs)
+    mine = res[plan.own0:plan.own1].contiguous()
+    parts = [None] * world
+    dist.all_gather_object(parts, (plan.g0, mine.numpy()))
+    if rank == 0:
+        full = np.concatenate([a for _, a in sorted(parts, key=lambda t: t[0])], axis=0)
+        np.save(out_path, full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,grows,cols", [(2, 64, 48), (3, 70, 33)])
+def test_sharded_schedule_equals_monolithic(oracle, tmp_path, world, grows, cols):
+    pkw = dict(octaves=6, noiseSize=40, gaussIterations=7, flowIterations=3, erosionIterations=4, xpos=11, zpos=5)
+    out = str(tmp_path / "sharded.npy")
+    mp.spawn(_worker, args=(world, _free_port(), grows, cols, pkw, out), nprocs=world, join=True)
+    got = np.load(out)
+    want = oracle.pipeline(grows, cols, octaves=6, noise_size=40, gauss_iterations=7, flow_iterations=3,
+                           erosion_iterations=4, xpos=11, zpos=5)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_stripe_plan_partitions_rows():
+    from noize_job_amd.sharded import StripePlan, split_iterations
+    for world, grows in ((1, 10), (2, 64), (3, 70), (8, 16384)):
+        plans = [StripePlan(r, world, grows, 16, 4) for r in range(world)]
+        assert plans[0].g0 == 0 and plans[-1].g0 + plans[-1].nown == grows
+        for a, b in zip(plans, plans[1:]):
+            assert a.g0 + a.nown == b.g0
+        assert plans[0].up is None and plans[-1].down is None
+        for pl in plans:
+            st = pl.stripe()
+            assert (st.rows, st.own0, st.own1, st.grow0) == (pl.nown + 8, 4, 4 + pl.nown, pl.g0 - 4)
+    assert split_iterations(17, 3) == [3, 3, 3, 3, 3, 2] and split_iterations(5, 16) == [5]
+    assert sum(split_iterations(17, 4)) == 17 and max(split_iterations(17, 4)) <= 4
+
+
+def test_lockstep_driver_equals_monolithic(oracle):
+    # the same schedule with all ranks in one process (the driver the single-GPU rehearsal uses)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from noize_job_amd import sharded as sh
+    from oracle_stripe_ops import OracleStripeOps
+    world, grows, cols = 4, 96, 40
+    p = sh.PipelineParams(octaves=5, noiseSize=30, gaussIterations=5, flowIterations=4, erosionIterations=3)
+    ops = OracleStripeOps()
+    halo = sh.halo_rows_needed(ops, p)
+    plans = [sh.StripePlan(r, world, grows, cols, halo) for r in range(world)]
+    bufs = [(torch.full((pl.rows, cols), float("nan")), torch.full((pl.rows, cols), float("nan")),
+             torch.full((5, pl.rows, cols), float("nan")), torch.full((5, pl.rows, cols), float("nan")))
+            for pl in plans]
+
+    def copy_rows(dst, d0, src, s0, n):
+        dst[d0:d0 + n] = src[s0:s0 + n]
+
+    res = sh.run_pipeline_lockstep([ops] * world, plans, p, bufs, copy_rows)
+    got = np.concatenate([r[pl.own0:pl.own1].numpy() for r, pl in zip(res, plans)], axis=0)
+    want = oracle.pipeline(grows, cols, octaves=5, noise_size=30, gauss_iterations=5, flow_iterations=4,
+                           erosion_iterations=3)
+    assert np.array_equal(got, want)
