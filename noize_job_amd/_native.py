@@ -81,7 +81,33 @@ SIGNATURES = {
 }
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process: KFD admits a single compute context per process, and the PyTorch
+    wheel bundles its own libamdhip64 (same SONAME as /opt/rocm's, but requested by torch under the
+    unversioned name, so the loader would map a second copy if ours were resident first and that
+    copy finds no device).  When torch is installed, map its copy first; libnoize_hip.so then binds to
+    it by SONAME and torch, RCCL and this library share streams and allocations.  Without torch the
+    system runtime in /opt/rocm is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def _load():
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "noize_job_amd: %s is missing -- the HIP extension is not built (run __graft_entry__.build()); "
