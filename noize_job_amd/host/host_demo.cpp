@@ -1,0 +1,61 @@
+// host_demo.cpp -- the metric pipeline driven from the C++ host mirror (noize_pipeline.hpp).
+// Writes the resulting plane as raw little-endian fp32 so the test suite can compare it with the oracle.
+//   usage: host_demo <resolution> <out.f32> [gauss_iterations flow_iterations erosion_iterations]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "noize_pipeline.hpp"
+
+using namespace noize;
+
+int main(int argc, char **argv) {
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s <resolution> <out.f32> [G F E]\n", argv[0]);
+        return 2;
+    }
+    int res = std::atoi(argv[1]);
+    int G = argc > 3 ? std::atoi(argv[3]) : 17, F = argc > 4 ? std::atoi(argv[4]) : 5, E = argc > 5 ? std::atoi(argv[5]) : 5;
+    try {
+        nz_ctx *ctx = nullptr;
+        check(nz_ctx_create(0, &ctx), "nz_ctx_create");
+        {
+            DeviceTile tile(ctx, (size_t)res * res);
+            NoiseStage noise(ctx);
+            noise.noiseType = FractalNoise::Simplex;
+            noise.hurst = 0.4f;
+            noise.octaves = 13;
+            noise.noiseSize = 1700;
+            KernelFilterStage gauss(ctx);
+            gauss.filter = NZ_GAUSS5_S1;
+            gauss.iterations = G;
+            FlowMapStage flow(ctx);
+            flow.iterations = F;
+            flow.normMin = 0.0f;
+            flow.normMax = 0.005f;
+            ErosionStage erosion(ctx);
+            erosion.iterations = E;
+            BasePipeline pipe({&noise, &gauss, &flow, &erosion});
+            GeneratorData gd;
+            gd.uuid = "host-demo";
+            gd.data = &tile;
+            gd.resolution = res;
+            int completed = 0;
+            pipe.Enqueue(&gd, nullptr, [&](StageIO *) { completed++; });
+            pipe.RunToCompletion();
+            if (completed != 1) throw std::runtime_error("completeAction did not fire");
+            std::vector<float> host((size_t)res * res);
+            tile.CopyTo(host.data());
+            FILE *f = std::fopen(argv[2], "wb");
+            if (!f) throw std::runtime_error("cannot open output");
+            std::fwrite(host.data(), sizeof(float), host.size(), f);
+            std::fclose(f);
+            pipe.Destroy();
+        }
+        nz_ctx_destroy(ctx);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "host_demo: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

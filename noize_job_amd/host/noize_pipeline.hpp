@@ -1,0 +1,347 @@
+// noize_pipeline.hpp -- C++ host side above the C ABI: the reference's Pipeline / PipelineStage operator
+// API for the hot path, for hosts written in a compiled language (the reference's own host language,
+// C#, has no toolchain in this image; its P/Invoke form is in INTEGRATION.md).
+//
+// Same class names, field names, argument meaning and error behaviour as
+//   Pipeline/Stage/PipelineStage.cs:10-62, Pipeline/Stage/StageIO.cs:8-11,
+//   Pipeline/Stage/StageIOTypes/{GeneratorData,MeshStageData}.cs, Pipeline/Stage/PipelineDefinition.cs:18-25,
+//   Pipeline/Executable/Pipeline.cs:19-287, Noise/NoiseStage.cs:13-61, Filter/KernelFilterStage.cs:13-51,
+//   Filter/Kernel/Blur/Stage{Gaussian,Smooth}Blur.cs, Geologic/Stage/FlowMapStage.cs:16-220,
+//   Mesh/Stage/MeshTileStage.cs:28-61.
+// Header-only; link with -lnoize_hip.
+#pragma once
+
+#include <deque>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/noize_hip.h"
+
+namespace noize {
+
+struct NoizeError : std::runtime_error {
+    int32_t status;
+    NoizeError(int32_t s, const std::string &where)
+        : std::runtime_error(where + " failed with status " + std::to_string(s) + ": " + nz_last_error()), status(s) {}
+};
+
+inline void check(int32_t status, const char *where) {
+    if (status != NZ_OK) throw NoizeError(status, where);
+}
+
+// Unity.Jobs.JobHandle
+struct JobHandle {
+    nz_ctx *ctx = nullptr;
+    nz_handle id = 0;
+    bool IsCompleted() const {
+        if (!ctx || id == 0) return true;
+        int32_t done = 0;
+        check(nz_handle_query(ctx, id, &done), "nz_handle_query");
+        return done != 0;
+    }
+    void Complete() const {
+        if (ctx && id) check(nz_handle_wait(ctx, id), "nz_handle_wait");
+    }
+};
+
+// NativeArray<float> / NativeSlice<float> in HBM
+struct DeviceTile {
+    nz_ctx *ctx = nullptr;
+    float *ptr = nullptr;
+    size_t Length = 0;
+    bool owned = false;
+    DeviceTile() = default;
+    DeviceTile(nz_ctx *c, size_t n) : ctx(c), Length(n), owned(true) { check(nz_tile_alloc(c, n, &ptr), "nz_tile_alloc"); }
+    DeviceTile(const DeviceTile &) = delete;
+    DeviceTile &operator=(const DeviceTile &) = delete;
+    ~DeviceTile() { Dispose(); }
+    bool IsCreated() const { return ptr != nullptr; }
+    void Dispose() {
+        if (owned && ptr) nz_tile_free(ctx, ptr);
+        ptr = nullptr;
+    }
+    void CopyFrom(const float *host) {
+        check(nz_tile_upload(ctx, ptr, host, Length, 0, nullptr), "nz_tile_upload");
+        check(nz_ctx_synchronize(ctx), "nz_ctx_synchronize");
+    }
+    void CopyTo(float *host) const {
+        check(nz_tile_download(ctx, ptr, host, Length, 0, nullptr), "nz_tile_download");
+        check(nz_ctx_synchronize(ctx), "nz_ctx_synchronize");
+    }
+};
+
+// ---- StageIO payloads ------------------------------------------------------------------------
+struct StageIO {
+    std::string uuid;
+    DeviceTile *data = nullptr;  // NativeSlice<float>
+    virtual ~StageIO() = default;
+};
+
+struct GeneratorData : StageIO {
+    int resolution = 512, xpos = 0, zpos = 0;
+};
+
+struct MeshBuffers {  // stands in for UnityEngine.Mesh + Mesh.MeshData (PositionStream32 layout)
+    std::unique_ptr<DeviceTile> vertices, indices;
+    size_t vertexCount = 0, indexCount = 0;
+};
+
+struct MeshStageData : StageIO {
+    int resolution = 512, inputResolution = 512, marginPix = 5;
+    float tileSize = 512.f, tileHeight = 512.f;
+    int xpos = 0, zpos = 0;
+    MeshBuffers *mesh = nullptr;
+};
+
+struct PipelineWorkItem {
+    StageIO *data = nullptr;
+    std::function<void(StageIO *)> completeAction;
+    std::function<void(StageIO *, JobHandle)> scheduledAction;
+    JobHandle dependency;
+};
+
+// ---- PipelineStage ---------------------------------------------------------------------------
+class PipelineStage {
+  public:
+    explicit PipelineStage(nz_ctx *c) : ctx(c) {}
+    virtual ~PipelineStage() = default;
+    std::vector<std::function<void(PipelineWorkItem &, JobHandle)>> OnStageScheduledAction;
+
+    virtual void ResizeNativeContainers(size_t) {}
+    virtual bool IsSchedulable(const PipelineWorkItem &) { return true; }
+    virtual void Schedule(PipelineWorkItem &, JobHandle) {}
+    virtual void TransformData(PipelineWorkItem &) {}
+    virtual void OnStageComplete() {}
+    virtual void OnDestroy() {}
+
+    template <class T>
+    T *CheckRequirements(PipelineWorkItem &requirements) {
+        T *d = dynamic_cast<T *>(requirements.data);
+        if (!d) throw std::runtime_error("Unhandled stageio");  // PipelineStage.cs:37
+        if (d->data->Length != dataLength) {
+            dataLength = d->data->Length;
+            ResizeNativeContainers(dataLength);
+        }
+        return d;
+    }
+    void ReceiveHandledInput(PipelineWorkItem &requirements, JobHandle dependency) {
+        Schedule(requirements, dependency);
+        TransformData(requirements);
+        for (auto &a : OnStageScheduledAction) a(requirements, jobHandle);
+    }
+
+  protected:
+    nz_ctx *ctx;
+    JobHandle jobHandle;
+    size_t dataLength = 0;
+    JobHandle done(nz_handle h) { return JobHandle{ctx, h}; }
+};
+
+enum class FractalNoise { Sin, Perlin, PeriodicPerlin, Simplex, RotatedSimplex, Cellular, DomainRotatedPerlin, DomainRotatedSimplex };
+
+class NoiseStage : public PipelineStage {
+  public:
+    using PipelineStage::PipelineStage;
+    FractalNoise noiseType = FractalNoise::Sin;
+    float hurst = 0.f, startingAmplitude = 1.f, stepdown = 2.f, detuneRate = 0.f;
+    int octaves = 1, noiseSize = 1000;
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = CheckRequirements<GeneratorData>(requirements);
+        nz_handle h = 0;
+        check(nz_fractal(ctx, (int)noiseType, d->data->ptr, d->resolution, hurst, startingAmplitude, stepdown,
+                         detuneRate, octaves, d->xpos, d->zpos, noiseSize, dependency.id, &h), "nz_fractal");
+        jobHandle = done(h);
+    }
+};
+
+class TmpStage : public PipelineStage {  // stages that own one scratch plane
+  public:
+    using PipelineStage::PipelineStage;
+    void ResizeNativeContainers(size_t) override { tmp.reset(new DeviceTile(ctx, dataLength)); }
+    void OnDestroy() override { tmp.reset(); }
+
+  protected:
+    std::unique_ptr<DeviceTile> tmp;
+};
+
+class KernelFilterStage : public TmpStage {
+  public:
+    using TmpStage::TmpStage;
+    int filter = NZ_GAUSS9_S1;
+    int iterations = 1;
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = CheckRequirements<GeneratorData>(requirements);
+        nz_handle h = 0;
+        check(nz_kernel_filter_stage(ctx, d->data->ptr, tmp->ptr, filter, iterations, d->resolution, dependency.id, &h),
+              "nz_kernel_filter_stage");
+        jobHandle = done(h);
+    }
+};
+
+inline int limitWidth(int width) {  // BlurHelper.limitWidth, Filter/Kernel/Blur/BlurKernels.cs:29-36
+    if (width % 2 == 0) width += 1;
+    if (width > 25) width = 25;
+    return width < 3 ? 3 : width;
+}
+
+class StageGaussianBlur : public TmpStage {
+  public:
+    using TmpStage::TmpStage;
+    int iterations = 1, sigma = 0, width = 3;
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = CheckRequirements<GeneratorData>(requirements);
+        nz_handle h = 0;
+        check(nz_gauss_blur_stage(ctx, d->data->ptr, tmp->ptr, limitWidth(width), sigma, iterations, d->resolution,
+                                  dependency.id, &h), "nz_gauss_blur_stage");
+        jobHandle = done(h);
+    }
+};
+
+class StageSmoothBlur : public TmpStage {
+  public:
+    using TmpStage::TmpStage;
+    int iterations = 1, width = 1;
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = CheckRequirements<GeneratorData>(requirements);
+        nz_handle h = 0;
+        check(nz_smooth_blur_stage(ctx, d->data->ptr, tmp->ptr, limitWidth(width), iterations, d->resolution,
+                                   dependency.id, &h), "nz_smooth_blur_stage");
+        jobHandle = done(h);
+    }
+};
+
+class ErosionStage : public TmpStage {  // ErosionKernelJob x iterations (no stage wrapper in the reference)
+  public:
+    using TmpStage::TmpStage;
+    int iterations = 1;
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = CheckRequirements<GeneratorData>(requirements);
+        nz_handle h = 0;
+        check(nz_erosion_stage(ctx, d->data->ptr, tmp->ptr, iterations, d->resolution, dependency.id, &h),
+              "nz_erosion_stage");
+        jobHandle = done(h);
+    }
+};
+
+class FlowMapStage : public PipelineStage {
+  public:
+    using PipelineStage::PipelineStage;
+    int iterations = 5;
+    float normMin = -.1f, normMax = .1f;
+    void ResizeNativeContainers(size_t) override {
+        work.reset(new DeviceTile(ctx, nz_flowmap_stage_work_floats(resolution)));
+    }
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *g = dynamic_cast<GeneratorData *>(requirements.data);
+        if (!g) throw std::runtime_error("Unhandled stageio");
+        resolution = g->resolution;
+        auto *d = CheckRequirements<GeneratorData>(requirements);
+        nz_handle h = 0;
+        check(nz_flowmap_stage(ctx, d->data->ptr, work->ptr, iterations, normMin, normMax, d->resolution,
+                               dependency.id, &h), "nz_flowmap_stage");
+        jobHandle = done(h);
+    }
+    void OnDestroy() override { work.reset(); }
+
+  private:
+    int resolution = 0;
+    std::unique_ptr<DeviceTile> work;
+};
+
+class MeshTileStage : public PipelineStage {
+  public:
+    using PipelineStage::PipelineStage;
+    int meshType = NZ_MESH_SQUARE_GRID;
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = dynamic_cast<MeshStageData *>(requirements.data);
+        if (!d || !d->mesh) throw std::runtime_error("Unhandled stageio");
+        MeshBuffers &m = *d->mesh;
+        size_t nv = nz_mesh_vertex_count(d->resolution), ni = nz_mesh_index_count(d->resolution);
+        if (m.vertexCount != nv) {  // Mesh.AllocateWritableMeshData(1)
+            m.vertices.reset(new DeviceTile(ctx, nv * 12));
+            m.indices.reset(new DeviceTile(ctx, ni));
+            m.vertexCount = nv;
+            m.indexCount = ni;
+        }
+        nz_handle h = 0;
+        check(nz_heightmap_mesh(ctx, meshType, m.vertices->ptr, reinterpret_cast<uint32_t *>(m.indices->ptr),
+                                d->resolution, d->inputResolution, d->marginPix, d->tileHeight, d->tileSize,
+                                d->data->ptr, dependency.id, &h), "nz_heightmap_mesh");
+        jobHandle = done(h);
+    }
+};
+
+// ---- BasePipeline (Pipeline/Executable/Pipeline.cs) --------------------------------------------
+class BasePipeline {
+  public:
+    std::string alias = "Unnamed Pipeline";
+    explicit BasePipeline(std::vector<PipelineStage *> stages) : stage_instances(std::move(stages)) { Setup(); }
+
+    void Enqueue(StageIO *input, std::function<void(StageIO *, JobHandle)> scheduleAction = nullptr,
+                 std::function<void(StageIO *)> completeAction = nullptr, JobHandle dependency = JobHandle()) {
+        queue.push_back(PipelineWorkItem{input, completeAction, scheduleAction, dependency});
+    }
+    void Schedule(PipelineWorkItem wi) {
+        activeItem = std::move(wi);
+        if (stage_instances.empty()) throw std::runtime_error("No stages in pipeline");
+        pipelineBeingScheduled = true;
+        stage_instances[0]->ReceiveHandledInput(activeItem, activeItem.dependency);
+    }
+    void Update() {
+        if (!pipelineRunning && !pipelineBeingScheduled && !queue.empty()) {
+            PipelineWorkItem wi = queue.front();
+            queue.pop_front();
+            Schedule(wi);
+        }
+    }
+    bool LateUpdate() {
+        if (pipelineRunning && pipelineHandle.IsCompleted()) {
+            pipelineHandle.Complete();
+            for (auto *s : stage_instances) s->OnStageComplete();
+            if (activeItem.completeAction) activeItem.completeAction(activeItem.data);
+            pipelineRunning = false;
+            return true;
+        }
+        return false;
+    }
+    void RunToCompletion() {
+        while (!queue.empty() || pipelineRunning) {
+            Update();
+            if (pipelineRunning) {
+                pipelineHandle.Complete();
+                LateUpdate();
+            }
+        }
+    }
+    void Destroy() {
+        for (auto *s : stage_instances) s->OnDestroy();
+    }
+
+  private:
+    void Setup() {
+        PipelineStage *previous = nullptr;
+        for (auto *stage : stage_instances) {
+            if (previous)
+                previous->OnStageScheduledAction.push_back(
+                    [stage](PipelineWorkItem &wi, JobHandle h) { stage->ReceiveHandledInput(wi, h); });
+            previous = stage;
+        }
+        if (previous)
+            previous->OnStageScheduledAction.push_back([this](PipelineWorkItem &wi, JobHandle h) {
+                pipelineHandle = h;
+                pipelineRunning = true;
+                pipelineBeingScheduled = false;
+                if (activeItem.scheduledAction) activeItem.scheduledAction(wi.data, h);
+            });
+    }
+    std::vector<PipelineStage *> stage_instances;
+    std::deque<PipelineWorkItem> queue;
+    PipelineWorkItem activeItem;
+    JobHandle pipelineHandle;
+    bool pipelineBeingScheduled = false, pipelineRunning = false;
+};
+
+}  // namespace noize
