@@ -283,3 +283,16 @@ def test_job_handles(nj, ctx):
     a, b = ctx.record(), ctx.record()
     b.Complete()
     assert ctx.elapsed_ms(a, b) >= 0.0
+
+
+def test_cpp_host_mirror_runs_the_metric_pipeline(oracle, tmp_path):
+    # noize_job_amd/host/noize_pipeline.hpp: the same stage graph from a compiled host, C ABI only
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "noize_job_amd", "host", "host_demo")
+    assert os.path.exists(exe), "host_demo not built (run __graft_entry__.build())"
+    out = str(tmp_path / "plane.f32")
+    subprocess.check_call([exe, "256", out, "17", "5", "5"])
+    got = np.fromfile(out, dtype=np.float32).reshape(256, 256)
+    assert np.array_equal(got, oracle.pipeline(256, 256))
