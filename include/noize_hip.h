@@ -177,6 +177,14 @@ int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_t iteration
                          float normMax, int32_t resolution, nz_handle dep, nz_handle *out);
 
 /* stripe forms for sharded runs: state = {water, fN, fS, fE, fW} planes of the stripe's shape. */
+/* `iterations` (<= nz_flow_fused_max_iterations()) whole iterations in one launch on an on-chip tile; needs
+ * 2*iterations valid ghost rows of height (and of every state_in plane unless `first`).  first != 0: the
+ * initial state (water 1e-4, flux 0) is implied and state_in is not read.  last != 0: the launch ends in
+ * velocity + normalise and writes `dst` only; otherwise it writes the five state_out planes. */
+int32_t nz_flow_fused_max_iterations(void);
+int32_t nz_flow_fused_stripe(nz_ctx *ctx, const float *height, const float *const *state_in, float *const *state_out,
+                             float *dst, const nz_stripe *st, int32_t iterations, int32_t first, int32_t last,
+                             float normMin, float normMax, nz_handle dep, nz_handle *out);
 int32_t nz_flow_first_stripe(nz_ctx *ctx, const float *height, float *water, float *fN, float *fS,
                              float *fE, float *fW, const nz_stripe *st, nz_handle dep, nz_handle *out);
 int32_t nz_flow_iter_stripe(nz_ctx *ctx, const float *height, const float *water_in, const float *fN_in,

@@ -686,7 +686,7 @@ extern "C" int32_t nz_map_normalize_values(nz_ctx *ctx, float *src, float *tmp, 
 }
 
 extern "C" size_t nz_flowmap_stage_work_floats(int32_t resolution) {
-    return resolution > 0 ? (size_t)10 * resolution * resolution : 0;
+    return resolution > 0 ? (size_t)11 * resolution * resolution : 0;  // the reference stage's 11 planes
 }
 
 extern "C" int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
@@ -702,17 +702,50 @@ extern "C" int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_
         A[i] = work + (size_t)i * n;
         B[i] = work + (size_t)(5 + i) * n;
     }
-    // iteration 1: water == 0.0001 (fillStage, FlowMapStage.cs:129) and flux == 0 (defined) are implied
-    NZ_TRY(nz_launch_flow_iter(ctx->stream, src, nullptr, nullptr, nullptr, nullptr, nullptr, A[0], A[1], A[2], A[3],
-                               A[4], g, 1));
+    // `iterations` split into launches of <= nz_flow_fused_max() iterations that keep the tile on chip.
+    // The first launch implies water == 0.0001 (fillStage, FlowMapStage.cs:129) and flux == 0 (defined);
+    // the last one ends in writeStage + normStage (FlowMapStage.cs:179-194), args = {normMin, normMax,
+    // normMax - normMin} (:48-51).
+    int cap = nz_flow_fused_max();
+    int launches = (iterations + cap - 1) / cap;
+    int base = iterations / launches, rem = iterations % launches;
     float **cur = A, **nxt = B;
-    for (int i = 1; i < iterations; i++) {
-        NZ_TRY(nz_launch_flow_iter(ctx->stream, src, cur[0], cur[1], cur[2], cur[3], cur[4], nxt[0], nxt[1], nxt[2],
-                                   nxt[3], nxt[4], g, 0));
+    // The result overwrites the height plane, which the last launch still reads with a halo: the
+    // first launch keeps a private copy of it (the stage's 11th plane) for the later ones.
+    float *hcopy = work + (size_t)10 * n;
+    for (int i = 0; i < launches; i++) {
+        int nit = base + (i < rem ? 1 : 0);
+        int first = i == 0, last = i == launches - 1;
+        const float *hsrc = first ? src : hcopy;
+        float *dst = !last ? nullptr : (launches == 1 ? hcopy : src);
+        NZ_TRY(nz_launch_flow_fused(ctx->stream, hsrc, first ? nullptr : cur, last ? nullptr : nxt, dst,
+                                    (first && !last) ? hcopy : nullptr, g, nit, first, last, normMin, normMax - normMin));
         float **s = cur; cur = nxt; nxt = s;
     }
-    // writeStage + normStage, FlowMapStage.cs:179-194; args = {normMin, normMax, normMax - normMin} (:48-51)
-    NZ_TRY(nz_launch_velocity(ctx->stream, src, cur[1], cur[2], cur[3], cur[4], g, 1, normMin, normMax - normMin));
+    if (launches == 1) NZ_TRY(nz_launch_copy(ctx->stream, src, hcopy, n));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_flow_fused_max_iterations(void) { return nz_flow_fused_max(); }
+
+extern "C" int32_t nz_flow_fused_stripe(nz_ctx *ctx, const float *height, const float *const *state_in,
+                                        float *const *state_out, float *dst, const nz_stripe *st, int32_t iterations,
+                                        int32_t first, int32_t last, float normMin, float normMax, nz_handle dep,
+                                        nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(iterations >= 1 && iterations <= nz_flow_fused_max(), "iterations %d cannot be fused", iterations);
+    NZ_TRY(nz_check_stripe(st, 2 * iterations));
+    NZ_REQUIRE(height, "height is NULL");
+    NZ_REQUIRE(first || state_in, "state_in is NULL");
+    NZ_REQUIRE(last ? dst != nullptr : state_out != nullptr, "output plane is NULL");
+    for (int i = 0; i < 5; i++) {
+        NZ_REQUIRE(first || state_in[i], "state_in[%d] is NULL", i);
+        NZ_REQUIRE(last || state_out[i], "state_out[%d] is NULL", i);
+    }
+    NZ_REQUIRE(!last || dst != height, "dst must not alias height");
+    NZ_TRY(nz_launch_flow_fused(ctx->stream, height, first ? nullptr : state_in, last ? nullptr : state_out,
+                                last ? dst : nullptr, nullptr, nz_geom_from_stripe(*st), iterations, first, last, normMin,
+                                normMax - normMin));
     return nz_ctx_finish(ctx, out);
 }
 

@@ -17,6 +17,8 @@
 //
 // Arithmetic follows the C# order exactly (W,E,S,N; csum = ((x+y)+z)+w; true divisions), no FMA
 // contraction, so results are bit-identical to the CPU restatement.
+#include <cstdlib>
+
 #include "nz_internal.hpp"
 
 namespace {
@@ -258,7 +260,278 @@ __global__ __launch_bounds__(CT) void flow_iter_kernel(const float *__restrict__
     }
 }
 
+
+// ---- multi-iteration fused kernel -----------------------------------------------------------------
+// n iterations (outflow + water update) on an LDS/register-resident tile, optionally starting from
+// the implied initial state (FIRST: water 1e-4, flux 0) and optionally ending in the velocity +
+// normalise epilogue (LAST; the last water update is dead and skipped).  HBM traffic per launch: one
+// read of height (+ five state planes unless FIRST) and one write of the five state planes (or of the
+// single output plane when LAST), for n iterations.
+//
+// A workgroup of 512 threads holds a 48 x 128 tile (halo 2n included); every thread owns three groups
+// of 4 consecutive cells whose height, water and four flux values stay in registers for the whole
+// launch.  West/east neighbours come from the adjacent lane with a wave-shift DPP move (no LDS);
+// south/north neighbours (rows z-1 / z+1) go through three LDS planes (total height, fN, fS) with
+// 16-byte accesses; pitch 132 floats keeps those conflict free.  Cells outside the grid never feed a
+// cell inside it: border cells substitute their own value for a clamped neighbour, exactly what
+// clamp-to-edge reads return (ReadTileData.GetData, Pipeline/Tiles/TileData.cs:106-116).
+constexpr int FT_TH = 48, FT_TW = 128, FT_NT = 512, FT_LP = FT_TW + 4;
+constexpr int FT_G = FT_TH * FT_TW / 4 / FT_NT;  // groups per thread = 3
+constexpr int FT_MAX_N = 3;
+
+__device__ __forceinline__ float wave_from_prev_lane(float v) {  // lane i <- lane i-1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_from_next_lane(float v) {  // lane i <- lane i+1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+struct f4 {
+    float v[4];
+};
+
+__device__ __forceinline__ f4 lds_load4(const float *p) {
+    float4 t = *reinterpret_cast<const float4 *>(p);
+    return f4{{t.x, t.y, t.z, t.w}};
+}
+__device__ __forceinline__ void lds_store4(float *p, const float v[4]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__device__ __forceinline__ void load_group(const float *__restrict__ p, const nz_geom &g, int gx0, int gz, bool fast,
+                                           float out[4]) {
+    if (fast) {
+        float4 t = *reinterpret_cast<const float4 *>(p + (size_t)gz * g.pitch + gx0);
+        out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+    } else {
+        size_t row = (size_t)clampi(gz, g.zc0, g.zc1) * g.pitch;
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[e] = p[row + clampi(gx0 + e, 0, g.cols - 1)];
+    }
+}
+
+__device__ __forceinline__ void store_group(float *__restrict__ p, const nz_geom &g, int gx0, int gz, bool fast,
+                                            const float v[4]) {
+    if (fast) {
+        *reinterpret_cast<float4 *>(p + (size_t)gz * g.pitch + gx0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (gx0 + e < g.cols) p[(size_t)gz * g.pitch + gx0 + e] = v[e];
+    }
+}
+
+template <bool FIRST, bool LAST, int OCC>
+__global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__restrict__ h, const float *__restrict__ w_in,
+                                                          const float *__restrict__ fN_in, const float *__restrict__ fS_in,
+                                                          const float *__restrict__ fE_in, const float *__restrict__ fW_in,
+                                                          float *__restrict__ w_out, float *__restrict__ fN_out,
+                                                          float *__restrict__ fS_out, float *__restrict__ fE_out,
+                                                          float *__restrict__ fW_out, float *__restrict__ dst,
+                                                          float *__restrict__ h_out, nz_geom g, int n, float nmin,
+                                                          float nrange, int aligned) {
+    __shared__ __attribute__((aligned(16))) float s_tot[FT_TH * FT_LP];
+    __shared__ __attribute__((aligned(16))) float s_fn[FT_TH * FT_LP];
+    __shared__ __attribute__((aligned(16))) float s_fs[FT_TH * FT_LP];
+
+    const int tid = threadIdx.x;
+    const int H = 2 * n, HX = (H + 3) & ~3;
+    const int OW = FT_TW - 2 * HX, OH = FT_TH - 2 * H;
+    const int tiles_x = (g.cols + OW - 1) / OW;
+    const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    const int ox0 = bx * OW, oz0 = g.or0 + by * OH;
+    const int lx0 = ox0 - HX, lz0 = oz0 - H;
+    // tile strictly inside the grid: no cell is a border cell, every load is in range
+    const bool inner = lx0 > 0 && lx0 + FT_TW < g.cols && lz0 > g.zc0 && lz0 + FT_TH - 1 < g.zc1;
+    const bool fast = inner && aligned;
+
+    float hh[FT_G][4], ww[FT_G][4], fW[FT_G][4], fE[FT_G][4], fS[FT_G][4], fN[FT_G][4];
+    int grow[FT_G], gcol[FT_G];
+#pragma unroll
+    for (int j = 0; j < FT_G; j++) {
+        grow[j] = (tid >> 5) + j * (FT_NT / 32);
+        gcol[j] = (tid & 31) * 4;
+        int gx0 = lx0 + gcol[j], gz = lz0 + grow[j];
+        load_group(h, g, gx0, gz, fast, hh[j]);
+        if (FIRST) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                ww[j][e] = 0.0001f;  // fillStage, FlowMapStage.cs:129
+                fW[j][e] = 0.0f; fE[j][e] = 0.0f; fS[j][e] = 0.0f; fN[j][e] = 0.0f;
+            }
+        } else {
+            load_group(w_in, g, gx0, gz, fast, ww[j]);
+            load_group(fW_in, g, gx0, gz, fast, fW[j]);
+            load_group(fE_in, g, gx0, gz, fast, fE[j]);
+            load_group(fS_in, g, gx0, gz, fast, fS[j]);
+            load_group(fN_in, g, gx0, gz, fast, fN[j]);
+        }
+    }
+
+    for (int it = 0; it < n; it++) {
+        // ---- 1. publish water + height
+#pragma unroll
+        for (int j = 0; j < FT_G; j++) {
+            float tot[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) tot[e] = ww[j][e] + hh[j][e];
+            lds_store4(&s_tot[grow[j] * FT_LP + gcol[j]], tot);
+        }
+        __syncthreads();
+        // ---- 2. outflow (ComputeFlowStep), publish fN / fS
+#pragma unroll
+        for (int j = 0; j < FT_G; j++) {
+            int r = grow[j];
+            f4 tS = lds_load4(&s_tot[(r > 0 ? r - 1 : r) * FT_LP + gcol[j]]);
+            f4 tN = lds_load4(&s_tot[(r < FT_TH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);
+            float tot[4];  // recomputed rather than kept live across the barrier (same value)
+#pragma unroll
+            for (int e = 0; e < 4; e++) tot[e] = ww[j][e] + hh[j][e];
+            float left = wave_from_prev_lane(tot[3]), right = wave_from_next_lane(tot[0]);
+            int gx0 = lx0 + gcol[j], gz = lz0 + r;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float self = tot[e];
+                float tW = e > 0 ? tot[e - 1] : left;
+                float tE = e < 3 ? tot[e + 1] : right;
+                float ts = tS.v[e], tn = tN.v[e];
+                if (!inner) {
+                    if (gx0 + e <= 0) tW = self;
+                    if (gx0 + e >= g.cols - 1) tE = self;
+                    if (gz <= g.zc0) ts = self;
+                    if (gz >= g.zc1) tn = self;
+                }
+                flux4 f = compute_flow(self, ww[j][e], tW, tE, ts, tn, flux4{fW[j][e], fE[j][e], fS[j][e], fN[j][e]});
+                fW[j][e] = f.w; fE[j][e] = f.e; fS[j][e] = f.s; fN[j][e] = f.n;
+            }
+            lds_store4(&s_fn[r * FT_LP + gcol[j]], fN[j]);
+            lds_store4(&s_fs[r * FT_LP + gcol[j]], fS[j]);
+        }
+        __syncthreads();
+        if (LAST && it == n - 1) break;
+        // ---- 3. water update (UpdateWaterStep)
+#pragma unroll
+        for (int j = 0; j < FT_G; j++) {
+            int r = grow[j];
+            f4 nS = lds_load4(&s_fn[(r > 0 ? r - 1 : r) * FT_LP + gcol[j]]);            // fN of row z-1
+            f4 sN = lds_load4(&s_fs[(r < FT_TH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);    // fS of row z+1
+            float eW = wave_from_prev_lane(fE[j][3]), wE = wave_from_next_lane(fW[j][0]);
+            int gx0 = lx0 + gcol[j], gz = lz0 + r;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float inE = e > 0 ? fE[j][e - 1] : eW;
+                float inW = e < 3 ? fW[j][e + 1] : wE;
+                float inN = nS.v[e], inS = sN.v[e];
+                if (!inner) {
+                    if (gx0 + e <= 0) inE = fE[j][e];
+                    if (gx0 + e >= g.cols - 1) inW = fW[j][e];
+                    if (gz <= g.zc0) inN = fN[j][e];
+                    if (gz >= g.zc1) inS = fS[j][e];
+                }
+                ww[j][e] = update_water(ww[j][e], flux4{fW[j][e], fE[j][e], fS[j][e], fN[j][e]}, inE, inW, inN, inS);
+            }
+        }
+    }
+
+    // ---- epilogue: interior groups only
+#pragma unroll
+    for (int j = 0; j < FT_G; j++) {
+        int r = grow[j];
+        int gx0 = lx0 + gcol[j], gz = lz0 + r;
+        bool interior = r >= H && r < H + OH && gcol[j] >= HX && gcol[j] < HX + OW && gz < g.or1 && gx0 < g.cols;
+        float out[4];
+        if (LAST) {
+            // CreateVelocityField + NormalizeMap, FlowMapComponents.cs:120-139,157-165
+            f4 nS = lds_load4(&s_fn[(r > 0 ? r - 1 : r) * FT_LP + gcol[j]]);
+            f4 sN = lds_load4(&s_fs[(r < FT_TH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);
+            float eW = wave_from_prev_lane(fE[j][3]), wE = wave_from_next_lane(fW[j][0]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float fE_w = e > 0 ? fE[j][e - 1] : eW;
+                float fW_e = e < 3 ? fW[j][e + 1] : wE;
+                float fN_s = nS.v[e], fS_n = sN.v[e];
+                if (!inner) {
+                    if (gx0 + e <= 0) fE_w = fE[j][e];
+                    if (gx0 + e >= g.cols - 1) fW_e = fW[j][e];
+                    if (gz <= g.zc0) fN_s = fN[j][e];
+                    if (gz >= g.zc1) fS_n = fS[j][e];
+                }
+                float dl = fE_w - fW[j][e];
+                float dr = fE[j][e] - fW_e;
+                float dt = fS_n - fN[j][e];
+                float db = fS[j][e] - fN_s;
+                float vx = (dl + dr) * 0.5f;
+                float vy = (dt + db) * 0.5f;
+                float v = sqrtf(vx * vx + vy * vy);
+                if (nrange < 1e-12f) v = 0.0f;
+                out[e] = (v - nmin) / nrange;
+            }
+        }
+        if (interior) {
+            bool vec = aligned && gx0 + 4 <= g.cols;
+            if (h_out) store_group(h_out, g, gx0, gz, vec, hh[j]);  // private copy of the height plane
+            if (LAST) {
+                store_group(dst, g, gx0, gz, vec, out);
+            } else {
+                store_group(w_out, g, gx0, gz, vec, ww[j]);
+                store_group(fW_out, g, gx0, gz, vec, fW[j]);
+                store_group(fE_out, g, gx0, gz, vec, fE[j]);
+                store_group(fS_out, g, gx0, gz, vec, fS[j]);
+                store_group(fN_out, g, gx0, gz, vec, fN[j]);
+            }
+        }
+    }
+}
+
 }  // namespace
+
+int nz_flow_fused_max() { return FT_MAX_N; }
+
+// n iterations; `first`: implied initial state, inputs unread; `last`: velocity+normalise into dst
+int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const in[5], float *const out[5], float *dst,
+                             float *h_out, const nz_geom &g, int n, int first, int last, float nmin, float nrange) {
+    if (n < 1 || n > FT_MAX_N) {
+        nz_set_error("flow_fused: n=%d unsupported", n);
+        return NZ_ERR_INVALID;
+    }
+    if (g.or1 <= g.or0) return NZ_OK;
+    int H = 2 * n, HX = (H + 3) & ~3;
+    int OW = FT_TW - 2 * HX, OH = FT_TH - 2 * H;
+    long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
+    uintptr_t bits = reinterpret_cast<uintptr_t>(h) | (uintptr_t)(g.pitch * 4);
+    if (!first)
+        for (int i = 0; i < 5; i++) bits |= reinterpret_cast<uintptr_t>(in[i]);
+    if (h_out) bits |= reinterpret_cast<uintptr_t>(h_out);
+    if (last)
+        bits |= reinterpret_cast<uintptr_t>(dst);
+    else
+        for (int i = 0; i < 5; i++) bits |= reinterpret_cast<uintptr_t>(out[i]);
+    int aligned = (bits & 15) == 0;
+    const float *w_in = first ? nullptr : in[0], *fN_in = first ? nullptr : in[1], *fS_in = first ? nullptr : in[2];
+    const float *fE_in = first ? nullptr : in[3], *fW_in = first ? nullptr : in[4];
+    float *w_out = last ? nullptr : out[0], *fN_out = last ? nullptr : out[1], *fS_out = last ? nullptr : out[2];
+    float *fE_out = last ? nullptr : out[3], *fW_out = last ? nullptr : out[4];
+    // OCC = waves per SIMD the register allocator must leave room for: 4 -> two 512-thread workgroups per CU
+    static const int occ = getenv("NZ_FLOW_OCC") ? atoi(getenv("NZ_FLOW_OCC")) : 4;
+#define NZ_FF(F, L)                                                                                                  \
+    do {                                                                                                             \
+        if (occ >= 4)                                                                                                \
+            hipLaunchKernelGGL((flow_fused_kernel<F, L, 4>), dim3((unsigned)blocks), dim3(FT_NT), 0, s, h, w_in,     \
+                               fN_in, fS_in, fE_in, fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n,   \
+                               nmin, nrange, aligned);                                                                     \
+        else                                                                                                         \
+            hipLaunchKernelGGL((flow_fused_kernel<F, L, 2>), dim3((unsigned)blocks), dim3(FT_NT), 0, s, h, w_in,     \
+                               fN_in, fS_in, fE_in, fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n,   \
+                               nmin, nrange, aligned);                                                                     \
+    } while (0)
+    if (first && last) NZ_FF(true, true);
+    else if (first) NZ_FF(true, false);
+    else if (last) NZ_FF(false, true);
+    else NZ_FF(false, false);
+#undef NZ_FF
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
 
 int32_t nz_launch_fill(hipStream_t s, float *data, size_t n, float value) {
     if (n == 0) return NZ_OK;

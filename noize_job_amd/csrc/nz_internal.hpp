@@ -135,5 +135,12 @@ int32_t nz_launch_flow_iter(hipStream_t s, const float *h, const float *w_in, co
                             float *fN_out, float *fS_out, float *fE_out, float *fW_out, const nz_geom &g,
                             int first);
 
+// n <= nz_flow_fused_max() iterations per launch on an on-chip tile; state planes are {water,fN,fS,fE,fW}
+int nz_flow_fused_max();
+// h_out (nullable): the launch also stores its interior height cells there (a private copy, so that a
+// later launch may overwrite the caller's plane)
+int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const in[5], float *const out[5], float *dst,
+                             float *h_out, const nz_geom &g, int n, int first, int last, float nmin, float nrange);
+
 int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *indices, int res, int in_res,
                        float tile_height, float tile_size, const float *heights);

@@ -71,7 +71,8 @@ def halo_rows_needed(ops, p):
     cap = max(1, ops.kernel_filter_max_fused(p.filter))
     g = max(split_iterations(p.gaussIterations, cap)) * k_off if p.gaussIterations > 0 else 0
     e = min(p.erosionIterations, ops.erosion_max_fused()) if p.erosionIterations > 0 else 0
-    return max(g, 2 if p.flowIterations > 0 else 0, e, 1)
+    f = 2 * max(split_iterations(p.flowIterations, ops.flow_fused_max())) if p.flowIterations > 0 else 0
+    return max(g, f, e, 1)
 
 
 def pipeline_steps(ops, plan, p, bufs, result):
@@ -90,16 +91,17 @@ def pipeline_steps(ops, plan, p, bufs, result):
             ops.kernel_filter(cur, nxt, plan, p.filter, T)
             cur, nxt = nxt, cur
     if p.flowIterations > 0:
-        yield [cur], 2, 2                               # height, read at +-2 rows by every iteration
-        ops.flow_first(cur, S0, plan)
+        # whole iterations fused on chip, <= flow_fused_max() per launch; a launch of n iterations reads
+        # height and state 2n rows beyond the owned rows
+        chunks = split_iterations(p.flowIterations, ops.flow_fused_max())
+        yield [cur], 2 * max(chunks), 2 * max(chunks)   # height: exchanged once, read by every launch
         s_cur, s_nxt = S0, S1
-        for _ in range(1, p.flowIterations):
-            # water is read at +-2 rows, the four flux planes at +-1: one grouped exchange
-            yield [s_cur[i] for i in range(FLOW_PLANES)], 2, 2
-            ops.flow_iter(cur, s_cur, s_nxt, plan)
+        for i, n in enumerate(chunks):
+            first, last = i == 0, i == len(chunks) - 1
+            if not first:
+                yield [s_cur[k] for k in range(FLOW_PLANES)], 2 * n, 2 * n
+            ops.flow_fused(cur, s_cur, s_nxt, nxt, plan, n, first, last, p.normMin, p.normMax)
             s_cur, s_nxt = s_nxt, s_cur
-        yield [s_cur[1], s_cur[2]], 1, 1                # velocity reads fN(z-1), fS(z+1)
-        ops.flow_velocity(nxt, s_cur, plan, p.normMin, p.normMax)
         cur, nxt = nxt, cur
     left = p.erosionIterations
     while left > 0:
@@ -178,6 +180,17 @@ class HipStripeOps:
     def erosion(self, src, dst, plan, E):
         st = plan.stripe()
         self._call("nz_erosion_stripe", src.data_ptr(), dst.data_ptr(), C.byref(st), E)
+
+    def flow_fused_max(self):
+        return self.lib.nz_flow_fused_max_iterations()
+
+    def flow_fused(self, h, S_in, S_out, dst, plan, n, first, last, normMin, normMax):
+        st = plan.stripe()
+        arr = N.dev_ptr * FLOW_PLANES
+        pin = arr(*[S_in[i].data_ptr() for i in range(FLOW_PLANES)])
+        pout = arr(*[S_out[i].data_ptr() for i in range(FLOW_PLANES)])
+        self._call("nz_flow_fused_stripe", h.data_ptr(), pin, pout, dst.data_ptr(), C.byref(st), n, int(first),
+                   int(last), normMin, normMax)
 
     def flow_first(self, h, S, plan):
         st = plan.stripe()

@@ -57,6 +57,31 @@ class OracleStripeOps:
         for i in range(4):
             S_out[1 + i].numpy()[plan.own0:plan.own1] = fl[i][sl]
 
+    def flow_fused_max(self):
+        return 3
+
+    def flow_fused(self, h, S_in, S_out, dst, plan, n, first, last, normMin, normMax):
+        v0, v1 = self._valid(plan)
+        hv = h.numpy()[v0:v1]
+        if first:
+            w = np.full_like(hv, 0.0001)
+            fl = [np.zeros_like(hv) for _ in range(4)]
+        else:
+            w = S_in[0].numpy()[v0:v1]
+            fl = [S_in[i].numpy()[v0:v1] for i in range(1, 5)]
+        for it in range(n):
+            fl = O.flow_step(hv, w, *fl)
+            if not (last and it == n - 1):
+                w = O.water_step(w, *fl)
+        sl = slice(plan.own0 - v0, plan.own1 - v0)
+        if last:
+            out = O.normalize(O.velocity(*fl), normMin, normMax)
+            dst.numpy()[plan.own0:plan.own1] = out[sl]
+        else:
+            S_out[0].numpy()[plan.own0:plan.own1] = w[sl]
+            for i in range(4):
+                S_out[1 + i].numpy()[plan.own0:plan.own1] = fl[i][sl]
+
     def flow_first(self, h, S, plan):
         self._flow(h, None, S, plan, True)
 
