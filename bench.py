@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--stripe-rows", type=int, default=2048, help="rows per rank at N>1")
     ap.add_argument("--cols", type=int, default=16384, help="grid columns at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="run the row-stripe path even with one rank (rehearsal)")
     ap.add_argument("--cpu-res", type=int, default=4096)
     return ap.parse_args()
 
@@ -88,8 +89,10 @@ def main():
                              "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -98,7 +101,7 @@ def main():
     p = sh.PipelineParams(gaussIterations=G_IT, flowIterations=F_IT, erosionIterations=E_IT)
     marks = []  # per step: handles at stage boundaries
 
-    if world == 1:
+    if not sharded:
         res = args.res
         cells = res * res
         data = torch.empty(cells, dtype=torch.float32, device="cuda")
@@ -145,7 +148,7 @@ def main():
         parallelism = "row-stripe dp%d" % world
 
     def fence():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -154,10 +157,10 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(world == 1)
+        step(not sharded)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -206,9 +209,9 @@ def main():
                                "note": ("fBm noise is fp32-VALU-bound, not HBM-bound: %.1f%% of the %.0f Gops/s "
                                         "non-FMA VALU peak" % (100 * stages_out["noise"]["frac_valu"], VALU_PEAK_GOPS))
                                if dom == "noise" else "stage time / launches of its dominant kernel"}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(args.cpu_res)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -144,6 +144,7 @@ int32_t nz_erosion_stage(nz_ctx *ctx, float *src, float *tmp, int32_t iterations
  * nz_*_halo_rows(...) valid ghost rows on each side; reads `src`, writes `dst` (owned rows only). */
 int32_t nz_kernel_filter_halo_rows(int32_t filter, int32_t iterations);
 int32_t nz_kernel_filter_max_fused(int32_t filter);
+int32_t nz_erosion_max_fused_iterations(void);
 int32_t nz_kernel_filter_stripe(nz_ctx *ctx, const float *src, float *dst, const nz_stripe *st,
                                 int32_t filter, int32_t iterations, nz_handle dep, nz_handle *out);
 int32_t nz_erosion_stripe(nz_ctx *ctx, const float *src, float *dst, const nz_stripe *st,

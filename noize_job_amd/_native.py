@@ -63,6 +63,7 @@ SIGNATURES = {
     "nz_erosion_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
     "nz_kernel_filter_halo_rows": (_i, [_i, _i]),
     "nz_kernel_filter_max_fused": (_i, [_i]),
+    "nz_erosion_max_fused_iterations": (_i, []),
     "nz_kernel_filter_stripe": (_i, [ctx_p, dev_ptr, dev_ptr, stripe_p, _i, _i] + _tail),
     "nz_erosion_stripe": (_i, [ctx_p, dev_ptr, dev_ptr, stripe_p, _i] + _tail),
     "nz_fill_array": (_i, [ctx_p, dev_ptr, _i, _f] + _tail),

@@ -587,6 +587,8 @@ extern "C" int32_t nz_erosion_kernel(nz_ctx *ctx, float *src, int32_t resolution
     return nz_ctx_finish(ctx, out);
 }
 
+extern "C" int32_t nz_erosion_max_fused_iterations(void) { return nz_erosion_max_fused(); }
+
 extern "C" int32_t nz_kernel_filter_max_fused(int32_t filter) {
     nz_kernel_taps t;
     if (filter_taps(filter, &t) != NZ_OK) return 0;

@@ -19,6 +19,8 @@
 // LDS layout: pitch 132 floats (= 4 * 33): in the X pass the 64 lanes of a wave read the same
 // column run of 64 different rows with ds_read_b128, and 33 being odd spreads every 16-lane group
 // over all 16 four-bank slots; in the Z pass lanes read consecutive float4 columns of one row.
+#include <cstdlib>
+
 #include "nz_internal.hpp"
 
 namespace {
@@ -190,6 +192,259 @@ __global__ __launch_bounds__(CT) void conv_fused_kernel(const float *__restrict_
     store_tile(A, dst, g, lx0, lz0, HX, OW, H, OH);
 }
 
+// ---- register-resident fused kernel ------------------------------------------------------------------
+// Same contract as conv_fused_kernel (T applications of X pass + Z pass on a 64 x 128 tile, halo
+// included), but the tile never sits in LDS: each of the 256 threads keeps a 4-column x 8-row block in
+// registers for the whole launch.  The X pass takes its (K-1)/2 west / east neighbours from the
+// adjacent lanes with wave-shift DPP moves; the Z pass needs (K-1)/2 rows from the thread above and
+// below, and only those boundary rows travel through LDS (16-byte accesses, double buffered: one
+// barrier per application).  Global loads and stores go register <-> HBM directly, 16 B per lane.
+// Clamp-to-edge is applied when a window is assembled: a tap beyond the grid takes the border cell's
+// current value (RWTileData.GetData, Pipeline/Tiles/TileData.cs:72-82), so no fix-up pass is needed.
+constexpr int RB = 8;  // rows per thread
+
+__device__ __forceinline__ float dpp_prev(float v) {  // lane i <- lane i-1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_next(float v) {  // lane i <- lane i+1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+template <int KS, bool UNIT>
+__global__ __launch_bounds__(CT) void conv_reg_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
+                                                     nz_kernel_taps taps, int T, int aligned) {
+    constexpr int O = (KS - 1) / 2;
+    constexpr int WN = 4 + 2 * O;   // X window
+    constexpr int ZN = RB + 2 * O;  // Z window
+    // boundary rows of every 8-row block: [parity][block][top|bottom][o][column group]
+    __shared__ float4 s_edge[2][TH / RB][2][O][TW / 4];
+
+    const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
+    const int H = T * O, HX = (H + 3) & ~3;
+    const int OW = TW - 2 * HX, OH = TH - 2 * H;
+    int ox0, oz0;
+    tile_origin(g, OW, OH, ox0, oz0);
+    const int lx0 = ox0 - HX, lz0 = oz0 - H;
+    const int gx0 = lx0 + cg * 4, gzb = lz0 + rb * RB;
+    const bool inside = lx0 >= 0 && lx0 + TW <= g.cols && lz0 >= g.zc0 && lz0 + TH - 1 <= g.zc1;
+    const bool fast = inside && aligned;
+
+    float v[RB][4];
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+        if (fast) {
+            float4 t = *reinterpret_cast<const float4 *>(src + (size_t)(gzb + r) * g.pitch + gx0);
+            v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+        } else {
+            size_t row = (size_t)clampi(gzb + r, g.zc0, g.zc1) * g.pitch;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[r][e] = src[row + clampi(gx0 + e, 0, g.cols - 1)];
+        }
+    }
+    // window indices of the last grid column / first and last grid rows, for the clamps of edge tiles
+    const int icx = g.cols - 1 - gx0 + O;
+    const int iz0 = g.zc0 - gzb + O, iz1 = g.zc1 - gzb + O;
+
+    for (int t = 0; t < T; t++) {
+        // ---- X pass (KernelSampleXOperator: taps k ascending), in place row by row
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            float w[WN];
+#pragma unroll
+            for (int o = 0; o < O; o++) {
+                w[o] = dpp_prev(v[r][4 - O + o]);
+                w[4 + O + o] = dpp_next(v[r][o]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) w[O + e] = v[r][e];
+            if (!inside) {
+                if (gx0 == 0) {
+#pragma unroll
+                    for (int o = 0; o < O; o++) w[o] = w[O];
+                }
+                if (icx >= O && icx < WN - 1) {
+                    float wc = w[O];
+#pragma unroll
+                    for (int i = O + 1; i < WN; i++) wc = (i == icx) ? w[i] : wc;
+#pragma unroll
+                    for (int i = O + 1; i < WN; i++) w[i] = (i > icx) ? wc : w[i];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float total = w[e] * taps.kx[0];  // 0 + a*b == a*b
+#pragma unroll
+                for (int kk = 1; kk < KS; kk++) total += w[e + kk] * taps.kx[kk];
+                v[r][e] = UNIT ? total : total * taps.factor;
+            }
+        }
+        // ---- exchange the block's boundary rows
+        const int par = t & 1;
+#pragma unroll
+        for (int o = 0; o < O; o++) {
+            s_edge[par][rb][0][o][cg] = make_float4(v[o][0], v[o][1], v[o][2], v[o][3]);
+            s_edge[par][rb][1][o][cg] = make_float4(v[RB - O + o][0], v[RB - O + o][1], v[RB - O + o][2], v[RB - O + o][3]);
+        }
+        __syncthreads();
+        float z[ZN][4];
+#pragma unroll
+        for (int o = 0; o < O; o++) {
+            // rows gzb-O+o (bottom rows of the block above) and gzb+RB+o (top rows of the block below)
+            float4 a = rb > 0 ? s_edge[par][rb - 1][1][o][cg] : make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+            float4 b = rb < TH / RB - 1 ? s_edge[par][rb + 1][0][o][cg]
+                                        : make_float4(v[RB - 1][0], v[RB - 1][1], v[RB - 1][2], v[RB - 1][3]);
+            z[o][0] = a.x; z[o][1] = a.y; z[o][2] = a.z; z[o][3] = a.w;
+            z[RB + O + o][0] = b.x; z[RB + O + o][1] = b.y; z[RB + O + o][2] = b.z; z[RB + O + o][3] = b.w;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) z[O + r][e] = v[r][e];
+        if (!inside) {
+            if (iz0 > 0 && iz0 < ZN) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float c = z[0][e];
+#pragma unroll
+                    for (int i = 1; i < ZN; i++) c = (i == iz0) ? z[i][e] : c;
+#pragma unroll
+                    for (int i = 0; i < ZN - 1; i++) z[i][e] = (i < iz0) ? c : z[i][e];
+                }
+            }
+            if (iz1 >= 0 && iz1 < ZN - 1) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float c = z[0][e];
+#pragma unroll
+                    for (int i = 1; i < ZN; i++) c = (i == iz1) ? z[i][e] : c;
+#pragma unroll
+                    for (int i = 1; i < ZN; i++) z[i][e] = (i > iz1) ? c : z[i][e];
+                }
+            }
+        }
+        // ---- Z pass (KernelSampleZOperator: k descending, Kernel[k_off - k])
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float total = z[r + 2 * O][e] * taps.kz[0];
+#pragma unroll
+                for (int kk = 1; kk < KS; kk++) total += z[r + 2 * O - kk][e] * taps.kz[kk];
+                v[r][e] = UNIT ? total : total * taps.factor;
+            }
+        }
+    }
+
+    // ---- store the interior
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+        int lr = rb * RB + r, gz = gzb + r;
+        bool in = lr >= H && lr < H + OH && cg * 4 >= HX && cg * 4 < HX + OW && gz < g.or1 && gx0 < g.cols;
+        if (in) {
+            if (aligned && gx0 + 4 <= g.cols) {
+                *reinterpret_cast<float4 *>(dst + (size_t)gz * g.pitch + gx0) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (gx0 + e < g.cols) dst[(size_t)gz * g.pitch + gx0 + e] = v[r][e];
+            }
+        }
+    }
+}
+
+// E applications of the {-1,0} min window fused as one window min over [x-E,x] x [z-E,z], register
+// resident like conv_reg_kernel: the X pass reaches E <= 4 cells into the lane on the left (DPP), the Z
+// pass E rows into the block above (LDS).  Cells outside the grid are loaded as +FLT_MAX: the clamped
+// tap they stand for duplicates a cell that is already inside the window, so they must not win a min.
+template <int E>
+__global__ __launch_bounds__(CT) void erosion_reg_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                        nz_geom g, int aligned) {
+    __shared__ float4 s_edge[TH / RB][E][TW / 4];
+    constexpr float BIG = 3.40282347e+38f;
+    constexpr int HX = 4;
+    const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
+    const int OW = TW - HX, OH = TH - E;
+    int ox0, oz0;
+    tile_origin(g, OW, OH, ox0, oz0);
+    const int lx0 = ox0 - HX, lz0 = oz0 - E;
+    const int gx0 = lx0 + cg * 4, gzb = lz0 + rb * RB;
+    const bool inside = lx0 >= 0 && lx0 + TW <= g.cols && lz0 >= g.zc0 && lz0 + TH - 1 <= g.zc1;
+    const bool fast = inside && aligned;
+    float v[RB][4];
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+        int gz = gzb + r;
+        if (fast) {
+            float4 t = *reinterpret_cast<const float4 *>(src + (size_t)gz * g.pitch + gx0);
+            v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+        } else {
+            bool zin = gz >= g.zc0 && gz <= g.zc1;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                int gx = gx0 + e;
+                v[r][e] = (zin && gx >= 0 && gx < g.cols) ? src[(size_t)gz * g.pitch + gx] : BIG;
+            }
+        }
+    }
+    // X: min over [x-E, x]
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+        float w[4 + E];
+#pragma unroll
+        for (int o = 0; o < E; o++) w[o] = dpp_prev(v[r][4 - E + o]);
+        if (cg == 0) {  // no lane to the left inside this tile row: halo garbage, keep it neutral
+#pragma unroll
+            for (int o = 0; o < E; o++) w[o] = BIG;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) w[E + e] = v[r][e];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float m = w[e];
+#pragma unroll
+            for (int k = 1; k <= E; k++) m = fminf(m, w[e + k]);
+            v[r][e] = m;
+        }
+    }
+    // Z: min over [z-E, z]; the E rows above come from the block above
+#pragma unroll
+    for (int o = 0; o < E; o++)
+        s_edge[rb][o][cg] = make_float4(v[RB - E + o][0], v[RB - E + o][1], v[RB - E + o][2], v[RB - E + o][3]);
+    __syncthreads();
+    float z[RB + E][4];
+#pragma unroll
+    for (int o = 0; o < E; o++) {
+        float4 a = rb > 0 ? s_edge[rb - 1][o][cg] : make_float4(BIG, BIG, BIG, BIG);
+        z[o][0] = a.x; z[o][1] = a.y; z[o][2] = a.z; z[o][3] = a.w;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; r++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) z[E + r][e] = v[r][e];
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+        int lr = rb * RB + r, gz = gzb + r;
+        float out[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float m = z[r][e];
+#pragma unroll
+            for (int k = 1; k <= E; k++) m = fminf(m, z[r + k][e]);
+            out[e] = m;
+        }
+        bool in = lr >= E && cg * 4 >= HX && gz < g.or1 && gx0 < g.cols;
+        if (in) {
+            if (aligned && gx0 + 4 <= g.cols) {
+                *reinterpret_cast<float4 *>(dst + (size_t)gz * g.pitch + gx0) = make_float4(out[0], out[1], out[2], out[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (gx0 + e < g.cols) dst[(size_t)gz * g.pitch + gx0 + e] = out[e];
+            }
+        }
+    }
+}
+
 // generic single passes straight from global memory (any odd/even kernelSize <= 25); neighbour
 // reuse is served by L1/L2.  One thread per cell.
 __global__ __launch_bounds__(CT) void conv_pass_x_kernel(const float *__restrict__ src, float *__restrict__ dst,
@@ -216,57 +471,6 @@ __global__ __launch_bounds__(CT) void conv_pass_z_kernel(const float *__restrict
     dst[(size_t)z * g.pitch + x] = total * taps.factor;
 }
 
-// E applications of min-X{-1,0} then min-Z{-1,0} == min over the clamped window [x-E,x] x [z-E,z]
-// (min is exact, so the fusion is bit-identical).  E == 0 is not used.
-__global__ __launch_bounds__(CT) void erosion_fused_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                          nz_geom g, int E) {
-    __shared__ __attribute__((aligned(16))) float A[TH * LP];
-    const int HX = (E + 3) & ~3;
-    const int OW = TW - HX, OH = TH - E;
-    int ox0, oz0;
-    tile_origin(g, OW, OH, ox0, oz0);
-    const int lx0 = ox0 - HX, lz0 = oz0 - E;
-    const bool inside = lx0 >= 0 && lx0 + TW <= g.cols && lz0 >= g.zc0 && lz0 + TH - 1 <= g.zc1;
-    const int tid = threadIdx.x;
-    load_tile(A, src, g, lx0, lz0, inside);
-    __syncthreads();
-    constexpr int PER = TH * TW / CT;
-    float m[PER];
-    // X: min over [c-E, c]
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        int idx = tid + j * CT;
-        int r = idx / TW, c = idx % TW;
-        float v = 3.40282347e+38f;
-        for (int k = E; k >= 0; k--) v = fminf(v, A[r * LP + max(c - k, 0)]);
-        m[j] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        int idx = tid + j * CT;
-        A[(idx / TW) * LP + idx % TW] = m[j];
-    }
-    __syncthreads();
-    // Z: min over [r-E, r]
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        int idx = tid + j * CT;
-        int r = idx / TW, c = idx % TW;
-        float v = 3.40282347e+38f;
-        for (int k = E; k >= 0; k--) v = fminf(v, A[max(r - k, 0) * LP + c]);
-        m[j] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        int idx = tid + j * CT;
-        A[(idx / TW) * LP + idx % TW] = m[j];
-    }
-    __syncthreads();
-    store_tile(A, dst, g, lx0, lz0, HX, OW, E, OH);
-}
-
 // single min passes with the reference's window k in [-k_off, k_off) (KernelOperators.cs:84-90,109-116)
 __global__ __launch_bounds__(CT) void min_pass_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                      nz_geom g, int k_off, int along_z) {
@@ -288,7 +492,16 @@ int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom 
     int H = T * O, HX = (H + 3) & ~3;
     int OW = TW - 2 * HX, OH = TH - 2 * H;
     long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
-    hipLaunchKernelGGL((conv_fused_kernel<KS>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, T);
+    static const int use_lds = getenv("NZ_CONV_LDS") ? atoi(getenv("NZ_CONV_LDS")) : 0;
+    if (use_lds) {
+        hipLaunchKernelGGL((conv_fused_kernel<KS>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, T);
+    } else {
+        int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
+        if (k.factor == 1.0f)
+            hipLaunchKernelGGL((conv_reg_kernel<KS, true>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, T, aligned);
+        else
+            hipLaunchKernelGGL((conv_reg_kernel<KS, false>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, T, aligned);
+    }
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -340,7 +553,7 @@ int32_t nz_launch_conv_pass_z(hipStream_t s, const float *src, float *dst, const
     return NZ_OK;
 }
 
-int nz_erosion_max_fused() { return 16; }
+int nz_erosion_max_fused() { return 4; }
 
 int32_t nz_launch_erosion_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g, int E) {
     if (E < 1 || E > nz_erosion_max_fused()) {
@@ -348,10 +561,15 @@ int32_t nz_launch_erosion_fused(hipStream_t s, const float *src, float *dst, con
         return NZ_ERR_INVALID;
     }
     if (g.or1 <= g.or0) return NZ_OK;
-    int HX = (E + 3) & ~3;
-    int OW = TW - HX, OH = TH - E;
+    int OW = TW - 4, OH = TH - E;
     long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
-    hipLaunchKernelGGL(erosion_fused_kernel, dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, E);
+    int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
+    switch (E) {
+        case 1: hipLaunchKernelGGL((erosion_reg_kernel<1>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 2: hipLaunchKernelGGL((erosion_reg_kernel<2>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 3: hipLaunchKernelGGL((erosion_reg_kernel<3>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, aligned); break;
+        default: hipLaunchKernelGGL((erosion_reg_kernel<4>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, aligned); break;
+    }
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

@@ -22,6 +22,36 @@ __device__ __forceinline__ float stepf_(float y, float x) { return x >= y ? 1.0f
 __device__ __forceinline__ float mod289f(float x) { return x - floorf(x * (1.0f / 289.0f)) * 289.0f; }
 __device__ __forceinline__ float mod7f(float x) { return x - floorf(x * (1.0f / 7.0f)) * 7.0f; }
 __device__ __forceinline__ float permutef(float x) { return mod289f((34.0f * x + 1.0f) * x); }
+
+// Exact-product forms.  fmaf(a, b, c) == round(round(a*b) + c) whenever a*b is exactly representable,
+// so where both factors are small integers (every hash argument of snoise / cnoise / cellular is an
+// integer below 2^12, every product below 2^24) the fused instruction returns the very same bits as
+// the reference's separate multiply and add, one VALU slot cheaper.  NOT valid for psrnoise's first
+// permute, whose un-reduced argument overflows 2^24.
+#ifndef NZ_EXACT_FMA
+#define NZ_EXACT_FMA 1
+#endif
+__device__ __forceinline__ float mod289i(float x) {  // x: integer-valued, |x| < 2^24
+#if NZ_EXACT_FMA
+    return __builtin_fmaf(-floorf(x * (1.0f / 289.0f)), 289.0f, x);
+#else
+    return mod289f(x);
+#endif
+}
+__device__ __forceinline__ float permutei(float x) {  // x: integer-valued, 0 <= x <= 700
+#if NZ_EXACT_FMA
+    return mod289i(__builtin_fmaf(34.0f, x, 1.0f) * x);
+#else
+    return permutef(x);
+#endif
+}
+__device__ __forceinline__ float twice_minus_one(float f) {  // 2*f is exact
+#if NZ_EXACT_FMA
+    return __builtin_fmaf(2.0f, f, -1.0f);
+#else
+    return 2.0f * f - 1.0f;
+#endif
+}
 __device__ __forceinline__ float taylor_inv_sqrt(float r) { return 1.79284291400159f - 0.85373472095314f * r; }
 __device__ __forceinline__ float fadef(float t) { return t * t * t * (t * (t * 6.0f - 15.0f) + 10.0f); }
 __device__ __forceinline__ float rectify(float v) { return (1.0f + v) / 2.0f * 1.0f; }
@@ -77,19 +107,20 @@ __device__ __forceinline__ float snoise2(float vx, float vy) {
     float x12x = x0x + Cx, x12y = x0y + Cx, x12z = x0x + Cz, x12w = x0y + Cz;
     x12x -= i1x;
     x12y -= i1y;
-    ix = mod289f(ix);
-    iy = mod289f(iy);
-    float p0 = permutef(permutef(iy + 0.0f) + ix + 0.0f);
-    float p1 = permutef(permutef(iy + i1y) + ix + i1x);
-    float p2 = permutef(permutef(iy + 1.0f) + ix + 1.0f);
+    ix = mod289i(ix);
+    iy = mod289i(iy);
+    // (adding the literal 0 of the first corner is the identity on these non-negative integers)
+    float p0 = permutei(permutei(iy) + ix);
+    float p1 = permutei(permutei(iy + i1y) + ix + i1x);
+    float p2 = permutei(permutei(iy + 1.0f) + ix + 1.0f);
     float m0 = fmaxf(0.5f - (x0x * x0x + x0y * x0y), 0.0f);
     float m1 = fmaxf(0.5f - (x12x * x12x + x12y * x12y), 0.0f);
     float m2 = fmaxf(0.5f - (x12z * x12z + x12w * x12w), 0.0f);
     m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
     m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
-    float xa = 2.0f * fracf_(p0 * Cw) - 1.0f;
-    float xb = 2.0f * fracf_(p1 * Cw) - 1.0f;
-    float xc = 2.0f * fracf_(p2 * Cw) - 1.0f;
+    float xa = twice_minus_one(fracf_(p0 * Cw));
+    float xb = twice_minus_one(fracf_(p1 * Cw));
+    float xc = twice_minus_one(fracf_(p2 * Cw));
     float h0 = fabsf(xa) - 0.5f, h1 = fabsf(xb) - 0.5f, h2 = fabsf(xc) - 0.5f;
     float a00 = xa - floorf(xa + 0.5f);
     float a01 = xb - floorf(xb + 0.5f);
@@ -420,7 +451,10 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         case NZ_NOISE_PERLIN: return launch_basis<NZ_NOISE_PERLIN, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
         case NZ_NOISE_PERIODIC_PERLIN:
             return launch_basis<NZ_NOISE_PERIODIC_PERLIN, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
-        case NZ_NOISE_SIMPLEX: return launch_basis<NZ_NOISE_SIMPLEX, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
+#ifndef NZ_FR_VEC
+#define NZ_FR_VEC 2
+#endif
+        case NZ_NOISE_SIMPLEX: return launch_basis<NZ_NOISE_SIMPLEX, NZ_FR_VEC>(s, dst, rows, cols, pitch, p, d_rgrad);
         case NZ_NOISE_ROTATED_SIMPLEX:
             return launch_basis<NZ_NOISE_ROTATED_SIMPLEX, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
         case NZ_NOISE_CELLULAR: return launch_basis<NZ_NOISE_CELLULAR, 2>(s, dst, rows, cols, pitch, p, d_rgrad);

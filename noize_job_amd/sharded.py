@@ -163,7 +163,7 @@ class HipStripeOps:
         return self.lib.nz_kernel_filter_max_fused(filter)
 
     def erosion_max_fused(self):
-        return 16
+        return self.lib.nz_erosion_max_fused_iterations()
 
     def _call(self, name, *args):
         N.check(getattr(self.lib, name)(self.ctx._h, *args, 0, None), name)
