@@ -57,6 +57,36 @@ static int32_t build_rgrad_table(nz_ctx *ctx) {
     return NZ_OK;
 }
 
+// Host copies of the reference's hash helpers; plain IEEE fp32, no contraction.
+static float h_mod289(float x) { return x - floorf(x * (1.0f / 289.0f)) * 289.0f; }
+static float h_permute(float x) { return h_mod289((34.0f * x + 1.0f) * x); }
+
+static int32_t build_simplex_tables(nz_ctx *ctx) {
+    // see nz_fractal.hip, snoise2_tab: T1[i] = 16*permute(i); T2[j] = gradient terms of p = permute(j), computed
+    // with exactly the operations of noise.snoise (x = 2*frac(p*C.w) - 1; h = |x| - 0.5; a0 = x - floor(x + 0.5);
+    // 1.79284291400159 - 0.85373472095314*(a0*a0 + h*h)).
+    constexpr int T1 = 292, T2 = 580;
+    std::vector<int32_t> buf(T1 + T2 * 4);
+    for (int i = 0; i < T1; i++) buf[i] = 16 * (int32_t)h_permute((float)i);
+    float *t2 = reinterpret_cast<float *>(buf.data() + T1);
+    for (int j = 0; j < T2; j++) {
+        float p = h_permute((float)j);
+        float y = p * 0.024390243902439f;
+        float x = 2.0f * (y - floorf(y)) - 1.0f;
+        float h = fabsf(x) - 0.5f;
+        float ox = floorf(x + 0.5f);
+        float a0 = x - ox;
+        float nrm = 1.79284291400159f - 0.85373472095314f * (a0 * a0 + h * h);
+        t2[4 * j + 0] = a0;
+        t2[4 * j + 1] = h;
+        t2[4 * j + 2] = nrm;
+        t2[4 * j + 3] = 0.0f;
+    }
+    NZ_HIP(hipMalloc(&ctx->d_simplex, buf.size() * sizeof(int32_t)));
+    NZ_HIP(hipMemcpy(ctx->d_simplex, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return NZ_OK;
+}
+
 static int32_t ctx_create(int32_t device, hipStream_t stream, bool own, nz_ctx **out) {
     NZ_REQUIRE(out, "out is NULL");
     *out = nullptr;
@@ -82,6 +112,7 @@ static int32_t ctx_create(int32_t device, hipStream_t stream, bool own, nz_ctx *
         ctx->stream = stream;
     }
     int32_t rc = build_rgrad_table(ctx);
+    if (rc == NZ_OK) rc = build_simplex_tables(ctx);
     if (rc != NZ_OK) {
         if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -104,6 +135,7 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     for (hipEvent_t ev : ctx->events)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->d_rgrad) (void)hipFree(ctx->d_rgrad);
+    if (ctx->d_simplex) (void)hipFree(ctx->d_simplex);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -311,7 +343,7 @@ static int32_t fractal_impl(nz_ctx *ctx, int noiseType, float *dst, int rows, in
     p.detune_rate = detune;
     p.norm = calc_fractal_norm(hurst, octaves);
     p.octaves = octaves;
-    return nz_launch_fractal(ctx->stream, noiseType, dst, rows, cols, pitch, p, ctx->d_rgrad);
+    return nz_launch_fractal(ctx->stream, noiseType, dst, rows, cols, pitch, p, ctx->d_rgrad, ctx->d_simplex);
 }
 
 // SeparableKernelFilter tables, Filter/Kernel/KernelJob.cs:97-136.  Gaussian bodies are

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(CT) void flow_iter_kernel(const float *__restrict__
 // clamp-to-edge reads return (ReadTileData.GetData, Pipeline/Tiles/TileData.cs:106-116).
 constexpr int FT_TH = 48, FT_TW = 128, FT_NT = 512, FT_LP = FT_TW + 4;
 constexpr int FT_G = FT_TH * FT_TW / 4 / FT_NT;  // groups per thread = 3
-constexpr int FT_MAX_N = 3;
+constexpr int FT_MAX_N = 5;  // 2n halo rows: n = 5 leaves a 28 x 104 interior
 
 __device__ __forceinline__ float wave_from_prev_lane(float v) {  // lane i <- lane i-1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
@@ -485,7 +485,10 @@ __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__r
 
 }  // namespace
 
-int nz_flow_fused_max() { return FT_MAX_N; }
+int nz_flow_fused_max() {
+    static const int cap = getenv("NZ_FLOW_NMAX") ? atoi(getenv("NZ_FLOW_NMAX")) : 3;
+    return cap < 1 ? 1 : (cap > FT_MAX_N ? FT_MAX_N : cap);
+}
 
 // n iterations; `first`: implied initial state, inputs unread; `last`: velocity+normalise into dst
 int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const in[5], float *const out[5], float *dst,

@@ -12,6 +12,8 @@
 // VALU-bound (~1.1 k fp32 ops per cell for 13 simplex octaves against 4 B written): one thread
 // produces VEC consecutive cells of a row so the octave chains of different cells interleave, and
 // stores them with one 8/16-byte coalesced write.
+#include <cstdlib>
+
 #include "nz_internal.hpp"
 
 namespace {
@@ -367,6 +369,105 @@ __device__ __forceinline__ float noise_value(float x, float z, const float2 *tab
     }
 }
 
+// ---- simplex fBm with tabulated lattice hashes -------------------------------------------------------
+// In snoise the gradient of a lattice corner is a pure function of two small integers: the inner
+// permute argument iy+{0,i1.y,1} in [0,289] and the outer one permute(..)+ix+{0,i1.x,1} in [0,577]
+// (mod289 of any |integer| < 2.3e6 lies in [0,288]; every product is < 2^24, so all of this is exact
+// integer arithmetic in fp32).  Two tables built by the host with the reference's own operation
+// sequence therefore return bit-identical gradients:
+//   T1[i]  = 16 * permute(i)                                   (a byte offset into T2)
+//   T2[j]  = {a0, h, 1.79284291400159 - 0.85373472095314*(a0*a0 + h*h), 0} of p = permute(j)
+// and a corner costs one ds_read_b32, one ds_read_b128 and three integer adds instead of two
+// permutes and the gradient decode (26 fp32 ops + 4 floors).  About 87 VALU slots per octave-cell
+// instead of 151.
+constexpr int NZ_T1_N = 292, NZ_T2_N = 580;
+
+__device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1, const float4 *s_t2) {
+    const float Cx = 0.211324865405187f, Cy = 0.366025403784439f, Cz = -0.577350269189626f;
+    float s = vx * Cy + vy * Cy;
+    float fx = floorf(vx + s), fy = floorf(vy + s);
+    float t = fx * Cx + fy * Cx;
+    float x0x = vx - fx + t, x0y = vy - fy + t;
+    bool gt = x0x > x0y;
+    float i1x = gt ? 1.0f : 0.0f, i1y = gt ? 0.0f : 1.0f;
+    float x12x = x0x + Cx, x12y = x0y + Cx, x12z = x0x + Cz, x12w = x0y + Cz;
+    x12x -= i1x;
+    x12y -= i1y;
+    int ixi = (int)mod289i(fx), iyi = (int)mod289i(fy);
+    ixi = min(max(ixi, 0), 288);  // only reachable for |coordinate| > 2.3e6, where fp32 has no fraction left
+    iyi = min(max(iyi, 0), 288);
+    int ix16 = ixi << 4;
+    int k0 = s_t1[iyi], k1 = s_t1[iyi + (gt ? 0 : 1)], k2 = s_t1[iyi + 1];
+    const char *t2 = reinterpret_cast<const char *>(s_t2);
+    float4 g0 = *reinterpret_cast<const float4 *>(t2 + (k0 + ix16));
+    float4 g1 = *reinterpret_cast<const float4 *>(t2 + (k1 + ix16 + (gt ? 16 : 0)));
+    float4 g2 = *reinterpret_cast<const float4 *>(t2 + (k2 + ix16 + 16));
+    float m0 = fmaxf(0.5f - (x0x * x0x + x0y * x0y), 0.0f);
+    float m1 = fmaxf(0.5f - (x12x * x12x + x12y * x12y), 0.0f);
+    float m2 = fmaxf(0.5f - (x12z * x12z + x12w * x12w), 0.0f);
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
+    m0 *= g0.z;
+    m1 *= g1.z;
+    m2 *= g2.z;
+    float q0 = g0.x * x0x + g0.y * x0y;
+    float q1 = g1.x * x12x + g1.y * x12y;
+    float q2 = g2.x * x12z + g2.y * x12w;
+    return 130.0f * (m0 * q0 + m1 * q1 + m2 * q2);
+}
+
+constexpr int FT_ROWS = 8;  // rows per workgroup: amortises the 10 KB table copy
+
+template <int VEC>
+__global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restrict__ dst, int rows, int cols, int pitch,
+                                                                 int blocks_per_row, nz_fractal_params p,
+                                                                 const int *__restrict__ t1g,
+                                                                 const float4 *__restrict__ t2g) {
+    __shared__ int s_t1[NZ_T1_N];
+    __shared__ float4 s_t2[NZ_T2_N];
+    for (int i = threadIdx.x; i < NZ_T1_N; i += 256) s_t1[i] = t1g[i];
+    for (int i = threadIdx.x; i < NZ_T2_N; i += 256) s_t2[i] = t2g[i];
+    __syncthreads();
+    int by = blockIdx.x / blocks_per_row;
+    int bx = blockIdx.x - by * blocks_per_row;
+    int x0 = (bx * 256 + threadIdx.x) * VEC;
+    if (x0 >= cols) return;
+    float xi[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; c++) xi[c] = ((float)(x0 + c) + p.posx) / p.noise_size;
+    int zend = min(rows, (by + 1) * FT_ROWS);
+    for (int z = by * FT_ROWS; z < zend; z++) {
+        float zi = ((float)z + p.posz) / p.noise_size;
+        float t[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; c++) t[c] = 0.0f;
+        float detune = 0.0f, f = 1.0f, a = p.amp;
+        for (int i = 0; i < p.octaves; i++) {
+            float zV = f * zi;
+#pragma unroll
+            for (int c = 0; c < VEC; c++) {
+                float xV = f * xi[c];
+                t[c] += a * rectify(snoise2_tab(xV, zV, s_t1, s_t2));
+            }
+            detune += p.detune_rate;
+            f *= (p.stepdown - detune);
+            a *= p.G;
+        }
+        float *row = dst + (size_t)z * pitch;
+        float o[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; c++) o[c] = t[c] / p.norm;
+        bool full = x0 + VEC <= cols && ((reinterpret_cast<uintptr_t>(row + x0) & (VEC * 4 - 1)) == 0);
+        if (full && VEC == 2) {
+            *reinterpret_cast<float2 *>(row + x0) = make_float2(o[0], o[VEC - 1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < VEC; c++)
+                if (x0 + c < cols) row[x0 + c] = o[c];
+        }
+    }
+}
+
 constexpr int FR_THREADS = 256;
 
 // FractalGenerator.NoiseValue (Fractal.cs:114-131) for VEC consecutive cells of one row.
@@ -445,7 +546,19 @@ int32_t launch_basis(hipStream_t s, float *dst, int rows, int cols, int pitch, c
 }  // namespace
 
 int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, int cols, int pitch,
-                          const nz_fractal_params &p, const float *d_rgrad) {
+                          const nz_fractal_params &p, const float *d_rgrad, const void *d_simplex) {
+    static const int use_tab = getenv("NZ_SIMPLEX_TAB") ? atoi(getenv("NZ_SIMPLEX_TAB")) : 1;
+    if (noiseType == NZ_NOISE_SIMPLEX && use_tab && d_simplex) {
+        constexpr int VEC = 2;
+        int bpr = (cols + 256 * VEC - 1) / (256 * VEC);
+        long long blocks = (long long)bpr * ((rows + FT_ROWS - 1) / FT_ROWS);
+        const int *t1 = reinterpret_cast<const int *>(d_simplex);
+        const float4 *t2 = reinterpret_cast<const float4 *>(t1 + NZ_T1_N);
+        hipLaunchKernelGGL((fractal_simplex_tab_kernel<VEC>), dim3((unsigned)blocks), dim3(256), 0, s, dst, rows, cols,
+                           pitch, bpr, p, t1, t2);
+        NZ_HIP(hipGetLastError());
+        return NZ_OK;
+    }
     switch (noiseType) {
         case NZ_NOISE_SIN: return launch_basis<NZ_NOISE_SIN, 4>(s, dst, rows, cols, pitch, p, d_rgrad);
         case NZ_NOISE_PERLIN: return launch_basis<NZ_NOISE_PERLIN, 2>(s, dst, rows, cols, pitch, p, d_rgrad);

@@ -41,6 +41,8 @@ struct nz_ctx {
     uint64_t last_handle = 0;
     // psrnoise gradient tables (rot 0 and rot 0.62), built with the host libm
     float *d_rgrad = nullptr;
+    // snoise lattice tables: int T1[292] (16*permute(i)) followed by float4 T2[580] (gradient of permute(j))
+    void *d_simplex = nullptr;
     // stage scratch owned by the ctx (grown on demand)
     float *scratch = nullptr;
     size_t scratch_floats = 0;
@@ -100,7 +102,7 @@ int32_t nz_check_stripe(const nz_stripe *st, int halo);
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------------
 int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, int cols, int pitch,
-                          const nz_fractal_params &p, const float *d_rgrad);
+                          const nz_fractal_params &p, const float *d_rgrad, const void *d_simplex);
 
 int nz_conv_max_fused(int ksize);
 // T fused applications of (X pass, Z pass) src -> dst on rows [or0, or1)
