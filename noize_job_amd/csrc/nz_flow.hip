@@ -486,7 +486,7 @@ __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__r
 }  // namespace
 
 int nz_flow_fused_max() {
-    static const int cap = getenv("NZ_FLOW_NMAX") ? atoi(getenv("NZ_FLOW_NMAX")) : 3;
+    static const int cap = getenv("NZ_FLOW_NMAX") ? atoi(getenv("NZ_FLOW_NMAX")) : 5;
     return cap < 1 ? 1 : (cap > FT_MAX_N ? FT_MAX_N : cap);
 }
 

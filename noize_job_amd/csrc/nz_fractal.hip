@@ -402,6 +402,8 @@ __device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1
     float4 g0 = *reinterpret_cast<const float4 *>(t2 + (k0 + ix16));
     float4 g1 = *reinterpret_cast<const float4 *>(t2 + (k1 + ix16 + (gt ? 16 : 0)));
     float4 g2 = *reinterpret_cast<const float4 *>(t2 + (k2 + ix16 + 16));
+    // keep the padding lane live: a 16-byte LDS read takes 4 LDS cycles per wave, the 12-byte form 8
+    asm volatile("" ::"v"(g0.w), "v"(g1.w), "v"(g2.w));
     float m0 = fmaxf(0.5f - (x0x * x0x + x0y * x0y), 0.0f);
     float m1 = fmaxf(0.5f - (x12x * x12x + x12y * x12y), 0.0f);
     float m2 = fmaxf(0.5f - (x12z * x12z + x12w * x12w), 0.0f);
@@ -416,7 +418,10 @@ __device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1
     return 130.0f * (m0 * q0 + m1 * q1 + m2 * q2);
 }
 
-constexpr int FT_ROWS = 8;  // rows per workgroup: amortises the 10 KB table copy
+#ifndef NZ_FT_ROWS
+#define NZ_FT_ROWS 8
+#endif
+constexpr int FT_ROWS = NZ_FT_ROWS;  // rows per workgroup: amortises the 10 KB table copy
 
 template <int VEC>
 __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restrict__ dst, int rows, int cols, int pitch,
@@ -458,7 +463,9 @@ __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restr
 #pragma unroll
         for (int c = 0; c < VEC; c++) o[c] = t[c] / p.norm;
         bool full = x0 + VEC <= cols && ((reinterpret_cast<uintptr_t>(row + x0) & (VEC * 4 - 1)) == 0);
-        if (full && VEC == 2) {
+        if (full && VEC == 4) {
+            *reinterpret_cast<float4 *>(row + x0) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+        } else if (full && VEC == 2) {
             *reinterpret_cast<float2 *>(row + x0) = make_float2(o[0], o[VEC - 1]);
         } else {
 #pragma unroll
@@ -549,7 +556,10 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
                           const nz_fractal_params &p, const float *d_rgrad, const void *d_simplex) {
     static const int use_tab = getenv("NZ_SIMPLEX_TAB") ? atoi(getenv("NZ_SIMPLEX_TAB")) : 1;
     if (noiseType == NZ_NOISE_SIMPLEX && use_tab && d_simplex) {
-        constexpr int VEC = 2;
+#ifndef NZ_FT_VEC
+#define NZ_FT_VEC 2
+#endif
+        constexpr int VEC = NZ_FT_VEC;
         int bpr = (cols + 256 * VEC - 1) / (256 * VEC);
         long long blocks = (long long)bpr * ((rows + FT_ROWS - 1) / FT_ROWS);
         const int *t1 = reinterpret_cast<const int *>(d_simplex);
