@@ -275,7 +275,13 @@ __global__ __launch_bounds__(CT) void flow_iter_kernel(const float *__restrict__
 // 16-byte accesses; pitch 132 floats keeps those conflict free.  Cells outside the grid never feed a
 // cell inside it: border cells substitute their own value for a clamped neighbour, exactly what
 // clamp-to-edge reads return (ReadTileData.GetData, Pipeline/Tiles/TileData.cs:106-116).
-constexpr int FT_TH = 48, FT_TW = 128, FT_NT = 512, FT_LP = FT_TW + 4;
+#ifndef NZ_FT_NT
+#define NZ_FT_NT 512
+#endif
+#ifndef NZ_FT_OCC
+#define NZ_FT_OCC 4
+#endif
+constexpr int FT_TH = 48, FT_TW = 128, FT_NT = NZ_FT_NT, FT_LP = FT_TW + 4;
 constexpr int FT_G = FT_TH * FT_TW / 4 / FT_NT;  // groups per thread = 3
 constexpr int FT_MAX_N = 5;  // 2n halo rows: n = 5 leaves a 28 x 104 interior
 
@@ -519,7 +525,7 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
 #define NZ_FF(F, L)                                                                                                  \
     do {                                                                                                             \
         if (occ >= 4)                                                                                                \
-            hipLaunchKernelGGL((flow_fused_kernel<F, L, 4>), dim3((unsigned)blocks), dim3(FT_NT), 0, s, h, w_in,     \
+            hipLaunchKernelGGL((flow_fused_kernel<F, L, NZ_FT_OCC>), dim3((unsigned)blocks), dim3(FT_NT), 0, s, h, w_in,     \
                                fN_in, fS_in, fE_in, fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n,   \
                                nmin, nrange, aligned);                                                                     \
         else                                                                                                         \
