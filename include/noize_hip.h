@@ -208,6 +208,19 @@ int32_t nz_heightmap_mesh(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_
                           float tileHeight, float tileSize, const float *heights, nz_handle dep,
                           nz_handle *out);
 
+/* ---- element-wise stages either side of the path ------------------------------ */
+/* ConstantJobScheduleDelegate, Filter/ConstantJob.cs:47-53; operation = ConstantStage.ConstantOperationType
+ * {MULTIPLY = 0, BINARIZE = 1} (Filter/ConstantStage.cs:15-18) */
+int32_t nz_constant_job(nz_ctx *ctx, int32_t operation, float *srcL, float *tmp, float constantValue,
+                        int32_t resolution, nz_handle dep, nz_handle *out);
+/* ReductionJobScheduleDelegate, Filter/ReductionJob.cs:54-60; operation = ReductionType {SUBTRACT, MULTIPLY,
+ * ROOTSUMSQUARES, MAX, MIN} (Filter/Reduce/ReduceStage.cs:12-18); the result lands in srcL */
+int32_t nz_reduction_job(nz_ctx *ctx, int32_t operation, float *srcL, const float *srcR, float *tmp,
+                         int32_t resolution, nz_handle dep, nz_handle *out);
+/* CurveJobScheduleDelegate, Filter/Curve/CurveJob.cs:91-97; `curve` = DEVICE array of curveSize samples */
+int32_t nz_curve_job(nz_ctx *ctx, float *src, float *tmp, const float *curve, int32_t curveSize,
+                     int32_t resolution, nz_handle dep, nz_handle *out);
+
 #ifdef __cplusplus
 }
 #endif

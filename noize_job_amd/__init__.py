@@ -7,9 +7,10 @@ it is missing: there is no CPU or PyTorch fallback in the product path.
 from . import _native
 from ._native import NoizeError, Stripe
 from .runtime import Context, DeviceTile, JobHandle
-from .pipeline import (BasePipeline, BlurHelper, ErosionStage, FlowMapStage, FractalNoise, GaussSigma,
+from .pipeline import (BasePipeline, BlurHelper, ConstantOperationType, ConstantStage, CurveStage, ErosionStage, FlowMapStage, FractalNoise, GaussSigma,
                        GeneratorData, KernelFilterStage, KernelFilterType, MeshBuffers, MeshStageData,
-                       MeshTileStage, MeshType, NoiseStage, PipelineStage, PipelineWorkItem, StageGaussianBlur,
+                       MeshTileStage, MeshType, NoiseStage, PipelineStage, PipelineWorkItem, ReduceData, ReduceStage,
+                       ReductionType, StageGaussianBlur,
                        StageIO, StageSmoothBlur)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -855,3 +855,37 @@ extern "C" int32_t nz_heightmap_mesh(nz_ctx *ctx, int32_t meshType, void *vertic
                           heights));
     return nz_ctx_finish(ctx, out);
 }
+
+// ---------------------------------------------------------------------------------------------
+// element-wise stages
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t nz_constant_job(nz_ctx *ctx, int32_t operation, float *srcL, float *tmp, float constantValue,
+                                   int32_t resolution, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(srcL, "srcL is NULL");
+    (void)tmp;  // element-wise: updated in place, no flush copy
+    NZ_TRY(nz_launch_constant(ctx->stream, operation, srcL, (size_t)resolution * resolution, constantValue));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_reduction_job(nz_ctx *ctx, int32_t operation, float *srcL, const float *srcR, float *tmp,
+                                    int32_t resolution, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(srcL && srcR, "srcL/srcR is NULL");
+    (void)tmp;
+    NZ_TRY(nz_launch_reduce(ctx->stream, operation, srcL, srcR, (size_t)resolution * resolution));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_curve_job(nz_ctx *ctx, float *src, float *tmp, const float *curve, int32_t curveSize,
+                                int32_t resolution, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(src && curve, "src/curve is NULL");
+    NZ_REQUIRE(curveSize >= 2 && curveSize <= 16384, "curve length %d out of range [2,16384]", curveSize);
+    (void)tmp;
+    NZ_TRY(nz_launch_curve(ctx->stream, src, (size_t)resolution * resolution, curve, curveSize));
+    return nz_ctx_finish(ctx, out);
+}

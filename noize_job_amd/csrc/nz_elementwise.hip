@@ -1,0 +1,125 @@
+// nz_elementwise.hip -- per-cell stages either side of the hot path:
+// ConstantJob<ConstantMultiply|ConstantBinarize> (Filter/ConstantJob.cs, Filter/Operators/SimpleMutation.cs:16-55),
+// ReductionJob<Subtract|Multiply|RootSumSquares|Max|Min Tiles> (Filter/ReductionJob.cs, SimpleMutation.cs:57-171),
+// CurveJob<CurveOperator> (Filter/Curve/CurveJob.cs:56-89).
+// Pure streaming kernels: 16 B per lane, in place (the reference's tmp + flush copy is not needed for an
+// element-wise update); 8 or 12 B/cell.
+#include "nz_internal.hpp"
+
+namespace {
+
+constexpr int CT = 256;
+
+template <int OP>
+__device__ __forceinline__ float constant_op(float v, float c) {
+    if constexpr (OP == 0) return v * c;          // ConstantMultiply
+    else return v >= c ? 1.0f : 0.0f;             // ConstantBinarize
+}
+
+template <int OP>
+__device__ __forceinline__ float reduce_op(float a, float b) {
+    if constexpr (OP == 0) return a - b;                         // SubtractTiles
+    else if constexpr (OP == 1) return a * b;                    // MultiplyTiles
+    else if constexpr (OP == 2) return sqrtf((a * a) + (b * b)); // RootSumSquaresTiles
+    else if constexpr (OP == 3) return fmaxf(a, b);              // MaxTiles
+    else return fminf(a, b);                                     // MinTiles
+}
+
+template <int OP>
+__global__ __launch_bounds__(CT) void constant_kernel(float *data, size_t n, float c, int aligned) {
+    size_t i = ((size_t)blockIdx.x * CT + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (aligned && i + 4 <= n) {
+        float4 v = *reinterpret_cast<float4 *>(data + i);
+        v.x = constant_op<OP>(v.x, c); v.y = constant_op<OP>(v.y, c);
+        v.z = constant_op<OP>(v.z, c); v.w = constant_op<OP>(v.w, c);
+        *reinterpret_cast<float4 *>(data + i) = v;
+    } else {
+        for (size_t k = i; k < n && k < i + 4; k++) data[k] = constant_op<OP>(data[k], c);
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(CT) void reduce_kernel(float *l, const float *__restrict__ r, size_t n, int aligned) {
+    size_t i = ((size_t)blockIdx.x * CT + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (aligned && i + 4 <= n) {
+        float4 a = *reinterpret_cast<float4 *>(l + i);
+        float4 b = *reinterpret_cast<const float4 *>(r + i);
+        a.x = reduce_op<OP>(a.x, b.x); a.y = reduce_op<OP>(a.y, b.y);
+        a.z = reduce_op<OP>(a.z, b.z); a.w = reduce_op<OP>(a.w, b.w);
+        *reinterpret_cast<float4 *>(l + i) = a;
+    } else {
+        for (size_t k = i; k < n && k < i + 4; k++) l[k] = reduce_op<OP>(l[k], r[k]);
+    }
+}
+
+// CurveOperator.Apply, Filter/Curve/CurveJob.cs:69-80
+__device__ __forceinline__ float curve_apply(float v, const float *__restrict__ curve, int curveSize) {
+    float rect = fmaxf(0.0f, fminf(1.0f, v)) * (float)curveSize;
+    float lowerIdx = fminf(floorf(rect), (float)(curveSize - 2));
+    float left = curve[(int)lowerIdx];
+    float right = curve[(int)lowerIdx + 1];
+    float value = left + (rect - lowerIdx) * (right - left);  // math.lerp
+    value = fmaxf(0.0f, value);
+    return fminf(1.0f, value);
+}
+
+__global__ __launch_bounds__(CT) void curve_kernel(float *data, size_t n, const float *__restrict__ curve, int curveSize,
+                                                  int aligned) {
+    extern __shared__ float s_curve[];
+    for (int i = threadIdx.x; i < curveSize; i += CT) s_curve[i] = curve[i];
+    __syncthreads();
+    size_t i = ((size_t)blockIdx.x * CT + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (aligned && i + 4 <= n) {
+        float4 v = *reinterpret_cast<float4 *>(data + i);
+        v.x = curve_apply(v.x, s_curve, curveSize); v.y = curve_apply(v.y, s_curve, curveSize);
+        v.z = curve_apply(v.z, s_curve, curveSize); v.w = curve_apply(v.w, s_curve, curveSize);
+        *reinterpret_cast<float4 *>(data + i) = v;
+    } else {
+        for (size_t k = i; k < n && k < i + 4; k++) data[k] = curve_apply(data[k], s_curve, curveSize);
+    }
+}
+
+unsigned blocks_for(size_t n) { return (unsigned)((n + (size_t)CT * 4 - 1) / ((size_t)CT * 4)); }
+
+}  // namespace
+
+int32_t nz_launch_constant(hipStream_t s, int op, float *data, size_t n, float c) {
+    if (n == 0) return NZ_OK;
+    int aligned = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
+    if (op == 0) hipLaunchKernelGGL(constant_kernel<0>, dim3(blocks_for(n)), dim3(CT), 0, s, data, n, c, aligned);
+    else if (op == 1) hipLaunchKernelGGL(constant_kernel<1>, dim3(blocks_for(n)), dim3(CT), 0, s, data, n, c, aligned);
+    else {
+        nz_set_error("unknown ConstantOperationType %d", op);
+        return NZ_ERR_INVALID;
+    }
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_reduce(hipStream_t s, int op, float *l, const float *r, size_t n) {
+    if (n == 0) return NZ_OK;
+    int aligned = ((reinterpret_cast<uintptr_t>(l) | reinterpret_cast<uintptr_t>(r)) & 15) == 0;
+    dim3 grid(blocks_for(n)), block(CT);
+    switch (op) {
+        case 0: hipLaunchKernelGGL(reduce_kernel<0>, grid, block, 0, s, l, r, n, aligned); break;
+        case 1: hipLaunchKernelGGL(reduce_kernel<1>, grid, block, 0, s, l, r, n, aligned); break;
+        case 2: hipLaunchKernelGGL(reduce_kernel<2>, grid, block, 0, s, l, r, n, aligned); break;
+        case 3: hipLaunchKernelGGL(reduce_kernel<3>, grid, block, 0, s, l, r, n, aligned); break;
+        case 4: hipLaunchKernelGGL(reduce_kernel<4>, grid, block, 0, s, l, r, n, aligned); break;
+        default: nz_set_error("unknown ReductionType %d", op); return NZ_ERR_INVALID;
+    }
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_curve(hipStream_t s, float *data, size_t n, const float *curve, int curveSize) {
+    if (n == 0) return NZ_OK;
+    int aligned = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
+    hipLaunchKernelGGL(curve_kernel, dim3(blocks_for(n)), dim3(CT), (size_t)curveSize * sizeof(float), s, data, n, curve,
+                       curveSize, aligned);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}

@@ -146,3 +146,8 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
 
 int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *indices, int res, int in_res,
                        float tile_height, float tile_size, const float *heights);
+
+// element-wise stages (nz_elementwise.hip)
+int32_t nz_launch_constant(hipStream_t s, int op, float *data, size_t n, float c);
+int32_t nz_launch_reduce(hipStream_t s, int op, float *l, const float *r, size_t n);
+int32_t nz_launch_curve(hipStream_t s, float *data, size_t n, const float *curve, int curveSize);

@@ -70,6 +70,19 @@ class GaussSigma(enum.IntEnum):  # Filter/Kernel/Blur/BlurKernels.cs:8-25; sigma
     s8d00 = 15
 
 
+class ConstantOperationType(enum.IntEnum):  # Filter/ConstantStage.cs:15-18
+    MULTIPLY = 0
+    BINARIZE = 1
+
+
+class ReductionType(enum.IntEnum):  # Filter/Reduce/ReduceStage.cs:12-18
+    SUBTRACT = 0
+    MULTIPLY = 1
+    ROOTSUMSQUARES = 2
+    MAX = 3
+    MIN = 4
+
+
 class MeshType(enum.IntEnum):  # Mesh/Stage/MeshTileStage.cs:23-26
     SquareGridHeightMap = 0
     OvershootSquareGridHeightMap = 1
@@ -113,6 +126,15 @@ class MeshStageData(StageIO):  # StageIOTypes/MeshStageData.cs:9-21
         self.xpos = xpos
         self.zpos = zpos
         self.mesh = mesh  # MeshBuffers, stands in for UnityEngine.Mesh
+
+
+class ReduceData(StageIO):  # StageIOTypes/ReduceData.cs:9-17
+    def __init__(self, uuid="", data=None, rightData=None, resolution=512, xpos=0, zpos=0):
+        super().__init__(uuid, data)
+        self.rightData = rightData
+        self.resolution = resolution
+        self.xpos = xpos
+        self.zpos = zpos
 
 
 class MeshBuffers:
@@ -308,6 +330,89 @@ class ErosionStage(PipelineStage):
     def OnDestroy(self):
         if self.tmp is not None and self.tmp.IsCreated:
             self.tmp.Dispose()
+
+
+class ConstantStage(PipelineStage):  # Filter/ConstantStage.cs:13-56
+    def __init__(self, ctx, operation=ConstantOperationType.MULTIPLY, value=0.5):
+        super().__init__(ctx)
+        self.operation = operation
+        self.value = value
+        self.tmp = None
+
+    def ResizeNativeContainers(self, size):
+        self._resize_tmp()
+
+    def Schedule(self, requirements, dependency):
+        self.CheckRequirements(GeneratorData, requirements)
+        d = requirements.data
+        self.jobHandle = self.ctx.call("nz_constant_job", int(self.operation), d.data.ptr, self.tmp.ptr, self.value,
+                                       d.resolution, dep=dependency)
+
+    def OnDestroy(self):
+        if self.tmp is not None and self.tmp.IsCreated:
+            self.tmp.Dispose()
+
+
+class ReduceStage(PipelineStage):  # Filter/Reduce/ReduceStage.cs:20-69
+    def __init__(self, ctx, operation=ReductionType.SUBTRACT):
+        super().__init__(ctx)
+        self.operation = operation
+        self.tmp = None
+
+    def ResizeNativeContainers(self, size):
+        self._resize_tmp()
+
+    def Schedule(self, requirements, dependency):
+        self.CheckRequirements(ReduceData, requirements)
+        d = requirements.data
+        self.jobHandle = self.ctx.call("nz_reduction_job", int(self.operation), d.data.ptr, d.rightData.ptr,
+                                       self.tmp.ptr, d.resolution, dep=dependency)
+
+    def TransformData(self, inputData):  # :53-62: downstream stages see a GeneratorData
+        d = inputData.data
+        inputData.data = GeneratorData(d.uuid, d.data, d.resolution, d.xpos, d.zpos)
+
+    def OnDestroy(self):
+        if self.tmp is not None and self.tmp.IsCreated:
+            self.tmp.Dispose()
+
+
+class CurveStage(PipelineStage):  # Filter/Curve/CurveStage.cs:13-71
+    """`unityCurve` is any callable t in [0,1) -> value (stands in for UnityEngine.AnimationCurve.Evaluate)."""
+
+    def __init__(self, ctx, unityCurve=None, samples=256):
+        super().__init__(ctx)
+        self.unityCurve = unityCurve if unityCurve is not None else (lambda t: t)
+        self.samples = samples
+        self.curve = None
+        self.tmp = None
+
+    def ExtractCurve(self):  # :32-40
+        host = np.array([self.unityCurve(np.float32(i) / np.float32(self.samples)) for i in range(self.samples)],
+                        np.float32)
+        if self.curve is None or not self.curve.IsCreated:
+            self.curve = self.ctx.alloc(self.samples)
+        self.curve.CopyFrom(host)
+        return host
+
+    def ResizeNativeContainers(self, size):
+        if self.curve is not None and self.curve.IsCreated:
+            self.curve.Dispose()
+        self.curve = None
+        self.ExtractCurve()
+        self._resize_tmp()
+
+    def Schedule(self, requirements, dependency):
+        self.CheckRequirements(GeneratorData, requirements)
+        d = requirements.data
+        self.jobHandle = self.ctx.call("nz_curve_job", d.data.ptr, self.tmp.ptr, self.curve.ptr, self.samples,
+                                       d.resolution, dep=dependency)
+
+    def OnDestroy(self):
+        for t in (self.curve, self.tmp):
+            if t is not None and t.IsCreated:
+                t.Dispose()
+        self.curve = self.tmp = None
 
 
 class FlowMapStage(PipelineStage):  # Geologic/Stage/FlowMapStage.cs:16-220

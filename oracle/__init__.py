@@ -75,6 +75,9 @@ def lib():
         L.nzo_normalize.argtypes = [f32p, f32p, f32p, i, i]
         L.nzo_flowmap.argtypes = [f32p, i, i, i, f, f]
         L.nzo_mesh_heightmap.argtypes = [i, f32p, i, i, i, f, f, f32p, u32p]
+        L.nzo_constant.argtypes = [f32p, f32p, i, f, i, i]
+        L.nzo_reduce.argtypes = [f32p, f32p, f32p, i, i, i]
+        L.nzo_curve.argtypes = [f32p, f32p, f32p, i, i, i]
         L.nzo_pipeline.argtypes = [f32p, f32p, i, i, i, f, f, f, f, i, i, i, i, i, i, i, f, f, i]
         # the GPU box grants a CPU share, not the whole host: size the OpenMP team to the affinity mask
         try:
@@ -288,3 +291,33 @@ def pipeline(rows, cols, noise_type=SIMPLEX, hurst=0.4, amp=1.0, stepdown=2.0, d
     if rc:
         raise ValueError("nzo_pipeline rc=%d" % rc)
     return data
+
+
+# ---- element-wise stages --------------------------------------------------------------------
+CONST_MULTIPLY, CONST_BINARIZE = 0, 1
+RED_SUBTRACT, RED_MULTIPLY, RED_ROOTSUMSQUARES, RED_MAX, RED_MIN = range(5)
+
+
+def constant(a, op, value):
+    a = _plane(a).copy()
+    tmp = np.empty_like(a)
+    if lib().nzo_constant(_p(a), _p(tmp), op, value, *a.shape):
+        raise ValueError("bad constant op")
+    return a
+
+
+def reduce(left, right, op):
+    left, right = _plane(left).copy(), _plane(right)
+    tmp = np.empty_like(left)
+    if lib().nzo_reduce(_p(left), _p(right), _p(tmp), op, *left.shape):
+        raise ValueError("bad reduction op")
+    return left
+
+
+def curve(a, samples):
+    a = _plane(a).copy()
+    tmp = np.empty_like(a)
+    samples = np.ascontiguousarray(samples, np.float32)
+    if lib().nzo_curve(_p(a), _p(tmp), _p(samples), len(samples), *a.shape):
+        raise ValueError("bad curve")
+    return a

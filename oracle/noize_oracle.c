@@ -911,6 +911,69 @@ int nzo_mesh_heightmap(int meshType, const float *heights, int resolution, int i
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Element-wise stages: Filter/Operators/SimpleMutation.cs, Filter/ConstantJob.cs,
+ * Filter/ReductionJob.cs, Filter/Curve/CurveJob.cs -- parallel rows into tmp, then the serial flush
+ * ---------------------------------------------------------------------------------------- */
+
+/* ConstantMultiply / ConstantBinarize, SimpleMutation.cs:16-55; op = ConstantStage.ConstantOperationType */
+int nzo_constant(float *src, float *tmp, int op, float value, int rows, int cols) {
+    if (op < 0 || op > 1) return -1;
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z < rows; z++) {
+        for (int x = 0; x < cols; x++) {
+            int c = tile_idx(x, z, rows, cols);
+            tmp[c] = op == 0 ? src[c] * value : (src[c] >= value ? 1.0f : 0.0f);
+        }
+    }
+    flush_write_slice(src, tmp, (size_t)rows * cols);
+    return 0;
+}
+
+/* Subtract / Multiply / RootSumSquares / Max / Min Tiles, SimpleMutation.cs:57-171; op = ReductionType */
+int nzo_reduce(float *srcL, const float *srcR, float *tmp, int op, int rows, int cols) {
+    if (op < 0 || op > 4) return -1;
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z < rows; z++) {
+        for (int x = 0; x < cols; x++) {
+            int c = tile_idx(x, z, rows, cols);
+            float a = srcL[c], b = srcR[c], v;
+            switch (op) {
+                case 0: v = a - b; break;
+                case 1: v = a * b; break;
+                case 2: v = sqrtf((a * a) + (b * b)); break;
+                case 3: v = maxf_(a, b); break;
+                default: v = minf_(a, b); break;
+            }
+            tmp[c] = v;
+        }
+    }
+    flush_write_slice(srcL, tmp, (size_t)rows * cols);
+    return 0;
+}
+
+/* CurveOperator.Apply, CurveJob.cs:69-80 */
+int nzo_curve(float *src, float *tmp, const float *curve, int curveSize, int rows, int cols) {
+    if (curveSize < 2) return -1;
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z < rows; z++) {
+        for (int x = 0; x < cols; x++) {
+            int c = tile_idx(x, z, rows, cols);
+            float v = src[c];
+            float cl = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); /* clamp(v,0,1) = max(0,min(1,v)) */
+            float rect = cl * (float)curveSize;
+            float lowerIdx = minf_(floorf(rect), (float)(curveSize - 2));
+            float left = curve[(int)lowerIdx], right = curve[(int)lowerIdx + 1];
+            float value = lerpf_(left, right, (rect - lowerIdx));
+            value = maxf_(0.0f, value);
+            value = minf_(1.0f, value);
+            tmp[c] = value;
+        }
+    }
+    flush_write_slice(src, tmp, (size_t)rows * cols);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Metric pipeline (README.md:23-32): noise -> KernelFilterStage(iterations) -> FlowMapStage ->
  * ErosionKernelJob x E, every stage reference-shaped.
  * ---------------------------------------------------------------------------------------- */

@@ -130,6 +130,11 @@ int nzo_mesh_heightmap(int meshType, const float *heights, int resolution, int i
                        int marginPix, float tileHeight, float tileSize, float *vtx,
                        uint32_t *idx);
 
+/* ---- element-wise stages ---- */
+int nzo_constant(float *src, float *tmp, int op, float value, int rows, int cols);      /* Filter/ConstantJob.cs */
+int nzo_reduce(float *srcL, const float *srcR, float *tmp, int op, int rows, int cols); /* Filter/ReductionJob.cs */
+int nzo_curve(float *src, float *tmp, const float *curve, int curveSize, int rows, int cols); /* Filter/Curve/CurveJob.cs */
+
 /* reference-shaped metric pipeline on one tile (bench cpu_baseline): fractal -> kernel filter x G
  * -> flowmap(F) -> erosion x E.  tmp must hold rows*cols floats. */
 int nzo_pipeline(float *data, float *tmp, int rows, int cols, int noiseType, float hurst,

@@ -296,3 +296,46 @@ def test_cpp_host_mirror_runs_the_metric_pipeline(oracle, tmp_path):
     subprocess.check_call([exe, "256", out, "17", "5", "5"])
     got = np.fromfile(out, dtype=np.float32).reshape(256, 256)
     assert np.array_equal(got, oracle.pipeline(256, 256))
+
+
+# ---- element-wise stages ------------------------------------------------------
+def test_constant_reduce_curve_stages(nj, ctx, oracle):
+    res = 130
+    rng = np.random.default_rng(21)
+    a = (rng.random((res, res), dtype=f32) * f32(1.4) - f32(0.2)).astype(f32)
+    b = rng.random((res, res), dtype=f32)
+    for op in (0, 1):
+        got = run(nj.ConstantStage(ctx, nj.ConstantOperationType(op), 0.37), nj, gen(nj, ctx, res, host=a))
+        assert np.array_equal(got, oracle.constant(a, op, 0.37)), op
+    for op in range(5):
+        d = nj.ReduceData("r", ctx.from_host(a), ctx.from_host(b), res)
+        wi = nj.PipelineWorkItem(d)
+        st = nj.ReduceStage(ctx, nj.ReductionType(op))
+        st.ReceiveHandledInput(wi, nj.JobHandle())
+        st.jobHandle.Complete()
+        assert isinstance(wi.data, nj.GeneratorData)  # TransformData, ReduceStage.cs:53-62
+        assert np.array_equal(wi.data.data.ToArray((res, res)), oracle.reduce(a, b, op)), op
+    for fn, samples in ((lambda t: 1.0 - t, 256), (lambda t: t * t * (3.0 - 2.0 * t), 64), (lambda t: 1.5 * t - 0.1, 7)):
+        st = nj.CurveStage(ctx, fn, samples)
+        got = run(st, nj, gen(nj, ctx, res, host=a))
+        host = np.array([fn(f32(i) / f32(samples)) for i in range(samples)], f32)
+        assert np.array_equal(got, oracle.curve(a, host)), samples
+    with pytest.raises(Exception, match="Unhandled stageio"):
+        run(nj.ReduceStage(ctx, nj.ReductionType.MAX), nj, gen(nj, ctx, res, host=a))
+
+
+def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):
+    # BasicDemo "ParallelFlowMap": Perlin fBm -> Invert (curve) -> FlowMapStage -> CurveBoostContrast
+    res = 128
+    data = ctx.alloc(res * res)
+    invert, boost = (lambda t: 1.0 - t), (lambda t: min(1.0, 4.0 * t))
+    stages = [nj.NoiseStage(ctx, nj.FractalNoise.Perlin, 0.5938, 1.0, 6, 1.9168, 0.0317, 658), nj.CurveStage(ctx, invert, 256),
+              nj.FlowMapStage(ctx, 1, 0.0, 0.005), nj.CurveStage(ctx, boost, 256)]
+    pipe = nj.BasePipeline(stages)
+    pipe.Enqueue(nj.GeneratorData("demo", data, res, 0, 0))
+    pipe.RunToCompletion()
+    want = oracle.fractal(oracle.PERLIN, res, res, 0.5938, 1.0, 1.9168, 0.0317, 6, 0, 0, 658)
+    want = oracle.curve(want, np.array([invert(f32(i) / f32(256)) for i in range(256)], f32))
+    want = oracle.flowmap(want, 1, 0.0, 0.005)
+    want = oracle.curve(want, np.array([boost(f32(i) / f32(256)) for i in range(256)], f32))
+    assert np.array_equal(data.ToArray((res, res)), want)

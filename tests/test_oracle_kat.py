@@ -347,3 +347,29 @@ def test_pipeline_equals_stage_composition(oracle):
     a = oracle.erosion_min(a, 2)
     b = oracle.pipeline(R, R, gauss_iterations=3, flow_iterations=2, erosion_iterations=2)
     assert np.array_equal(a, b)
+
+
+# ---- element-wise stages ------------------------------------------------------
+def test_constant_reduce_curve_known_answers(oracle):
+    a = np.array([[0.1, 0.5], [0.75, 1.5]], f32)
+    b = np.array([[0.4, 0.5], [0.25, -2.0]], f32)
+    assert np.array_equal(oracle.constant(a, oracle.CONST_MULTIPLY, 0.5), a * f32(0.5))
+    assert np.array_equal(oracle.constant(a, oracle.CONST_BINARIZE, 0.5), np.array([[0, 1], [1, 1]], f32))  # >=
+    assert np.array_equal(oracle.reduce(a, b, oracle.RED_SUBTRACT), a - b)
+    assert np.array_equal(oracle.reduce(a, b, oracle.RED_MULTIPLY), a * b)
+    assert np.array_equal(oracle.reduce(a, b, oracle.RED_ROOTSUMSQUARES), np.sqrt(a * a + b * b))
+    assert np.array_equal(oracle.reduce(a, b, oracle.RED_MAX), np.maximum(a, b))
+    assert np.array_equal(oracle.reduce(a, b, oracle.RED_MIN), np.minimum(a, b))
+    # CurveOperator.Apply: rect = clamp(v)*N, lower = min(floor(rect), N-2), lerp, clamp to [0,1]
+    n = 4
+    samples = np.array([0.0, 0.2, 0.9, 1.2], f32)
+    v = np.array([[-1.0, 0.0, 0.3], [0.5, 0.99, 7.0]], f32)
+    got = oracle.curve(v, samples)
+    want = []
+    for x in v.reshape(-1):
+        rect = f32(min(max(x, f32(0)), f32(1)) * f32(n))
+        lo = min(np.floor(rect), f32(n - 2))
+        val = samples[int(lo)] + f32(rect - lo) * f32(samples[int(lo) + 1] - samples[int(lo)])
+        want.append(min(f32(1), max(f32(0), f32(val))))
+    assert np.array_equal(got.reshape(-1), np.array(want, f32))
+    assert got[1, 2] == 1.0  # v = 1 -> rect = 4 -> lower 2, t = 2 -> extrapolates past the last sample, clamped
