@@ -34,10 +34,19 @@ extern "C" int32_t nz_device_count(int32_t *count) {
     return NZ_OK;
 }
 
+#define NZ_TRY_(expr)             \
+    do {                          \
+        int32_t rc__ = (expr);    \
+        if (rc__) return rc__;    \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
 static constexpr size_t NZ_EVENT_RING = 4096;
+
+static int32_t ctx_sync_all(nz_ctx *ctx);
+extern "C" int32_t nz_ctx_set_bands(nz_ctx *ctx, int32_t bands);
 
 static int32_t build_rgrad_table(nz_ctx *ctx) {
     // rgrad2 of noise.psrnoise: the hash is an exact integer in
@@ -119,6 +128,10 @@ static int32_t ctx_create(int32_t device, hipStream_t stream, bool own, nz_ctx *
         return rc;
     }
     *out = ctx;
+    if (const char *env = getenv("NZ_BANDS")) {
+        int nb = atoi(env);
+        if (nb > 1) return nz_ctx_set_bands(ctx, nb);
+    }
     return NZ_OK;
 }
 
@@ -131,7 +144,12 @@ extern "C" int32_t nz_ctx_create_on_stream(int32_t device, void *hip_stream, nz_
 extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     if (!ctx) return NZ_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)ctx_sync_all(ctx);
+    for (hipStream_t bs : ctx->bstreams) (void)hipStreamDestroy(bs);
+    for (int k = 0; k < 2; k++)
+        for (hipEvent_t ev : ctx->bev[k]) (void)hipEventDestroy(ev);
+    if (ctx->hstream) (void)hipStreamDestroy(ctx->hstream);
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     for (hipEvent_t ev : ctx->events)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->d_rgrad) (void)hipFree(ctx->d_rgrad);
@@ -145,38 +163,147 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
 extern "C" int32_t nz_ctx_synchronize(nz_ctx *ctx) {
     NZ_REQUIRE(ctx, "ctx is NULL");
     NZ_HIP(hipSetDevice(ctx->device));
-    NZ_HIP(hipStreamSynchronize(ctx->stream));
-    return NZ_OK;
+    return ctx_sync_all(ctx);
 }
 
 extern "C" void *nz_ctx_stream(nz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep) {
+static int32_t bands_join(nz_ctx *ctx) {
+    // the main stream catches up with every band: needed before any call that is not band-aware
+    if (!ctx->bands_active) return NZ_OK;
+    for (int b = 0; b < ctx->nbands; b++)
+        if (ctx->bev_valid[b]) NZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->bev[ctx->bev_prev][b], 0));
+    ctx->bands_active = false;
+    return NZ_OK;
+}
+
+static int32_t ctx_sync_all(nz_ctx *ctx) {
+    NZ_HIP(hipStreamSynchronize(ctx->stream));
+    for (hipStream_t bs : ctx->bstreams) NZ_HIP(hipStreamSynchronize(bs));
+    if (ctx->hstream) NZ_HIP(hipStreamSynchronize(ctx->hstream));
+    return NZ_OK;
+}
+
+int32_t nz_ctx_begin_banded(nz_ctx *ctx, nz_handle dep) {
     NZ_REQUIRE(ctx, "ctx is NULL");
     NZ_HIP(hipSetDevice(ctx->device));
-    // all work of a ctx is ordered on one stream, so a dependency on one of its own handles is
-    // already satisfied by stream order; anything else is a caller error
+    // all work of a ctx is ordered on its streams, so a dependency on one of its own handles is
+    // already satisfied by that order; anything else is a caller error
     NZ_REQUIRE(dep <= ctx->last_handle, "dependency handle %llu was not issued by this context",
                (unsigned long long)dep);
     return NZ_OK;
 }
 
+int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep) {
+    int32_t rc = nz_ctx_begin_banded(ctx, dep);
+    if (rc) return rc;
+    return bands_join(ctx);
+}
+
+static int32_t handle_new_event(nz_ctx *ctx, hipEvent_t **ev, uint64_t *h) {
+    if (ctx->events.empty()) ctx->events.assign(NZ_EVENT_RING, nullptr);
+    *h = ctx->last_handle + 1;
+    *ev = &ctx->events[*h % NZ_EVENT_RING];
+    if (!**ev) NZ_HIP(hipEventCreate(*ev));
+    return NZ_OK;
+}
+
 int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out) {
     if (!out) return NZ_OK;
-    if (ctx->events.empty()) ctx->events.assign(NZ_EVENT_RING, nullptr);
-    uint64_t h = ctx->last_handle + 1;
-    hipEvent_t &ev = ctx->events[h % NZ_EVENT_RING];
-    if (!ev) NZ_HIP(hipEventCreate(&ev));
-    NZ_HIP(hipEventRecord(ev, ctx->stream));
+    hipEvent_t *ev;
+    uint64_t h;
+    int32_t rc = handle_new_event(ctx, &ev, &h);
+    if (rc) return rc;
+    if (ctx->bands_active) {
+        // marker = all bands done, recorded on a side stream so that neither the main stream nor the
+        // band streams wait for it
+        for (int b = 0; b < ctx->nbands; b++)
+            if (ctx->bev_valid[b]) NZ_HIP(hipStreamWaitEvent(ctx->hstream, ctx->bev[ctx->bev_prev][b], 0));
+        NZ_HIP(hipEventRecord(*ev, ctx->hstream));
+    } else {
+        NZ_HIP(hipEventRecord(*ev, ctx->stream));
+    }
     ctx->last_handle = h;
     *out = h;
+    return NZ_OK;
+}
+
+// Runs `launch(stream, geom)` once per row band of [g.or0, g.or1).  Band b waits for the previous
+// launch of bands b-1 and b+1 (read-after-write of their halo rows and write-after-read of the plane
+// they may still be reading); with `stagger` it also waits for band b-1 of THIS launch, which
+// serialises a halo-free stage band by band so that later stages of early bands can start under it.
+template <class F>
+static int32_t banded_launch(nz_ctx *ctx, const nz_geom &g, bool stagger, F launch) {
+    int rows = g.or1 - g.or0;
+    if (ctx->nbands <= 1 || rows < 128 * ctx->nbands) {
+        int32_t rc = bands_join(ctx);
+        if (rc) return rc;
+        return launch(ctx->stream, g);
+    }
+    const int B = ctx->nbands;
+    if (ctx->bands_active && (ctx->band_or0 != g.or0 || ctx->band_or1 != g.or1)) {
+        int32_t rc = bands_join(ctx);  // a different partition: start over from a full barrier
+        if (rc) return rc;
+    }
+    if (!ctx->bands_active) {
+        NZ_HIP(hipEventRecord(ctx->fork_ev, ctx->stream));
+        for (int b = 0; b < B; b++) {
+            NZ_HIP(hipStreamWaitEvent(ctx->bstreams[b], ctx->fork_ev, 0));
+            ctx->bev_valid[b] = 0;
+        }
+        ctx->bands_active = true;
+        ctx->band_or0 = g.or0;
+        ctx->band_or1 = g.or1;
+    }
+    const int prev = ctx->bev_prev, cur = prev ^ 1;
+    for (int b = 0; b < B; b++) {
+        nz_geom gb = g;
+        gb.or0 = g.or0 + (int)(((long long)rows * b / B) & ~7LL);
+        gb.or1 = b == B - 1 ? g.or1 : g.or0 + (int)(((long long)rows * (b + 1) / B) & ~7LL);
+        hipStream_t bs = ctx->bstreams[b];
+        if (b > 0 && ctx->bev_valid[b - 1]) NZ_HIP(hipStreamWaitEvent(bs, ctx->bev[prev][b - 1], 0));
+        if (b + 1 < B && ctx->bev_valid[b + 1]) NZ_HIP(hipStreamWaitEvent(bs, ctx->bev[prev][b + 1], 0));
+        if (stagger && b > 0) NZ_HIP(hipStreamWaitEvent(bs, ctx->bev[cur][b - 1], 0));
+        int32_t rc = launch(bs, gb);
+        if (rc) return rc;
+        NZ_HIP(hipEventRecord(ctx->bev[cur][b], bs));
+    }
+    for (int b = 0; b < B; b++) ctx->bev_valid[b] = 1;
+    ctx->bev_prev = cur;
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_ctx_set_bands(nz_ctx *ctx, int32_t bands) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    NZ_REQUIRE(bands >= 1 && bands <= 64, "bands %d out of range [1,64]", bands);
+    NZ_HIP(hipSetDevice(ctx->device));
+    int32_t rc = bands_join(ctx);
+    if (rc) return rc;
+    rc = ctx_sync_all(ctx);
+    if (rc) return rc;
+    while ((int)ctx->bstreams.size() < bands) {
+        hipStream_t st;
+        NZ_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ctx->bstreams.push_back(st);
+        for (int k = 0; k < 2; k++) {
+            hipEvent_t ev;
+            NZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->bev[k].push_back(ev);
+        }
+        ctx->bev_valid.push_back(0);
+    }
+    if (bands > 1 && !ctx->hstream) {
+        NZ_HIP(hipStreamCreateWithFlags(&ctx->hstream, hipStreamNonBlocking));
+        NZ_HIP(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+    }
+    ctx->nbands = bands;
     return NZ_OK;
 }
 
 int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out) {
     if (floats > ctx->scratch_floats) {
         if (ctx->scratch) {
-            NZ_HIP(hipStreamSynchronize(ctx->stream));
+            NZ_TRY_(ctx_sync_all(ctx));
             NZ_HIP(hipFree(ctx->scratch));
             ctx->scratch = nullptr;
             ctx->scratch_floats = 0;
@@ -210,7 +337,8 @@ extern "C" int32_t nz_handle_query(nz_ctx *ctx, nz_handle h, int32_t *is_complet
         *is_completed = 1;  // default(JobHandle).IsCompleted == true
         return NZ_OK;
     }
-    hipError_t e = handle_live(ctx, h) ? hipEventQuery(ctx->events[h % NZ_EVENT_RING]) : hipStreamQuery(ctx->stream);
+    hipError_t e = handle_live(ctx, h) ? hipEventQuery(ctx->events[h % NZ_EVENT_RING])
+                                      : (ctx->bands_active ? hipErrorNotReady : hipStreamQuery(ctx->stream));
     if (e == hipSuccess) {
         *is_completed = 1;
     } else if (e == hipErrorNotReady) {
@@ -231,7 +359,7 @@ extern "C" int32_t nz_handle_wait(nz_ctx *ctx, nz_handle h) {
     if (handle_live(ctx, h)) {
         NZ_HIP(hipEventSynchronize(ctx->events[h % NZ_EVENT_RING]));
     } else {
-        NZ_HIP(hipStreamSynchronize(ctx->stream));
+        NZ_TRY_(ctx_sync_all(ctx));
     }
     return NZ_OK;
 }
@@ -263,7 +391,7 @@ extern "C" int32_t nz_tile_free(nz_ctx *ctx, float *dev) {
     NZ_REQUIRE(ctx, "ctx is NULL");
     if (!dev) return NZ_OK;
     NZ_HIP(hipSetDevice(ctx->device));
-    NZ_HIP(hipStreamSynchronize(ctx->stream));  // Dispose(handle): free after the work that uses it
+    NZ_TRY_(ctx_sync_all(ctx));  // Dispose(handle): free after the work that uses it
     NZ_HIP(hipFree(dev));
     return NZ_OK;
 }
@@ -326,7 +454,8 @@ static float calc_fractal_norm(float hurst, int octaves) {
     return t;
 }
 
-static int32_t fractal_impl(nz_ctx *ctx, int noiseType, float *dst, int rows, int cols, int pitch, float hurst,
+static int32_t fractal_impl(nz_ctx *ctx, hipStream_t stream, int noiseType, float *dst, int rows, int cols, int pitch,
+                            float hurst,
                             float amp, float stepdown, float detune, int octaves, int xpos, int zpos_first_row,
                             int noiseSize) {
     NZ_REQUIRE(dst, "src is NULL");
@@ -343,7 +472,7 @@ static int32_t fractal_impl(nz_ctx *ctx, int noiseType, float *dst, int rows, in
     p.detune_rate = detune;
     p.norm = calc_fractal_norm(hurst, octaves);
     p.octaves = octaves;
-    return nz_launch_fractal(ctx->stream, noiseType, dst, rows, cols, pitch, p, ctx->d_rgrad, ctx->d_simplex);
+    return nz_launch_fractal(stream, noiseType, dst, rows, cols, pitch, p, ctx->d_rgrad, ctx->d_simplex);
 }
 
 // SeparableKernelFilter tables, Filter/Kernel/KernelJob.cs:97-136.  Gaussian bodies are
@@ -451,9 +580,13 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     int cap = (t.ksize & 1) ? conv_tcap(t.ksize) : 0;
     if (cap == 0 || iterations == 1) {
         for (int i = 0; i < iterations; i++) {
-            int32_t rc = nz_launch_conv_pass_x(ctx->stream, src, tmp, g, t);
+            int32_t rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+                return nz_launch_conv_pass_x(st, src, tmp, gb, t);
+            });
             if (rc) return rc;
-            rc = nz_launch_conv_pass_z(ctx->stream, tmp, src, g, t);
+            rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+                return nz_launch_conv_pass_z(st, tmp, src, gb, t);
+            });
             if (rc) return rc;
         }
         return NZ_OK;
@@ -464,7 +597,9 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
         int T = base + (i < rem ? 1 : 0);
-        int32_t rc = nz_launch_conv_fused(ctx->stream, cur, other, g, t, T);
+        int32_t rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            return nz_launch_conv_fused(st, cur, other, gb, t, T);
+        });
         if (rc) return rc;
         float *s = cur; cur = other; other = s;
     }
@@ -475,9 +610,13 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
     NZ_REQUIRE(src && tmp && src != tmp, "src/tmp must be two distinct planes");
     NZ_REQUIRE(iterations >= 1, "iterations < 1");
     if (iterations == 1) {  // ErosionKernelJob.ScheduleSeries KernelJob.cs:318-335: min-X then min-Z, size 3
-        int32_t rc = nz_launch_min_pass(ctx->stream, src, tmp, g, 3, 0);
+        int32_t rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            return nz_launch_min_pass(st, src, tmp, gb, 3, 0);
+        });
         if (rc) return rc;
-        return nz_launch_min_pass(ctx->stream, tmp, src, g, 3, 1);
+        return banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            return nz_launch_min_pass(st, tmp, src, gb, 3, 1);
+        });
     }
     int cap = nz_erosion_max_fused();
     int L = (iterations + cap - 1) / cap;
@@ -487,7 +626,9 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
         int E = base + (i < rem ? 1 : 0);
-        int32_t rc = nz_launch_erosion_fused(ctx->stream, cur, other, g, E);
+        int32_t rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            return nz_launch_erosion_fused(st, cur, other, gb, E);
+        });
         if (rc) return rc;
         float *s = cur; cur = other; other = s;
     }
@@ -498,6 +639,12 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
     do {                                     \
         int32_t rc_ = nz_ctx_begin(ctx, dep); \
         if (rc_) return rc_;                 \
+    } while (0)
+
+#define NZ_BEGIN_BANDED(ctx, dep)                    \
+    do {                                             \
+        int32_t rc_ = nz_ctx_begin_banded(ctx, dep); \
+        if (rc_) return rc_;                         \
     } while (0)
 
 #define NZ_TRY(expr)              \
@@ -512,10 +659,15 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
 extern "C" int32_t nz_fractal(nz_ctx *ctx, int32_t noiseType, float *src, int32_t resolution, float hurst,
                               float startingAmplitude, float stepdown, float detuneRate, int32_t octaves,
                               int32_t xpos, int32_t zpos, int32_t noiseSize, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
+    NZ_BEGIN_BANDED(ctx, dep);
     NZ_TRY(check_res(resolution));
-    NZ_TRY(fractal_impl(ctx, noiseType, src, resolution, resolution, resolution, hurst, startingAmplitude, stepdown,
-                        detuneRate, octaves, xpos, zpos, noiseSize));
+    // no halo: bands are serialised (stagger) so that the filters of the first bands can start under the
+    // noise of the later ones
+    NZ_TRY(banded_launch(ctx, nz_geom_tile(resolution), true, [&](hipStream_t st, const nz_geom &gb) {
+        return fractal_impl(ctx, st, noiseType, src ? src + (size_t)gb.or0 * resolution : nullptr, gb.or1 - gb.or0,
+                            resolution, resolution, hurst, startingAmplitude, stepdown, detuneRate, octaves, xpos,
+                            zpos + gb.or0, noiseSize);
+    }));
     return nz_ctx_finish(ctx, out);
 }
 
@@ -528,7 +680,7 @@ extern "C" int32_t nz_fractal_stripe(nz_ctx *ctx, int32_t noiseType, float *buf,
     int pitch = st->pitch > 0 ? st->pitch : st->cols;
     int rows = st->own1 - st->own0;
     if (rows > 0) {
-        NZ_TRY(fractal_impl(ctx, noiseType, buf + (size_t)st->own0 * pitch, rows, st->cols, pitch, hurst,
+        NZ_TRY(fractal_impl(ctx, ctx->stream, noiseType, buf + (size_t)st->own0 * pitch, rows, st->cols, pitch, hurst,
                             startingAmplitude, stepdown, detuneRate, octaves, xpos, zpos + st->grow0 + st->own0,
                             noiseSize));
     }
@@ -540,7 +692,7 @@ extern "C" int32_t nz_fractal_stripe(nz_ctx *ctx, int32_t noiseType, float *buf,
 // ---------------------------------------------------------------------------------------------
 extern "C" int32_t nz_kernel_filter_stage(nz_ctx *ctx, float *src, float *tmp, int32_t filter, int32_t iterations,
                                           int32_t resolution, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
+    NZ_BEGIN_BANDED(ctx, dep);
     NZ_TRY(check_res(resolution));
     nz_kernel_taps t;
     NZ_TRY(filter_taps(filter, &t));
@@ -555,7 +707,7 @@ extern "C" int32_t nz_kernel_filter(nz_ctx *ctx, float *src, float *tmp, int32_t
 
 extern "C" int32_t nz_gauss_blur_stage(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t sigma,
                                        int32_t iterations, int32_t resolution, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
+    NZ_BEGIN_BANDED(ctx, dep);
     NZ_TRY(check_res(resolution));
     nz_kernel_taps t;
     NZ_TRY(gauss_taps(width, sigma, &t));
@@ -570,7 +722,7 @@ extern "C" int32_t nz_gauss_filter(nz_ctx *ctx, float *src, float *tmp, int32_t 
 
 extern "C" int32_t nz_smooth_blur_stage(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t iterations,
                                         int32_t resolution, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
+    NZ_BEGIN_BANDED(ctx, dep);
     NZ_TRY(check_res(resolution));
     nz_kernel_taps t;
     NZ_TRY(smooth_taps(width, &t));
@@ -603,7 +755,7 @@ extern "C" int32_t nz_separable_series(nz_ctx *ctx, float *src, float *tmp, int3
 
 extern "C" int32_t nz_erosion_stage(nz_ctx *ctx, float *src, float *tmp, int32_t iterations, int32_t resolution,
                                     nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
+    NZ_BEGIN_BANDED(ctx, dep);
     NZ_TRY(check_res(resolution));
     NZ_TRY(erosion_iterations(ctx, src, tmp, nz_geom_tile(resolution), iterations));
     return nz_ctx_finish(ctx, out);
@@ -725,7 +877,7 @@ extern "C" size_t nz_flowmap_stage_work_floats(int32_t resolution) {
 
 extern "C" int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
                                     float normMax, int32_t resolution, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
+    NZ_BEGIN_BANDED(ctx, dep);
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(src && work, "src/work is NULL");
     NZ_REQUIRE(iterations >= 1, "iterations < 1");
@@ -752,11 +904,19 @@ extern "C" int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_
         int first = i == 0, last = i == launches - 1;
         const float *hsrc = first ? src : hcopy;
         float *dst = !last ? nullptr : (launches == 1 ? hcopy : src);
-        NZ_TRY(nz_launch_flow_fused(ctx->stream, hsrc, first ? nullptr : cur, last ? nullptr : nxt, dst,
-                                    (first && !last) ? hcopy : nullptr, g, nit, first, last, normMin, normMax - normMin));
+        NZ_TRY(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            return nz_launch_flow_fused(st, hsrc, first ? nullptr : cur, last ? nullptr : nxt, dst,
+                                        (first && !last) ? hcopy : nullptr, gb, nit, first, last, normMin,
+                                        normMax - normMin);
+        }));
         float **s = cur; cur = nxt; nxt = s;
     }
-    if (launches == 1) NZ_TRY(nz_launch_copy(ctx->stream, src, hcopy, n));
+    if (launches == 1) {
+        NZ_TRY(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            size_t off = (size_t)gb.or0 * gb.pitch;
+            return nz_launch_copy(st, src + off, hcopy + off, (size_t)(gb.or1 - gb.or0) * gb.pitch);
+        }));
+    }
     return nz_ctx_finish(ctx, out);
 }
 

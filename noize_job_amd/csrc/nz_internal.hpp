@@ -43,12 +43,25 @@ struct nz_ctx {
     float *d_rgrad = nullptr;
     // snoise lattice tables: int T1[292] (16*permute(i)) followed by float4 T2[580] (gradient of permute(j))
     void *d_simplex = nullptr;
+    // Banded asynchronous execution (nz_ctx_set_bands): the stage-level calls split a tile into row bands,
+    // one HIP stream per band; a band's launch waits only for the previous launch of its two neighbours, so
+    // compute-bound and memory-bound stages of different bands overlap on the GPU.
+    int nbands = 1;
+    std::vector<hipStream_t> bstreams;
+    std::vector<hipEvent_t> bev[2];   // [set][band]: events of the previous / current launch
+    std::vector<char> bev_valid;      // previous-launch event recorded since the last fork?
+    int bev_prev = 0;
+    bool bands_active = false;        // band streams hold work the main stream has not joined
+    int band_or0 = -1, band_or1 = -1; // row range the current partition was made for
+    hipEvent_t fork_ev = nullptr;
+    hipStream_t hstream = nullptr;    // carries the JobHandle markers of banded calls
     // stage scratch owned by the ctx (grown on demand)
     float *scratch = nullptr;
     size_t scratch_floats = 0;
 };
 
-int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep);           // set device, honour `dep`
+int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep);           // set device, honour `dep`, join the band streams
+int32_t nz_ctx_begin_banded(nz_ctx *ctx, nz_handle dep);    // same, but leaves the band streams running
 int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out);         // record the JobHandle marker
 int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out);
 
