@@ -210,12 +210,13 @@ __device__ __forceinline__ float dpp_next(float v) {  // lane i <- lane i+1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-template <int KS, bool UNIT>
-__global__ __launch_bounds__(CT) void conv_reg_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
+template <int KS, bool UNIT, int NT>
+__global__ __launch_bounds__(NT) void conv_reg_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
                                                      nz_kernel_taps taps, int T, int aligned) {
     constexpr int O = (KS - 1) / 2;
     constexpr int WN = 4 + 2 * O;   // X window
     constexpr int ZN = RB + 2 * O;  // Z window
+    constexpr int TH = NT / 32 * RB;  // tile rows: one 8-row block per 32 threads (shadows the file-level TH)
     // boundary rows of every 8-row block: [parity][block][top|bottom][o][column group]
     __shared__ float4 s_edge[2][TH / RB][2][O][TW / 4];
 
@@ -486,21 +487,28 @@ __global__ __launch_bounds__(CT) void min_pass_kernel(const float *__restrict__ 
     dst[(size_t)z * g.pitch + x] = v;
 }
 
+#ifndef NZ_CONV_NT
+#define NZ_CONV_NT 256
+#endif
+
 template <int KS>
 int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T) {
     constexpr int O = (KS - 1) / 2;
     int H = T * O, HX = (H + 3) & ~3;
-    int OW = TW - 2 * HX, OH = TH - 2 * H;
-    long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
     static const int use_lds = getenv("NZ_CONV_LDS") ? atoi(getenv("NZ_CONV_LDS")) : 0;
     if (use_lds) {
+        int OW = TW - 2 * HX, OH = TH - 2 * H;
+        long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
         hipLaunchKernelGGL((conv_fused_kernel<KS>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, T);
     } else {
+        constexpr int NT = NZ_CONV_NT, RTH = NT / 32 * RB;  // register tile: RTH rows x 128 columns
+        int OW = TW - 2 * HX, OH = RTH - 2 * H;
+        long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
         int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
         if (k.factor == 1.0f)
-            hipLaunchKernelGGL((conv_reg_kernel<KS, true>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, T, aligned);
+            hipLaunchKernelGGL((conv_reg_kernel<KS, true, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, src, dst, g, k, T, aligned);
         else
-            hipLaunchKernelGGL((conv_reg_kernel<KS, false>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, T, aligned);
+            hipLaunchKernelGGL((conv_reg_kernel<KS, false, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, src, dst, g, k, T, aligned);
     }
     NZ_HIP(hipGetLastError());
     return NZ_OK;
