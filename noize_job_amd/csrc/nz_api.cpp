@@ -70,12 +70,16 @@ static int32_t build_rgrad_table(nz_ctx *ctx) {
 static float h_mod289(float x) { return x - floorf(x * (1.0f / 289.0f)) * 289.0f; }
 static float h_permute(float x) { return h_mod289((34.0f * x + 1.0f) * x); }
 
+static float h_mod7(float x) { return x - floorf(x * (1.0f / 7.0f)) * 7.0f; }
+
 static int32_t build_simplex_tables(nz_ctx *ctx) {
-    // see nz_fractal.hip, snoise2_tab: T1[i] = 16*permute(i); T2[j] = gradient terms of p = permute(j), computed
-    // with exactly the operations of noise.snoise (x = 2*frac(p*C.w) - 1; h = |x| - 0.5; a0 = x - floor(x + 0.5);
-    // 1.79284291400159 - 0.85373472095314*(a0*a0 + h*h)).
-    constexpr int T1 = 292, T2 = 580;
-    std::vector<int32_t> buf(T1 + T2 * 4);
+    // Lattice tables of nz_fractal.hip (snoise2_tab, cnoise2_tab, cellular_rect_tab), every entry computed
+    // with exactly the operations of the corresponding Unity.Mathematics.noise function:
+    //   simplex : T1[292] int = 16*permute(i);      T2[580] float4 = {a0, h, 1.79284291400159 - 0.85373472095314*(a0*a0+h*h), 0}
+    //   perlin  : P1[292] int = 8*permute(i);       P2[584] float2 = {gx*norm, gy*norm} of permute(j)
+    //   cellular: C1[292] int = 8*permute(i-1);     C2[584] float2 = {ox, oy} of permute(a-1)
+    constexpr int T1 = 292, T2 = 580, B1 = 292, B2 = 584;
+    std::vector<int32_t> buf(T1 + T2 * 4 + 2 * (B1 + B2 * 2));
     for (int i = 0; i < T1; i++) buf[i] = 16 * (int32_t)h_permute((float)i);
     float *t2 = reinterpret_cast<float *>(buf.data() + T1);
     for (int j = 0; j < T2; j++) {
@@ -90,6 +94,30 @@ static int32_t build_simplex_tables(nz_ctx *ctx) {
         t2[4 * j + 1] = h;
         t2[4 * j + 2] = nrm;
         t2[4 * j + 3] = 0.0f;
+    }
+    int32_t *p1 = buf.data() + T1 + T2 * 4;
+    float *p2 = reinterpret_cast<float *>(p1 + B1);
+    for (int i = 0; i < B1; i++) p1[i] = 8 * (int32_t)h_permute((float)i);
+    for (int j = 0; j < B2; j++) {  // noise.cnoise: gradient of i = permute(permute(ix) + iy), normalised
+        float i = h_permute((float)j);
+        float y = i * (1.0f / 41.0f);
+        float g = (y - floorf(y)) * 2.0f - 1.0f;
+        float gy = fabsf(g) - 0.5f;
+        float tx = floorf(g + 0.5f);
+        float gx = g - tx;
+        float nrm = 1.79284291400159f - 0.85373472095314f * (gx * gx + gy * gy);
+        p2[2 * j + 0] = gx * nrm;
+        p2[2 * j + 1] = gy * nrm;
+    }
+    int32_t *c1 = p1 + B1 + B2 * 2;
+    float *c2 = reinterpret_cast<float *>(c1 + B1);
+    const float K = 0.142857142857f, Ko = 0.428571428571f;
+    for (int i = 0; i < B1; i++) c1[i] = 8 * (int32_t)h_permute((float)(i - 1));
+    for (int a = 0; a < B2; a++) {  // noise.cellular: ox = frac(p*K) - Ko; oy = mod7(floor(p*K))*K - Ko
+        float p = h_permute((float)(a - 1));
+        float pk = p * K;
+        c2[2 * a + 0] = (pk - floorf(pk)) - Ko;
+        c2[2 * a + 1] = h_mod7(floorf(pk)) * K - Ko;
     }
     NZ_HIP(hipMalloc(&ctx->d_simplex, buf.size() * sizeof(int32_t)));
     NZ_HIP(hipMemcpy(ctx->d_simplex, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -475,6 +475,122 @@ __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restr
     }
 }
 
+// ---- Perlin and cellular fBm with the same table technique ---------------------------------------------
+// cnoise: corner gradient (gx, gy) * taylorInvSqrt(gx^2 + gy^2) is a function of j = permute(ix) + iy;
+// cellular: the feature-point offset (ox, oy) is a function of a = permute(Pi.x + oi) + Pi.y + oi.
+// Tables (host-built with the reference's operation sequence, so bit-identical):
+//   P1[i] = 8*permute(i), i in [0,289];          P2[j] = {gx*norm, gy*norm} of permute(j), j in [0,577]
+//   C1[i+1] = 8*permute(i), i in [-1,289];        C2[a+1] = {ox, oy} of permute(a), a in [-1,578]
+constexpr int NZ_TB1_N = 292, NZ_TB2_N = 584;
+
+__device__ __forceinline__ float cnoise2_tab(float Px, float Py, const int *s_t1, const float2 *s_t2) {
+    float flx = floorf(Px), fly = floorf(Py);
+    float frx = Px - flx, fry = Py - fly;
+    int ix0 = (int)mod289i(flx + 0.0f), iy0 = (int)mod289i(fly + 0.0f);
+    int ix1 = (int)mod289i(flx + 1.0f), iy1 = (int)mod289i(fly + 1.0f);
+    ix0 = min(max(ix0, 0), 288); iy0 = min(max(iy0, 0), 288);
+    ix1 = min(max(ix1, 0), 288); iy1 = min(max(iy1, 0), 288);
+    float Pf0 = frx, Pf1 = fry, Pf2 = frx - 1.0f, Pf3 = fry - 1.0f;
+    int a0 = s_t1[ix0], a1 = s_t1[ix1];
+    const char *t2 = reinterpret_cast<const char *>(s_t2);
+    float2 g00 = *reinterpret_cast<const float2 *>(t2 + (a0 + 8 * iy0));
+    float2 g10 = *reinterpret_cast<const float2 *>(t2 + (a1 + 8 * iy0));
+    float2 g01 = *reinterpret_cast<const float2 *>(t2 + (a0 + 8 * iy1));
+    float2 g11 = *reinterpret_cast<const float2 *>(t2 + (a1 + 8 * iy1));
+    float n00 = g00.x * Pf0 + g00.y * Pf1;
+    float n10 = g10.x * Pf2 + g10.y * Pf1;
+    float n01 = g01.x * Pf0 + g01.y * Pf3;
+    float n11 = g11.x * Pf2 + g11.y * Pf3;
+    float fdx = fadef(Pf0), fdy = fadef(Pf1);
+    float nx0 = lerpf_(n00, n10, fdx);
+    float nx1 = lerpf_(n01, n11, fdx);
+    return 2.3f * lerpf_(nx0, nx1, fdy);
+}
+
+__device__ __forceinline__ float cellular_rect_tab(float Px, float Py, const int *s_t1, const float2 *s_t2) {
+    float fx = floorf(Px), fy = floorf(Py);
+    int Pix = (int)mod289i(fx), Piy = (int)mod289i(fy);
+    Pix = min(max(Pix, 0), 288);
+    Piy = min(max(Piy, 0), 288);
+    float Pfx = Px - fx, Pfy = Py - fy;
+    const char *t2 = reinterpret_cast<const char *>(s_t2);
+    const float xoff[3] = {0.5f, -0.5f, -1.5f};
+    const float of[3] = {-0.5f, 0.5f, 1.5f};
+    float d[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int px8 = s_t1[Pix + c];  // 8 * permute(Pi.x + oi[c]), table index shifted by one
+        float bx = Pfx + xoff[c];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float2 o = *reinterpret_cast<const float2 *>(t2 + (px8 + 8 * (Piy + k)));
+            float dx = bx + o.x;
+            float dy = Pfy - of[k] + o.y;
+            d[c][k] = dx * dx + dy * dy;
+        }
+    }
+    float d1[3], d2[3], d1a[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        d1a[k] = fminf(d[0][k], d[1][k]);
+        d2[k] = fmaxf(d[0][k], d[1][k]);
+        d2[k] = fminf(d2[k], d[2][k]);
+        d1[k] = fminf(d1a[k], d2[k]);
+        d2[k] = fmaxf(d1a[k], d2[k]);
+    }
+    if (!(d1[0] < d1[1])) { float t = d1[0]; d1[0] = d1[1]; d1[1] = t; }
+    if (!(d1[0] < d1[2])) { float t = d1[0]; d1[0] = d1[2]; d1[2] = t; }
+    d1[1] = fminf(d1[1], d2[1]);
+    d1[2] = fminf(d1[2], d2[2]);
+    d1[1] = fminf(d1[1], d1[2]);
+    d1[1] = fminf(d1[1], d2[0]);
+    float F1 = sqrtf(d1[0]), F2 = sqrtf(d1[1]);
+    return rectify(F1) * rectify(F2);
+}
+
+template <int BASIS, int VEC>
+__global__ __launch_bounds__(256) void fractal_tab2_kernel(float *__restrict__ dst, int rows, int cols, int pitch,
+                                                          int blocks_per_row, nz_fractal_params p,
+                                                          const int *__restrict__ t1g, const float2 *__restrict__ t2g) {
+    __shared__ int s_t1[NZ_TB1_N];
+    __shared__ float2 s_t2[NZ_TB2_N];
+    for (int i = threadIdx.x; i < NZ_TB1_N; i += 256) s_t1[i] = t1g[i];
+    for (int i = threadIdx.x; i < NZ_TB2_N; i += 256) s_t2[i] = t2g[i];
+    __syncthreads();
+    int by = blockIdx.x / blocks_per_row;
+    int bx = blockIdx.x - by * blocks_per_row;
+    int x0 = (bx * 256 + threadIdx.x) * VEC;
+    if (x0 >= cols) return;
+    float xi[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; c++) xi[c] = ((float)(x0 + c) + p.posx) / p.noise_size;
+    int zend = min(rows, (by + 1) * 8);
+    for (int z = by * 8; z < zend; z++) {
+        float zi = ((float)z + p.posz) / p.noise_size;
+        float t[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; c++) t[c] = 0.0f;
+        float detune = 0.0f, f = 1.0f, a = p.amp;
+        for (int i = 0; i < p.octaves; i++) {
+            float zV = f * zi;
+#pragma unroll
+            for (int c = 0; c < VEC; c++) {
+                float xV = f * xi[c];
+                float nv = BASIS == NZ_NOISE_PERLIN ? rectify(cnoise2_tab(xV, zV, s_t1, s_t2))
+                                                    : cellular_rect_tab(xV, zV, s_t1, s_t2);
+                t[c] += a * nv;
+            }
+            detune += p.detune_rate;
+            f *= (p.stepdown - detune);
+            a *= p.G;
+        }
+        float *row = dst + (size_t)z * pitch;
+#pragma unroll
+        for (int c = 0; c < VEC; c++)
+            if (x0 + c < cols) row[x0 + c] = t[c] / p.norm;
+    }
+}
+
 constexpr int FR_THREADS = 256;
 
 // FractalGenerator.NoiseValue (Fractal.cs:114-131) for VEC consecutive cells of one row.
@@ -554,7 +670,7 @@ int32_t launch_basis(hipStream_t s, float *dst, int rows, int cols, int pitch, c
 
 int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, int cols, int pitch,
                           const nz_fractal_params &p, const float *d_rgrad, const void *d_simplex) {
-    static const int use_tab = getenv("NZ_SIMPLEX_TAB") ? atoi(getenv("NZ_SIMPLEX_TAB")) : 1;
+    static const int use_tab = getenv("NZ_NOISE_TAB") ? atoi(getenv("NZ_NOISE_TAB")) : 1;
     if (noiseType == NZ_NOISE_SIMPLEX && use_tab && d_simplex) {
 #ifndef NZ_FT_VEC
 #define NZ_FT_VEC 2
@@ -566,6 +682,23 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         const float4 *t2 = reinterpret_cast<const float4 *>(t1 + NZ_T1_N);
         hipLaunchKernelGGL((fractal_simplex_tab_kernel<VEC>), dim3((unsigned)blocks), dim3(256), 0, s, dst, rows, cols,
                            pitch, bpr, p, t1, t2);
+        NZ_HIP(hipGetLastError());
+        return NZ_OK;
+    }
+    if ((noiseType == NZ_NOISE_PERLIN || noiseType == NZ_NOISE_CELLULAR) && use_tab && d_simplex) {
+        // table block layout: see build_lattice_tables() in nz_api.cpp
+        const char *base = reinterpret_cast<const char *>(d_simplex) + (NZ_T1_N * 4 + NZ_T2_N * 16);
+        if (noiseType == NZ_NOISE_CELLULAR) base += NZ_TB1_N * 4 + NZ_TB2_N * 8;
+        const int *t1 = reinterpret_cast<const int *>(base);
+        const float2 *t2 = reinterpret_cast<const float2 *>(base + NZ_TB1_N * 4);
+        int bpr = (cols + 255) / 256;
+        long long blocks = (long long)bpr * ((rows + 7) / 8);
+        if (noiseType == NZ_NOISE_PERLIN)
+            hipLaunchKernelGGL((fractal_tab2_kernel<NZ_NOISE_PERLIN, 1>), dim3((unsigned)blocks), dim3(256), 0, s, dst, rows,
+                               cols, pitch, bpr, p, t1, t2);
+        else
+            hipLaunchKernelGGL((fractal_tab2_kernel<NZ_NOISE_CELLULAR, 1>), dim3((unsigned)blocks), dim3(256), 0, s, dst,
+                               rows, cols, pitch, bpr, p, t1, t2);
         NZ_HIP(hipGetLastError());
         return NZ_OK;
     }
