@@ -1,0 +1,163 @@
+"""Full-size (BASELINE.json configs 2/3) and degenerate-size checks on the GPU.
+
+The oracle finishes a 4096^2 pass in about a second on the GPU box's host cores, so the metric
+pipeline is compared with it directly at full size, bit for bit; size-independent properties
+(composition of min filters, constant / mass preservation of normalised kernels, tile seams,
+sharded == monolithic) are checked at the same size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+R = 4096
+
+
+def _run(nj, stage, d):
+    stage.ReceiveHandledInput(nj.PipelineWorkItem(d), nj.JobHandle())
+    stage.jobHandle.Complete()
+
+
+def test_metric_pipeline_4096_equals_oracle(nj, ctx, oracle):
+    data = ctx.alloc(R * R)
+    stages = [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700),
+              nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), nj.FlowMapStage(ctx, 5, 0.0, 0.005),
+              nj.ErosionStage(ctx, 5)]
+    pipe = nj.BasePipeline(stages, "config3")
+    pipe.Enqueue(nj.GeneratorData("t", data, R, 0, 0))
+    pipe.RunToCompletion()
+    got = data.ToArray((R, R))
+    want = oracle.pipeline(R, R)
+    assert np.array_equal(got, want)
+    # config 3 ends in the mesh: Overshoot, R_in 4096, R_m 4088 (off 4), tileSize = tileHeight = 1000
+    md = nj.MeshStageData("m", data, R - 8, R, 4, 1000.0, 1000.0)
+    ms = nj.MeshTileStage(ctx, nj.MeshType.OvershootSquareGridHeightMap)
+    _run(nj, ms, md)
+    vtx, idx = oracle.mesh_heightmap(oracle.MESH_OVERSHOOT, want, R - 8, 4, 1000.0, 1000.0)
+    assert np.array_equal(md.mesh.index_array(), idx)
+    assert np.array_equal(md.mesh.vertices.ToArray().reshape(-1, 12), vtx)
+    pipe.Destroy()
+    for t in (data, md.mesh.vertices, md.mesh.indices):
+        t.Dispose()
+
+
+def test_config2_noise_offsets_and_seams(nj, ctx, oracle):
+    # config 2: simplex 13 octaves, noiseSize 1700, offsets (0,0) and (12288, 20480); neighbouring tiles
+    # continue each other across the seam (world offsets are added cells)
+    st = nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700)
+    a = nj.GeneratorData("a", ctx.alloc(R * R), R, 12288, 20480)
+    _run(nj, st, a)
+    ga = a.data.ToArray((R, R))
+    assert np.array_equal(ga, oracle.fractal(oracle.SIMPLEX, R, R, 0.4, 1.0, 2.0, 0.0, 13, 12288, 20480, 1700))
+    b = nj.GeneratorData("b", ctx.alloc(R * R), R, 12288 + R - 1, 20480)  # overlaps the last column of `a`
+    _run(nj, st, b)
+    gb = b.data.ToArray((R, R))
+    assert np.array_equal(ga[:, R - 1], gb[:, 0])
+    assert 0.0 < ga.min() and ga.max() < 1.0
+    a.data.Dispose(); b.data.Dispose()
+
+
+def test_filter_properties_at_full_size(nj, ctx):
+    const = np.full((R, R), 0.625, f32)
+    d = nj.GeneratorData("c", ctx.from_host(const), R, 0, 0)
+    _run(nj, nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), d)
+    out = d.data.ToArray((R, R))
+    assert np.all(out == out[0, 0]) and abs(out[0, 0] - 0.625) < 2e-6   # clamp-to-edge keeps constants constant
+    imp = np.zeros((R, R), f32)
+    imp[R // 2, R // 2] = 1.0
+    d2 = nj.GeneratorData("i", ctx.from_host(imp), R, 0, 0)
+    _run(nj, nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), d2)
+    out = d2.data.ToArray((R, R))
+    assert abs(float(out.sum(dtype=np.float64)) - 1.0) < 1e-4 and out.max() == out[R // 2, R // 2]
+    # symmetric kernel and input: symmetric output up to rounding (the X pass sums taps ascending, the Z pass
+    # descending, KernelOperators.cs:34-40,59-65, so the two orders differ in the last bits)
+    assert np.allclose(out, out.T, rtol=1e-5, atol=1e-12)
+    assert np.count_nonzero(out) <= (2 * 34 + 1) ** 2                       # support grows by 2 per application
+    d.data.Dispose(); d2.data.Dispose()
+
+
+def test_erosion_composition_at_full_size(nj, ctx):
+    rng = np.random.default_rng(99)
+    t = rng.random((R, R), dtype=f32)
+    a = nj.GeneratorData("a", ctx.from_host(t), R, 0, 0)
+    _run(nj, nj.ErosionStage(ctx, 5), a)
+    b = nj.GeneratorData("b", ctx.from_host(t), R, 0, 0)
+    _run(nj, nj.ErosionStage(ctx, 2), b)
+    _run(nj, nj.ErosionStage(ctx, 3), b)
+    ga, gb = a.data.ToArray((R, R)), b.data.ToArray((R, R))
+    assert np.array_equal(ga, gb)                      # E applications compose: 5 == 2 then 3
+    assert np.all(ga <= t) and ga.min() == t.min()     # a min filter never raises a cell
+    # closed form: min over the clamped window [x-5,x] x [z-5,z]
+    z, x = 1234, 4095
+    assert ga[z, x] == t[z - 5:z + 1, x - 5:x + 1].min() and ga[0, 0] == t[0, 0] and ga[3, 2] == t[:4, :3].min()
+    a.data.Dispose(); b.data.Dispose()
+
+
+def test_flowmap_flat_at_full_size(nj, ctx):
+    d = nj.GeneratorData("f", ctx.from_host(np.full((R, R), 0.3, f32)), R, 0, 0)
+    _run(nj, nj.FlowMapStage(ctx, 5, -0.1, 0.1), d)
+    assert np.array_equal(d.data.ToArray((R, R)), np.full((R, R), 0.5, f32))
+    d.data.Dispose()
+
+
+def test_sharded_4096_equals_monolithic(nj, ctx):
+    import torch
+    from noize_job_amd import sharded as sh
+    p = sh.PipelineParams()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        c2 = nj.Context(0, stream=stream.cuda_stream)
+        ops = sh.HipStripeOps(c2)
+        halo = sh.halo_rows_needed(ops, p)
+        world = 8
+        plans = [sh.StripePlan(r, world, R, R, halo) for r in range(world)]
+        nan = float("nan")
+        bufs = [(torch.full((pl.rows, R), nan, device="cuda"), torch.full((pl.rows, R), nan, device="cuda"),
+                 torch.full((5, pl.rows, R), nan, device="cuda"), torch.full((5, pl.rows, R), nan, device="cuda"))
+                for pl in plans]
+        res = sh.run_pipeline_lockstep([ops] * world, plans, p, bufs,
+                                       lambda dst, d0, src, s0, n: dst[d0:d0 + n].copy_(src[s0:s0 + n]))
+        stream.synchronize()
+        got = np.concatenate([r[pl.own0:pl.own1].cpu().numpy() for r, pl in zip(res, plans)], axis=0)
+        c2.close()
+    data = ctx.alloc(R * R)
+    stages = [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700),
+              nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), nj.FlowMapStage(ctx, 5, 0.0, 0.005),
+              nj.ErosionStage(ctx, 5)]
+    pipe = nj.BasePipeline(stages)
+    pipe.Enqueue(nj.GeneratorData("mono", data, R, 0, 0))
+    pipe.RunToCompletion()
+    assert np.array_equal(got, data.ToArray((R, R)))
+    pipe.Destroy()
+    data.Dispose()
+
+
+@pytest.mark.parametrize("res", [1, 2, 3, 5, 9])
+def test_degenerate_resolutions(nj, ctx, oracle, res):
+    # every stage on tiles smaller than any kernel window or workgroup tile
+    rng = np.random.default_rng(res)
+    t = rng.random((res, res), dtype=f32)
+    for basis in range(8):
+        d = nj.GeneratorData("n", ctx.alloc(res * res), res, 7, 11)
+        _run(nj, nj.NoiseStage(ctx, nj.FractalNoise(basis), 0.5, 1.0, 3, 2.0, 0.0, 13), d)
+        want = oracle.fractal(basis, res, res, 0.5, 1.0, 2.0, 0.0, 3, 7, 11, 13)
+        got = d.data.ToArray((res, res))
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-6) and (basis == 0 or np.array_equal(got, want))
+    for ft, it in ((2, 1), (2, 4), (0, 2), (8, 3)):
+        d = nj.GeneratorData("g", ctx.from_host(t), res, 0, 0)
+        _run(nj, nj.KernelFilterStage(ctx, nj.KernelFilterType(ft), it), d)
+        assert np.array_equal(d.data.ToArray((res, res)), oracle.kernel_filter(t, ft, it)), (ft, it)
+    for it in (1, 2, 5):
+        d = nj.GeneratorData("e", ctx.from_host(t), res, 0, 0)
+        _run(nj, nj.ErosionStage(ctx, it), d)
+        assert np.array_equal(d.data.ToArray((res, res)), oracle.erosion_min(t, it))
+    for it in (1, 3, 5, 7):
+        d = nj.GeneratorData("f", ctx.from_host(t), res, 0, 0)
+        _run(nj, nj.FlowMapStage(ctx, it, 0.0, 0.005), d)
+        assert np.array_equal(d.data.ToArray((res, res)), oracle.flowmap(t, it, 0.0, 0.005)), it
+    if res >= 2:
+        h = rng.random((res + 1, res + 1), dtype=f32)
+        md = nj.MeshStageData("m", ctx.from_host(h), res, res + 1, 0, 10.0, 20.0)
+        _run(nj, nj.MeshTileStage(ctx, nj.MeshType.SquareGridHeightMap), md)
+        vtx, idx = oracle.mesh_heightmap(oracle.MESH_SQUARE, h, res, 0, 20.0, 10.0)
+        assert np.array_equal(md.mesh.index_array(), idx)
+        assert np.array_equal(md.mesh.vertices.ToArray().reshape(-1, 12), vtx)
