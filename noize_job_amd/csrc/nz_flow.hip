@@ -327,8 +327,8 @@ __device__ __forceinline__ void store_group(float *__restrict__ p, const nz_geom
     }
 }
 
-template <bool FIRST, bool LAST, int OCC>
-__global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__restrict__ h, const float *__restrict__ w_in,
+template <bool FIRST, bool LAST, bool EDGE>
+__device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float *s_fs, int tile, const float *__restrict__ h, const float *__restrict__ w_in,
                                                           const float *__restrict__ fN_in, const float *__restrict__ fS_in,
                                                           const float *__restrict__ fE_in, const float *__restrict__ fW_in,
                                                           float *__restrict__ w_out, float *__restrict__ fN_out,
@@ -336,19 +336,15 @@ __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__r
                                                           float *__restrict__ fW_out, float *__restrict__ dst,
                                                           float *__restrict__ h_out, nz_geom g, int n, float nmin,
                                                           float nrange, int aligned) {
-    __shared__ __attribute__((aligned(16))) float s_tot[FT_TH * FT_LP];
-    __shared__ __attribute__((aligned(16))) float s_fn[FT_TH * FT_LP];
-    __shared__ __attribute__((aligned(16))) float s_fs[FT_TH * FT_LP];
-
     const int tid = threadIdx.x;
     const int H = 2 * n, HX = (H + 3) & ~3;
     const int OW = FT_TW - 2 * HX, OH = FT_TH - 2 * H;
     const int tiles_x = (g.cols + OW - 1) / OW;
-    const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    const int by = tile / tiles_x, bx = tile - by * tiles_x;
     const int ox0 = bx * OW, oz0 = g.or0 + by * OH;
     const int lx0 = ox0 - HX, lz0 = oz0 - H;
     // tile strictly inside the grid: no cell is a border cell, every load is in range
-    const bool inner = lx0 > 0 && lx0 + FT_TW < g.cols && lz0 > g.zc0 && lz0 + FT_TH - 1 < g.zc1;
+    constexpr bool inner = !EDGE;
     const bool fast = inner && aligned;
 
     float hh[FT_G][4], ww[FT_G][4], fW[FT_G][4], fE[FT_G][4], fS[FT_G][4], fN[FT_G][4];
@@ -487,6 +483,34 @@ __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__r
             }
         }
     }
+}
+
+// The interior instantiation (tile strictly inside the grid) carries no border selects; the choice is
+// uniform per workgroup.
+template <bool FIRST, bool LAST, int OCC>
+__global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__restrict__ h, const float *__restrict__ w_in,
+                                                               const float *__restrict__ fN_in, const float *__restrict__ fS_in,
+                                                               const float *__restrict__ fE_in, const float *__restrict__ fW_in,
+                                                               float *__restrict__ w_out, float *__restrict__ fN_out,
+                                                               float *__restrict__ fS_out, float *__restrict__ fE_out,
+                                                               float *__restrict__ fW_out, float *__restrict__ dst,
+                                                               float *__restrict__ h_out, nz_geom g, int n, float nmin,
+                                                               float nrange, int aligned) {
+    __shared__ __attribute__((aligned(16))) float s_tot[FT_TH * FT_LP];
+    __shared__ __attribute__((aligned(16))) float s_fn[FT_TH * FT_LP];
+    __shared__ __attribute__((aligned(16))) float s_fs[FT_TH * FT_LP];
+    const int H = 2 * n, HX = (H + 3) & ~3;
+    const int OW = FT_TW - 2 * HX, OH = FT_TH - 2 * H;
+    const int tiles_x = (g.cols + OW - 1) / OW;
+    const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    const int lx0 = bx * OW - HX, lz0 = g.or0 + by * OH - H;
+    const bool inner = lx0 > 0 && lx0 + FT_TW < g.cols && lz0 > g.zc0 && lz0 + FT_TH - 1 < g.zc1;
+    if (inner)
+        flow_fused_body<FIRST, LAST, false>(s_tot, s_fn, s_fs, blockIdx.x, h, w_in, fN_in, fS_in, fE_in, fW_in, w_out,
+                                            fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n, nmin, nrange, aligned);
+    else
+        flow_fused_body<FIRST, LAST, true>(s_tot, s_fn, s_fs, blockIdx.x, h, w_in, fN_in, fS_in, fE_in, fW_in, w_out,
+                                           fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n, nmin, nrange, aligned);
 }
 
 }  // namespace
