@@ -226,6 +226,11 @@ int32_t nz_reduction_job(nz_ctx *ctx, int32_t operation, float *srcL, const floa
 int32_t nz_curve_job(nz_ctx *ctx, float *src, float *tmp, const float *curve, int32_t curveSize,
                      int32_t resolution, nz_handle dep, nz_handle *out);
 
+/* ThermalErosionFilterDelegate, Filter/Kernel/Blur/ThermalErosionFilter.cs:149-157: `iterations` x 4 phases of
+ * in-place talus relaxation on disjoint 2x2 blocks (talus in degrees) */
+int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, float incrementRatio, float meshHeightWidthRatio,
+                           int32_t iterations, int32_t resolution, nz_handle dep, nz_handle *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ from .runtime import Context, DeviceTile, JobHandle
 from .pipeline import (BasePipeline, BlurHelper, ConstantOperationType, ConstantStage, CurveStage, ErosionStage, FlowMapStage, FractalNoise, GaussSigma,
                        GeneratorData, KernelFilterStage, KernelFilterType, MeshBuffers, MeshStageData,
                        MeshTileStage, MeshType, NoiseStage, PipelineStage, PipelineWorkItem, ReduceData, ReduceStage,
-                       ReductionType, StageGaussianBlur,
+                       ReductionType, StageGaussianBlur, StageThermalErosion,
                        StageIO, StageSmoothBlur)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -1077,3 +1077,19 @@ extern "C" int32_t nz_curve_job(nz_ctx *ctx, float *src, float *tmp, const float
     NZ_TRY(nz_launch_curve(ctx->stream, src, (size_t)resolution * resolution, curve, curveSize));
     return nz_ctx_finish(ctx, out);
 }
+
+// ThermalErosionFilterDelegate, Filter/Kernel/Blur/ThermalErosionFilter.cs:149-157 (Schedule :117-144)
+extern "C" int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, float incrementRatio,
+                                      float meshHeightWidthRatio, int32_t iterations, int32_t resolution, nz_handle dep,
+                                      nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(src, "src is NULL");
+    NZ_REQUIRE(iterations >= 0, "iterations < 0");
+    float t = (talus / 90.0f) * 3.14159f / 2.0f;                             // :131
+    float maxDiff = (tanf(t) * meshHeightWidthRatio) / (float)resolution;   // :132
+    for (int i = 0; i < iterations; i++)
+        for (int flip = 0; flip < 4; flip++)
+            NZ_TRY(nz_launch_thermal_phase(ctx->stream, src, resolution, flip, maxDiff, incrementRatio));
+    return nz_ctx_finish(ctx, out);
+}

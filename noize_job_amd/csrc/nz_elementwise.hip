@@ -82,6 +82,41 @@ __global__ __launch_bounds__(CT) void curve_kernel(float *data, size_t n, const 
     }
 }
 
+// ThermalErosionFilter (Filter/Kernel/Blur/ThermalErosionFilter.cs:21-147): one launch per phase; a phase
+// relaxes disjoint 2x2 blocks in place (rectify :84-99 applied to the six pairs in the order xy, xz, xw, yz,
+// yw, zw :74-81), so the result does not depend on the execution order within a phase.
+__device__ __forceinline__ void thermal_rectify(float &a, float &b, float maxDiff, float increment) {
+    float diff = fabsf(a - b);
+    if (diff > maxDiff) {
+        float excess = diff - maxDiff;
+        if (a > b) {
+            b += increment * excess;
+            a -= increment * excess;
+        } else {
+            a += increment * excess;
+            b -= increment * excess;
+        }
+    }
+}
+
+__global__ __launch_bounds__(CT) void thermal_phase_kernel(float *data, int resolution, int flip, float maxDiff,
+                                                          float increment) {
+    int job = blockIdx.y;  // IJobFor index, (resolution / 2) - 1 jobs
+    int z = (job + 1) * 2 - (flip > 1 ? 1 : 0);
+    int offset = 1 + ((flip % 2 != 0) ? 1 : 0);
+    int x = offset + 2 * (blockIdx.x * CT + threadIdx.x);
+    if (x >= resolution - 1) return;
+    size_t i0 = (size_t)z * resolution + x, i2 = (size_t)(z + 1) * resolution + x;
+    float vx = data[i0], vy = data[i0 + 1], vz = data[i2], vw = data[i2 + 1];
+    thermal_rectify(vx, vy, maxDiff, increment);
+    thermal_rectify(vx, vz, maxDiff, increment);
+    thermal_rectify(vx, vw, maxDiff, increment);
+    thermal_rectify(vy, vz, maxDiff, increment);
+    thermal_rectify(vy, vw, maxDiff, increment);
+    thermal_rectify(vz, vw, maxDiff, increment);
+    data[i0] = vx; data[i0 + 1] = vy; data[i2] = vz; data[i2 + 1] = vw;
+}
+
 unsigned blocks_for(size_t n) { return (unsigned)((n + (size_t)CT * 4 - 1) / ((size_t)CT * 4)); }
 
 }  // namespace
@@ -120,6 +155,17 @@ int32_t nz_launch_curve(hipStream_t s, float *data, size_t n, const float *curve
     int aligned = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
     hipLaunchKernelGGL(curve_kernel, dim3(blocks_for(n)), dim3(CT), (size_t)curveSize * sizeof(float), s, data, n, curve,
                        curveSize, aligned);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_thermal_phase(hipStream_t s, float *data, int resolution, int flip, float maxDiff, float increment) {
+    int jobs = resolution / 2 - 1;
+    if (jobs <= 0) return NZ_OK;
+    int per_row = (resolution - 1) / 2;  // upper bound on the blocks of a row
+    if (per_row <= 0) return NZ_OK;
+    dim3 grid((per_row + CT - 1) / CT, jobs);
+    hipLaunchKernelGGL(thermal_phase_kernel, grid, dim3(CT), 0, s, data, resolution, flip, maxDiff, increment);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

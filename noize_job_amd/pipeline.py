@@ -415,6 +415,21 @@ class CurveStage(PipelineStage):  # Filter/Curve/CurveStage.cs:13-71
         self.curve = self.tmp = None
 
 
+class StageThermalErosion(PipelineStage):  # Filter/Kernel/Blur/StageThermalErosion.cs:12-29
+    def __init__(self, ctx, iterations=1, talus=45, increment=0.5, meshHeightWidthRatio=0.75):
+        super().__init__(ctx)
+        self.iterations = iterations
+        self.talus = talus
+        self.increment = increment
+        self.meshHeightWidthRatio = meshHeightWidthRatio
+
+    def Schedule(self, requirements, dependency):
+        self.CheckRequirements(GeneratorData, requirements)
+        d = requirements.data
+        self.jobHandle = self.ctx.call("nz_thermal_erosion", d.data.ptr, float(self.talus), self.increment,
+                                       self.meshHeightWidthRatio, self.iterations, d.resolution, dep=dependency)
+
+
 class FlowMapStage(PipelineStage):  # Geologic/Stage/FlowMapStage.cs:16-220
     def __init__(self, ctx, iterations=5, normMin=-0.1, normMax=0.1):
         super().__init__(ctx)

@@ -78,6 +78,7 @@ def lib():
         L.nzo_constant.argtypes = [f32p, f32p, i, f, i, i]
         L.nzo_reduce.argtypes = [f32p, f32p, f32p, i, i, i]
         L.nzo_curve.argtypes = [f32p, f32p, f32p, i, i, i]
+        L.nzo_thermal_erosion.argtypes = [f32p, i, f, f, f, i]
         L.nzo_pipeline.argtypes = [f32p, f32p, i, i, i, f, f, f, f, i, i, i, i, i, i, i, f, f, i]
         # the GPU box grants a CPU share, not the whole host: size the OpenMP team to the affinity mask
         try:
@@ -320,4 +321,11 @@ def curve(a, samples):
     samples = np.ascontiguousarray(samples, np.float32)
     if lib().nzo_curve(_p(a), _p(tmp), _p(samples), len(samples), *a.shape):
         raise ValueError("bad curve")
+    return a
+
+
+def thermal_erosion(a, talus=45.0, increment=0.5, ratio=0.75, iterations=1):
+    a = _plane(a).copy()
+    assert a.shape[0] == a.shape[1]
+    lib().nzo_thermal_erosion(_p(a), a.shape[0], talus, increment, ratio, iterations)
     return a

@@ -973,6 +973,51 @@ int nzo_curve(float *src, float *tmp, const float *curve, int curveSize, int row
     return 0;
 }
 
+/* ThermalErosionFilter, Filter/Kernel/Blur/ThermalErosionFilter.cs:21-147 */
+static inline void thermal_rectify(float *a, float *b, float maxDiff, float increment) { /* :84-99 */
+    float diff = fabsf(*a - *b);
+    if (diff > maxDiff) {
+        float excess = diff - maxDiff;
+        if (*a > *b) {
+            *b += increment * excess;
+            *a -= increment * excess;
+        } else {
+            *a += increment * excess;
+            *b -= increment * excess;
+        }
+    }
+}
+
+int nzo_thermal_erosion(float *src, int resolution, float talus, float incrementRatio,
+                        float meshHeightWidthRatio, int iterations) {
+    float t = (talus / 90.0f) * 3.14159f / 2.0f;                           /* :131 */
+    float maxDiff = (tanf(t) * meshHeightWidthRatio) / (float)resolution; /* :132 */
+    int jobs = resolution / 2 - 1;                                        /* :137 */
+    for (int i = 0; i < iterations; i++) {
+        for (int flip = 0; flip < 4; flip++) {
+#pragma omp parallel for schedule(static)
+            for (int job = 0; job < jobs; job++) { /* Execute :102-120 */
+                int offset = 1, z = job + 1;
+                if (flip % 2 != 0) offset += 1;
+                z *= 2;
+                if (flip > 1) z -= 1;
+                for (int x = offset; x < resolution - 1; x += 2) {
+                    float *p0 = src + (size_t)z * resolution + x, *p2 = src + (size_t)(z + 1) * resolution + x;
+                    float vx = p0[0], vy = p0[1], vz = p2[0], vw = p2[1];
+                    thermal_rectify(&vx, &vy, maxDiff, incrementRatio); /* rectifyNeighborhood :74-81 */
+                    thermal_rectify(&vx, &vz, maxDiff, incrementRatio);
+                    thermal_rectify(&vx, &vw, maxDiff, incrementRatio);
+                    thermal_rectify(&vy, &vz, maxDiff, incrementRatio);
+                    thermal_rectify(&vy, &vw, maxDiff, incrementRatio);
+                    thermal_rectify(&vz, &vw, maxDiff, incrementRatio);
+                    p0[0] = vx; p0[1] = vy; p2[0] = vz; p2[1] = vw;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Metric pipeline (README.md:23-32): noise -> KernelFilterStage(iterations) -> FlowMapStage ->
  * ErosionKernelJob x E, every stage reference-shaped.

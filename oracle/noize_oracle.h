@@ -135,6 +135,9 @@ int nzo_constant(float *src, float *tmp, int op, float value, int rows, int cols
 int nzo_reduce(float *srcL, const float *srcR, float *tmp, int op, int rows, int cols); /* Filter/ReductionJob.cs */
 int nzo_curve(float *src, float *tmp, const float *curve, int curveSize, int rows, int cols); /* Filter/Curve/CurveJob.cs */
 
+int nzo_thermal_erosion(float *src, int resolution, float talus, float incrementRatio,
+                        float meshHeightWidthRatio, int iterations); /* Filter/Kernel/Blur/ThermalErosionFilter.cs */
+
 /* reference-shaped metric pipeline on one tile (bench cpu_baseline): fractal -> kernel filter x G
  * -> flowmap(F) -> erosion x E.  tmp must hold rows*cols floats. */
 int nzo_pipeline(float *data, float *tmp, int rows, int cols, int noiseType, float hurst,

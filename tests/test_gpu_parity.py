@@ -339,3 +339,11 @@ def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):
     want = oracle.flowmap(want, 1, 0.0, 0.005)
     want = oracle.curve(want, np.array([boost(f32(i) / f32(256)) for i in range(256)], f32))
     assert np.array_equal(data.ToArray((res, res)), want)
+
+
+def test_thermal_erosion_stage(nj, ctx, oracle):
+    for res in (2, 3, 8, 65, 256):
+        t = np.random.default_rng(res).random((res, res), dtype=f32)
+        for iters, talus, inc, ratio in ((1, 45, 0.5, 0.75), (3, 20, 0.25, 0.3), (2, 80, 0.5, 2.0)):
+            got = run(nj.StageThermalErosion(ctx, iters, talus, inc, ratio), nj, gen(nj, ctx, res, host=t))
+            assert np.array_equal(got, oracle.thermal_erosion(t, float(talus), inc, ratio, iters)), (res, iters)

@@ -373,3 +373,21 @@ def test_constant_reduce_curve_known_answers(oracle):
         want.append(min(f32(1), max(f32(0), f32(val))))
     assert np.array_equal(got.reshape(-1), np.array(want, f32))
     assert got[1, 2] == 1.0  # v = 1 -> rect = 4 -> lower 2, t = 2 -> extrapolates past the last sample, clamped
+
+
+def test_thermal_erosion_known_answers(oracle):
+    # ThermalErosionFilter.cs: maxDiff = tan(talus) * ratio / res; pairs steeper than maxDiff move `increment` of
+    # the excess each way; four phases of disjoint 2x2 blocks starting at (x, z) = (1|2, 2|1)
+    res = 8
+    a = np.zeros((res, res), f32)
+    a[2, 1] = 1.0
+    out = oracle.thermal_erosion(a, 45.0, 0.5, 0.75, 1)
+    md = f32(np.tan(f32(f32(45.0 / 90.0) * f32(3.14159)) / f32(2.0)) * f32(0.75)) / f32(res)
+    assert out.sum() == pytest.approx(1.0, abs=1e-6)      # mass is conserved
+    assert out[2, 1] < 1.0 and out[2, 2] > 0 and out[3, 1] > 0
+    assert np.array_equal(out[0], a[0]) and np.array_equal(out[:, 0], a[:, 0])  # row 0 / column 0 are never touched
+    flat = np.full((res, res), 0.25, f32)
+    assert np.array_equal(oracle.thermal_erosion(flat, 30.0, 0.5, 0.75, 3), flat)
+    # a slope gentler than the talus angle is a fixed point
+    ramp = np.tile(np.arange(res, dtype=f32) * (md * f32(0.5)), (res, 1))
+    assert np.array_equal(oracle.thermal_erosion(ramp, 45.0, 0.5, 0.75, 2), ramp)
