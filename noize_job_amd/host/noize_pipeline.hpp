@@ -226,6 +226,94 @@ class ErosionStage : public TmpStage {  // ErosionKernelJob x iterations (no sta
     }
 };
 
+// ---- element-wise stages (Filter/ConstantStage.cs, Filter/Reduce/ReduceStage.cs, Filter/Curve/CurveStage.cs,
+//      Filter/Kernel/Blur/StageThermalErosion.cs) ---------------------------------------------------------
+struct ReduceData : StageIO {  // StageIOTypes/ReduceData.cs
+    int resolution = 512, xpos = 0, zpos = 0;
+    DeviceTile *rightData = nullptr;
+};
+
+class ConstantStage : public TmpStage {
+  public:
+    using TmpStage::TmpStage;
+    int operation = 0;  // ConstantOperationType {MULTIPLY, BINARIZE}
+    float value = 0.5f;
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = CheckRequirements<GeneratorData>(requirements);
+        nz_handle h = 0;
+        check(nz_constant_job(ctx, operation, d->data->ptr, tmp->ptr, value, d->resolution, dependency.id, &h),
+              "nz_constant_job");
+        jobHandle = done(h);
+    }
+};
+
+class ReduceStage : public TmpStage {
+  public:
+    using TmpStage::TmpStage;
+    int operation = 0;  // ReductionType {SUBTRACT, MULTIPLY, ROOTSUMSQUARES, MAX, MIN}
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = CheckRequirements<ReduceData>(requirements);
+        nz_handle h = 0;
+        check(nz_reduction_job(ctx, operation, d->data->ptr, d->rightData->ptr, tmp->ptr, d->resolution, dependency.id, &h),
+              "nz_reduction_job");
+        jobHandle = done(h);
+    }
+    void TransformData(PipelineWorkItem &inputData) override {  // ReduceStage.cs:53-62
+        auto *d = static_cast<ReduceData *>(inputData.data);
+        out.uuid = d->uuid;
+        out.data = d->data;
+        out.resolution = d->resolution;
+        out.xpos = d->xpos;
+        out.zpos = d->zpos;
+        inputData.data = &out;
+    }
+
+  private:
+    GeneratorData out;
+};
+
+class CurveStage : public TmpStage {
+  public:
+    using TmpStage::TmpStage;
+    std::function<float(float)> unityCurve = [](float t) { return t; };  // AnimationCurve.Evaluate
+    int samples = 256;
+    void ResizeNativeContainers(size_t n) override {
+        TmpStage::ResizeNativeContainers(n);
+        std::vector<float> host(samples);
+        for (int i = 0; i < samples; i++) host[i] = unityCurve((float)i / (float)samples);  // ExtractCurve :32-40
+        curve.reset(new DeviceTile(ctx, samples));
+        curve->CopyFrom(host.data());
+    }
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = CheckRequirements<GeneratorData>(requirements);
+        nz_handle h = 0;
+        check(nz_curve_job(ctx, d->data->ptr, tmp->ptr, curve->ptr, samples, d->resolution, dependency.id, &h),
+              "nz_curve_job");
+        jobHandle = done(h);
+    }
+    void OnDestroy() override {
+        TmpStage::OnDestroy();
+        curve.reset();
+    }
+
+  private:
+    std::unique_ptr<DeviceTile> curve;
+};
+
+class StageThermalErosion : public PipelineStage {
+  public:
+    using PipelineStage::PipelineStage;
+    int iterations = 1, talus = 45;
+    float increment = 0.5f, meshHeightWidthRatio = 0.75f;
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = CheckRequirements<GeneratorData>(requirements);
+        nz_handle h = 0;
+        check(nz_thermal_erosion(ctx, d->data->ptr, (float)talus, increment, meshHeightWidthRatio, iterations,
+                                 d->resolution, dependency.id, &h), "nz_thermal_erosion");
+        jobHandle = done(h);
+    }
+};
+
 class FlowMapStage : public PipelineStage {
   public:
     using PipelineStage::PipelineStage;
