@@ -48,21 +48,29 @@ static constexpr size_t NZ_EVENT_RING = 4096;
 static int32_t ctx_sync_all(nz_ctx *ctx);
 extern "C" int32_t nz_ctx_set_bands(nz_ctx *ctx, int32_t bands);
 
+static float h_mod289(float x);
+static float h_permute(float x);
+
 static int32_t build_rgrad_table(nz_ctx *ctx) {
-    // rgrad2 of noise.psrnoise: the hash is an exact integer in
-    // [0, 289], so (cos u, sin u) is tabulated with the same libm the CPU restatement calls.
-    std::vector<float> tab(2 * NZ_RGRAD_N * 2);
+    // noise.psrnoise.  Every hash argument is an integer-valued float, so both
+    // permutes are pure functions of small integers and are tabulated with the reference's own fp32
+    // operations (the first one overflows 2^24 and rounds; the table reproduces that rounding because it is
+    // computed the same way).  (cos u, sin u) of rgrad2 come from the host libm the CPU restatement calls.
+    std::vector<int32_t> buf(NZ_PSR_T1 + 2 * NZ_PSR_T2 * 2);
+    for (int i = 0; i < NZ_PSR_T1; i++) buf[i] = 8 * ((int32_t)h_permute((float)(i - 8)) + 16);
+    float *t2 = reinterpret_cast<float *>(buf.data() + NZ_PSR_T1);
     const float rots[2] = {0.0f, 0.62f};  // PeriodicPerlinGetter / RotatedSimplexGetter, Fractal.cs:184,201
     for (int t = 0; t < 2; t++) {
-        for (int h = 0; h < NZ_RGRAD_N; h++) {
-            float u = (float)h * 0.0243902439f + rots[t];
+        for (int j = 0; j < NZ_PSR_T2; j++) {
+            float h = h_permute((float)(j - 16));
+            float u = h * 0.0243902439f + rots[t];
             u = (u - floorf(u)) * 6.28318530718f;
-            tab[(t * NZ_RGRAD_N + h) * 2 + 0] = cosf(u);
-            tab[(t * NZ_RGRAD_N + h) * 2 + 1] = sinf(u);
+            t2[(t * NZ_PSR_T2 + j) * 2 + 0] = cosf(u);
+            t2[(t * NZ_PSR_T2 + j) * 2 + 1] = sinf(u);
         }
     }
-    NZ_HIP(hipMalloc((void **)&ctx->d_rgrad, tab.size() * sizeof(float)));
-    NZ_HIP(hipMemcpy(ctx->d_rgrad, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    NZ_HIP(hipMalloc((void **)&ctx->d_rgrad, buf.size() * sizeof(int32_t)));
+    NZ_HIP(hipMemcpy(ctx->d_rgrad, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     return NZ_OK;
 }
 

@@ -136,16 +136,43 @@ __device__ __forceinline__ float snoise2(float vx, float vy) {
     return 130.0f * (m0 * g0 + m1 * g1 + m2 * g2);
 }
 
-// rgrad2 through the host-built table: hash is an exact integer in [0, 289]
-__device__ __forceinline__ float2 rgrad2_tab(float px, float py, const float2 *tab) {
-    float h = permutef(permutef(px) + py);
-    int idx = (int)h;
-    idx = idx < 0 ? 0 : (idx > NZ_RGRAD_N - 1 ? NZ_RGRAD_N - 1 : idx);
-    return tab[idx];
+// rgrad2 through the host-built tables: both hash arguments are integer-valued, so permute(p.x) is one
+// table read (byte offset of the second table's row) and permute(. + p.y) + cos/sin a second one.
+struct psr_tables {
+    const int *t1;
+    const float2 *t2;
+};
+__device__ __forceinline__ float2 rgrad2_tab(float px, float py, const psr_tables &tab) {
+    int i1 = min(max((int)px + 8, 0), NZ_PSR_T1 - 1);
+    int off = tab.t1[i1] + 8 * (int)py;
+    off = min(max(off, 0), (NZ_PSR_T2 - 1) * 8);
+    return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(tab.t2) + off);
+}
+
+// C fmod for the arguments psrnoise feeds it: x is a multiple of 0.5 (lattice coordinates) and per a small
+// integer.  fmod is exact by definition (x - trunc(x/per)*per with no rounding); here trunc(x * (1/per)) may be
+// off by one, but q*per and x - q*per are exact for |x| < 2^22 (coordinates beyond that have no fractional
+// precision left in fp32 anyway), so one correction step lands on the same value as the library loop,
+// without its data-dependent iteration.
+#ifndef NZ_PSR_FMOD
+#define NZ_PSR_FMOD 0  // measured: the library fmodf is faster for these arguments (0.70 vs 0.80 ms)
+#endif
+__device__ __forceinline__ float fmod_lattice(float x, float per, float inv_per) {
+#if !NZ_PSR_FMOD
+    return fmodf(x, per);
+#endif
+    float q = truncf(x * inv_per);
+    float r = __builtin_fmaf(-q, per, x);  // exact: q*per is an integer below 2^23 (|x| < 2^22)
+    bool pos = x >= 0.0f;
+    bool add = pos ? (r < 0.0f) : (r <= -per);
+    bool sub = pos ? (r >= per) : (r > 0.0f);
+    r = add ? r + per : r;
+    r = sub ? r - per : r;
+    return r;
 }
 
 // noise.psrnoise(float2 pos, float2 per = (1010,102), rot), Appendix A.4
-__device__ __forceinline__ float psrnoise2(float posx, float posy, const float2 *tab) {
+__device__ __forceinline__ float psrnoise2(float posx, float posy, const psr_tables &tab) {
     const float perx = 1010.0f, pery = 102.0f;
     posy += 0.001f;
     float uvx = posx + posy * 0.5f, uvy = posy;
@@ -159,8 +186,9 @@ __device__ __forceinline__ float psrnoise2(float posx, float posy, const float2 
     float d0x = posx - p0x, d0y = posy - p0y;
     float d1x = posx - p1x, d1y = posy - p1y;
     float d2x = posx - p2x, d2y = posy - p2y;
-    float xw0 = fmodf(p0x, perx), xw1 = fmodf(p1x, perx), xw2 = fmodf(p2x, perx);
-    float yw0 = fmodf(p0y, pery), yw1 = fmodf(p1y, pery), yw2 = fmodf(p2y, pery);
+    const float ipx = 1.0f / 1010.0f, ipy = 1.0f / 102.0f;
+    float xw0 = fmod_lattice(p0x, perx, ipx), xw1 = fmod_lattice(p1x, perx, ipx), xw2 = fmod_lattice(p2x, perx, ipx);
+    float yw0 = fmod_lattice(p0y, pery, ipy), yw1 = fmod_lattice(p1y, pery, ipy), yw2 = fmod_lattice(p2y, pery, ipy);
     float iu0 = xw0 + 0.5f * yw0, iu1 = xw1 + 0.5f * yw1, iu2 = xw2 + 0.5f * yw2;
     float2 g0 = rgrad2_tab(iu0, yw0, tab);
     float2 g1 = rgrad2_tab(iu1, yw1, tab);
@@ -345,7 +373,7 @@ __device__ __forceinline__ void domain_rotate(float x, float z, float &xr, float
 
 // IMakeNoise.NoiseValue of the eight getters, Fractal.cs:141-278
 template <int BASIS>
-__device__ __forceinline__ float noise_value(float x, float z, const float2 *tab) {
+__device__ __forceinline__ float noise_value(float x, float z, const psr_tables &tab) {
     if constexpr (BASIS == NZ_NOISE_SIN) {
         float vx = 0.5f + (0.5f * sinf(x));
         float vy = 0.5f + (0.5f * sinf(z));
@@ -592,6 +620,7 @@ __global__ __launch_bounds__(256) void fractal_tab2_kernel(float *__restrict__ d
 }
 
 constexpr int FR_THREADS = 256;
+constexpr int FR_ROWS = 8;
 
 // FractalGenerator.NoiseValue (Fractal.cs:114-131) for VEC consecutive cells of one row.
 template <int BASIS, int VEC>
@@ -600,53 +629,61 @@ __global__ __launch_bounds__(FR_THREADS) void fractal_kernel(float *__restrict__
                                                             nz_fractal_params p,
                                                             const float2 *__restrict__ rgrad) {
     constexpr bool USES_TAB = BASIS == NZ_NOISE_PERIODIC_PERLIN || BASIS == NZ_NOISE_ROTATED_SIMPLEX;
-    __shared__ float2 s_tab[USES_TAB ? NZ_RGRAD_N : 1];
+    __shared__ float2 s_tab[USES_TAB ? NZ_PSR_T2 : 1];
+    __shared__ int s_t1[USES_TAB ? NZ_PSR_T1 : 1];
     if constexpr (USES_TAB) {
-        const float2 *src = rgrad + (BASIS == NZ_NOISE_ROTATED_SIMPLEX ? NZ_RGRAD_N : 0);
-        for (int i = threadIdx.x; i < NZ_RGRAD_N; i += FR_THREADS) s_tab[i] = src[i];
+        const int *t1g = reinterpret_cast<const int *>(rgrad);
+        const float2 *src = reinterpret_cast<const float2 *>(t1g + NZ_PSR_T1) +
+                            (BASIS == NZ_NOISE_ROTATED_SIMPLEX ? NZ_PSR_T2 : 0);
+        for (int i = threadIdx.x; i < NZ_PSR_T1; i += FR_THREADS) s_t1[i] = t1g[i];
+        for (int i = threadIdx.x; i < NZ_PSR_T2; i += FR_THREADS) s_tab[i] = src[i];
         __syncthreads();
     }
-    int z = blockIdx.x / blocks_per_row;
-    int bx = blockIdx.x - z * blocks_per_row;
+    const psr_tables tabs{s_t1, s_tab};
+    int by = blockIdx.x / blocks_per_row;
+    int bx = blockIdx.x - by * blocks_per_row;
     int x0 = (bx * FR_THREADS + threadIdx.x) * VEC;
-    if (z >= rows || x0 >= cols) return;
-
-    float zi = ((float)z + p.posz) / p.noise_size;
-    float xi[VEC], t[VEC];
+    if (x0 >= cols) return;
+    float xi[VEC];
 #pragma unroll
-    for (int c = 0; c < VEC; c++) {
-        xi[c] = ((float)(x0 + c) + p.posx) / p.noise_size;
-        t[c] = 0.0f;
-    }
-    float detune = 0.0f, f = 1.0f, a = p.amp;
-    for (int i = 0; i < p.octaves; i++) {
-        float zV = f * zi;
+    for (int c = 0; c < VEC; c++) xi[c] = ((float)(x0 + c) + p.posx) / p.noise_size;
+    // FR_ROWS rows per workgroup: amortises the table fill of the periodic bases
+    int zend = min(rows, (by + 1) * FR_ROWS);
+    for (int z = by * FR_ROWS; z < zend; z++) {
+        float zi = ((float)z + p.posz) / p.noise_size;
+        float t[VEC];
 #pragma unroll
-        for (int c = 0; c < VEC; c++) {
-            float xV = f * xi[c];
-            t[c] += a * noise_value<BASIS>(xV, zV, s_tab);
+        for (int c = 0; c < VEC; c++) t[c] = 0.0f;
+        float detune = 0.0f, f = 1.0f, a = p.amp;
+        for (int i = 0; i < p.octaves; i++) {
+            float zV = f * zi;
+#pragma unroll
+            for (int c = 0; c < VEC; c++) {
+                float xV = f * xi[c];
+                t[c] += a * noise_value<BASIS>(xV, zV, tabs);
+            }
+            detune += p.detune_rate;
+            f *= (p.stepdown - detune);
+            a *= p.G;
         }
-        detune += p.detune_rate;
-        f *= (p.stepdown - detune);
-        a *= p.G;
-    }
-    float *row = dst + (size_t)z * pitch;
-    float o[VEC];
+        float *row = dst + (size_t)z * pitch;
+        float o[VEC];
 #pragma unroll
-    for (int c = 0; c < VEC; c++) o[c] = t[c] / p.norm;
-    bool full = x0 + VEC <= cols && ((reinterpret_cast<uintptr_t>(row + x0) & (VEC * 4 - 1)) == 0);
-    if (full) {
-        if constexpr (VEC == 4) {
-            *reinterpret_cast<float4 *>(row + x0) = make_float4(o[0], o[1], o[2], o[3]);
-        } else if constexpr (VEC == 2) {
-            *reinterpret_cast<float2 *>(row + x0) = make_float2(o[0], o[1]);
+        for (int c = 0; c < VEC; c++) o[c] = t[c] / p.norm;
+        bool full = x0 + VEC <= cols && ((reinterpret_cast<uintptr_t>(row + x0) & (VEC * 4 - 1)) == 0);
+        if (full) {
+            if constexpr (VEC == 4) {
+                *reinterpret_cast<float4 *>(row + x0) = make_float4(o[0], o[1], o[2], o[3]);
+            } else if constexpr (VEC == 2) {
+                *reinterpret_cast<float2 *>(row + x0) = make_float2(o[0], o[1]);
+            } else {
+                row[x0] = o[0];
+            }
         } else {
-            row[x0] = o[0];
-        }
-    } else {
 #pragma unroll
-        for (int c = 0; c < VEC; c++)
-            if (x0 + c < cols) row[x0 + c] = o[c];
+            for (int c = 0; c < VEC; c++)
+                if (x0 + c < cols) row[x0 + c] = o[c];
+        }
     }
 }
 
@@ -655,7 +692,7 @@ int32_t launch_basis(hipStream_t s, float *dst, int rows, int cols, int pitch, c
                      const float *d_rgrad) {
     int per_block = FR_THREADS * VEC;
     int bpr = (cols + per_block - 1) / per_block;
-    long long blocks = (long long)bpr * rows;
+    long long blocks = (long long)bpr * ((rows + FR_ROWS - 1) / FR_ROWS);
     if (blocks > 0x7fffffffLL) {
         nz_set_error("fractal grid too large");
         return NZ_ERR_INVALID;

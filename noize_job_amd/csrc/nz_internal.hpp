@@ -67,7 +67,9 @@ int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out);
 
 // ---- kernel parameter blocks ----------------------------------------------------------------
 constexpr int NZ_MAX_KSIZE = 25;
-constexpr int NZ_RGRAD_N = 320;  // entries per rotation table (hash values are in [0, 289])
+// psrnoise tables: T1[i] = 8 * (permute(i - 8) + 16) for the first, un-reduced permute (argument in [-8, 1063]);
+// T2[rot][j] = (cos u, sin u) of the gradient hashed from a = j - 16 (second permute + rgrad2), a in [-16, 403]
+constexpr int NZ_PSR_T1 = 1072, NZ_PSR_T2 = 420;
 
 struct nz_kernel_taps {
     float kx[NZ_MAX_KSIZE];
