@@ -191,15 +191,6 @@ int32_t nz_flow_fused_max_iterations(void);
 int32_t nz_flow_fused_stripe(nz_ctx *ctx, const float *height, const float *const *state_in, float *const *state_out,
                              float *dst, const nz_stripe *st, int32_t iterations, int32_t first, int32_t last,
                              float normMin, float normMax, nz_handle dep, nz_handle *out);
-int32_t nz_flow_first_stripe(nz_ctx *ctx, const float *height, float *water, float *fN, float *fS,
-                             float *fE, float *fW, const nz_stripe *st, nz_handle dep, nz_handle *out);
-int32_t nz_flow_iter_stripe(nz_ctx *ctx, const float *height, const float *water_in, const float *fN_in,
-                            const float *fS_in, const float *fE_in, const float *fW_in, float *water_out,
-                            float *fN_out, float *fS_out, float *fE_out, float *fW_out,
-                            const nz_stripe *st, nz_handle dep, nz_handle *out);
-int32_t nz_flow_velocity_stripe(nz_ctx *ctx, float *dst, const float *fN, const float *fS, const float *fE,
-                                const float *fW, const nz_stripe *st, float normMin, float normMax,
-                                nz_handle dep, nz_handle *out);
 
 /* ---- mesh: HeightMapMeshJobScheduleDelegate, Mesh/Job/HeightMapMeshJob.cs:55-65 -------------- */
 /* (Mesh, MeshData) -> device vertex stream of (resolution+1)^2 records

@@ -77,9 +77,6 @@ SIGNATURES = {
     "nz_flow_fused_max_iterations": (_i, []),
     "nz_flow_fused_stripe": (_i, [ctx_p, dev_ptr, C.POINTER(dev_ptr), C.POINTER(dev_ptr), dev_ptr, stripe_p, _i, _i, _i,
                                   _f, _f] + _tail),
-    "nz_flow_first_stripe": (_i, [ctx_p] + [dev_ptr] * 6 + [stripe_p] + _tail),
-    "nz_flow_iter_stripe": (_i, [ctx_p] + [dev_ptr] * 11 + [stripe_p] + _tail),
-    "nz_flow_velocity_stripe": (_i, [ctx_p] + [dev_ptr] * 5 + [stripe_p, _f, _f] + _tail),
     "nz_constant_job": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _f, _i] + _tail),
     "nz_reduction_job": (_i, [ctx_p, _i, dev_ptr, dev_ptr, dev_ptr, _i] + _tail),
     "nz_curve_job": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, _i, _i] + _tail),

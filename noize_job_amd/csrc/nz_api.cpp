@@ -979,41 +979,6 @@ extern "C" int32_t nz_flow_fused_stripe(nz_ctx *ctx, const float *height, const 
     return nz_ctx_finish(ctx, out);
 }
 
-extern "C" int32_t nz_flow_first_stripe(nz_ctx *ctx, const float *height, float *water, float *fN, float *fS,
-                                        float *fE, float *fW, const nz_stripe *st, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
-    NZ_TRY(nz_check_stripe(st, 2));
-    NZ_REQUIRE(height && water && fN && fS && fE && fW, "plane is NULL");
-    NZ_TRY(nz_launch_flow_iter(ctx->stream, height, nullptr, nullptr, nullptr, nullptr, nullptr, water, fN, fS, fE, fW,
-                               nz_geom_from_stripe(*st), 1));
-    return nz_ctx_finish(ctx, out);
-}
-
-extern "C" int32_t nz_flow_iter_stripe(nz_ctx *ctx, const float *height, const float *water_in, const float *fN_in,
-                                       const float *fS_in, const float *fE_in, const float *fW_in, float *water_out,
-                                       float *fN_out, float *fS_out, float *fE_out, float *fW_out,
-                                       const nz_stripe *st, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
-    NZ_TRY(nz_check_stripe(st, 2));
-    NZ_REQUIRE(height && water_in && fN_in && fS_in && fE_in && fW_in && water_out && fN_out && fS_out && fE_out &&
-                   fW_out,
-               "plane is NULL");
-    NZ_TRY(nz_launch_flow_iter(ctx->stream, height, water_in, fN_in, fS_in, fE_in, fW_in, water_out, fN_out, fS_out,
-                               fE_out, fW_out, nz_geom_from_stripe(*st), 0));
-    return nz_ctx_finish(ctx, out);
-}
-
-extern "C" int32_t nz_flow_velocity_stripe(nz_ctx *ctx, float *dst, const float *fN, const float *fS,
-                                           const float *fE, const float *fW, const nz_stripe *st, float normMin,
-                                           float normMax, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
-    NZ_TRY(nz_check_stripe(st, 1));
-    NZ_REQUIRE(dst && fN && fS && fE && fW, "plane is NULL");
-    NZ_TRY(nz_launch_velocity(ctx->stream, dst, fN, fS, fE, fW, nz_geom_from_stripe(*st), 1, normMin,
-                              normMax - normMin));
-    return nz_ctx_finish(ctx, out);
-}
-
 // ---------------------------------------------------------------------------------------------
 // mesh
 // ---------------------------------------------------------------------------------------------

@@ -4,21 +4,16 @@
 // (Filter/Kernel/KernelJob.cs:18-54,165-185; operators Filter/Kernel/KernelOperators.cs:18-67) and
 // the KernelMin{X,Z}Operator pair of ErosionKernelJob (KernelJob.cs:317-347, KernelOperators.cs:69-118).
 //
-// conv_fused_kernel: one workgroup stages a 64 x 128 tile (rows x cols, halo included) in LDS with
-// coalesced 16-byte loads, runs T applications of (X pass, Z pass) on it without touching HBM and
-// stores the (64-2H) x (128-2HX) interior, H = T*(K-1)/2.  HBM traffic per launch is one read and
-// one write of the plane for T filter applications (the reference moves 32 B/cell per application:
-// two passes + two serial flush copies).  The FlushWriteSlice copies (Pipeline/Tiles/TileData.cs:15-40)
-// do not exist here: passes ping-pong between `src` and `tmp`.
+// conv_reg_kernel / erosion_reg_kernel: one workgroup owns a 64 x 128 tile (rows x cols, halo included)
+// held entirely in registers, runs T applications of (X pass, Z pass) on it without touching HBM and
+// stores the (64-2H) x (128-2HX) interior, H = T*(K-1)/2.  HBM traffic per launch is one read and one
+// write of the plane for T filter applications (the reference moves 32 B/cell per application: two
+// passes + two serial flush copies).  The FlushWriteSlice copies (Pipeline/Tiles/TileData.cs:15-40) do
+// not exist here: launches ping-pong between `src` and `tmp`.
 //
 // Arithmetic order is the reference's: X pass sums taps k ascending, Z pass sums k descending
 // (KernelOperators.cs:34-40,59-65), product then add (no FMA contraction), then * factor.
-// Clamp-to-edge (TileData.cs:72-77) is applied per pass: cells outside the global grid are
-// re-replicated from the border after every Z pass.
-//
-// LDS layout: pitch 132 floats (= 4 * 33): in the X pass the 64 lanes of a wave read the same
-// column run of 64 different rows with ds_read_b128, and 33 being odd spreads every 16-lane group
-// over all 16 four-bank slots; in the Z pass lanes read consecutive float4 columns of one row.
+// Clamp-to-edge (TileData.cs:72-77) is applied per pass when a window is assembled.
 #include <cstdlib>
 
 #include "nz_internal.hpp"
@@ -28,7 +23,6 @@ namespace {
 constexpr int CT = 256;      // threads per workgroup
 constexpr int TW = 128;      // LDS tile width, cells
 constexpr int TH = 64;       // LDS tile height, rows
-constexpr int LP = TW + 4;   // LDS pitch, floats
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -40,161 +34,8 @@ __device__ __forceinline__ void tile_origin(const nz_geom &g, int OW, int OH, in
     oz0 = g.or0 + by * OH;
 }
 
-// stage the TH x TW tile whose (0,0) is global (lz0, lx0) into LDS, clamping reads to the grid
-__device__ __forceinline__ void load_tile(float *A, const float *__restrict__ src, const nz_geom &g, int lx0,
-                                          int lz0, bool inside) {
-    const int tid = threadIdx.x;
-    bool vec_ok = inside && ((g.pitch & 3) == 0) && ((lx0 & 3) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-    if (vec_ok) {
-#pragma unroll
-        for (int i = 0; i < TH * TW / 4 / CT; i++) {
-            int idx = tid + i * CT;
-            int r = idx / (TW / 4), c4 = idx % (TW / 4);
-            float4 v = *reinterpret_cast<const float4 *>(src + (size_t)(lz0 + r) * g.pitch + lx0 + c4 * 4);
-            *reinterpret_cast<float4 *>(&A[r * LP + c4 * 4]) = v;
-        }
-    } else {
-        for (int i = 0; i < TH * TW / CT; i++) {
-            int idx = tid + i * CT;
-            int r = idx / TW, c = idx % TW;
-            int gx = clampi(lx0 + c, 0, g.cols - 1);
-            int gz = clampi(lz0 + r, g.zc0, g.zc1);
-            A[r * LP + c] = src[(size_t)gz * g.pitch + gx];
-        }
-    }
-}
-
-// write the [r0, r0+OH) x [c0, c0+OW) interior of the LDS tile to dst
-__device__ __forceinline__ void store_tile(const float *A, float *__restrict__ dst, const nz_geom &g, int lx0,
-                                           int lz0, int c0, int OW, int r0, int OH) {
-    const int tid = threadIdx.x;
-    int ox0 = lx0 + c0, oz0 = lz0 + r0;
-    bool vec_ok = ((g.pitch & 3) == 0) && ((ox0 & 3) == 0) && ((OW & 3) == 0) && (ox0 + OW <= g.cols) &&
-                  ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
-    if (vec_ok) {
-        int w4 = OW / 4;
-        for (int idx = tid; idx < OH * w4; idx += CT) {
-            int r = idx / w4, c4 = idx - r * w4;
-            int gz = oz0 + r;
-            if (gz < g.or1) {
-                float4 v = *reinterpret_cast<const float4 *>(&A[(r0 + r) * LP + c0 + c4 * 4]);
-                *reinterpret_cast<float4 *>(dst + (size_t)gz * g.pitch + ox0 + c4 * 4) = v;
-            }
-        }
-    } else {
-        for (int idx = tid; idx < OH * OW; idx += CT) {
-            int r = idx / OW, c = idx - r * OW;
-            int gz = oz0 + r, gx = ox0 + c;
-            if (gz < g.or1 && gx < g.cols) dst[(size_t)gz * g.pitch + gx] = A[(r0 + r) * LP + c0 + c];
-        }
-    }
-}
-
-// cells of the tile that lie outside the grid take the value of the nearest grid cell (per-pass
-// clamp-to-edge of RWTileData.GetData)
-__device__ __forceinline__ void replicate_border(float *A, const nz_geom &g, int lx0, int lz0) {
-    for (int idx = threadIdx.x; idx < TH * TW; idx += CT) {
-        int r = idx / TW, c = idx % TW;
-        int gx = lx0 + c, gz = lz0 + r;
-        int cx = clampi(gx, 0, g.cols - 1), cz = clampi(gz, g.zc0, g.zc1);
-        if (cx != gx || cz != gz) {
-            int sr = clampi(cz - lz0, 0, TH - 1), sc = clampi(cx - lx0, 0, TW - 1);
-            A[r * LP + c] = A[sr * LP + sc];
-        }
-    }
-}
-
-template <int KS>
-__global__ __launch_bounds__(CT) void conv_fused_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                       nz_geom g, nz_kernel_taps taps, int T) {
-    constexpr int O = (KS - 1) / 2;
-    constexpr int OX4 = (O + 3) & ~3;  // aligned read margin of the X pass
-    __shared__ __attribute__((aligned(16))) float A[TH * LP];
-
-    const int H = T * O, HX = (H + 3) & ~3;
-    const int OW = TW - 2 * HX, OH = TH - 2 * H;
-    int ox0, oz0;
-    tile_origin(g, OW, OH, ox0, oz0);
-    const int lx0 = ox0 - HX, lz0 = oz0 - H;
-    const bool inside = lx0 >= 0 && lx0 + TW <= g.cols && lz0 >= g.zc0 && lz0 + TH - 1 <= g.zc1;
-    const int tid = threadIdx.x;
-
-    load_tile(A, src, g, lx0, lz0, inside);
-    __syncthreads();
-
-    for (int t = 0; t < T; t++) {
-        // ---- X pass: 4 row-runs of 8 cells per thread; lanes of a wave take 64 different rows
-        float acc[4][8];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int item = tid + j * CT;
-            int r = item & (TH - 1), run = item >> 6;
-            float in[8 + 2 * OX4];
-#pragma unroll
-            for (int q = 0; q < (8 + 2 * OX4) / 4; q++) {
-                int cc = clampi(run * 2 - OX4 / 4 + q, 0, TW / 4 - 1);
-                float4 v = *reinterpret_cast<const float4 *>(&A[r * LP + cc * 4]);
-                in[4 * q + 0] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                float total = 0.0f;
-#pragma unroll
-                for (int kk = 0; kk < KS; kk++) total += in[OX4 - O + e + kk] * taps.kx[kk];
-                acc[j][e] = total * taps.factor;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int item = tid + j * CT;
-            int r = item & (TH - 1), run = item >> 6;
-            float *p = &A[r * LP + run * 8];
-            *reinterpret_cast<float4 *>(p) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-            *reinterpret_cast<float4 *>(p + 4) = make_float4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
-        }
-        __syncthreads();
-
-        // ---- Z pass: one 4-column x 8-row block per thread; lanes take consecutive float4 columns
-        {
-            int cg = tid & 31, rr = tid >> 5;
-            float4 in[8 + 2 * O];
-#pragma unroll
-            for (int q = 0; q < 8 + 2 * O; q++) {
-                int r = clampi(rr * 8 - O + q, 0, TH - 1);
-                in[q] = *reinterpret_cast<const float4 *>(&A[r * LP + cg * 4]);
-            }
-            float4 outv[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                float4 total = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-                for (int kk = 0; kk < KS; kk++) {  // k = O - kk descending, Kernel[k_off - k] = kz[kk]
-                    float4 v = in[e + 2 * O - kk];
-                    float w = taps.kz[kk];
-                    total.x += v.x * w; total.y += v.y * w; total.z += v.z * w; total.w += v.w * w;
-                }
-                outv[e] = make_float4(total.x * taps.factor, total.y * taps.factor, total.z * taps.factor,
-                                      total.w * taps.factor);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 8; e++)
-                *reinterpret_cast<float4 *>(&A[(rr * 8 + e) * LP + cg * 4]) = outv[e];
-        }
-        __syncthreads();
-        if (!inside && t + 1 < T) {
-            replicate_border(A, g, lx0, lz0);
-            __syncthreads();
-        }
-    }
-    store_tile(A, dst, g, lx0, lz0, HX, OW, H, OH);
-}
-
 // ---- register-resident fused kernel ------------------------------------------------------------------
-// Same contract as conv_fused_kernel (T applications of X pass + Z pass on a 64 x 128 tile, halo
-// included), but the tile never sits in LDS: each of the 256 threads keeps a 4-column x 8-row block in
+// T applications of X pass + Z pass on a 64 x 128 tile (halo included).  The tile never sits in LDS: each of the 256 threads keeps a 4-column x 8-row block in
 // registers for the whole launch.  The X pass takes its (K-1)/2 west / east neighbours from the
 // adjacent lanes with wave-shift DPP moves; the Z pass needs (K-1)/2 rows from the thread above and
 // below, and only those boundary rows travel through LDS (16-byte accesses, double buffered: one
@@ -495,12 +336,7 @@ template <int KS>
 int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T) {
     constexpr int O = (KS - 1) / 2;
     int H = T * O, HX = (H + 3) & ~3;
-    static const int use_lds = getenv("NZ_CONV_LDS") ? atoi(getenv("NZ_CONV_LDS")) : 0;
-    if (use_lds) {
-        int OW = TW - 2 * HX, OH = TH - 2 * H;
-        long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
-        hipLaunchKernelGGL((conv_fused_kernel<KS>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, T);
-    } else {
+    {
         constexpr int NT = NZ_CONV_NT, RTH = NT / 32 * RB;  // register tile: RTH rows x 128 columns
         int OW = TW - 2 * HX, OH = RTH - 2 * H;
         long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);

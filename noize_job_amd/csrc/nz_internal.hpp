@@ -123,7 +123,7 @@ int nz_conv_max_fused(int ksize);
 // T fused applications of (X pass, Z pass) src -> dst on rows [or0, or1)
 int32_t nz_launch_conv_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g,
                              const nz_kernel_taps &k, int T);
-// single unfused passes (src -> dst), used when the launch count must be even
+// single unfused passes (src -> dst): any kernelSize <= 25, and single applications
 int32_t nz_launch_conv_pass_x(hipStream_t s, const float *src, float *dst, const nz_geom &g,
                               const nz_kernel_taps &k);
 int32_t nz_launch_conv_pass_z(hipStream_t s, const float *src, float *dst, const nz_geom &g,
@@ -145,13 +145,6 @@ int32_t nz_launch_water_step(hipStream_t s, const float *w, float *w_out, const 
 int32_t nz_launch_velocity(hipStream_t s, float *dst, const float *fN, const float *fS, const float *fE,
                            const float *fW, const nz_geom &g, int normalize, float nmin, float nrange);
 int32_t nz_launch_normalize(hipStream_t s, const float *src, float *dst, size_t n, float nmin, float nrange);
-// fused flow+water iteration through LDS.  first != 0: water_in == 1e-4 and flux_in == 0 are
-// implied and not read.
-int32_t nz_launch_flow_iter(hipStream_t s, const float *h, const float *w_in, const float *fN_in,
-                            const float *fS_in, const float *fE_in, const float *fW_in, float *w_out,
-                            float *fN_out, float *fS_out, float *fE_out, float *fW_out, const nz_geom &g,
-                            int first);
-
 // n <= nz_flow_fused_max() iterations per launch on an on-chip tile; state planes are {water,fN,fS,fE,fW}
 int nz_flow_fused_max();
 // h_out (nullable): the launch also stores its interior height cells there (a private copy, so that a

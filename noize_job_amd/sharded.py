@@ -192,20 +192,6 @@ class HipStripeOps:
         self._call("nz_flow_fused_stripe", h.data_ptr(), pin, pout, dst.data_ptr(), C.byref(st), n, int(first),
                    int(last), normMin, normMax)
 
-    def flow_first(self, h, S, plan):
-        st = plan.stripe()
-        self._call("nz_flow_first_stripe", h.data_ptr(), *[S[i].data_ptr() for i in range(FLOW_PLANES)], C.byref(st))
-
-    def flow_iter(self, h, S_in, S_out, plan):
-        st = plan.stripe()
-        self._call("nz_flow_iter_stripe", h.data_ptr(), *[S_in[i].data_ptr() for i in range(FLOW_PLANES)],
-                   *[S_out[i].data_ptr() for i in range(FLOW_PLANES)], C.byref(st))
-
-    def flow_velocity(self, dst, S, plan, normMin, normMax):
-        st = plan.stripe()
-        self._call("nz_flow_velocity_stripe", dst.data_ptr(), *[S[i].data_ptr() for i in range(1, FLOW_PLANES)],
-                   C.byref(st), normMin, normMax)
-
 
 class TorchComm:
     """Neighbour halo exchange with torch.distributed P2P (backend `nccl` = RCCL over xGMI on the GPU

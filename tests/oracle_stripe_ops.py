@@ -41,22 +41,6 @@ class OracleStripeOps:
         out = O.erosion_min(src.numpy()[v0:v1], E)
         dst.numpy()[plan.own0:plan.own1] = out[plan.own0 - v0:plan.own1 - v0]
 
-    def _flow(self, h, S_in, S_out, plan, first):
-        v0, v1 = self._valid(plan)
-        hv = h.numpy()[v0:v1]
-        if first:
-            w = np.full_like(hv, 0.0001)
-            fl = [np.zeros_like(hv) for _ in range(4)]
-        else:
-            w = S_in[0].numpy()[v0:v1]
-            fl = [S_in[i].numpy()[v0:v1] for i in range(1, 5)]
-        fl = O.flow_step(hv, w, *fl)          # N, S, E, W
-        w = O.water_step(w, *fl)
-        sl = slice(plan.own0 - v0, plan.own1 - v0)
-        S_out[0].numpy()[plan.own0:plan.own1] = w[sl]
-        for i in range(4):
-            S_out[1 + i].numpy()[plan.own0:plan.own1] = fl[i][sl]
-
     def flow_fused_max(self):
         return 3
 
@@ -81,15 +65,3 @@ class OracleStripeOps:
             S_out[0].numpy()[plan.own0:plan.own1] = w[sl]
             for i in range(4):
                 S_out[1 + i].numpy()[plan.own0:plan.own1] = fl[i][sl]
-
-    def flow_first(self, h, S, plan):
-        self._flow(h, None, S, plan, True)
-
-    def flow_iter(self, h, S_in, S_out, plan):
-        self._flow(h, S_in, S_out, plan, False)
-
-    def flow_velocity(self, dst, S, plan, normMin, normMax):
-        v0, v1 = self._valid(plan)
-        v = O.velocity(*[S[i].numpy()[v0:v1] for i in range(1, 5)])
-        out = O.normalize(v, normMin, normMax)
-        dst.numpy()[plan.own0:plan.own1] = out[plan.own0 - v0:plan.own1 - v0]

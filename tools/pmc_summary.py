@@ -15,10 +15,9 @@ import json
 import re
 import sys
 
-STAGE_OF = [("fractal_simplex_tab_kernel", "noise"), ("fractal_kernel", "noise"), ("conv_reg_kernel", "gauss"),
-            ("conv_fused_kernel", "gauss"), ("erosion_reg_kernel<3>", "erosion"), ("flow_iter_kernel<false>", "flow"),
-            ("flow_iter_kernel<true>", "flow_first"), ("velocity_kernel", "flow_velocity"),
-            ("erosion_fused_kernel", "erosion"), ("flow_fused_kernel", "flow"), ("min_pass_kernel", "erosion_pass")]
+STAGE_OF = [("fractal_simplex_tab_kernel", "noise"), ("fractal_tab2_kernel", "noise"), ("fractal_kernel", "noise"),
+            ("conv_reg_kernel", "gauss"), ("conv_pass", "gauss_pass"), ("erosion_reg_kernel", "erosion"),
+            ("min_pass_kernel", "erosion_pass"), ("flow_fused_kernel", "flow"), ("velocity_kernel", "flow_velocity")]
 
 
 def short(name):
