@@ -5,8 +5,11 @@ A step = one pass of the metric pipeline (simplex fBm 13 oct -> Gauss5 x17 -> Fl
 erosion x5) over one device-resident grid; nothing crosses PCIe inside the timed region.
   N = 1 : the 4096^2 tile BASELINE.json's metric is quoted on.
   N > 1 : one process per GPU (torch.distributed, backend nccl = RCCL); the grid is row-stripe
-          sharded, 2048 x 16384 cells per rank (N = 8 is BASELINE config 5, 16384^2), with neighbour
-          halo exchange before every stencil launch -> "scaling": "weak".
+          sharded, 2048 x 16384 cells per rank (N = 8 is BASELINE config 5, 16384^2) -> "scaling":
+          "weak".  The stripes are independent: the source is closed-form noise, so every rank
+          recomputes the 49 ghost rows per side the stencils consume (--halo recompute, default; no
+          data-path collective).  --halo exchange swaps ghost rows with the neighbour ranks over
+          RCCL before every stencil launch instead (the form an uploaded height map would need).
 Rank 0 prints ONE JSON line.  `roofline` describes the stage that takes the most GPU time, `stages`
 every stage; both come from HIP events recorded on the kernels' stream inside the timed steps.
 `cpu_baseline` is the CPU oracle (reference-shaped restatement of the Burst jobs) timed on this
@@ -34,16 +37,26 @@ KERNEL_OF = {"noise": "fractal_simplex_tab_kernel<2>", "gauss": "conv_reg_kernel
 NOISE_OPS_PER_OCTAVE_CELL = 90.0  # VALU slots of the table-driven simplex octave (ISA count: 172 per 2 cells + LDS)
 
 
+MAX_MARKED_STEPS = 200  # per-stage markers are kept for the last steps only (the handle ring holds 4096)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # the GPU's clocks keep ramping for some tens of ms of continuous work (0.96 ms/step over 5 steps,
+    # 0.89 over 20, 0.85 over 100 and beyond, tools/probe_host_enqueue.py): the defaults time steady state
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--res", type=int, default=4096, help="tile resolution at N=1")
     ap.add_argument("--stripe-rows", type=int, default=2048, help="rows per rank at N>1")
     ap.add_argument("--cols", type=int, default=16384, help="grid columns at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="run the row-stripe path even with one rank (rehearsal)")
+    ap.add_argument("--halo", choices=("recompute", "exchange"), default="recompute",
+                    help="N>1: ghost rows recomputed from the closed-form noise (no data-path communication) or "
+                         "exchanged with the neighbour ranks over RCCL before every launch")
+    ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "P"), default=None,
+                    help="one-process rehearsal of rank R of a P-rank job (needs --halo recompute)")
     ap.add_argument("--cpu-res", type=int, default=4096)
     return ap.parse_args()
 
@@ -93,7 +106,9 @@ def main():
                              "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
-    sharded = world > 1 or args.sharded
+    sharded = world > 1 or args.sharded or args.as_rank is not None
+    if args.as_rank is not None and (world != 1 or args.halo != "recompute"):
+        raise SystemExit("--as-rank is a single-process rehearsal of the communication-free schedule")
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -102,7 +117,7 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = nj.Context(local_rank, stream=stream.cuda_stream)
 
-    p = sh.PipelineParams(gaussIterations=G_IT, flowIterations=F_IT, erosionIterations=E_IT)
+    p = sh.PipelineParams(gaussIterations=G_IT, flowIterations=F_IT, erosionIterations=E_IT, haloMode=args.halo)
     marks = []  # per step: handles at stage boundaries
 
     if not sharded:
@@ -135,21 +150,27 @@ def main():
     else:
         ops = sh.HipStripeOps(ctx)
         halo = sh.halo_rows_needed(ops, p)
-        plan = sh.StripePlan(rank, world, args.stripe_rows * world, args.cols, halo)
-        cells = plan.grows * plan.cols
+        prank, pworld = args.as_rank if args.as_rank is not None else (rank, world)
+        plan = sh.StripePlan(prank, pworld, args.stripe_rows * pworld, args.cols, halo,
+                             neighbours_own_halo=args.halo == "exchange")
+        cells = plan.nown * world * plan.cols  # every rank owns stripe_rows rows
         bufs = (torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
                 torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
                 torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
                 torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"))
-        comm = sh.TorchComm(dist)
+        comm = sh.TorchComm(dist) if args.halo == "exchange" else sh.NoComm()
 
         def step(record):
             sh.run_pipeline(ops, comm, plan, p, bufs)
 
-        workload = "%dx%d grid as %d row stripes of %dx%d (halo exchange over RCCL): simplex-13oct -> Gauss5_S1 x%d " \
-                   "-> FlowMap x%d -> ValueErosion x%d" % (plan.grows, plan.cols, world, args.stripe_rows, plan.cols,
-                                                            G_IT, F_IT, E_IT)
+        how = "ghost rows exchanged over RCCL before every launch" if args.halo == "exchange" else \
+            "%d ghost rows per side recomputed from the closed-form noise, no data-path communication" % halo
+        workload = "%dx%d grid as %d row stripes of %dx%d (%s): simplex-13oct -> Gauss5_S1 x%d " \
+                   "-> FlowMap x%d -> ValueErosion x%d" % (plan.grows, plan.cols, pworld, args.stripe_rows, plan.cols,
+                                                            how, G_IT, F_IT, E_IT)
         parallelism = "row-stripe dp%d" % world
+        if args.as_rank is not None:
+            parallelism = "rehearsal of rank %d of %d on one GPU" % (prank, pworld)
 
     def fence():
         if sharded:
@@ -160,8 +181,8 @@ def main():
         step(False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(not sharded)
+    for i in range(args.steps):
+        step(not sharded and args.steps - i <= MAX_MARKED_STEPS)
     fence()
     dt = time.perf_counter() - t0
     if sharded:

@@ -3,10 +3,20 @@ reference only has independent clamped tiles, Scripts/MeshTileGenerator.cs:166-1
 
 Rank r of P owns rows [r*R/P, (r+1)*R/P) x all columns of a (grows x cols) grid.  The
 noise stage needs no communication (world offsets, Noise/Fractal/Fractal.cs:109-116); every other
-stage is a small-radius stencil, so before each launch the ranks exchange the ghost rows that launch
-consumes with their two neighbours (rank-1 / rank+1 only).  Because the kernels compute each cell
-with the same operations wherever it sits, the sharded result equals the single-GPU monolithic
-result bit for bit; the only clamps are at the global border.
+stage is a small-radius stencil.  Two ways of feeding the stencils their ghost rows:
+
+  * haloMode "recompute" (default for the metric pipeline, whose source is closed-form noise): each
+    rank evaluates the noise on its owned rows plus the total stencil radius of the pipeline
+    (Gauss 17x2 + flow 5x2 + erosion 5 = 49 rows) and every launch produces a window that shrinks by
+    the radius it consumed.  No data-path communication at all; ~2.4 % redundant rows per side at
+    2048-row stripes.
+  * haloMode "exchange": before each launch the ranks exchange the ghost rows that launch consumes
+    with their two neighbours (rank-1 / rank+1 only) -- the form a pipeline needs whose source plane
+    is not recomputable (an uploaded height map).
+
+Because the kernels compute each cell with the same operations wherever it sits, either way the
+sharded result equals the single-GPU monolithic result bit for bit; the only clamps are at the
+global border.
 
 The schedule below is host logic shared by two compute back ends:
   * HipStripeOps  -- the product path: C-ABI stripe entry points on device buffers (torch CUDA tensors
@@ -14,6 +24,7 @@ The schedule below is host logic shared by two compute back ends:
     (= RCCL over xGMI);
   * any object with the same methods (tests/ supplies one built on the CPU oracle, driven over `gloo`).
 """
+import copy
 import ctypes as C
 
 from . import _native as N
@@ -23,7 +34,7 @@ class StripePlan:
     """Geometry of one rank's stripe.  Every plane buffer has `halo` ghost rows above and below the
     owned rows (the ones hanging over the global border are never read)."""
 
-    def __init__(self, rank, world, grows, cols, halo):
+    def __init__(self, rank, world, grows, cols, halo, neighbours_own_halo=True):
         assert 0 <= rank < world and grows >= world
         base, rem = divmod(grows, world)
         self.rank, self.world, self.grows, self.cols, self.halo = rank, world, grows, cols, halo
@@ -32,10 +43,24 @@ class StripePlan:
         self.rows = self.nown + 2 * halo                 # rows in every buffer
         self.own0, self.own1 = halo, halo + self.nown
         self.grow0 = self.g0 - halo
-        assert self.nown >= halo, "stripe thinner than the halo"
+        # an exchange takes ghost rows from the adjacent rank only; recomputed ghost rows may reach further
+        assert self.nown >= halo or not neighbours_own_halo, "stripe thinner than the halo"
 
     def stripe(self, pitch=0):
         return N.Stripe(self.cols, self.rows, self.grow0, self.grows, self.own0, self.own1, pitch)
+
+    def widened(self, up, down):
+        """The same buffer with the produced rows grown by `up` rows above and `down` rows below the
+        owned ones, clipped to the global grid: what a launch has to produce so that later launches
+        find their ghost rows without an exchange."""
+        if up == 0 and down == 0:
+            return self
+        assert up <= self.halo and down <= self.halo
+        v = copy.copy(self)
+        v.own0 = max(self.own0 - up, -self.grow0)
+        v.own1 = min(self.own1 + down, self.grows - self.grow0)
+        v.g0, v.nown = self.grow0 + v.own0, v.own1 - v.own0
+        return v
 
     @property
     def up(self):
@@ -58,7 +83,8 @@ class PipelineParams:
 
     def __init__(self, noiseType=3, hurst=0.4, startingAmplitude=1.0, stepdown=2.0, detuneRate=0.0, octaves=13,
                  xpos=0, zpos=0, noiseSize=1700, filter=2, gaussIterations=17, flowIterations=5, normMin=0.0,
-                 normMax=0.005, erosionIterations=5):
+                 normMax=0.005, erosionIterations=5, haloMode="exchange"):
+        assert haloMode in ("exchange", "recompute")
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -66,50 +92,75 @@ class PipelineParams:
 FLOW_PLANES = 5  # water, fN, fS, fE, fW: state buffers are [5, rows, cols]
 
 
+def _launch_radii(ops, p):
+    """Per launch of the schedule: (stage, fused applications, rows consumed above, rows consumed below)."""
+    out = []
+    if p.gaussIterations > 0:
+        k_off = ops.kernel_filter_halo_rows(p.filter, 1)
+        cap = max(1, ops.kernel_filter_max_fused(p.filter))
+        out += [("gauss", T, T * k_off, T * k_off) for T in split_iterations(p.gaussIterations, cap)]
+    if p.flowIterations > 0:
+        # whole iterations fused on chip, <= flow_fused_max() per launch; a launch of n iterations reads
+        # height and state 2n rows beyond the rows it produces
+        out += [("flow", n, 2 * n, 2 * n) for n in split_iterations(p.flowIterations, ops.flow_fused_max())]
+    left = p.erosionIterations
+    while left > 0:
+        E = min(left, ops.erosion_max_fused())
+        out.append(("erosion", E, E, 0))                # the min window reaches upwards only
+        left -= E
+    return out
+
+
 def halo_rows_needed(ops, p):
-    k_off = ops.kernel_filter_halo_rows(p.filter, 1)
-    cap = max(1, ops.kernel_filter_max_fused(p.filter))
-    g = max(split_iterations(p.gaussIterations, cap)) * k_off if p.gaussIterations > 0 else 0
-    e = min(p.erosionIterations, ops.erosion_max_fused()) if p.erosionIterations > 0 else 0
-    f = 2 * max(split_iterations(p.flowIterations, ops.flow_fused_max())) if p.flowIterations > 0 else 0
-    return max(g, f, e, 1)
+    """Ghost rows every plane buffer needs on each side: the widest single launch when ghost rows are
+    exchanged before each launch, the whole pipeline's radius when they are recomputed."""
+    radii = _launch_radii(ops, p)
+    if p.haloMode == "recompute":
+        return max(sum(r[2] for r in radii), sum(r[3] for r in radii), 1)
+    return max([max(r[2], r[3]) for r in radii] + [1])
 
 
 def pipeline_steps(ops, plan, p, bufs, result):
     """The sharded metric pipeline as a generator: yields (planes, up_rows, down_rows) wherever the
-    ranks must exchange ghost rows, runs the stripe kernels in between.  bufs = (A, B, S0, S1): two
-    height planes [plan.rows, cols] and two flow-state buffers [5, plan.rows, cols].  The plane whose
-    owned rows hold the result is appended to `result`."""
+    ranks must exchange ghost rows (never in haloMode "recompute"), runs the stripe kernels in between.
+    bufs = (A, B, S0, S1): two height planes [plan.rows, cols] and two flow-state buffers
+    [5, plan.rows, cols].  The plane whose owned rows hold the result is appended to `result`."""
     A, B, S0, S1 = bufs
     cur, nxt = A, B
-    ops.fractal(cur, plan, p)
-    if p.gaussIterations > 0:
-        k_off = ops.kernel_filter_halo_rows(p.filter, 1)
-        cap = max(1, ops.kernel_filter_max_fused(p.filter))
-        for T in split_iterations(p.gaussIterations, cap):
-            yield [cur], T * k_off, T * k_off
-            ops.kernel_filter(cur, nxt, plan, p.filter, T)
+    s_cur, s_nxt = S0, S1
+    radii = _launch_radii(ops, p)
+    recompute = p.haloMode == "recompute"
+    # rows beyond the owned ones that the remaining launches will still consume
+    need_up = sum(r[2] for r in radii) if recompute else 0
+    need_down = sum(r[3] for r in radii) if recompute else 0
+    ops.fractal(cur, plan.widened(need_up, need_down), p)
+    flow_launches = [i for i, r in enumerate(radii) if r[0] == "flow"]
+    for i, (stage, n, up, down) in enumerate(radii):
+        if recompute:
+            need_up, need_down = need_up - up, need_down - down
+        win = plan.widened(need_up, need_down)
+        if stage == "gauss":
+            if not recompute:
+                yield [cur], up, down
+            ops.kernel_filter(cur, nxt, win, p.filter, n)
             cur, nxt = nxt, cur
-    if p.flowIterations > 0:
-        # whole iterations fused on chip, <= flow_fused_max() per launch; a launch of n iterations reads
-        # height and state 2n rows beyond the owned rows
-        chunks = split_iterations(p.flowIterations, ops.flow_fused_max())
-        yield [cur], 2 * max(chunks), 2 * max(chunks)   # height: exchanged once, read by every launch
-        s_cur, s_nxt = S0, S1
-        for i, n in enumerate(chunks):
-            first, last = i == 0, i == len(chunks) - 1
-            if not first:
-                yield [s_cur[k] for k in range(FLOW_PLANES)], 2 * n, 2 * n
-            ops.flow_fused(cur, s_cur, s_nxt, nxt, plan, n, first, last, p.normMin, p.normMax)
+        elif stage == "flow":
+            first, last = i == flow_launches[0], i == flow_launches[-1]
+            if not recompute:
+                if first:  # height: exchanged once, read by every launch
+                    widest = max(radii[j][2] for j in flow_launches)
+                    yield [cur], widest, widest
+                else:
+                    yield [s_cur[k] for k in range(FLOW_PLANES)], up, down
+            ops.flow_fused(cur, s_cur, s_nxt, nxt, win, n, first, last, p.normMin, p.normMax)
             s_cur, s_nxt = s_nxt, s_cur
-        cur, nxt = nxt, cur
-    left = p.erosionIterations
-    while left > 0:
-        E = min(left, ops.erosion_max_fused())
-        yield [cur], E, 0                               # the min window reaches upwards only
-        ops.erosion(cur, nxt, plan, E)
-        cur, nxt = nxt, cur
-        left -= E
+            if last:
+                cur, nxt = nxt, cur
+        else:
+            if not recompute:
+                yield [cur], up, down
+            ops.erosion(cur, nxt, win, n)
+            cur, nxt = nxt, cur
     result.append(cur)
 
 

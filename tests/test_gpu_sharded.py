@@ -15,7 +15,8 @@ def _run_lockstep(nj, world, grows, cols, p):
         ctx = nj.Context(0, stream=stream.cuda_stream)
         ops = sh.HipStripeOps(ctx)
         halo = sh.halo_rows_needed(ops, p)
-        plans = [sh.StripePlan(r, world, grows, cols, halo) for r in range(world)]
+        plans = [sh.StripePlan(r, world, grows, cols, halo, neighbours_own_halo=p.haloMode == "exchange")
+                 for r in range(world)]
         nan = float("nan")
         bufs = [(torch.full((pl.rows, cols), nan, device="cuda"), torch.full((pl.rows, cols), nan, device="cuda"),
                  torch.full((5, pl.rows, cols), nan, device="cuda"), torch.full((5, pl.rows, cols), nan, device="cuda"))
@@ -31,11 +32,14 @@ def _run_lockstep(nj, world, grows, cols, p):
     return out
 
 
-@pytest.mark.parametrize("world", [1, 2, 4, 8])
-def test_sharded_equals_monolithic_and_oracle(nj, ctx, oracle, world):
+@pytest.mark.parametrize("world,mode", [(1, "exchange"), (2, "exchange"), (4, "exchange"), (8, "exchange"),
+                                        (1, "recompute"), (2, "recompute"), (8, "recompute"), (16, "recompute")])
+def test_sharded_equals_monolithic_and_oracle(nj, ctx, oracle, world, mode):
+    # "recompute" at 16 ranks: 32-row stripes with 49 ghost rows, so a rank recomputes rows of two neighbours
     from noize_job_amd import sharded as sh
     res = 512
-    p = sh.PipelineParams(octaves=13, gaussIterations=17, flowIterations=5, erosionIterations=5, xpos=100, zpos=900)
+    p = sh.PipelineParams(octaves=13, gaussIterations=17, flowIterations=5, erosionIterations=5, xpos=100, zpos=900,
+                          haloMode=mode)
     got = _run_lockstep(nj, world, res, res, p)
     # monolithic run of the same kernels through the tile API
     data = ctx.alloc(res * res)
@@ -52,10 +56,12 @@ def test_sharded_equals_monolithic_and_oracle(nj, ctx, oracle, world):
     data.Dispose()
 
 
-def test_rectangular_stripes_uneven_split(nj, oracle):
+@pytest.mark.parametrize("mode", ["exchange", "recompute"])
+def test_rectangular_stripes_uneven_split(nj, oracle, mode):
     from noize_job_amd import sharded as sh
     grows, cols = 333, 200  # rows do not divide by the world size, cols are not a multiple of the tile width
-    p = sh.PipelineParams(octaves=8, noiseSize=300, gaussIterations=5, flowIterations=3, erosionIterations=7)
+    p = sh.PipelineParams(octaves=8, noiseSize=300, gaussIterations=5, flowIterations=3, erosionIterations=7,
+                          haloMode=mode)
     got = _run_lockstep(nj, 3, grows, cols, p)
     want = oracle.pipeline(grows, cols, octaves=8, noise_size=300, gauss_iterations=5, flow_iterations=3,
                            erosion_iterations=7)

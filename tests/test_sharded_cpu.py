@@ -30,10 +30,12 @@ def _worker(rank, world, port, grows, cols, pkw, out_path):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     ops = OracleStripeOps()
     p = sh.PipelineParams(**pkw)
-    plan = sh.StripePlan(rank, world, grows, cols, sh.halo_rows_needed(ops, p))
+    plan = sh.StripePlan(rank, world, grows, cols, sh.halo_rows_needed(ops, p),
+                         neighbours_own_halo=p.haloMode == "exchange")
     bufs = (torch.full((plan.rows, cols), float("nan")), torch.full((plan.rows, cols), float("nan")),
             torch.full((5, plan.rows, cols), float("nan")), torch.full((5, plan.rows, cols), float("nan")))
-    res = sh.run_pipeline(ops, sh.TorchComm(dist), plan, p, bufs)
+    comm = sh.TorchComm(dist) if p.haloMode == "exchange" else sh.NoComm()  # "recompute" never communicates
+    res = sh.run_pipeline(ops, comm, plan, p, bufs)
     mine = res[plan.own0:plan.own1].contiguous()
     parts = [None] * world
     dist.all_gather_object(parts, (plan.g0, mine.numpy()))
@@ -44,9 +46,11 @@ def _worker(rank, world, port, grows, cols, pkw, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,grows,cols", [(2, 64, 48), (3, 70, 33)])
-def test_sharded_schedule_equals_monolithic(oracle, tmp_path, world, grows, cols):
-    pkw = dict(octaves=6, noiseSize=40, gaussIterations=7, flowIterations=3, erosionIterations=4, xpos=11, zpos=5)
+@pytest.mark.parametrize("world,grows,cols,mode", [(2, 64, 48, "exchange"), (3, 70, 33, "exchange"),
+                                                    (2, 64, 48, "recompute"), (3, 70, 33, "recompute")])
+def test_sharded_schedule_equals_monolithic(oracle, tmp_path, world, grows, cols, mode):
+    pkw = dict(octaves=6, noiseSize=40, gaussIterations=7, flowIterations=3, erosionIterations=4, xpos=11, zpos=5,
+               haloMode=mode)
     out = str(tmp_path / "sharded.npy")
     mp.spawn(_worker, args=(world, _free_port(), grows, cols, pkw, out), nprocs=world, join=True)
     got = np.load(out)
@@ -71,17 +75,57 @@ def test_stripe_plan_partitions_rows():
     assert sum(split_iterations(17, 4)) == 17 and max(split_iterations(17, 4)) <= 4
 
 
-def test_lockstep_driver_equals_monolithic(oracle):
+def test_recompute_mode_needs_the_whole_pipeline_radius():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from noize_job_amd import sharded as sh
+    from oracle_stripe_ops import OracleStripeOps
+    ops = OracleStripeOps()
+    p = sh.PipelineParams(haloMode="recompute")            # Gauss5 x17, flow x5, erosion x5
+    assert sh.halo_rows_needed(ops, p) == 17 * 2 + 5 * 2 + 5
+    assert sh.halo_rows_needed(ops, sh.PipelineParams()) == max(3 * 2, 2 * 3, 5)  # oracle ops: flow fused <= 3
+    plan = sh.StripePlan(3, 8, 16384, 64, 49)
+    win = plan.widened(49, 44)
+    assert (win.own0, win.own1, win.g0, win.nown) == (0, 49 + 2048 + 44, 3 * 2048 - 49, 2048 + 93)
+    top = sh.StripePlan(0, 8, 16384, 64, 49).widened(49, 44)   # clipped at the global border
+    assert (top.own0, top.g0, top.nown) == (49, 0, 2048 + 44)
+    # every launch of the schedule shrinks the window; the last one produces exactly the owned rows
+    calls = []
+
+    class Rec(OracleStripeOps):
+        def fractal(self, buf, pl, p):
+            calls.append((pl.own0, pl.own1))
+
+        def kernel_filter(self, src, dst, pl, f, T):
+            calls.append((pl.own0, pl.own1))
+
+        def flow_fused(self, h, si, so, dst, pl, *a):
+            calls.append((pl.own0, pl.own1))
+
+        def erosion(self, src, dst, pl, E):
+            calls.append((pl.own0, pl.own1))
+
+    res = []
+    steps = list(sh.pipeline_steps(Rec(), plan, p, (0, 1, [0] * 5, [1] * 5), res))
+    assert steps == []                                         # nothing to exchange
+    assert calls[0] == (0, 49 + 2048 + 44) and calls[-1] == (plan.own0, plan.own1)
+    assert all(a[0] <= b[0] and a[1] >= b[1] for a, b in zip(calls, calls[1:]))
+
+
+@pytest.mark.parametrize("mode", ["exchange", "recompute"])
+def test_lockstep_driver_equals_monolithic(oracle, mode):
     # the same schedule with all ranks in one process (the driver the single-GPU rehearsal uses)
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from noize_job_amd import sharded as sh
     from oracle_stripe_ops import OracleStripeOps
     world, grows, cols = 4, 96, 40
-    p = sh.PipelineParams(octaves=5, noiseSize=30, gaussIterations=5, flowIterations=4, erosionIterations=3)
+    p = sh.PipelineParams(octaves=5, noiseSize=30, gaussIterations=5, flowIterations=4, erosionIterations=3,
+                          haloMode=mode)
     ops = OracleStripeOps()
     halo = sh.halo_rows_needed(ops, p)
-    plans = [sh.StripePlan(r, world, grows, cols, halo) for r in range(world)]
+    plans = [sh.StripePlan(r, world, grows, cols, halo, neighbours_own_halo=mode == "exchange")
+             for r in range(world)]
     bufs = [(torch.full((pl.rows, cols), float("nan")), torch.full((pl.rows, cols), float("nan")),
              torch.full((5, pl.rows, cols), float("nan")), torch.full((5, pl.rows, cols), float("nan")))
             for pl in plans]

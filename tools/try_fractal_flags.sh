@@ -1,11 +1,12 @@
 #!/bin/bash
+# rebuilds nz_fractal.hip with each flag set on the GPU box and times the noise stage
 set -e
 cd "$(dirname "$0")/../noize_job_amd/csrc"
 BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -fno-slp-vectorize"
-for extra in "-DNZ_PSR_FMOD=0" "-DNZ_PSR_FMOD=1"; do
+mkdir -p build
+for extra in "-DNZ_FT_ROWS=8" "-DNZ_FT_ROWS=4" "-DNZ_FT_ROWS=2" "-DNZ_FT_ROWS=1"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE $extra -c nz_fractal.hip -o build/nz_fractal.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libnoize_hip.so
   echo "== flags: [$extra]"
-  for b in 2 4 0 6; do python3 ../../tools/bench_stage.py noise --basis $b --reps 10 2>/dev/null; done
+  for r in 2048 4096 8192; do python3 ../../tools/bench_stage.py noise --res $r --reps 20 2>/dev/null; done
 done
-cd ../.. && python3 -m pytest tests -m gpu -q -k "fractal or fixtures or degenerate" 2>&1 | tail -1
