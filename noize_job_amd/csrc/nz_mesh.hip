@@ -5,8 +5,10 @@
 // Mesh/Generators/SquareGridHeightMap.cs:12-106, Mesh/Streams/PositionStream.cs:75-134,
 // Mesh/Streams/Triangle.cs:19-27).
 //
-// Vertex record = {float3 position; float3 normal; float4 tangent; float2 texCoord0} = 48 B = three
-// 16-byte stores per vertex.  The index buffer has a closed form (vi = (R+1) z + x,
+// Vertex record = {float3 position; float3 normal; float4 tangent; float2 texCoord0} = 48 B.  A
+// workgroup builds the records of 256 consecutive vertices in LDS (12 KB) and streams them out as a
+// flat float4 array, so every store instruction writes 1 KB contiguous per wave instead of 16-byte
+// pieces at a 48-byte stride.  The index buffer has a closed form (vi = (R+1) z + x,
 // ti = 2R(z-1) + 2(x-1)), so it is written as a flat array, one uint4 (16 B) per lane, fully
 // coalesced, without reading anything.  Integer output is bit-exact by construction.
 #include "nz_internal.hpp"
@@ -34,14 +36,24 @@ __device__ __forceinline__ float mesh_h(const mesh_params &g, const float *__res
     return heights[((z + g.off) * g.in_res) + x + g.off];
 }
 
+// write-once output streams: non-temporal 16-byte stores
+template <typename T>
+__device__ __forceinline__ void nt_store(T *p, const T &v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(T) == 16, "16-byte records");
+    __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(&v), reinterpret_cast<v4f *>(p));
+}
+
 __device__ __forceinline__ float interpolate_edge(float a, float b) { return a - (b - a); }
 
 __global__ __launch_bounds__(CT) void mesh_vertex_kernel(float4 *__restrict__ vtx, const float *__restrict__ heights,
                                                         mesh_params g) {
+    __shared__ float4 s_rec[CT * 3];
     const int R = g.res;
-    size_t vi = (size_t)blockIdx.x * CT + threadIdx.x;
-    size_t nv = (size_t)(R + 1) * (R + 1);
-    if (vi >= nv) return;
+    const size_t base = (size_t)blockIdx.x * CT;
+    size_t vi = base + threadIdx.x;
+    const size_t nv = (size_t)(R + 1) * (R + 1);
+    if (vi >= nv) vi = nv - 1;  // lanes past the end rebuild the last vertex; their records are not stored
     int z = (int)(vi / (R + 1));
     int x = (int)(vi - (size_t)z * (R + 1));
     // Execute(): Overshoot :77-102 / Square :84-105
@@ -79,10 +91,19 @@ __global__ __launch_bounds__(CT) void mesh_vertex_kernel(float4 *__restrict__ vt
         uvx = ((float)x) / ((float)R + 1.0f);
         uvy = ((float)z) / ((float)R + 1.0f);
     }
-    float4 *o = vtx + vi * 3;
+    float4 *o = s_rec + threadIdx.x * 3;  // 12-dword stride: the 16-byte LDS stores of 16 lanes hit distinct banks
     o[0] = make_float4(px, py, pz, rs * nx);
     o[1] = make_float4(rs * ny, rs * nz, tgx, tgy);
     o[2] = make_float4(tgz, 0.0f /* tangent.w of `new Vertex()` */, uvx, uvy);
+    __syncthreads();
+    const size_t left = nv - base;
+    const int nrec = (int)(left < (size_t)CT ? left : (size_t)CT) * 3;
+    float4 *out = vtx + base * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int j = k * CT + threadIdx.x;
+        if (j < nrec) nt_store(out + j, s_rec[j]);
+    }
 }
 
 // flat index i -> triangle i/3 (ti), corner i%3.  ti = 2R(z-1) + 2(x-1) + s, s in {0,1}:
@@ -107,7 +128,7 @@ __global__ __launch_bounds__(CT) void mesh_index_kernel(uint32_t *__restrict__ i
         v.y = mesh_index((uint32_t)i + 1, R);
         v.z = mesh_index((uint32_t)i + 2, R);
         v.w = mesh_index((uint32_t)i + 3, R);
-        *reinterpret_cast<uint4 *>(idx + i) = v;
+        nt_store(reinterpret_cast<uint4 *>(idx + i), v);
     } else {
         for (size_t k = i; k < n && k < i + 4; k++) idx[k] = mesh_index((uint32_t)k, R);
     }
