@@ -614,7 +614,32 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     NZ_REQUIRE(src && tmp && src != tmp, "src/tmp must be two distinct planes");
     NZ_REQUIRE(iterations >= 1, "iterations < 1");
     int cap = (t.ksize & 1) ? conv_tcap(t.ksize) : 0;
-    if (cap == 0 || iterations == 1) {
+    if (nz_conv_has_wide(t.ksize)) {  // one launch per application, ping-pong, copy back after an odd count
+        float *cur = src, *other = tmp;
+        for (int i = 0; i < iterations; i++) {
+            NZ_TRY_(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+                return nz_launch_conv_wide(st, cur, other, gb, t);
+            }));
+            float *s = cur; cur = other; other = s;
+        }
+        if (cur != src) {
+            NZ_TRY_(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+                size_t off = (size_t)gb.or0 * gb.pitch;
+                return nz_launch_copy(st, src + off, tmp + off, (size_t)(gb.or1 - gb.or0) * gb.pitch);
+            }));
+        }
+        return NZ_OK;
+    }
+    if (cap > 0 && iterations == 1) {  // the delegate's single application: one launch into tmp, copy back
+        NZ_TRY_(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            return nz_launch_conv_fused(st, src, tmp, gb, t, 1);
+        }));
+        return banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            size_t off = (size_t)gb.or0 * gb.pitch;
+            return nz_launch_copy(st, src + off, tmp + off, (size_t)(gb.or1 - gb.or0) * gb.pitch);
+        });
+    }
+    if (cap == 0) {  // even or out-of-table sizes: the two passes as launched by the reference
         for (int i = 0; i < iterations; i++) {
             int32_t rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
                 return nz_launch_conv_pass_x(st, src, tmp, gb, t);
@@ -645,13 +670,15 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
 static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geom &g, int iterations) {
     NZ_REQUIRE(src && tmp && src != tmp, "src/tmp must be two distinct planes");
     NZ_REQUIRE(iterations >= 1, "iterations < 1");
-    if (iterations == 1) {  // ErosionKernelJob.ScheduleSeries KernelJob.cs:318-335: min-X then min-Z, size 3
-        int32_t rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
-            return nz_launch_min_pass(st, src, tmp, gb, 3, 0);
-        });
-        if (rc) return rc;
+    if (iterations == 1) {
+        // ErosionKernelJob.ScheduleSeries KernelJob.cs:318-335: min-X then min-Z (size 3) = the min over
+        // {x-1,x} x {z-1,z}; one launch into tmp, then the copy back that stands for the flush
+        NZ_TRY_(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            return nz_launch_erosion_fused(st, src, tmp, gb, 1);
+        }));
         return banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
-            return nz_launch_min_pass(st, tmp, src, gb, 3, 1);
+            size_t off = (size_t)gb.or0 * gb.pitch;
+            return nz_launch_copy(st, src + off, tmp + off, (size_t)(gb.or1 - gb.or0) * gb.pitch);
         });
     }
     int cap = nz_erosion_max_fused();

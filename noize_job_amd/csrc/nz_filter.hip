@@ -313,19 +313,121 @@ __global__ __launch_bounds__(CT) void conv_pass_z_kernel(const float *__restrict
     dst[(size_t)z * g.pitch + x] = total * taps.factor;
 }
 
-// single min passes with the reference's window k in [-k_off, k_off) (KernelOperators.cs:84-90,109-116)
-__global__ __launch_bounds__(CT) void min_pass_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                     nz_geom g, int k_off, int along_z) {
-    int x = blockIdx.x * CT + threadIdx.x;
-    int z = g.or0 + blockIdx.y;
-    if (x >= g.cols || z >= g.or1) return;
-    float v = 3.40282347e+38f;
-    for (int k = -k_off; k < k_off; k++) {
-        int xx = along_z ? x : clampi(x + k, 0, g.cols - 1);
-        int zz = along_z ? clampi(z + k, g.zc0, g.zc1) : z;
-        v = fminf(v, src[(size_t)zz * g.pitch + xx]);
+// ---- wide separable kernels (odd kernelSize 11..25): both passes of one application in one launch -----
+// Used by the Gaussian / box blur stages (StageGaussianBlur / StageSmoothBlur, width <= 25,
+// Filter/Kernel/Blur/BlurJob.cs:11-52).  A workgroup produces a 32 x 128 output tile.  Source rows
+// [z0-O, z0+32+O) x columns [x0-16, x0+144), clamped to the grid (RWTileData.GetData), are staged in LDS
+// as 160-float rows: 16-byte loads, five whole 128-byte lines per row.  The X pass runs on all 32+2O rows
+// into a second LDS plane, 8 consecutive outputs per thread from one register window; the Z pass reads
+// that plane column-wise, 4 columns x 4 rows per thread, and stores 16 bytes per lane.  Clamped source
+// rows give the X-pass value of the clamped row, which is what the reference's Z pass reads after the flush.
+constexpr int WD_H = 32, WD_W = 128, WD_XH = 16, WD_AP = WD_W + 2 * WD_XH;
+
+template <int O, bool UNIT>
+__global__ __launch_bounds__(CT) void conv_wide_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
+                                                      nz_kernel_taps taps, int aligned) {
+    constexpr int KS = 2 * O + 1;
+    constexpr int NR = WD_H + 2 * O;          // staged rows
+    constexpr int OFF = WD_XH - O;            // first window column of output column 0
+    constexpr int OFA = OFF & ~3, SH = OFF & 3;
+    constexpr int NF = (SH + 8 + 2 * O + 3) / 4;  // float4s per X window
+    __shared__ float4 s_a[NR * WD_AP / 4];
+    __shared__ float4 s_b[NR * WD_W / 4];
+    const int tid = threadIdx.x;
+    const int tiles_x = (g.cols + WD_W - 1) / WD_W;
+    const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    const int x0 = bx * WD_W, z0 = g.or0 + by * WD_H;
+
+    const bool inside = aligned && x0 - WD_XH >= 0 && x0 + WD_W + WD_XH <= g.cols && z0 - O >= g.zc0 &&
+                        z0 + WD_H + O - 1 <= g.zc1;
+    for (int i = tid; i < NR * (WD_AP / 4); i += CT) {
+        int r = i / (WD_AP / 4), c4 = i - r * (WD_AP / 4);
+        int gx = x0 - WD_XH + 4 * c4;
+        float4 t;
+        if (inside) {
+            t = *reinterpret_cast<const float4 *>(src + (size_t)(z0 - O + r) * g.pitch + gx);
+        } else {
+            const float *row = src + (size_t)clampi(z0 - O + r, g.zc0, g.zc1) * g.pitch;
+            t.x = row[clampi(gx, 0, g.cols - 1)];
+            t.y = row[clampi(gx + 1, 0, g.cols - 1)];
+            t.z = row[clampi(gx + 2, 0, g.cols - 1)];
+            t.w = row[clampi(gx + 3, 0, g.cols - 1)];
+        }
+        s_a[i] = t;
     }
-    dst[(size_t)z * g.pitch + x] = v;
+    __syncthreads();
+
+    // ---- X pass (KernelSampleXOperator: taps k ascending)
+    {
+        const int tx = tid & 15, ry = tid >> 4;
+        for (int r = ry; r < NR; r += CT / 16) {
+            float w[NF * 4];
+            const float4 *a = s_a + (r * WD_AP + OFA + 8 * tx) / 4;
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                float4 t = a[f];
+                w[4 * f] = t.x; w[4 * f + 1] = t.y; w[4 * f + 2] = t.z; w[4 * f + 3] = t.w;
+            }
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float total = w[SH + e] * taps.kx[0];  // 0 + a*b == a*b
+#pragma unroll
+                for (int kk = 1; kk < KS; kk++) total += w[SH + e + kk] * taps.kx[kk];
+                o[e] = UNIT ? total : total * taps.factor;
+            }
+            float4 *b = s_b + (r * WD_W + 8 * tx) / 4;
+            b[0] = make_float4(o[0], o[1], o[2], o[3]);
+            b[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    }
+    __syncthreads();
+
+    // ---- Z pass (KernelSampleZOperator: taps k descending, first term is row z+o with K[0])
+    {
+        const int cg = tid & 31, rg = tid >> 5;
+        float v[4 + 2 * O][4];
+#pragma unroll
+        for (int i = 0; i < 4 + 2 * O; i++) {
+            float4 t = s_b[((rg * 4 + i) * WD_W) / 4 + cg];
+            v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+        }
+        const int gx = x0 + 4 * cg;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float total = v[j + 2 * O][e] * taps.kz[0];
+#pragma unroll
+                for (int kk = 1; kk < KS; kk++) total += v[j + 2 * O - kk][e] * taps.kz[kk];
+                o[e] = UNIT ? total : total * taps.factor;
+            }
+            int gz = z0 + rg * 4 + j;
+            if (gz < g.or1 && gx < g.cols) {
+                float *out = dst + (size_t)gz * g.pitch + gx;
+                if (aligned && gx + 4 <= g.cols) {
+                    *reinterpret_cast<float4 *>(out) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (gx + e < g.cols) out[e] = o[e];
+                }
+            }
+        }
+    }
+}
+
+template <int O>
+int32_t launch_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k) {
+    long long blocks = (long long)((g.cols + WD_W - 1) / WD_W) * ((g.or1 - g.or0 + WD_H - 1) / WD_H);
+    int aligned = (g.pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    if (k.factor == 1.0f)
+        hipLaunchKernelGGL((conv_wide_kernel<O, true>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, aligned);
+    else
+        hipLaunchKernelGGL((conv_wide_kernel<O, false>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, aligned);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
 }
 
 #ifndef NZ_CONV_NT
@@ -379,6 +481,25 @@ int32_t nz_launch_conv_fused(hipStream_t s, const float *src, float *dst, const 
     return NZ_ERR_INVALID;
 }
 
+// one application (X pass + Z pass) of an odd kernel of 11..25 taps, src -> dst
+bool nz_conv_has_wide(int ksize) { return (ksize & 1) && ksize >= 11 && ksize <= 25; }
+
+int32_t nz_launch_conv_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k) {
+    if (g.or1 <= g.or0) return NZ_OK;
+    switch (k.ksize) {
+        case 11: return launch_wide<5>(s, src, dst, g, k);
+        case 13: return launch_wide<6>(s, src, dst, g, k);
+        case 15: return launch_wide<7>(s, src, dst, g, k);
+        case 17: return launch_wide<8>(s, src, dst, g, k);
+        case 19: return launch_wide<9>(s, src, dst, g, k);
+        case 21: return launch_wide<10>(s, src, dst, g, k);
+        case 23: return launch_wide<11>(s, src, dst, g, k);
+        case 25: return launch_wide<12>(s, src, dst, g, k);
+    }
+    nz_set_error("conv_wide: kernelSize %d unsupported", k.ksize);
+    return NZ_ERR_INVALID;
+}
+
 int32_t nz_launch_conv_pass_x(hipStream_t s, const float *src, float *dst, const nz_geom &g,
                               const nz_kernel_taps &k) {
     if (g.or1 <= g.or0) return NZ_OK;
@@ -414,14 +535,6 @@ int32_t nz_launch_erosion_fused(hipStream_t s, const float *src, float *dst, con
         case 3: hipLaunchKernelGGL((erosion_reg_kernel<3>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, aligned); break;
         default: hipLaunchKernelGGL((erosion_reg_kernel<4>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, aligned); break;
     }
-    NZ_HIP(hipGetLastError());
-    return NZ_OK;
-}
-
-int32_t nz_launch_min_pass(hipStream_t s, const float *src, float *dst, const nz_geom &g, int ksize, int along_z) {
-    if (g.or1 <= g.or0) return NZ_OK;
-    dim3 grid((g.cols + CT - 1) / CT, g.or1 - g.or0);
-    hipLaunchKernelGGL(min_pass_kernel, grid, dim3(CT), 0, s, src, dst, g, (ksize - 1) / 2, along_z);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

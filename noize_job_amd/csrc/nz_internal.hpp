@@ -123,6 +123,9 @@ int nz_conv_max_fused(int ksize);
 // T fused applications of (X pass, Z pass) src -> dst on rows [or0, or1)
 int32_t nz_launch_conv_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g,
                              const nz_kernel_taps &k, int T);
+// one whole application of a wide odd kernel (11..25 taps), src -> dst
+bool nz_conv_has_wide(int ksize);
+int32_t nz_launch_conv_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k);
 // single unfused passes (src -> dst): any kernelSize <= 25, and single applications
 int32_t nz_launch_conv_pass_x(hipStream_t s, const float *src, float *dst, const nz_geom &g,
                               const nz_kernel_taps &k);
@@ -132,7 +135,6 @@ int32_t nz_launch_conv_pass_z(hipStream_t s, const float *src, float *dst, const
 int nz_erosion_max_fused();
 int32_t nz_launch_erosion_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g, int E);
 // one reference min pass, window k in [-k_off, k_off), along x (along_z == 0) or z
-int32_t nz_launch_min_pass(hipStream_t s, const float *src, float *dst, const nz_geom &g, int ksize, int along_z);
 
 int32_t nz_launch_fill(hipStream_t s, float *data, size_t n, float value);
 int32_t nz_launch_copy(hipStream_t s, float *dst, const float *src, size_t n);

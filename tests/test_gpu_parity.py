@@ -109,6 +109,24 @@ def test_gaussian_blur_stage(nj, ctx, oracle, sigma, width, iters):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("width", [11, 13, 15, 17, 19, 21, 23, 25])
+def test_wide_blur_kernels_interior_and_edge_tiles(nj, ctx, oracle, width):
+    # 11..25 taps run the one-launch-per-application kernel: 32 x 128 output tiles, so 300 / 301 cells have
+    # interior tiles (16-byte loads), edge tiles (clamped loads) and, at 301, unaligned rows
+    for res, iters in ((300, 2), (301, 1)):
+        t = np.random.default_rng(width * 1000 + res).random((res, res), dtype=f32)
+        d = gen(nj, ctx, res, host=t)
+        got = run(nj.StageGaussianBlur(ctx, iters, nj.GaussSigma(width % 16), width), nj, d)
+        assert np.array_equal(got, oracle.gauss(t, width, width % 16, iters))
+        d.data.Dispose()
+    res = 300
+    t = np.random.default_rng(width).random((res, res), dtype=f32)
+    d = gen(nj, ctx, res, host=t)
+    got = run(nj.StageSmoothBlur(ctx, 3, width), nj, d)   # factor 1, taps 1/width; odd count: copy back
+    assert np.array_equal(got, oracle.smooth(t, width, 3))
+    d.data.Dispose()
+
+
 def test_gauss_filter_delegate_even_width_quirk(nj, ctx, oracle):
     # GaussFilter.Schedule called directly with an even width: 5-tap body, kernelSize 4 (BlurJob.cs:11-21)
     res = 40

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Times the stages outside the metric pipeline (SURVEY.md 8a rows not in the metric, 8f "next" rows)
+on one device-resident tile: every noise basis, every KernelFilterType, wide Gaussian / box blurs,
+value erosion, the element-wise stages, thermal erosion and the mesh.  Back-to-back launches, HIP events.
+usage: bench_next.py [--res 4096] [--reps 10] [--json out.json]"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import noize_job_amd as nj  # noqa: E402
+
+HBM = 8000.0  # GB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--res", type=int, default=4096)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    res, cells = a.res, a.res * a.res
+    rows = []
+    with nj.Context(0) as ctx:
+        data, right = ctx.alloc(cells), ctx.alloc(cells)
+        gd = nj.GeneratorData("b", data, res, 0, 0)
+        rd = nj.ReduceData("b", data, right, res, 0, 0)
+        md = nj.MeshStageData("b", data, res - 8, res, 4, 1000.0, 1000.0)
+        seed = nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700)
+
+        def run(name, stage, item, bytes_per_cell, note=""):
+            wi = nj.PipelineWorkItem(item)
+            for _ in range(2):
+                stage.Schedule(wi, nj.JobHandle())
+            ctx.synchronize()
+            best = 1e9
+            for _ in range(3):
+                h0 = ctx.record()
+                for _ in range(a.reps):
+                    stage.Schedule(wi, nj.JobHandle())
+                h1 = ctx.record()
+                h1.Complete()
+                best = min(best, ctx.elapsed_ms(h0, h1) / a.reps)
+            gbs = bytes_per_cell * cells / (best * 1e-3) / 1e9
+            rows.append({"stage": name, "ms": round(best, 4), "Mcells/s": round(cells / best / 1e3),
+                         "algorithmic_B_per_cell": bytes_per_cell, "algorithmic_GB/s": round(gbs, 1),
+                         "frac_hbm": round(gbs / HBM, 3), "note": note})
+            print("%-44s %8.4f ms %9.0f Mcells/s  %6.0f B/cell  %7.0f GB/s (%5.1f %% of 8 TB/s) %s" % (
+                name, best, cells / best / 1e3, bytes_per_cell, gbs, 100 * gbs / HBM, note))
+            stage.OnDestroy()
+
+        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        right.CopyFrom(data.ToArray())
+        for basis in nj.FractalNoise:
+            run("noise %s x13 oct" % basis.name, nj.NoiseStage(ctx, basis, 0.4, 1.0, 13, 2.0, 0.0, 1700), gd, 4,
+                "fp32-VALU bound")
+        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        for f in nj.KernelFilterType:
+            if f == nj.KernelFilterType.Sobel3_2D:
+                continue  # unsupported in the reference too (README marks it broken)
+            run("filter %s x6" % f.name, nj.KernelFilterStage(ctx, f, 6), gd, 8 * 6)
+            seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        for f in (nj.KernelFilterType.Gauss5_S1, nj.KernelFilterType.Gauss9_S1, nj.KernelFilterType.Smooth3):
+            run("filter %s x1 (the delegate's single application)" % f.name, nj.KernelFilterStage(ctx, f, 1), gd, 8)
+        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        for width in (5, 9, 13, 25):
+            run("gaussian blur width %d sigma 2.0 x2" % width,
+                nj.StageGaussianBlur(ctx, 2, nj.GaussSigma.s2d00, width), gd, 8 * 2)
+        run("box blur width 25 x2", nj.StageSmoothBlur(ctx, 2, 25), gd, 8 * 2)
+        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        run("value erosion x1", nj.ErosionStage(ctx, 1), gd, 8)
+        run("value erosion x8", nj.ErosionStage(ctx, 8), gd, 8 * 8)
+        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        run("flow map x1", nj.FlowMapStage(ctx, 1, 0.0, 0.005), gd, 24 + 20)
+        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        run("flow map x12", nj.FlowMapStage(ctx, 12, 0.0, 0.005), gd, 24 + 44 * 11 + 20)
+        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        run("constant MULTIPLY", nj.ConstantStage(ctx, nj.ConstantOperationType.MULTIPLY, 0.999), gd, 8)
+        run("constant BINARIZE", nj.ConstantStage(ctx, nj.ConstantOperationType.BINARIZE, 0.5), gd, 8)
+        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        for op in nj.ReductionType:
+            run("reduce %s" % op.name, nj.ReduceStage(ctx, op), rd, 12)
+            seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        run("curve LUT 256", nj.CurveStage(ctx, lambda t: 1.0 - t, 256), gd, 8)
+        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        run("thermal erosion x1 (4 phases)", nj.StageThermalErosion(ctx, 1), gd, 8 * 4,
+            "in place, 4 dependent colour phases")
+        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        vb = 4 + (48.0 * (res - 7) ** 2 + 24.0 * (res - 8) ** 2) / cells
+        run("mesh Overshoot %d^2" % (res - 8), nj.MeshTileStage(ctx, nj.MeshType.OvershootSquareGridHeightMap), md, vb,
+            "write-only streams")
+        run("mesh SquareGrid %d^2" % (res - 8), nj.MeshTileStage(ctx, nj.MeshType.SquareGridHeightMap), md, vb)
+    if a.json:
+        json.dump({"res": res, "rows": rows}, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
