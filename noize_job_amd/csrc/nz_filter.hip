@@ -58,8 +58,11 @@ __global__ __launch_bounds__(NT) void conv_reg_kernel(const float *__restrict__ 
     constexpr int WN = 4 + 2 * O;   // X window
     constexpr int ZN = RB + 2 * O;  // Z window
     constexpr int TH = NT / 32 * RB;  // tile rows: one 8-row block per 32 threads (shadows the file-level TH)
-    // boundary rows of every 8-row block: [parity][block][top|bottom][o][column group]
-    __shared__ float4 s_edge[2][TH / RB][2][O][TW / 4];
+    // boundary rows of every 8-row block: [parity][block][top|bottom][o][column group].  Double buffered
+    // (one barrier per application) while that fits 4 workgroups per CU; 7- and 9-tap kernels keep one
+    // buffer and pay a second barrier instead of halving the occupancy.
+    constexpr int NBUF = O >= 3 ? 1 : 2;
+    __shared__ float4 s_edge[NBUF][TH / RB][2][O][TW / 4];
 
     const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
     const int H = T * O, HX = (H + 3) & ~3;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(NT) void conv_reg_kernel(const float *__restrict__ 
             }
         }
         // ---- exchange the block's boundary rows
-        const int par = t & 1;
+        const int par = NBUF == 2 ? (t & 1) : 0;
 #pragma unroll
         for (int o = 0; o < O; o++) {
             s_edge[par][rb][0][o][cg] = make_float4(v[o][0], v[o][1], v[o][2], v[o][3]);
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(NT) void conv_reg_kernel(const float *__restrict__ 
             z[o][0] = a.x; z[o][1] = a.y; z[o][2] = a.z; z[o][3] = a.w;
             z[RB + O + o][0] = b.x; z[RB + O + o][1] = b.y; z[RB + O + o][2] = b.z; z[RB + O + o][3] = b.w;
         }
+        if (NBUF == 1 && t + 1 < T) __syncthreads();  // everyone has read the edges before they are rewritten
 #pragma unroll
         for (int r = 0; r < RB; r++)
 #pragma unroll
