@@ -57,12 +57,12 @@ static int32_t build_rgrad_table(nz_ctx *ctx) {
     // operations (the first one overflows 2^24 and rounds; the table reproduces that rounding because it is
     // computed the same way).  (cos u, sin u) of rgrad2 come from the host libm the CPU restatement calls.
     std::vector<int32_t> buf(NZ_PSR_T1 + 2 * NZ_PSR_T2 * 2);
-    for (int i = 0; i < NZ_PSR_T1; i++) buf[i] = 8 * ((int32_t)h_permute((float)(i - 8)) + 16);
+    for (int i = 0; i < NZ_PSR_T1; i++) buf[i] = 8 * ((int32_t)h_permute((float)(i - NZ_PSR_O1)) + NZ_PSR_O2);
     float *t2 = reinterpret_cast<float *>(buf.data() + NZ_PSR_T1);
     const float rots[2] = {0.0f, 0.62f};  // PeriodicPerlinGetter / RotatedSimplexGetter, Fractal.cs:184,201
     for (int t = 0; t < 2; t++) {
         for (int j = 0; j < NZ_PSR_T2; j++) {
-            float h = h_permute((float)(j - 16));
+            float h = h_permute((float)(j - NZ_PSR_O2));
             float u = h * 0.0243902439f + rots[t];
             u = (u - floorf(u)) * 6.28318530718f;
             t2[(t * NZ_PSR_T2 + j) * 2 + 0] = cosf(u);
@@ -508,6 +508,15 @@ static int32_t fractal_impl(nz_ctx *ctx, hipStream_t stream, int noiseType, floa
     p.detune_rate = detune;
     p.norm = calc_fractal_norm(hurst, octaves);
     p.octaves = octaves;
+    // largest |f| of FractalGenerator.NoiseValue's recurrence (Fractal.cs:121-127): lets a kernel decide once
+    // per row whether every octave stays inside the range its lattice tables cover
+    p.fmax = 0.0f;
+    float f = 1.0f, det = 0.0f;
+    for (int i = 0; i < octaves; i++) {
+        if (!(fabsf(f) <= p.fmax)) p.fmax = fabsf(f);
+        det += detune;
+        f *= (stepdown - det);
+    }
     return nz_launch_fractal(stream, noiseType, dst, rows, cols, pitch, p, ctx->d_rgrad, ctx->d_simplex);
 }
 

@@ -109,8 +109,8 @@ __device__ __forceinline__ float snoise2(float vx, float vy) {
     float x12x = x0x + Cx, x12y = x0y + Cx, x12z = x0x + Cz, x12w = x0y + Cz;
     x12x -= i1x;
     x12y -= i1y;
-    ix = mod289i(ix);
-    iy = mod289i(iy);
+    ix = mod289f(ix);  // plain form: the lattice coordinate itself may exceed 2^24 (the exact-FMA form may not)
+    iy = mod289f(iy);
     // (adding the literal 0 of the first corner is the identity on these non-negative integers)
     float p0 = permutei(permutei(iy) + ix);
     float p1 = permutei(permutei(iy + i1y) + ix + i1x);
@@ -143,32 +143,36 @@ struct psr_tables {
     const float2 *t2;
 };
 __device__ __forceinline__ float2 rgrad2_tab(float px, float py, const psr_tables &tab) {
-    int i1 = min(max((int)px + 8, 0), NZ_PSR_T1 - 1);
+    int i1 = min(max((int)px + NZ_PSR_O1, 0), NZ_PSR_T1 - 1);
     int off = tab.t1[i1] + 8 * (int)py;
     off = min(max(off, 0), (NZ_PSR_T2 - 1) * 8);
     return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(tab.t2) + off);
 }
+// Beyond |pos| ~ 2^21 the lattice coordinates no longer hold their halves, xw + 0.5 yw can come out as a
+// half-integer and T1 (indexed by the integer) does not apply: the first permute is evaluated directly
+// (IEEE mul/add/floor, the same value the host computes), the second one still comes from T2.
+__device__ __forceinline__ float2 rgrad2_direct(float px, float py, const psr_tables &tab) {
+    int a = (int)(permutef(px) + py) + NZ_PSR_O2;
+    a = min(max(a, 0), NZ_PSR_T2 - 1);
+    return tab.t2[a];
+}
 
-// C fmod for the arguments psrnoise feeds it: x is a multiple of 0.5 (lattice coordinates) and per a small
-// integer.  fmod is exact by definition (x - trunc(x/per)*per with no rounding); here trunc(x * (1/per)) may be
-// off by one, but q*per and x - q*per are exact for |x| < 2^22 (coordinates beyond that have no fractional
-// precision left in fp32 anyway), so one correction step lands on the same value as the library loop,
-// without its data-dependent iteration.
+// C fmod for the arguments psrnoise feeds it: x is a multiple of 0.5 (lattice coordinates), per a small
+// integer.  fmod is exact by definition (x - trunc(x/per)*per, no rounding).  With inv_lo a little BELOW
+// 1/per, q = floor(|x| * inv_lo) is the true quotient or one less for |x|/per < 2^21, q*per and |x| - q*per
+// are exact for |x| < 2^22, so r lands in [0, 2 per) and one conditional subtraction gives the library's
+// value, sign (and signed zero) copied from x -- 7 VALU slots, no data-dependent loop.
 #ifndef NZ_PSR_FMOD
-#define NZ_PSR_FMOD 0  // measured: the library fmodf is faster for these arguments (0.70 vs 0.80 ms)
+#define NZ_PSR_FMOD 1
 #endif
-__device__ __forceinline__ float fmod_lattice(float x, float per, float inv_per) {
-#if !NZ_PSR_FMOD
-    return fmodf(x, per);
-#endif
-    float q = truncf(x * inv_per);
-    float r = __builtin_fmaf(-q, per, x);  // exact: q*per is an integer below 2^23 (|x| < 2^22)
-    bool pos = x >= 0.0f;
-    bool add = pos ? (r < 0.0f) : (r <= -per);
-    bool sub = pos ? (r >= per) : (r > 0.0f);
-    r = add ? r + per : r;
-    r = sub ? r - per : r;
-    return r;
+constexpr float PSR_FAST_LIMIT = 2097152.0f;  // |pos| below this keeps every lattice coordinate under 2^22
+__device__ __forceinline__ float fmod_lattice(float x, float per, float inv_lo) {
+    float a = fabsf(x);
+    float q = floorf(a * inv_lo);
+    float r = __builtin_fmaf(-q, per, a);
+    float r2 = r - per;
+    r = r >= per ? r2 : r;
+    return copysignf(r, x);
 }
 
 // noise.psrnoise(float2 pos, float2 per = (1010,102), rot), Appendix A.4
@@ -186,13 +190,21 @@ __device__ __forceinline__ float psrnoise2(float posx, float posy, const psr_tab
     float d0x = posx - p0x, d0y = posy - p0y;
     float d1x = posx - p1x, d1y = posy - p1y;
     float d2x = posx - p2x, d2y = posy - p2y;
-    const float ipx = 1.0f / 1010.0f, ipy = 1.0f / 102.0f;
-    float xw0 = fmod_lattice(p0x, perx, ipx), xw1 = fmod_lattice(p1x, perx, ipx), xw2 = fmod_lattice(p2x, perx, ipx);
-    float yw0 = fmod_lattice(p0y, pery, ipy), yw1 = fmod_lattice(p1y, pery, ipy), yw2 = fmod_lattice(p2y, pery, ipy);
-    float iu0 = xw0 + 0.5f * yw0, iu1 = xw1 + 0.5f * yw1, iu2 = xw2 + 0.5f * yw2;
-    float2 g0 = rgrad2_tab(iu0, yw0, tab);
-    float2 g1 = rgrad2_tab(iu1, yw1, tab);
-    float2 g2 = rgrad2_tab(iu2, yw2, tab);
+    constexpr float ipx = (1.0f / 1010.0f) * (1.0f - 0x1p-22f), ipy = (1.0f / 102.0f) * (1.0f - 0x1p-22f);
+    float2 g0, g1, g2;
+    if (NZ_PSR_FMOD && fabsf(posx) < PSR_FAST_LIMIT && fabsf(posy) < PSR_FAST_LIMIT) {
+        float xw0 = fmod_lattice(p0x, perx, ipx), xw1 = fmod_lattice(p1x, perx, ipx), xw2 = fmod_lattice(p2x, perx, ipx);
+        float yw0 = fmod_lattice(p0y, pery, ipy), yw1 = fmod_lattice(p1y, pery, ipy), yw2 = fmod_lattice(p2y, pery, ipy);
+        g0 = rgrad2_tab(xw0 + 0.5f * yw0, yw0, tab);
+        g1 = rgrad2_tab(xw1 + 0.5f * yw1, yw1, tab);
+        g2 = rgrad2_tab(xw2 + 0.5f * yw2, yw2, tab);
+    } else {
+        float xw0 = fmodf(p0x, perx), xw1 = fmodf(p1x, perx), xw2 = fmodf(p2x, perx);
+        float yw0 = fmodf(p0y, pery), yw1 = fmodf(p1y, pery), yw2 = fmodf(p2y, pery);
+        g0 = rgrad2_direct(xw0 + 0.5f * yw0, yw0, tab);
+        g1 = rgrad2_direct(xw1 + 0.5f * yw1, yw1, tab);
+        g2 = rgrad2_direct(xw2 + 0.5f * yw2, yw2, tab);
+    }
     float w0 = g0.x * d0x + g0.y * d0y;
     float w1 = g1.x * d1x + g1.y * d1y;
     float w2 = g2.x * d2x + g2.y * d2y;
@@ -409,6 +421,10 @@ __device__ __forceinline__ float noise_value(float x, float z, const psr_tables 
 // permutes and the gradient decode (26 fp32 ops + 4 floors).  About 87 VALU slots per octave-cell
 // instead of 151.
 constexpr int NZ_T1_N = 292, NZ_T2_N = 580;
+// The tables hold hashes of lattice coordinates reduced to [0, 288]; fp32 mod289 only guarantees that range
+// for |integer| < 2.3e6 (and the skew of snoise stretches a coordinate by up to 1.73).  Samples beyond this
+// limit (NaN included) take the direct evaluation, which follows the reference's arithmetic wherever it leads.
+constexpr float NZ_TAB_LIMIT = 1048576.0f;
 
 __device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1, const float4 *s_t2) {
     const float Cx = 0.211324865405187f, Cy = 0.366025403784439f, Cz = -0.577350269189626f;
@@ -475,16 +491,43 @@ __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restr
 #pragma unroll
         for (int c = 0; c < VEC; c++) t[c] = 0.0f;
         float detune = 0.0f, f = 1.0f, a = p.amp;
-        for (int i = 0; i < p.octaves; i++) {
-            float zV = f * zi;
+        float reach = fabsf(zi);
 #pragma unroll
-            for (int c = 0; c < VEC; c++) {
-                float xV = f * xi[c];
-                t[c] += a * rectify(snoise2_tab(xV, zV, s_t1, s_t2));
+        for (int c = 0; c < VEC; c++) reach = fmaxf(reach, fabsf(xi[c]));
+        if (p.fmax * reach < NZ_TAB_LIMIT) {  // every octave of this row stays inside the tables' range
+            for (int i = 0; i < p.octaves; i++) {
+                float zV = f * zi;
+#pragma unroll
+                for (int c = 0; c < VEC; c++) {
+                    float xV = f * xi[c];
+                    t[c] += a * rectify(snoise2_tab(xV, zV, s_t1, s_t2));
+                }
+                detune += p.detune_rate;
+                f *= (p.stepdown - detune);
+                a *= p.G;
             }
-            detune += p.detune_rate;
-            f *= (p.stepdown - detune);
-            a *= p.G;
+        } else {
+            asm volatile("; guarded octave loop" ::: "memory");  // a real branch, never if-converted
+            for (int i = 0; i < p.octaves; i++) {
+                float zV = f * zi;
+                float xV[VEC], big = fabsf(zV);
+#pragma unroll
+                for (int c = 0; c < VEC; c++) {
+                    xV[c] = f * xi[c];
+                    big = fmaxf(big, fabsf(xV[c]));
+                }
+                if (big < NZ_TAB_LIMIT) {
+#pragma unroll
+                    for (int c = 0; c < VEC; c++) t[c] += a * rectify(snoise2_tab(xV[c], zV, s_t1, s_t2));
+                } else {
+                    asm volatile("; direct evaluation" ::: "memory");
+#pragma unroll
+                    for (int c = 0; c < VEC; c++) t[c] += a * rectify(snoise2(xV[c], zV));
+                }
+                detune += p.detune_rate;
+                f *= (p.stepdown - detune);
+                a *= p.G;
+            }
         }
         float *row = dst + (size_t)z * pitch;
         float o[VEC];
@@ -599,18 +642,43 @@ __global__ __launch_bounds__(256) void fractal_tab2_kernel(float *__restrict__ d
 #pragma unroll
         for (int c = 0; c < VEC; c++) t[c] = 0.0f;
         float detune = 0.0f, f = 1.0f, a = p.amp;
-        for (int i = 0; i < p.octaves; i++) {
-            float zV = f * zi;
+        float reach = fabsf(zi);
 #pragma unroll
-            for (int c = 0; c < VEC; c++) {
-                float xV = f * xi[c];
-                float nv = BASIS == NZ_NOISE_PERLIN ? rectify(cnoise2_tab(xV, zV, s_t1, s_t2))
-                                                    : cellular_rect_tab(xV, zV, s_t1, s_t2);
-                t[c] += a * nv;
+        for (int c = 0; c < VEC; c++) reach = fmaxf(reach, fabsf(xi[c]));
+        if (p.fmax * reach < NZ_TAB_LIMIT) {  // every octave of this row stays inside the tables' range
+            for (int i = 0; i < p.octaves; i++) {
+                float zV = f * zi;
+#pragma unroll
+                for (int c = 0; c < VEC; c++) {
+                    float xV = f * xi[c];
+                    t[c] += a * (BASIS == NZ_NOISE_PERLIN ? rectify(cnoise2_tab(xV, zV, s_t1, s_t2))
+                                                          : cellular_rect_tab(xV, zV, s_t1, s_t2));
+                }
+                detune += p.detune_rate;
+                f *= (p.stepdown - detune);
+                a *= p.G;
             }
-            detune += p.detune_rate;
-            f *= (p.stepdown - detune);
-            a *= p.G;
+        } else {
+            asm volatile("; guarded octave loop" ::: "memory");  // a real branch, never if-converted
+            for (int i = 0; i < p.octaves; i++) {
+                float zV = f * zi;
+#pragma unroll
+                for (int c = 0; c < VEC; c++) {
+                    float xV = f * xi[c];
+                    float nv;
+                    if (fmaxf(fabsf(xV), fabsf(zV)) < NZ_TAB_LIMIT) {
+                        nv = BASIS == NZ_NOISE_PERLIN ? rectify(cnoise2_tab(xV, zV, s_t1, s_t2))
+                                                      : cellular_rect_tab(xV, zV, s_t1, s_t2);
+                    } else {
+                        asm volatile("; direct evaluation" ::: "memory");
+                        nv = BASIS == NZ_NOISE_PERLIN ? rectify(cnoise2(xV, zV)) : cellular_rect(xV, zV);
+                    }
+                    t[c] += a * nv;
+                }
+                detune += p.detune_rate;
+                f *= (p.stepdown - detune);
+                a *= p.G;
+            }
         }
         float *row = dst + (size_t)z * pitch;
 #pragma unroll

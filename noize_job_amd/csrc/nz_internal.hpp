@@ -67,9 +67,12 @@ int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out);
 
 // ---- kernel parameter blocks ----------------------------------------------------------------
 constexpr int NZ_MAX_KSIZE = 25;
-// psrnoise tables: T1[i] = 8 * (permute(i - 8) + 16) for the first, un-reduced permute (argument in [-8, 1063]);
-// T2[rot][j] = (cos u, sin u) of the gradient hashed from a = j - 16 (second permute + rgrad2), a in [-16, 403]
-constexpr int NZ_PSR_T1 = 1072, NZ_PSR_T2 = 420;
+// psrnoise tables.  The hash arguments are iu = xw + 0.5 yw and yw with xw = fmod(., 1010), yw = fmod(., 102):
+// integers in (-1061, 1061) and (-102, 102), negative for negative lattice coordinates (C fmod keeps the sign).
+//   T1[i] = 8 * (permute(i - O1) + O2): the first, un-reduced permute, argument in [-O1, T1 - O1)
+//   T2[rot][j] = (cos u, sin u) of the gradient hashed from a = j - O2 (second permute + rgrad2), a = permute + yw
+constexpr int NZ_PSR_O1 = 1064, NZ_PSR_T1 = NZ_PSR_O1 + 1064;
+constexpr int NZ_PSR_O2 = 104, NZ_PSR_T2 = NZ_PSR_O2 + 392;
 
 struct nz_kernel_taps {
     float kx[NZ_MAX_KSIZE];
@@ -85,6 +88,7 @@ struct nz_fractal_params {
     float amp;            // StartingAmplitude
     float stepdown, detune_rate;
     float norm;           // CalcFractalNormValue
+    float fmax;           // max over the octaves of |frequency| (same fp32 recurrence as the kernels; NaN if it overflows)
     int octaves;
 };
 

@@ -45,6 +45,23 @@ def test_fractal_matches_oracle(nj, ctx, oracle, basis):
         d.data.Dispose()
 
 
+@pytest.mark.parametrize("basis", range(1, 8), ids=BASES[1:])
+def test_negative_and_huge_coordinates(nj, ctx, oracle, basis):
+    # lattice tables and the psrnoise kernels' branch-free fmod are exact while the coordinates keep their
+    # fractional bits; beyond that (and for negative lattice cells) the kernels must still follow the
+    # reference's fp32 arithmetic: negative positions, exact multiples of the psrnoise periods (1010, 102),
+    # coordinates up to ~4e7 where mod289 / fmod arguments are rounded integers
+    res = 64
+    for (octv, ns, xp, zp) in [(3, 1, -2100, -250), (3, 1, 1980, 60), (13, 7, -70000, -33333), (13, 3, 50000, 90000),
+                               (2, 1, -4194400, 4194200)]:
+        st = nj.NoiseStage(ctx, nj.FractalNoise(basis), 0.5, 1.0, octv, 2.0, 0.0, ns)
+        d = gen(nj, ctx, res, xpos=xp, zpos=zp)
+        got = run(st, nj, d)
+        want = oracle.fractal(basis, res, res, 0.5, 1.0, 2.0, 0.0, octv, xp, zp, ns)
+        assert np.array_equal(got, want), "%s ns=%d pos=(%d,%d)" % (BASES[basis], ns, xp, zp)
+        d.data.Dispose()
+
+
 def test_fractal_config1_plumbing(nj, ctx, oracle):
     # BASELINE config 1: 1024^2 Perlin, 8 octaves, hurst 0.5
     st = nj.NoiseStage(ctx, nj.FractalNoise.Perlin, 0.5, 1.0, 8, 2.0, 0.0, 1000)

@@ -138,7 +138,10 @@ def test_noise_ranges_and_continuity(oracle):
 
 def test_psrnoise_hash_is_a_small_integer(oracle):
     # the HIP kernel tabulates rgrad2 by this value (nz_fractal.hip); it must be an integer in [0, 289]
-    hs = [oracle.psr_hash(float(x), float(y)) for x in np.arange(-1.0, 1062.0, 0.5) for y in (0.0, 1.0, 57.0, 101.0)]
+    # arguments: iu = xw + 0.5 yw in (-1061, 1061), yw in (-102, 102); C fmod keeps the dividend's sign, so
+    # negative lattice coordinates hash negative arguments
+    hs = [oracle.psr_hash(float(x), float(y)) for x in np.arange(-1062.0, 1062.0, 0.5)
+          for y in (-101.0, -57.0, -1.0, 0.0, 1.0, 57.0, 101.0)]
     assert min(hs) >= 0.0 and max(hs) <= 289.0 and all(float(h).is_integer() for h in hs)
 
 
