@@ -9,7 +9,8 @@ from ._native import NoizeError, Stripe
 from .runtime import Context, DeviceTile, JobHandle
 from .pipeline import (BasePipeline, BlurHelper, ConstantOperationType, ConstantStage, CurveStage, ErosionStage, FlowMapStage, FractalNoise, GaussSigma,
                        GeneratorData, KernelFilterStage, KernelFilterType, MeshBuffers, MeshStageData,
-                       MeshTileStage, MeshType, NoiseStage, PipelineStage, PipelineWorkItem, ReduceData, ReduceStage,
+                       MeshTileStage, MeshType, NoiseStage, PipelineJoint, PipelineStage, PipelineWorkItem, ReduceData,
+                       ReducePipeline, ReduceStage, Upstream,
                        ReductionType, StageGaussianBlur, StageThermalErosion,
                        StageIO, StageSmoothBlur)
 

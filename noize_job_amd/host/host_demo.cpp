@@ -1,8 +1,10 @@
 // host_demo.cpp -- the metric pipeline driven from the C++ host mirror (noize_pipeline.hpp).
 // Writes the resulting plane as raw little-endian fp32 so the test suite can compare it with the oracle.
 //   usage: host_demo <resolution> <out.f32> [gauss_iterations flow_iterations erosion_iterations]
+//          host_demo <resolution> <out.f32> reduce      (ReducePipeline: simplex x cellular, MULTIPLY)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "noize_pipeline.hpp"
@@ -15,11 +17,46 @@ int main(int argc, char **argv) {
         return 2;
     }
     int res = std::atoi(argv[1]);
+    const bool reduce = argc > 3 && std::strcmp(argv[3], "reduce") == 0;
     int G = argc > 3 ? std::atoi(argv[3]) : 17, F = argc > 4 ? std::atoi(argv[4]) : 5, E = argc > 5 ? std::atoi(argv[5]) : 5;
     try {
         nz_ctx *ctx = nullptr;
         check(nz_ctx_create(0, &ctx), "nz_ctx_create");
-        {
+        if (reduce) {
+            DeviceTile tile(ctx, (size_t)res * res);
+            NoiseStage nl(ctx), nr(ctx);
+            nl.noiseType = FractalNoise::Simplex;
+            nl.hurst = 0.4f;
+            nl.octaves = 6;
+            nl.noiseSize = 300;
+            nr.noiseType = FractalNoise::Cellular;
+            nr.hurst = 0.5f;
+            nr.octaves = 3;
+            nr.noiseSize = 90;
+            ReduceStage mul(ctx);
+            mul.operation = 1;  // ReductionType.MULTIPLY
+            BasePipeline left({&nl}), right({&nr});
+            ReducePipeline red(ctx, {&mul}, &left, &right);
+            GeneratorData gd;
+            gd.uuid = "host-demo-reduce";
+            gd.data = &tile;
+            gd.resolution = res;
+            gd.xpos = 37;
+            gd.zpos = 11;
+            int completed = 0;
+            red.Enqueue(&gd, nullptr, [&](StageIO *) { completed++; });
+            red.RunToCompletion();
+            if (completed != 1) throw std::runtime_error("completeAction did not fire");
+            std::vector<float> host((size_t)res * res);
+            tile.CopyTo(host.data());
+            FILE *f = std::fopen(argv[2], "wb");
+            if (!f) throw std::runtime_error("cannot open output");
+            std::fwrite(host.data(), sizeof(float), host.size(), f);
+            std::fclose(f);
+            red.Destroy();
+            left.Destroy();
+            right.Destroy();
+        } else {
             DeviceTile tile(ctx, (size_t)res * res);
             NoiseStage noise(ctx);
             noise.noiseType = FractalNoise::Simplex;

@@ -11,6 +11,7 @@
 // Header-only; link with -lnoize_hip.
 #pragma once
 
+#include <algorithm>
 #include <deque>
 #include <functional>
 #include <memory>
@@ -367,6 +368,9 @@ class BasePipeline {
   public:
     std::string alias = "Unnamed Pipeline";
     explicit BasePipeline(std::vector<PipelineStage *> stages) : stage_instances(std::move(stages)) { Setup(); }
+    virtual ~BasePipeline() = default;
+    virtual std::vector<BasePipeline *> GetDependencies() { return {this}; }  // Pipeline.cs:63-65
+    bool Idle() const { return queue.empty() && !pipelineRunning && !pipelineBeingScheduled; }
 
     void Enqueue(StageIO *input, std::function<void(StageIO *, JobHandle)> scheduleAction = nullptr,
                  std::function<void(StageIO *)> completeAction = nullptr, JobHandle dependency = JobHandle()) {
@@ -378,7 +382,7 @@ class BasePipeline {
         pipelineBeingScheduled = true;
         stage_instances[0]->ReceiveHandledInput(activeItem, activeItem.dependency);
     }
-    void Update() {
+    virtual void Update() {
         if (!pipelineRunning && !pipelineBeingScheduled && !queue.empty()) {
             PipelineWorkItem wi = queue.front();
             queue.pop_front();
@@ -404,11 +408,11 @@ class BasePipeline {
             }
         }
     }
-    void Destroy() {
+    virtual void Destroy() {
         for (auto *s : stage_instances) s->OnDestroy();
     }
 
-  private:
+  protected:
     void Setup() {
         PipelineStage *previous = nullptr;
         for (auto *stage : stage_instances) {
@@ -430,6 +434,82 @@ class BasePipeline {
     PipelineWorkItem activeItem;
     JobHandle pipelineHandle;
     bool pipelineBeingScheduled = false, pipelineRunning = false;
+};
+
+// ---- ReducePipeline (Pipeline/Executable/ReducePipeline.cs:31-166) ------------------------------
+// One work item -> the same tile requested from both upstream pipelines (the right one into a plane this
+// pipeline owns) -> this pipeline's stages on a ReduceData of the two planes.
+class ReducePipeline : public BasePipeline {
+  public:
+    ReducePipeline(nz_ctx *ctx, std::vector<PipelineStage *> stages, BasePipeline *left, BasePipeline *right)
+        : BasePipeline(std::move(stages)), ctx(ctx), upstreamPipelineLeft(left), upstreamPipelineRight(right) {}
+
+    std::vector<BasePipeline *> GetDependencies() override {  // :52-62
+        std::vector<BasePipeline *> up{upstreamPipelineLeft, upstreamPipelineRight, this};
+        for (auto *p : upstreamPipelineLeft->GetDependencies()) up.push_back(p);
+        for (auto *p : upstreamPipelineRight->GetDependencies()) up.push_back(p);
+        return up;
+    }
+    void Update() override {  // OnUpdate :64-80
+        if (!pipelineRunning && !pipelineBeingScheduled && !upstreamsRunning && !queue.empty()) {
+            PipelineWorkItem wi = queue.front();
+            queue.pop_front();
+            upstreamsRunning = true;
+            ScheduleUpstreams(wi);
+        }
+    }
+    void RunToCompletion() {  // the frame loop over this pipeline and everything upstream of it
+        std::vector<BasePipeline *> pipes;
+        for (auto *p : GetDependencies())
+            if (std::find(pipes.begin(), pipes.end(), p) == pipes.end()) pipes.push_back(p);
+        bool busy = true;
+        while (busy) {
+            for (auto *p : pipes) p->Update();
+            for (auto *p : pipes) p->LateUpdate();
+            busy = upstreamsRunning;
+            for (auto *p : pipes) busy = busy || !p->Idle();
+        }
+    }
+    void Destroy() override {  // :157-163
+        rightData.reset();
+        BasePipeline::Destroy();
+    }
+
+  private:
+    void ScheduleUpstreams(const PipelineWorkItem &wi) {  // :82-121
+        auto *leftData = dynamic_cast<GeneratorData *>(wi.data);
+        if (!leftData) throw std::runtime_error("Unhandled stageio");
+        if (!rightData || rightData->Length != leftData->data->Length)
+            rightData.reset(new DeviceTile(ctx, leftData->data->Length));
+        left = leftData;
+        rightIO = *leftData;
+        rightIO.data = rightData.get();
+        doneLeft = doneRight = false;
+        action = wi.completeAction;
+        upstreamPipelineLeft->Enqueue(left, nullptr, [this](StageIO *res) { OnCompleteUpstream(res, true); });
+        upstreamPipelineRight->Enqueue(&rightIO, nullptr, [this](StageIO *res) { OnCompleteUpstream(res, false); });
+    }
+    void OnCompleteUpstream(StageIO *res, bool isLeft) {  // :123-149
+        (isLeft ? doneLeft : doneRight) = true;
+        if (!(doneLeft && doneRight)) return;
+        upstreamsRunning = false;
+        auto *d = static_cast<GeneratorData *>(res);
+        joined.uuid = d->uuid;
+        joined.resolution = d->resolution;
+        joined.data = left->data;
+        joined.rightData = rightIO.data;
+        joined.xpos = d->xpos;
+        joined.zpos = d->zpos;
+        Schedule(PipelineWorkItem{&joined, action, nullptr, JobHandle()});
+    }
+    nz_ctx *ctx;
+    BasePipeline *upstreamPipelineLeft, *upstreamPipelineRight;
+    bool upstreamsRunning = false, doneLeft = false, doneRight = false;
+    std::unique_ptr<DeviceTile> rightData;
+    GeneratorData *left = nullptr;
+    GeneratorData rightIO;
+    ReduceData joined;
+    std::function<void(StageIO *)> action;
 };
 
 }  // namespace noize

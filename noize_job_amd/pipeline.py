@@ -575,6 +575,109 @@ class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
                 self.pipelineHandle.Complete()
                 self.LateUpdate()
 
+    def GetDependencies(self):  # :63-65
+        return [self]
+
     def Destroy(self):  # :244-254,267-274
         for stage in self.stage_instances:
             stage.OnDestroy()
+
+
+class Upstream(enum.IntEnum):  # Pipeline/Executable/ReducePipeline.cs:27-30
+    LEFT = 0
+    RIGHT = 1
+
+
+class PipelineJoint:  # ReducePipeline.cs:18-25
+    def __init__(self, stages, action):
+        self.stages = stages
+        self.status = {Upstream.LEFT: False, Upstream.RIGHT: False}
+        self.action = action
+
+    @property
+    def ready(self):
+        return self.status[Upstream.LEFT] and self.status[Upstream.RIGHT]
+
+
+class ReducePipeline(BasePipeline):  # Pipeline/Executable/ReducePipeline.cs:31-166
+    """Takes one work item, requests the same tile from both upstream pipelines (the right one into a
+    plane this pipeline owns) and, once both have completed, runs its own stages on a ReduceData of the
+    two planes.  `ctx` allocates the right-hand plane (the reference's Persistent NativeArray)."""
+
+    def __init__(self, ctx, stages, upstreamPipelineLeft, upstreamPipelineRight, alias="Unnamed Pipeline"):
+        super().__init__(stages, alias)
+        self.ctx = ctx
+        self.upstreamPipelineLeft = upstreamPipelineLeft
+        self.upstreamPipelineRight = upstreamPipelineRight
+        self.upstreamsRunning = False
+        self.currentWorkItem = None
+        self.currentDataLength = 0
+        self.rightData = None
+
+    def GetDependencies(self):  # :52-62
+        return ([self.upstreamPipelineLeft, self.upstreamPipelineRight, self] +
+                self.upstreamPipelineLeft.GetDependencies() + self.upstreamPipelineRight.GetDependencies())
+
+    def Update(self):  # OnUpdate :64-80
+        if not self.pipelineRunning and not self.pipelineBeingScheduled and not self.upstreamsRunning:
+            if self.queue:
+                wi = self.queue.popleft()
+                self.upstreamsRunning = True
+                self.ScheduleUpstreams(wi)
+
+    def ScheduleUpstreams(self, wi):  # :82-121
+        leftData = wi.data
+        if not isinstance(leftData, GeneratorData):
+            raise Exception("Unhandled stageio %s" % type(leftData).__name__)
+        if leftData.data.Length != self.currentDataLength:
+            self.currentDataLength = leftData.data.Length
+            if self.rightData is not None and self.rightData.IsCreated:
+                self.rightData.Dispose()
+            self.rightData = self.ctx.alloc(self.currentDataLength)
+        if self.rightData is None or not self.rightData.IsCreated:
+            self.rightData = self.ctx.alloc(self.currentDataLength)
+        self.currentWorkItem = PipelineJoint(
+            {Upstream.LEFT: leftData,
+             Upstream.RIGHT: GeneratorData(leftData.uuid, self.rightData, leftData.resolution, leftData.xpos,
+                                           leftData.zpos)},
+            wi.completeAction)
+        self.upstreamPipelineLeft.Enqueue(self.currentWorkItem.stages[Upstream.LEFT], completeAction=self.OnCompleteLeft)
+        self.upstreamPipelineRight.Enqueue(self.currentWorkItem.stages[Upstream.RIGHT],
+                                           completeAction=self.OnCompleteRight)
+
+    def OnCompleteUpstream(self, res, side):  # :123-149
+        self.currentWorkItem.status[side] = True
+        self.currentWorkItem.stages[side] = res
+        if self.currentWorkItem.ready:
+            self.upstreamsRunning = False
+            j = self.currentWorkItem
+            self.Schedule(ReduceData(res.uuid, j.stages[Upstream.LEFT].data, j.stages[Upstream.RIGHT].data,
+                                     res.resolution, res.xpos, res.zpos), completeAction=j.action)
+
+    def OnCompleteLeft(self, res):
+        self.OnCompleteUpstream(res, Upstream.LEFT)
+
+    def OnCompleteRight(self, res):
+        self.OnCompleteUpstream(res, Upstream.RIGHT)
+
+    def RunToCompletion(self):
+        """Unity's frame loop over this pipeline and everything upstream of it."""
+        pipes = []
+        for pl in self.GetDependencies():
+            if pl not in pipes:
+                pipes.append(pl)
+        busy = True
+        while busy:
+            for pl in pipes:
+                pl.Update()
+            for pl in pipes:
+                if pl.pipelineRunning:
+                    pl.pipelineHandle.Complete()
+                    pl.LateUpdate()
+            busy = any(pl.queue or pl.dependencyHell or pl.pipelineRunning or pl.pipelineBeingScheduled or
+                       getattr(pl, "upstreamsRunning", False) for pl in pipes)
+
+    def Destroy(self):  # :157-163
+        if self.rightData is not None and self.rightData.IsCreated:
+            self.rightData.Dispose()
+        super().Destroy()

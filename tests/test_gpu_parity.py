@@ -331,6 +331,12 @@ def test_cpp_host_mirror_runs_the_metric_pipeline(oracle, tmp_path):
     subprocess.check_call([exe, "256", out, "17", "5", "5"])
     got = np.fromfile(out, dtype=np.float32).reshape(256, 256)
     assert np.array_equal(got, oracle.pipeline(256, 256))
+    # ReducePipeline of the C++ mirror: simplex (left) x cellular (right), MULTIPLY
+    subprocess.check_call([exe, "200", out, "reduce"])
+    got = np.fromfile(out, dtype=np.float32).reshape(200, 200)
+    a = oracle.fractal(oracle.SIMPLEX, 200, 200, 0.4, 1.0, 2.0, 0.0, 6, 37, 11, 300)
+    b = oracle.fractal(oracle.CELLULAR, 200, 200, 0.5, 1.0, 2.0, 0.0, 3, 37, 11, 90)
+    assert np.array_equal(got, oracle.reduce(a, b, 1))
 
 
 # ---- element-wise stages ------------------------------------------------------
@@ -357,6 +363,32 @@ def test_constant_reduce_curve_stages(nj, ctx, oracle):
         assert np.array_equal(got, oracle.curve(a, host)), samples
     with pytest.raises(Exception, match="Unhandled stageio"):
         run(nj.ReduceStage(ctx, nj.ReductionType.MAX), nj, gen(nj, ctx, res, host=a))
+
+
+def test_reduce_pipeline_fans_in_two_upstream_pipelines(nj, ctx, oracle):
+    # ReducePipeline.cs:82-148: the same tile is requested from both upstreams (the right one into the reduce
+    # pipeline's own plane), then the reduce stages run on the pair; two queued tiles go through one by one
+    res = 160
+    left = nj.BasePipeline([nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 6, 2.0, 0.0, 300),
+                            nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 2)], "left")
+    right = nj.BasePipeline([nj.NoiseStage(ctx, nj.FractalNoise.Cellular, 0.5, 1.0, 3, 2.0, 0.0, 90)], "right")
+    red = nj.ReducePipeline(ctx, [nj.ReduceStage(ctx, nj.ReductionType.MULTIPLY),
+                                  nj.CurveStage(ctx, lambda t: 1.0 - t, 256)], left, right, "reduce")
+    assert red.GetDependencies()[:3] == [left, right, red]
+    done = []
+    tiles = [nj.GeneratorData("t%d" % i, ctx.alloc(res * res), res, 37 * i, 11) for i in range(2)]
+    for t in tiles:
+        red.Enqueue(t, completeAction=lambda d: done.append(d.uuid))
+    red.RunToCompletion()
+    assert done == ["t0", "t1"]
+    lut = np.array([1.0 - f32(i) / f32(256) for i in range(256)], f32)
+    for i, t in enumerate(tiles):
+        a = oracle.kernel_filter(oracle.fractal(oracle.SIMPLEX, res, res, 0.4, 1.0, 2.0, 0.0, 6, 37 * i, 11, 300), 2, 2)
+        b = oracle.fractal(oracle.CELLULAR, res, res, 0.5, 1.0, 2.0, 0.0, 3, 37 * i, 11, 90)
+        assert np.array_equal(t.data.ToArray((res, res)), oracle.curve(oracle.reduce(a, b, 1), lut)), i
+    red.Destroy()
+    left.Destroy()
+    right.Destroy()
 
 
 def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):

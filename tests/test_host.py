@@ -85,3 +85,45 @@ def test_enum_values_match_the_reference(nj):
     assert int(nj.FractalNoise.Simplex) == 3 and int(nj.FractalNoise.DomainRotatedSimplex) == 7
     assert int(nj.KernelFilterType.Gauss5_S1) == 2 and int(nj.KernelFilterType.Prewitt3Vertical) == 13
     assert int(nj.GaussSigma.s8d00) == 15 and int(nj.MeshType.OvershootSquareGridHeightMap) == 1
+
+
+def test_reduce_pipeline_requests_both_upstreams_then_reduces(nj):
+    # ReducePipeline.cs:82-148 with stand-in stages: order of events and the ReduceData handed to the stages
+    log = []
+
+    class FakeCtx:
+        def alloc(self, n):
+            t = FakeTile(n)
+            t.IsCreated = True
+            t.Dispose = lambda: log.append(("dispose", n))
+            return t
+
+    class R(nj.PipelineStage):
+        def __init__(self):
+            super().__init__(ctx=None)
+
+        def Schedule(self, requirements, dependency):
+            self.CheckRequirements(nj.ReduceData, requirements)
+            d = requirements.data
+            log.append(("reduce", d.uuid, d.data.Length, d.rightData.Length, d.xpos, d.zpos))
+            self.jobHandle = nj.JobHandle(None, 1)
+
+    left = nj.BasePipeline([make_stage(nj, log, "L")], "left")
+    right = nj.BasePipeline([make_stage(nj, log, "R")], "right")
+    red = nj.ReducePipeline(FakeCtx(), [R()], left, right, "red")
+    assert red.GetDependencies() == [left, right, red, left, right]
+    done = []
+    red.Enqueue(nj.GeneratorData("u1", FakeTile(16), 4, 5, 6), completeAction=lambda d: done.append(d.uuid))
+    red.Enqueue(nj.GeneratorData("u2", FakeTile(16), 4, 7, 8), completeAction=lambda d: done.append(d.uuid))
+    red.RunToCompletion()
+    assert done == ["u1", "u2"]
+    events = [e for e in log if e[0] in ("L", "R", "reduce") and e[1] != "complete"]
+    assert events == [("L", "u1", 0), ("R", "u1", 0), ("reduce", "u1", 16, 16, 5, 6),
+                      ("L", "u2", 0), ("R", "u2", 0), ("reduce", "u2", 16, 16, 7, 8)]
+    red.Enqueue(nj.GeneratorData("u3", FakeTile(64), 8), completeAction=lambda d: done.append(d.uuid))
+    red.RunToCompletion()                   # a new length reallocates the right-hand plane (:92-99)
+    assert ("dispose", 16) in log and done[-1] == "u3"
+    red.Destroy()
+    assert ("dispose", 64) in log
+    with pytest.raises(Exception, match="Unhandled stageio"):
+        red.ScheduleUpstreams(nj.PipelineWorkItem(nj.MeshStageData("m", FakeTile(4))))
