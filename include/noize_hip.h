@@ -98,6 +98,12 @@ int32_t nz_tile_upload(nz_ctx *ctx, float *dev, const float *host, size_t n_floa
 int32_t nz_tile_download(nz_ctx *ctx, const float *dev, float *host, size_t n_floats, nz_handle dep, nz_handle *out);
 int32_t nz_bytes_download(nz_ctx *ctx, const void *dev, void *host, size_t n_bytes, nz_handle dep, nz_handle *out);
 
+/* FlushWriteSliceDelegate(write_, read_, deps), Pipeline/Tiles/TileData.cs:15-42: write_.CopyFrom(read_) as a
+ * job -- device to device here.  What Read/WriteGeneratorContextStage schedule
+ * (Pipeline/PipelineState/Stage/ReadGeneratorContextStage.cs:36-44, WriteGeneratorContextStage.cs:30-44). */
+int32_t nz_flush_write_slice(nz_ctx *ctx, float *write_, const float *read_, size_t n_floats, nz_handle dep,
+                             nz_handle *out);
+
 /* JobHandle: marker recorded on the stream after the last kernel of a call */
 int32_t nz_handle_record(nz_ctx *ctx, nz_handle *out);
 int32_t nz_handle_query(nz_ctx *ctx, nz_handle h, int32_t *is_completed); /* JobHandle.IsCompleted */

@@ -47,6 +47,7 @@ SIGNATURES = {
     "nz_tile_upload": (_i, [ctx_p, dev_ptr, C.c_void_p, _sz] + _tail),
     "nz_tile_download": (_i, [ctx_p, dev_ptr, C.c_void_p, _sz] + _tail),
     "nz_bytes_download": (_i, [ctx_p, dev_ptr, C.c_void_p, _sz] + _tail),
+    "nz_flush_write_slice": (_i, [ctx_p, dev_ptr, dev_ptr, _sz] + _tail),
     "nz_handle_record": (_i, [ctx_p, handle_p]),
     "nz_handle_query": (_i, [ctx_p, handle_t, C.POINTER(_i)]),
     "nz_handle_wait": (_i, [ctx_p, handle_t]),

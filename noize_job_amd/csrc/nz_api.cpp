@@ -884,6 +884,15 @@ extern "C" int32_t nz_erosion_stripe(nz_ctx *ctx, const float *src, float *dst, 
 // ---------------------------------------------------------------------------------------------
 // flow map
 // ---------------------------------------------------------------------------------------------
+extern "C" int32_t nz_flush_write_slice(nz_ctx *ctx, float *write_, const float *read_, size_t n_floats, nz_handle dep,
+                                        nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(write_ && read_, "write/read is NULL");
+    NZ_REQUIRE(write_ != read_, "write and read are the same slice");
+    if (n_floats) NZ_TRY(nz_launch_copy(ctx->stream, write_, read_, n_floats));
+    return nz_ctx_finish(ctx, out);
+}
+
 extern "C" int32_t nz_fill_array(nz_ctx *ctx, float *data, int32_t resolution, float value, nz_handle dep,
                                  nz_handle *out) {
     NZ_BEGIN(ctx, dep);

@@ -487,8 +487,9 @@ class MeshTileStage(PipelineStage):  # Mesh/Stage/MeshTileStage.cs:28-61
 
 # ---- BasePipeline -------------------------------------------------------------------------------
 class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
-    def __init__(self, stages, alias="Unnamed Pipeline"):
+    def __init__(self, stages, alias="Unnamed Pipeline", contextManager=None):
         self.alias = alias
+        self.contextManager = contextManager  # PipelineStateManager handed to every work item (:76-104)
         self.queue = collections.deque()  # ConcurrentQueue: deque.append is thread-safe
         self.dependencyHell = []
         self.activeItem = None
@@ -510,13 +511,13 @@ class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
         self.stage_instances[-1].OnStageScheduledAction.append(self.OnPipelineFullyScheduled)
 
     def Enqueue(self, input, scheduleAction=None, completeAction=None, dependency=None):  # :76-90
-        self.queue.append(PipelineWorkItem(input, completeAction, scheduleAction, dependency))
+        self.queue.append(PipelineWorkItem(input, completeAction, scheduleAction, dependency, self.contextManager))
 
     def Schedule(self, input=None, scheduleAction=None, completeAction=None, dependency=None):  # :91-120
         if isinstance(input, PipelineWorkItem):
             self.activeItem = input
         elif input is not None:
-            self.activeItem = PipelineWorkItem(input, completeAction, scheduleAction, dependency)
+            self.activeItem = PipelineWorkItem(input, completeAction, scheduleAction, dependency, self.contextManager)
         if not self.stage_instances:
             raise Exception("No stages in pipeline")
         self.pipelineBeingScheduled = True
@@ -604,8 +605,9 @@ class ReducePipeline(BasePipeline):  # Pipeline/Executable/ReducePipeline.cs:31-
     plane this pipeline owns) and, once both have completed, runs its own stages on a ReduceData of the
     two planes.  `ctx` allocates the right-hand plane (the reference's Persistent NativeArray)."""
 
-    def __init__(self, ctx, stages, upstreamPipelineLeft, upstreamPipelineRight, alias="Unnamed Pipeline"):
-        super().__init__(stages, alias)
+    def __init__(self, ctx, stages, upstreamPipelineLeft, upstreamPipelineRight, alias="Unnamed Pipeline",
+                 contextManager=None):
+        super().__init__(stages, alias, contextManager)
         self.ctx = ctx
         self.upstreamPipelineLeft = upstreamPipelineLeft
         self.upstreamPipelineRight = upstreamPipelineRight

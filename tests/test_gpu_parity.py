@@ -391,6 +391,38 @@ def test_reduce_pipeline_fans_in_two_upstream_pipelines(nj, ctx, oracle):
     right.Destroy()
 
 
+def test_context_buffers_keep_a_tile_resident_between_pipelines(nj, ctx, oracle, tmp_path):
+    # WriteGeneratorContextStage parks the producer's tile in a named device buffer; a consumer pipeline
+    # queued first waits for it (dependencyHell) and reads it back with ReadGeneratorContextStage
+    res = 128
+    mgr = nj.PipelineStateManager(ctx)
+    mgr.SetSavePath(str(tmp_path), "terrain", "v1")
+    producer = nj.BasePipeline([nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 8, 2.0, 0.0, 200),
+                                nj.WriteGeneratorContextStage(ctx, "height")], "producer", contextManager=mgr)
+    consumer = nj.BasePipeline([nj.ReadGeneratorContextStage(ctx, "height"),
+                                nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 3)], "consumer",
+                               contextManager=mgr)
+    out = nj.GeneratorData("out", ctx.alloc(res * res), res, 64, 32)
+    consumer.Enqueue(out)
+    consumer.Update()
+    assert not consumer.pipelineRunning and len(consumer.dependencyHell) == 1
+    producer.Enqueue(nj.GeneratorData("src", ctx.alloc(res * res), res, 64, 32))
+    producer.RunToCompletion()
+    consumer.RunToCompletion()
+    noise = oracle.fractal(oracle.SIMPLEX, res, res, 0.4, 1.0, 2.0, 0.0, 8, 64, 32, 200)
+    assert np.array_equal(mgr.GetBufferNoLoad("64_32__128__height").ToArray((res, res)), noise)
+    assert np.array_equal(out.data.ToArray((res, res)), oracle.kernel_filter(noise, 2, 3))
+    # the buffer in the reference's on-disk form, picked up by a fresh manager
+    mgr.SaveBufferToDisk("64_32__128__height")
+    mgr2 = nj.PipelineStateManager(ctx)
+    mgr2.SetSavePath(str(tmp_path), "terrain", "v1")
+    assert np.array_equal(mgr2.GetBuffer("64_32__128__height", res * res).ToArray((res, res)), noise)
+    for m in (mgr, mgr2):
+        m.OnDestroy()
+    producer.Destroy()
+    consumer.Destroy()
+
+
 def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):
     # BasicDemo "ParallelFlowMap": Perlin fBm -> Invert (curve) -> FlowMapStage -> CurveBoostContrast
     res = 128

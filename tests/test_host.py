@@ -127,3 +127,92 @@ def test_reduce_pipeline_requests_both_upstreams_then_reduces(nj):
     assert ("dispose", 64) in log
     with pytest.raises(Exception, match="Unhandled stageio"):
         red.ScheduleUpstreams(nj.PipelineWorkItem(nj.MeshStageData("m", FakeTile(4))))
+
+
+def test_context_stages_are_gated_by_the_state_manager(nj, tmp_path):
+    # Pipeline/PipelineState/Stage/*.cs: a read is schedulable once the named buffer exists and is not locked,
+    # a write while no earlier write is in flight; BasePipeline parks unschedulable items (dependencyHell)
+    import numpy as np
+    calls = []
+
+    class HostTile:
+        def __init__(self, n):
+            self.Length, self.ptr, self.a, self.IsCreated = n, id(self), np.zeros(n, np.float32), True
+
+        def ToArray(self, shape=None):
+            return self.a.copy()
+
+        def CopyFrom(self, host):
+            self.a[:] = host
+            return self
+
+        def Dispose(self):
+            self.IsCreated = False
+
+    class Handle:
+        def __init__(self, done=True):
+            self.IsCompleted, self.id = done, 1
+
+        def Complete(self):
+            self.IsCompleted = True
+
+    class FakeCtx:
+        pending = None
+
+        def alloc(self, n):
+            return HostTile(n)
+
+        def call(self, name, *args, dep=None):
+            calls.append((name, args[2]))
+            FakeCtx.pending = Handle(done=False)
+            return FakeCtx.pending
+
+        def record(self):
+            return Handle()
+
+    ctx = FakeCtx()
+    mgr = nj.PipelineStateManager(ctx)
+    rd, wr = nj.ReadGeneratorContextStage(ctx, "height"), nj.WriteGeneratorContextStage(ctx, "height")
+    gd = nj.GeneratorData("t", HostTile(16), 4, 3, -7)
+    assert not rd.IsSchedulable(nj.PipelineWorkItem(gd))                      # no stageManager
+    wi = nj.PipelineWorkItem(gd, stageManager=mgr)
+    assert not rd.IsSchedulable(wi) and wr.IsSchedulable(wi)                   # buffer does not exist yet
+    wr.Schedule(wi, nj.JobHandle())
+    assert mgr.BufferExists("3_-7__4__height") and calls == [("nz_flush_write_slice", 16)]
+    assert mgr.IsLocked("3_-7__4__height") and not rd.IsSchedulable(wi) and not wr.IsSchedulable(wi)
+    assert mgr.TrySetLock("3_-7__4__height", Handle(), Handle()) is False      # still locked
+    FakeCtx.pending.Complete()
+    assert not mgr.IsLocked("3_-7__4__height") and rd.IsSchedulable(wi) and wr.IsSchedulable(wi)
+    # callbacks, release, persistence hooks
+    hits = []
+    mgr.RegisterCallback("3_-7__4__height", lambda: hits.append(1))
+    mgr.TriggerUpdateCallbacks("3_-7__4__height")
+    assert hits == [1]
+    with pytest.raises(ValueError, match="No serde manager"):
+        mgr.SaveBufferToDisk("3_-7__4__height")
+    mgr.SetSavePath(str(tmp_path), "ctx", "v1")
+    mgr.GetBufferNoLoad("3_-7__4__height").a[:] = np.arange(16, dtype=np.float32)
+    mgr.SaveBufferToDisk("3_-7__4__height")
+    mgr2 = nj.PipelineStateManager(ctx)
+    mgr2.SetSavePath(str(tmp_path), "ctx", "v1")
+    assert np.array_equal(mgr2.GetBuffer("3_-7__4__height", 16).a, np.arange(16, dtype=np.float32))  # loaded from disk
+    assert np.array_equal(mgr2.GetBuffer("other", 4, ignoreSaved=True).a, np.zeros(4, np.float32))
+    with pytest.raises(KeyError):
+        mgr.GetBuffer("missing")
+    assert mgr.ReleaseBuffer("3_-7__4__height") and not mgr.BufferExists("3_-7__4__height")
+    mgr2.OnDestroy()
+    assert not mgr2.BufferExists("other")
+    # the pipeline hands its contextManager to work items; a read queued before the write waits in dependencyHell
+    mgr3 = nj.PipelineStateManager(ctx)
+    reader = nj.BasePipeline([nj.ReadGeneratorContextStage(ctx, "h")], "reader", contextManager=mgr3)
+    reader.Enqueue(nj.GeneratorData("t", HostTile(16), 4, 0, 0))
+    reader.Update()
+    assert not reader.pipelineRunning and len(reader.dependencyHell) == 1
+    writer = nj.BasePipeline([nj.WriteGeneratorContextStage(ctx, "h")], "writer", contextManager=mgr3)
+    writer.Enqueue(nj.GeneratorData("t", HostTile(16), 4, 0, 0))
+    writer.Update()
+    reader.Update()
+    assert not reader.pipelineRunning                                          # the write is still in flight
+    FakeCtx.pending.Complete()
+    reader.Update()
+    assert reader.pipelineRunning and not reader.dependencyHell
