@@ -223,6 +223,12 @@ int32_t nz_reduction_job(nz_ctx *ctx, int32_t operation, float *srcL, const floa
 int32_t nz_curve_job(nz_ctx *ctx, float *src, float *tmp, const float *curve, int32_t curveSize,
                      int32_t resolution, nz_handle dep, nz_handle *out);
 
+/* CropJobDelegate(input, inputResolution, output, outputResolution, dep), Filter/Sample/CropJob.cs:62-68.
+ * As in the reference, Offset stays 0 (ScheduleParallel :43-59 never sets it): the top-left
+ * outputResolution^2 corner, reads clamped to the input plane. */
+int32_t nz_crop_job(nz_ctx *ctx, const float *input, int32_t inputResolution, float *output,
+                    int32_t outputResolution, nz_handle dep, nz_handle *out);
+
 /* ThermalErosionFilterDelegate, Filter/Kernel/Blur/ThermalErosionFilter.cs:149-157: `iterations` x 4 phases of
  * in-place talus relaxation on disjoint 2x2 blocks (talus in degrees) */
 int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, float incrementRatio, float meshHeightWidthRatio,

@@ -7,7 +7,7 @@ it is missing: there is no CPU or PyTorch fallback in the product path.
 from . import _native
 from ._native import NoizeError, Stripe
 from .runtime import Context, DeviceTile, JobHandle
-from .pipeline import (BasePipeline, BlurHelper, ConstantOperationType, ConstantStage, CurveStage, ErosionStage, FlowMapStage, FractalNoise, GaussSigma,
+from .pipeline import (BasePipeline, BlurHelper, ConstantOperationType, ConstantStage, CropStage, CurveStage, DownsampleData, ErosionStage, FlowMapStage, FractalNoise, GaussSigma,
                        GeneratorData, KernelFilterStage, KernelFilterType, MeshBuffers, MeshStageData,
                        MeshTileStage, MeshType, NoiseStage, PipelineJoint, PipelineStage, PipelineWorkItem, ReduceData,
                        ReducePipeline, ReduceStage, Upstream,

@@ -1096,6 +1096,17 @@ extern "C" int32_t nz_curve_job(nz_ctx *ctx, float *src, float *tmp, const float
     return nz_ctx_finish(ctx, out);
 }
 
+// CropJobDelegate, Filter/Sample/CropJob.cs:62-68
+extern "C" int32_t nz_crop_job(nz_ctx *ctx, const float *input, int32_t inputResolution, float *output,
+                               int32_t outputResolution, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(inputResolution));
+    NZ_TRY(check_res(outputResolution));
+    NZ_REQUIRE(input && output && input != output, "input/output must be two distinct planes");
+    NZ_TRY(nz_launch_crop(ctx->stream, input, inputResolution, output, outputResolution));
+    return nz_ctx_finish(ctx, out);
+}
+
 // ThermalErosionFilterDelegate, Filter/Kernel/Blur/ThermalErosionFilter.cs:149-157 (Schedule :117-144)
 extern "C" int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, float incrementRatio,
                                       float meshHeightWidthRatio, int32_t iterations, int32_t resolution, nz_handle dep,

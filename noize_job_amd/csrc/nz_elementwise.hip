@@ -82,6 +82,17 @@ __global__ __launch_bounds__(CT) void curve_kernel(float *data, size_t n, const 
     }
 }
 
+// CropJob (Filter/Sample/CropJob.cs:34-41): out(x,z) = in(clamp(x + Offset), clamp(z + Offset)); the reference never
+// sets Offset, so it is 0 (top-left crop).  One thread per output cell; rows of different pitch on either side.
+__global__ __launch_bounds__(CT) void crop_kernel(const float *__restrict__ in, int in_res, float *__restrict__ out,
+                                                 int out_res, int offset) {
+    int x = blockIdx.x * CT + threadIdx.x;
+    int z = blockIdx.y;
+    if (x >= out_res) return;
+    int sx = min(max(x + offset, 0), in_res - 1), sz = min(max(z + offset, 0), in_res - 1);
+    out[(size_t)z * out_res + x] = in[(size_t)sz * in_res + sx];
+}
+
 // ThermalErosionFilter (Filter/Kernel/Blur/ThermalErosionFilter.cs:21-147): one launch per phase; a phase
 // relaxes disjoint 2x2 blocks in place (rectify :84-99 applied to the six pairs in the order xy, xz, xw, yz,
 // yw, zw :74-81), so the result does not depend on the execution order within a phase.
@@ -155,6 +166,14 @@ int32_t nz_launch_curve(hipStream_t s, float *data, size_t n, const float *curve
     int aligned = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
     hipLaunchKernelGGL(curve_kernel, dim3(blocks_for(n)), dim3(CT), (size_t)curveSize * sizeof(float), s, data, n, curve,
                        curveSize, aligned);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_crop(hipStream_t s, const float *in, int in_res, float *out, int out_res) {
+    if (out_res <= 0) return NZ_OK;
+    dim3 grid((out_res + CT - 1) / CT, out_res);
+    hipLaunchKernelGGL(crop_kernel, grid, dim3(CT), 0, s, in, in_res, out, out_res, 0);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

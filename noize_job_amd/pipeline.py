@@ -137,6 +137,14 @@ class ReduceData(StageIO):  # StageIOTypes/ReduceData.cs:9-17
         self.zpos = zpos
 
 
+class DownsampleData(StageIO):  # StageIOTypes/DownsampleData.cs:9-17
+    def __init__(self, uuid="", data=None, inputData=None, resolution=512, inputResolution=512):
+        super().__init__(uuid, data)
+        self.inputData = inputData
+        self.resolution = resolution
+        self.inputResolution = inputResolution
+
+
 class MeshBuffers:
     """What Mesh.AllocateWritableMeshData + PositionStream32.Setup provide (Mesh/Streams/
     PositionStream.cs:90-123): one interleaved 48-byte vertex stream and a uint32 index buffer."""
@@ -413,6 +421,18 @@ class CurveStage(PipelineStage):  # Filter/Curve/CurveStage.cs:13-71
             if t is not None and t.IsCreated:
                 t.Dispose()
         self.curve = self.tmp = None
+
+
+class CropStage(PipelineStage):  # Filter/Sample/CropStage.cs:11-19
+    """"CenterCropResolution" in the reference's menu; its job never sets the offset, so the crop is the
+    top-left corner (Filter/Sample/CropJob.cs:43-59) -- reproduced as is."""
+
+    def Schedule(self, requirements, dependency):
+        d = requirements.data  # (DownsampleData) cast
+        if not isinstance(d, DownsampleData):
+            raise Exception("Unhandled stageio %s" % type(d).__name__)
+        self.jobHandle = self.ctx.call("nz_crop_job", d.inputData.ptr, d.inputResolution, d.data.ptr, d.resolution,
+                                       dep=dependency)
 
 
 class StageThermalErosion(PipelineStage):  # Filter/Kernel/Blur/StageThermalErosion.cs:12-29

@@ -78,6 +78,7 @@ def lib():
         L.nzo_constant.argtypes = [f32p, f32p, i, f, i, i]
         L.nzo_reduce.argtypes = [f32p, f32p, f32p, i, i, i]
         L.nzo_curve.argtypes = [f32p, f32p, f32p, i, i, i]
+        L.nzo_crop.argtypes = [f32p, i, f32p, i]
         L.nzo_thermal_erosion.argtypes = [f32p, i, f, f, f, i]
         L.nzo_pipeline.argtypes = [f32p, f32p, i, i, i, f, f, f, f, i, i, i, i, i, i, i, f, f, i]
         # the GPU box grants a CPU share, not the whole host: size the OpenMP team to the affinity mask
@@ -322,6 +323,14 @@ def curve(a, samples):
     if lib().nzo_curve(_p(a), _p(tmp), _p(samples), len(samples), *a.shape):
         raise ValueError("bad curve")
     return a
+
+
+def crop(a, out_res):
+    a = _plane(a)
+    assert a.shape[0] == a.shape[1]
+    out = np.empty((out_res, out_res), np.float32)
+    lib().nzo_crop(_p(a), a.shape[0], _p(out), out_res)
+    return out
 
 
 def thermal_erosion(a, talus=45.0, increment=0.5, ratio=0.75, iterations=1):

@@ -951,6 +951,20 @@ int nzo_reduce(float *srcL, const float *srcR, float *tmp, int op, int rows, int
     return 0;
 }
 
+/* CropJob<ReadTileData,WriteTileData>.Execute, Filter/Sample/CropJob.cs:34-41.  ScheduleParallel (:43-59)
+ * never assigns `Offset`, so the "centre crop" takes the top-left corner: out(x,z) = in(x+0, z+0) with the
+ * read tile's clamp-to-edge (an output larger than the input repeats the last row / column). */
+int nzo_crop(const float *input, int inputResolution, float *output, int outputResolution) {
+    const int Offset = 0;
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z < outputResolution; z++) {
+        int zr = z + Offset;
+        for (int x = 0; x < outputResolution; x++)
+            output[(size_t)z * outputResolution + x] = input[tile_idx(x + Offset, zr, inputResolution, inputResolution)];
+    }
+    return 0;
+}
+
 /* CurveOperator.Apply, CurveJob.cs:69-80 */
 int nzo_curve(float *src, float *tmp, const float *curve, int curveSize, int rows, int cols) {
     if (curveSize < 2) return -1;

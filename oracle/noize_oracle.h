@@ -133,6 +133,7 @@ int nzo_mesh_heightmap(int meshType, const float *heights, int resolution, int i
 /* ---- element-wise stages ---- */
 int nzo_constant(float *src, float *tmp, int op, float value, int rows, int cols);      /* Filter/ConstantJob.cs */
 int nzo_reduce(float *srcL, const float *srcR, float *tmp, int op, int rows, int cols); /* Filter/ReductionJob.cs */
+int nzo_crop(const float *input, int inputResolution, float *output, int outputResolution); /* Filter/Sample/CropJob.cs */
 int nzo_curve(float *src, float *tmp, const float *curve, int curveSize, int rows, int cols); /* Filter/Curve/CurveJob.cs */
 
 int nzo_thermal_erosion(float *src, int resolution, float talus, float incrementRatio,

@@ -423,6 +423,19 @@ def test_context_buffers_keep_a_tile_resident_between_pipelines(nj, ctx, oracle,
     consumer.Destroy()
 
 
+def test_crop_stage(nj, ctx, oracle):
+    a = np.random.default_rng(5).random((150, 150), dtype=f32)
+    src = ctx.from_host(a)
+    for out_res in (64, 150, 161):
+        d = nj.DownsampleData("c", ctx.alloc(out_res * out_res), src, out_res, 150)
+        st = nj.CropStage(ctx)
+        st.ReceiveHandledInput(nj.PipelineWorkItem(d), nj.JobHandle())
+        st.jobHandle.Complete()
+        assert np.array_equal(d.data.ToArray((out_res, out_res)), oracle.crop(a, out_res)), out_res
+    with pytest.raises(Exception, match="Unhandled stageio"):
+        nj.CropStage(ctx).Schedule(nj.PipelineWorkItem(gen(nj, ctx, 8)), nj.JobHandle())
+
+
 def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):
     # BasicDemo "ParallelFlowMap": Perlin fBm -> Invert (curve) -> FlowMapStage -> CurveBoostContrast
     res = 128

@@ -394,3 +394,11 @@ def test_thermal_erosion_known_answers(oracle):
     # a slope gentler than the talus angle is a fixed point
     ramp = np.tile(np.arange(res, dtype=f32) * (md * f32(0.5)), (res, 1))
     assert np.array_equal(oracle.thermal_erosion(ramp, 45.0, 0.5, 0.75, 2), ramp)
+
+
+def test_crop_takes_the_top_left_corner_and_clamps(oracle):
+    # Filter/Sample/CropJob.cs:43-59 never sets Offset: the "centre crop" is the top-left corner; reads clamp
+    a = np.arange(36, dtype=f32).reshape(6, 6)
+    assert np.array_equal(oracle.crop(a, 4), a[:4, :4])
+    big = oracle.crop(a, 8)
+    assert np.array_equal(big[:6, :6], a) and np.array_equal(big[7], big[5]) and np.array_equal(big[:, 7], big[:, 5])
