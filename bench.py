@@ -105,6 +105,11 @@ def main():
             raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
                              "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # stdout carries the ONE JSON line only: whatever libraries print while they initialise (RCCL's version
+    # banner under NCCL_DEBUG=VERSION) is sent to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.sharded or args.as_rank is not None
     if args.as_rank is not None and (world != 1 or args.halo != "recompute"):
@@ -161,7 +166,12 @@ def main():
         comm = sh.TorchComm(dist) if args.halo == "exchange" else sh.NoComm()
 
         def step(record):
-            sh.run_pipeline(ops, comm, plan, p, bufs)
+            if record:  # stream markers where the stages begin (exchanges of a stage are charged to it)
+                hs = {}
+                sh.run_pipeline(ops, comm, plan, p, bufs, on_stage=lambda name: hs.__setitem__(name, ctx.record()))
+                marks.append([hs[n] for n in ("noise", "gauss", "flow", "erosion", "end")])
+            else:
+                sh.run_pipeline(ops, comm, plan, p, bufs)
 
         how = "ghost rows exchanged over RCCL before every launch" if args.halo == "exchange" else \
             "%d ghost rows per side recomputed from the closed-form noise, no data-path communication" % halo
@@ -182,7 +192,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(not sharded and args.steps - i <= MAX_MARKED_STEPS)
+        step(args.steps - i <= MAX_MARKED_STEPS)
     fence()
     dt = time.perf_counter() - t0
     if sharded:
@@ -208,7 +218,10 @@ def main():
             names = ["noise", "gauss", "flow", "erosion"]
             flow_cap = nj._native.lib.nz_flow_fused_max_iterations()
             flow_launches = len(sh.split_iterations(F_IT, flow_cap))
-            launches = {"noise": 1, "gauss": None, "flow": flow_launches + (1 if flow_launches == 1 else 0), "erosion": 2}
+            # the tile API ends a one-launch flow stage with a copy back into the caller's plane; stripes ping-pong
+            launches = {"noise": 1, "gauss": None,
+                        "flow": flow_launches + (1 if flow_launches == 1 and not sharded else 0), "erosion": 2}
+            rcells = cells // world  # rank 0's own cells: the stage figures are per GPU
             acc = {n: 0.0 for n in names}
             for hs in marks:
                 for i, n in enumerate(names):
@@ -216,14 +229,14 @@ def main():
             stages_out = {}
             for n in names:
                 ms = acc[n] / len(marks)
-                gbs = BYTES[n] * cells / (ms * 1e-3) / 1e9
+                gbs = BYTES[n] * rcells / (ms * 1e-3) / 1e9
                 stages_out[n] = {"kernel": KERNEL_OF[n], "ms": round(ms, 4), "algorithmic_GB/s": round(gbs, 1),
                                  "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
-            stages_out["noise"]["valu_Gops/s"] = round(13 * NOISE_OPS_PER_OCTAVE_CELL * cells /
+            stages_out["noise"]["valu_Gops/s"] = round(13 * NOISE_OPS_PER_OCTAVE_CELL * rcells /
                                                        (stages_out["noise"]["ms"] * 1e-3) / 1e9, 1)
             stages_out["noise"]["frac_valu"] = round(stages_out["noise"]["valu_Gops/s"] / VALU_PEAK_GOPS, 4)
             stages_out["gauss"]["launches"] = N_gauss = len(sh.split_iterations(G_IT, nj._native.lib.nz_kernel_filter_max_fused(2)))
-            if N_gauss & 1:
+            if N_gauss & 1 and not sharded:  # the tile API keeps the launch count even (result back in `src`)
                 stages_out["gauss"]["launches"] = N_gauss + 1
             out["stages"] = stages_out
             # `roofline`: the HBM-bound stage with the largest share of the step.  The fBm stage is reported
@@ -233,16 +246,19 @@ def main():
             s = stages_out[dom]
             out["roofline"] = {"kernel": s["kernel"], "bound": "hbm", "achieved": s["algorithmic_GB/s"],
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s["frac_hbm"],
-                               "traffic": pmc_traffic(dom),
+                               "traffic": None if sharded else pmc_traffic(dom),
                                "launches_per_step": n_launch, "avg_launch_ms": round(s["ms"] / n_launch, 4),
-                               "algorithmic_bytes_per_launch": round(BYTES[dom] * cells / n_launch),
+                               "algorithmic_bytes_per_launch": round(BYTES[dom] * rcells / n_launch),
                                "note": "largest HBM-bound stage (stage time / launches); its iterations are fused on "
                                        "chip, so algorithmic bytes per launch exceed the HBM bytes actually moved "
                                        "(traffic) and frac can exceed 1"}
+            if out["roofline"]["traffic"]:  # HBM bytes actually moved per launch (PMC) over the launch time
+                out["roofline"]["traffic_GB/s"] = round(out["roofline"]["traffic"] / (s["ms"] / n_launch * 1e-3) / 1e9, 1)
             out["valu_roofline"] = {"kernel": stages_out["noise"]["kernel"], "bound": "fp32-valu",
                                     "achieved": stages_out["noise"]["valu_Gops/s"], "peak": VALU_PEAK_GOPS,
                                     "unit": "Gop/s", "frac": stages_out["noise"]["frac_valu"],
-                                    "avg_launch_ms": stages_out["noise"]["ms"], "traffic": pmc_traffic("noise"),
+                                    "avg_launch_ms": stages_out["noise"]["ms"],
+                                    "traffic": None if sharded else pmc_traffic("noise"),
                                     "note": "fBm octave accumulation; %d VALU slots per octave-cell counted in the ISA"
                                             % int(NOISE_OPS_PER_OCTAVE_CELL)}
         if not args.no_cpu_baseline and not sharded:
@@ -251,8 +267,11 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if out is not None:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

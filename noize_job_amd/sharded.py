@@ -120,12 +120,17 @@ def halo_rows_needed(ops, p):
     return max([max(r[2], r[3]) for r in radii] + [1])
 
 
-def pipeline_steps(ops, plan, p, bufs, result):
+def pipeline_steps(ops, plan, p, bufs, result, on_stage=None):
     """The sharded metric pipeline as a generator: yields (planes, up_rows, down_rows) wherever the
     ranks must exchange ghost rows (never in haloMode "recompute"), runs the stripe kernels in between.
     bufs = (A, B, S0, S1): two height planes [plan.rows, cols] and two flow-state buffers
-    [5, plan.rows, cols].  The plane whose owned rows hold the result is appended to `result`."""
+    [5, plan.rows, cols].  The plane whose owned rows hold the result is appended to `result`.
+    `on_stage(name)` (optional) is called where a stage begins ("noise", "gauss", "flow", "erosion") and
+    once at the end ("end"): the hook bench.py hangs its stream markers on."""
     A, B, S0, S1 = bufs
+    mark = on_stage if on_stage is not None else (lambda name: None)
+    current = "noise"
+    mark(current)
     cur, nxt = A, B
     s_cur, s_nxt = S0, S1
     radii = _launch_radii(ops, p)
@@ -136,6 +141,9 @@ def pipeline_steps(ops, plan, p, bufs, result):
     ops.fractal(cur, plan.widened(need_up, need_down), p)
     flow_launches = [i for i, r in enumerate(radii) if r[0] == "flow"]
     for i, (stage, n, up, down) in enumerate(radii):
+        if stage != current:
+            current = stage
+            mark(current)
         if recompute:
             need_up, need_down = need_up - up, need_down - down
         win = plan.widened(need_up, need_down)
@@ -161,13 +169,14 @@ def pipeline_steps(ops, plan, p, bufs, result):
                 yield [cur], up, down
             ops.erosion(cur, nxt, win, n)
             cur, nxt = nxt, cur
+    mark("end")
     result.append(cur)
 
 
-def run_pipeline(ops, comm, plan, p, bufs):
+def run_pipeline(ops, comm, plan, p, bufs, on_stage=None):
     """One pass of the sharded metric pipeline on this rank; returns the plane holding the result."""
     result = []
-    for planes, up_rows, down_rows in pipeline_steps(ops, plan, p, bufs, result):
+    for planes, up_rows, down_rows in pipeline_steps(ops, plan, p, bufs, result, on_stage):
         comm.exchange(planes, plan, up_rows, down_rows)
     return result[0]
 
