@@ -86,8 +86,10 @@ static int32_t build_simplex_tables(nz_ctx *ctx) {
     //   simplex : T1[292] int = 16*permute(i);      T2[580] float4 = {a0, h, 1.79284291400159 - 0.85373472095314*(a0*a0+h*h), 0}
     //   perlin  : P1[292] int = 8*permute(i);       P2[584] float2 = {gx*norm, gy*norm} of permute(j)
     //   cellular: C1[292] int = 8*permute(i-1);     C2[584] float2 = {ox, oy} of permute(a-1)
-    constexpr int T1 = 292, T2 = 580, B1 = 292, B2 = 584;
-    std::vector<int32_t> buf(T1 + T2 * 4 + 2 * (B1 + B2 * 2));
+    //   3-D     : P3[580] int = permute(j);           G3c[292] / G3s[292] float4 = normalised corner gradient of
+    //             noise.cnoise(float3) / noise.snoise(float3) for the final hash value 0..288
+    constexpr int T1 = 292, T2 = 580, B1 = 292, B2 = 584, P3 = 580, G3 = 292;
+    std::vector<int32_t> buf(T1 + T2 * 4 + 2 * (B1 + B2 * 2) + P3 + 2 * G3 * 4);
     for (int i = 0; i < T1; i++) buf[i] = 16 * (int32_t)h_permute((float)i);
     float *t2 = reinterpret_cast<float *>(buf.data() + T1);
     for (int j = 0; j < T2; j++) {
@@ -126,6 +128,45 @@ static int32_t build_simplex_tables(nz_ctx *ctx) {
         float pk = p * K;
         c2[2 * a + 0] = (pk - floorf(pk)) - Ko;
         c2[2 * a + 1] = h_mod7(floorf(pk)) * K - Ko;
+    }
+    int32_t *p3 = c1 + B1 + B2 * 2;
+    for (int j = 0; j < P3; j++) p3[j] = (int32_t)h_permute((float)j);
+    float *g3c = reinterpret_cast<float *>(p3 + P3), *g3s = g3c + G3 * 4;
+    auto step = [](float y, float x) { return x >= y ? 1.0f : 0.0f; };  // math.step(y, x)
+    for (int h = 0; h < G3; h++) {
+        {  // noise.cnoise(float3): gradient decode of ixy0 / ixy1
+            float gx = (float)h * (1.0f / 7.0f);
+            float t = floorf(gx) * (1.0f / 7.0f);
+            float gy = (t - floorf(t)) - 0.5f;
+            gx = gx - floorf(gx);
+            float gz = 0.5f - fabsf(gx) - fabsf(gy);
+            float sz = step(gz, 0.0f);
+            gx -= sz * (step(0.0f, gx) - 0.5f);
+            gy -= sz * (step(0.0f, gy) - 0.5f);
+            float nr = 1.79284291400159f - 0.85373472095314f * (gx * gx + gy * gy + gz * gz);
+            g3c[4 * h + 0] = gx * nr;
+            g3c[4 * h + 1] = gy * nr;
+            g3c[4 * h + 2] = gz * nr;
+            g3c[4 * h + 3] = 0.0f;
+        }
+        {  // noise.snoise(float3): p -> (x, y, h) on the 7x7 grid, octahedron fold, normalisation
+            const float n_ = 0.142857142857f;
+            const float nsx = n_ * 2.0f - 0.0f, nsy = n_ * 0.5f - 1.0f, nsz = n_ * 1.0f - 0.0f;
+            float pp = (float)h;
+            float j = pp - 49.0f * floorf(pp * nsz * nsz);
+            float x_ = floorf(j * nsz);
+            float y_ = floorf(j - 7.0f * x_);
+            float X = x_ * nsx + nsy, Y = y_ * nsx + nsy;
+            float H = 1.0f - fabsf(X) - fabsf(Y);
+            float sx = floorf(X) * 2.0f + 1.0f, sy = floorf(Y) * 2.0f + 1.0f;
+            float sh = -step(H, 0.0f);
+            float ax = X + sx * sh, ay = Y + sy * sh;
+            float nr = 1.79284291400159f - 0.85373472095314f * (ax * ax + ay * ay + H * H);
+            g3s[4 * h + 0] = ax * nr;
+            g3s[4 * h + 1] = ay * nr;
+            g3s[4 * h + 2] = H * nr;
+            g3s[4 * h + 3] = 0.0f;
+        }
     }
     NZ_HIP(hipMalloc(&ctx->d_simplex, buf.size() * sizeof(int32_t)));
     NZ_HIP(hipMemcpy(ctx->d_simplex, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -412,8 +412,8 @@ __device__ __forceinline__ float noise_value(float x, float z, const psr_tables 
 // ---- simplex fBm with tabulated lattice hashes -------------------------------------------------------
 // In snoise the gradient of a lattice corner is a pure function of two small integers: the inner
 // permute argument iy+{0,i1.y,1} in [0,289] and the outer one permute(..)+ix+{0,i1.x,1} in [0,577]
-// (mod289 of any |integer| < 2.3e6 lies in [0,288]; every product is < 2^24, so all of this is exact
-// integer arithmetic in fp32).  Two tables built by the host with the reference's own operation
+// (fp32 mod289 of an |integer| < 2.3e6 lies in [0,289] -- 289 for some negative multiples of 289 --
+// and every product is < 2^24, so all of this is exact integer arithmetic in fp32).  Two tables built by the host with the reference's own operation
 // sequence therefore return bit-identical gradients:
 //   T1[i]  = 16 * permute(i)                                   (a byte offset into T2)
 //   T2[j]  = {a0, h, 1.79284291400159 - 0.85373472095314*(a0*a0 + h*h), 0} of p = permute(j)
@@ -421,7 +421,7 @@ __device__ __forceinline__ float noise_value(float x, float z, const psr_tables 
 // permutes and the gradient decode (26 fp32 ops + 4 floors).  About 87 VALU slots per octave-cell
 // instead of 151.
 constexpr int NZ_T1_N = 292, NZ_T2_N = 580;
-// The tables hold hashes of lattice coordinates reduced to [0, 288]; fp32 mod289 only guarantees that range
+// The tables hold hashes of lattice coordinates reduced to [0, 289]; fp32 mod289 only guarantees that range
 // for |integer| < 2.3e6 (and the skew of snoise stretches a coordinate by up to 1.73).  Samples beyond this
 // limit (NaN included) take the direct evaluation, which follows the reference's arithmetic wherever it leads.
 constexpr float NZ_TAB_LIMIT = 1048576.0f;
@@ -438,8 +438,10 @@ __device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1
     x12x -= i1x;
     x12y -= i1y;
     int ixi = (int)mod289i(fx), iyi = (int)mod289i(fy);
-    ixi = min(max(ixi, 0), 288);  // only reachable for |coordinate| > 2.3e6, where fp32 has no fraction left
-    iyi = min(max(iyi, 0), 288);
+    // fp32 mod289 returns 289 (not 0) for some negative multiples of 289 (-8959, -17629, ...): the tables carry
+    // that index; the clamps only guard the LDS reads, they never bind below NZ_TAB_LIMIT
+    ixi = min(max(ixi, 0), 289);
+    iyi = min(max(iyi, 0), 289);
     int ix16 = ixi << 4;
     int k0 = s_t1[iyi], k1 = s_t1[iyi + (gt ? 0 : 1)], k2 = s_t1[iyi + 1];
     const char *t2 = reinterpret_cast<const char *>(s_t2);
@@ -559,8 +561,8 @@ __device__ __forceinline__ float cnoise2_tab(float Px, float Py, const int *s_t1
     float frx = Px - flx, fry = Py - fly;
     int ix0 = (int)mod289i(flx + 0.0f), iy0 = (int)mod289i(fly + 0.0f);
     int ix1 = (int)mod289i(flx + 1.0f), iy1 = (int)mod289i(fly + 1.0f);
-    ix0 = min(max(ix0, 0), 288); iy0 = min(max(iy0, 0), 288);
-    ix1 = min(max(ix1, 0), 288); iy1 = min(max(iy1, 0), 288);
+    ix0 = min(max(ix0, 0), 289); iy0 = min(max(iy0, 0), 289);  // 289 is a legal value of fp32 mod289 (negative cells)
+    ix1 = min(max(ix1, 0), 289); iy1 = min(max(iy1, 0), 289);
     float Pf0 = frx, Pf1 = fry, Pf2 = frx - 1.0f, Pf3 = fry - 1.0f;
     int a0 = s_t1[ix0], a1 = s_t1[ix1];
     const char *t2 = reinterpret_cast<const char *>(s_t2);
@@ -581,8 +583,8 @@ __device__ __forceinline__ float cnoise2_tab(float Px, float Py, const int *s_t1
 __device__ __forceinline__ float cellular_rect_tab(float Px, float Py, const int *s_t1, const float2 *s_t2) {
     float fx = floorf(Px), fy = floorf(Py);
     int Pix = (int)mod289i(fx), Piy = (int)mod289i(fy);
-    Pix = min(max(Pix, 0), 288);
-    Piy = min(max(Piy, 0), 288);
+    Pix = min(max(Pix, 0), 289);  // 289 is a legal value of fp32 mod289 (negative cells)
+    Piy = min(max(Piy, 0), 289);
     float Pfx = Px - fx, Pfy = Py - fy;
     const char *t2 = reinterpret_cast<const char *>(s_t2);
     const float xoff[3] = {0.5f, -0.5f, -1.5f};
@@ -684,6 +686,135 @@ __global__ __launch_bounds__(256) void fractal_tab2_kernel(float *__restrict__ d
 #pragma unroll
         for (int c = 0; c < VEC; c++)
             if (x0 + c < cols) row[x0 + c] = t[c] / p.norm;
+    }
+}
+
+// ---- domain-rotated 3-D bases with tabulated hashes and gradients -------------------------------------
+// noise.cnoise(float3) / noise.snoise(float3) hash a corner with three nested permutes of small integers
+// and decode a gradient from the result: P3[j] = permute(j), j in [0,579] (permute only depends on j mod 289
+// and every product stays below 2^24), G3[h] = the normalised gradient of hash h, both built by the host
+// with the reference's operation sequence.  A corner costs three 4-byte and one 16-byte LDS read.
+constexpr int NZ_P3_N = 580, NZ_G3_N = 292;
+
+// mod289 of an integer-valued float as a table index.  In fp32 the result is 289, not 0, for some negative
+// multiples of 289 (-8959, -17629, ...); the tables are built over that range.
+__device__ __forceinline__ int lattice289(float f) { return min(max((int)mod289i(f), 0), 289); }
+
+__device__ __forceinline__ float cnoise3_tab(float Px, float Py, float Pz, const int *s_p, const float4 *s_g) {
+    float fl[3] = {floorf(Px), floorf(Py), floorf(Pz)};
+    float Pf0[3] = {Px - fl[0], Py - fl[1], Pz - fl[2]};
+    float Pf1[3] = {Pf0[0] - 1.0f, Pf0[1] - 1.0f, Pf0[2] - 1.0f};
+    int i0[3], i1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        i0[k] = lattice289(fl[k]);
+        i1[k] = lattice289(fl[k] + 1.0f);
+    }
+    int a0 = s_p[i0[0]], a1 = s_p[i1[0]];
+    int b[4] = {s_p[a0 + i0[1]], s_p[a1 + i0[1]], s_p[a0 + i1[1]], s_p[a1 + i1[1]]};
+    float n[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int z = 0; z < 2; z++) {
+            float4 g = s_g[s_p[b[k] + (z ? i1[2] : i0[2])]];
+            asm volatile("" ::"v"(g.w));  // keep the 16-byte read (a 12-byte one costs twice the LDS cycles)
+            float fx = (k & 1) ? Pf1[0] : Pf0[0];
+            float fy = (k & 2) ? Pf1[1] : Pf0[1];
+            float fz = z ? Pf1[2] : Pf0[2];
+            n[z][k] = g.x * fx + g.y * fy + g.z * fz;
+        }
+    }
+    float fdx = fadef(Pf0[0]), fdy = fadef(Pf0[1]), fdz = fadef(Pf0[2]);
+    float nz0 = lerpf_(n[0][0], n[1][0], fdz);
+    float nz1 = lerpf_(n[0][1], n[1][1], fdz);
+    float nz2 = lerpf_(n[0][2], n[1][2], fdz);
+    float nz3 = lerpf_(n[0][3], n[1][3], fdz);
+    float nyz0 = lerpf_(nz0, nz2, fdy);
+    float nyz1 = lerpf_(nz1, nz3, fdy);
+    return 2.2f * lerpf_(nyz0, nyz1, fdx);
+}
+
+__device__ __forceinline__ float snoise3_tab(float vx, float vy, float vz, const int *s_p, const float4 *s_g) {
+    const float Cx = 1.0f / 6.0f, Cy = 1.0f / 3.0f;
+    float v[3] = {vx, vy, vz};
+    float s = vx * Cy + vy * Cy + vz * Cy;
+    float i[3], x0[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) i[k] = floorf(v[k] + s);
+    float t = i[0] * Cx + i[1] * Cx + i[2] * Cx;
+#pragma unroll
+    for (int k = 0; k < 3; k++) x0[k] = v[k] - i[k] + t;
+    float g[3] = {stepf_(x0[1], x0[0]), stepf_(x0[2], x0[1]), stepf_(x0[0], x0[2])};
+    float l[3] = {1.0f - g[0], 1.0f - g[1], 1.0f - g[2]};
+    float lz[3] = {l[2], l[0], l[1]};
+    float i1[3], i2[3], xs[4][3];
+    int ii[3], o1[3], o2[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        i1[k] = fminf(g[k], lz[k]);
+        i2[k] = fmaxf(g[k], lz[k]);
+        xs[0][k] = x0[k];
+        xs[1][k] = x0[k] - i1[k] + Cx;
+        xs[2][k] = x0[k] - i2[k] + Cy;
+        xs[3][k] = x0[k] - 0.5f;
+        ii[k] = lattice289(i[k]);
+        o1[k] = (int)i1[k];
+        o2[k] = (int)i2[k];
+    }
+    const int oz[4] = {0, o1[2], o2[2], 1}, oy[4] = {0, o1[1], o2[1], 1}, ox[4] = {0, o1[0], o2[0], 1};
+    float acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int h = s_p[s_p[s_p[ii[2] + oz[k]] + ii[1] + oy[k]] + ii[0] + ox[k]];
+        float4 p = s_g[h];
+        asm volatile("" ::"v"(p.w));
+        float m = fmaxf(0.6f - (xs[k][0] * xs[k][0] + xs[k][1] * xs[k][1] + xs[k][2] * xs[k][2]), 0.0f);
+        m = m * m;
+        float pd = p.x * xs[k][0] + p.y * xs[k][1] + p.z * xs[k][2];
+        acc[k] = (m * m) * pd;
+    }
+    return 42.0f * (acc[0] + acc[1] + acc[2] + acc[3]);
+}
+
+template <int BASIS>
+__global__ __launch_bounds__(256) void fractal_tab3_kernel(float *__restrict__ dst, int rows, int cols, int pitch,
+                                                          int blocks_per_row, nz_fractal_params p,
+                                                          const int *__restrict__ p3g, const float4 *__restrict__ g3g) {
+    __shared__ int s_p[NZ_P3_N];
+    __shared__ float4 s_g[NZ_G3_N];
+    for (int i = threadIdx.x; i < NZ_P3_N; i += 256) s_p[i] = p3g[i];
+    for (int i = threadIdx.x; i < NZ_G3_N; i += 256) s_g[i] = g3g[i];
+    __syncthreads();
+    int by = blockIdx.x / blocks_per_row;
+    int bx = blockIdx.x - by * blocks_per_row;
+    int x0 = bx * 256 + threadIdx.x;
+    if (x0 >= cols) return;
+    float xi = ((float)x0 + p.posx) / p.noise_size;
+    int zend = min(rows, (by + 1) * 8);
+    for (int z = by * 8; z < zend; z++) {
+        float zi = ((float)z + p.posz) / p.noise_size;
+        float t = 0.0f, detune = 0.0f, f = 1.0f, a = p.amp;
+        // the rotation shrinks |x|, |z| (factor <= 1.16 on x + z), so the 2-D limit keeps the lattice in range
+        const bool small_row = p.fmax * fmaxf(fabsf(xi), fabsf(zi)) < NZ_TAB_LIMIT;
+        for (int i = 0; i < p.octaves; i++) {
+            float xV = f * xi, zV = f * zi;
+            float xr, zr, yr;
+            domain_rotate(xV, zV, xr, zr, yr);
+            float nv;
+            if (small_row || fmaxf(fabsf(xV), fabsf(zV)) < NZ_TAB_LIMIT) {
+                nv = BASIS == NZ_NOISE_DOMAIN_ROTATED_PERLIN ? cnoise3_tab(xr, zr, yr, s_p, s_g)
+                                                             : snoise3_tab(xr, zr, yr, s_p, s_g);
+            } else {
+                asm volatile("; direct evaluation" ::: "memory");  // a real branch, never if-converted
+                nv = BASIS == NZ_NOISE_DOMAIN_ROTATED_PERLIN ? cnoise3(xr, zr, yr) : snoise3(xr, zr, yr);
+            }
+            t += a * rectify(nv);
+            detune += p.detune_rate;
+            f *= (p.stepdown - detune);
+            a *= p.G;
+        }
+        dst[(size_t)z * pitch + x0] = t / p.norm;
     }
 }
 
@@ -804,6 +935,23 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         else
             hipLaunchKernelGGL((fractal_tab2_kernel<NZ_NOISE_CELLULAR, 1>), dim3((unsigned)blocks), dim3(256), 0, s, dst,
                                rows, cols, pitch, bpr, p, t1, t2);
+        NZ_HIP(hipGetLastError());
+        return NZ_OK;
+    }
+    if ((noiseType == NZ_NOISE_DOMAIN_ROTATED_PERLIN || noiseType == NZ_NOISE_DOMAIN_ROTATED_SIMPLEX) && use_tab &&
+        d_simplex) {
+        const char *base = reinterpret_cast<const char *>(d_simplex) + (NZ_T1_N * 4 + NZ_T2_N * 16) +
+                           2 * (NZ_TB1_N * 4 + NZ_TB2_N * 8);
+        const int *p3 = reinterpret_cast<const int *>(base);
+        const float4 *g3 = reinterpret_cast<const float4 *>(base + NZ_P3_N * 4);
+        int bpr = (cols + 255) / 256;
+        long long blocks = (long long)bpr * ((rows + 7) / 8);
+        if (noiseType == NZ_NOISE_DOMAIN_ROTATED_PERLIN)
+            hipLaunchKernelGGL((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_PERLIN>), dim3((unsigned)blocks), dim3(256), 0,
+                               s, dst, rows, cols, pitch, bpr, p, p3, g3);
+        else
+            hipLaunchKernelGGL((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_SIMPLEX>), dim3((unsigned)blocks), dim3(256), 0,
+                               s, dst, rows, cols, pitch, bpr, p, p3, g3 + NZ_G3_N);
         NZ_HIP(hipGetLastError());
         return NZ_OK;
     }

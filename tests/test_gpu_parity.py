@@ -62,6 +62,21 @@ def test_negative_and_huge_coordinates(nj, ctx, oracle, basis):
         d.data.Dispose()
 
 
+@pytest.mark.parametrize("basis", range(1, 8), ids=BASES[1:])
+def test_negative_lattice_cells_where_fp32_mod289_returns_289(nj, ctx, oracle, basis):
+    # x - floor(x * (1/289)) * 289 in fp32 is 289, not 0, for some negative multiples of 289 (first: -8959,
+    # -17629, -17918, -18207): the lattice tables must carry that index through like the reference's arithmetic
+    res = 128
+    for (octv, ns, xp, zp) in [(1, 1, -8990, -18260), (1, 1, -9020, 8930), (3, 1, -18000, -9000), (2, 2, -36000, -35900)]:
+        st = nj.NoiseStage(ctx, nj.FractalNoise(basis), 0.5, 1.0, octv, 2.0, 0.0, ns)
+        d = gen(nj, ctx, res, xpos=xp, zpos=zp)
+        got = run(st, nj, d)
+        want = oracle.fractal(basis, res, res, 0.5, 1.0, 2.0, 0.0, octv, xp, zp, ns)
+        assert np.array_equal(got, want), "%s ns=%d pos=(%d,%d): %d cells differ" % (
+            BASES[basis], ns, xp, zp, int((got != want).sum()))
+        d.data.Dispose()
+
+
 def test_fractal_config1_plumbing(nj, ctx, oracle):
     # BASELINE config 1: 1024^2 Perlin, 8 octaves, hurst 0.5
     st = nj.NoiseStage(ctx, nj.FractalNoise.Perlin, 0.5, 1.0, 8, 2.0, 0.0, 1000)
