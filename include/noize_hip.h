@@ -151,8 +151,10 @@ int32_t nz_smooth_blur_stage(nz_ctx *ctx, float *src, float *tmp, int32_t width,
 int32_t nz_erosion_stage(nz_ctx *ctx, float *src, float *tmp, int32_t iterations, int32_t resolution,
                          nz_handle dep, nz_handle *out);
 
-/* stripe forms: one launch that advances `iterations` applications on rows [own0, own1); needs
- * nz_*_halo_rows(...) valid ghost rows on each side; reads `src`, writes `dst` (owned rows only). */
+/* stripe forms: one launch that advances `iterations` applications on rows [own0, own1); the filter needs
+ * nz_kernel_filter_halo_rows(...) valid ghost rows on each side, the min erosion `iterations` rows ABOVE only
+ * (its window is {-1, 0}); rows beyond the global border are never needed.  Reads `src`, writes `dst`
+ * (owned rows only). */
 int32_t nz_kernel_filter_halo_rows(int32_t filter, int32_t iterations);
 int32_t nz_kernel_filter_max_fused(int32_t filter);
 int32_t nz_erosion_max_fused_iterations(void);

@@ -499,7 +499,8 @@ extern "C" int32_t nz_tile_download(nz_ctx *ctx, const float *dev, float *host, 
 // ---------------------------------------------------------------------------------------------
 // helpers shared by the stage entry points
 // ---------------------------------------------------------------------------------------------
-int32_t nz_check_stripe(const nz_stripe *st, int halo) {
+int32_t nz_check_stripe(const nz_stripe *st, int halo, int halo_below) {
+    if (halo_below < 0) halo_below = halo;  // symmetric stencil
     NZ_REQUIRE(st, "stripe is NULL");
     NZ_REQUIRE(st->cols > 0 && st->rows > 0 && st->grows > 0, "stripe: non-positive extent");
     NZ_REQUIRE(st->pitch == 0 || st->pitch >= st->cols, "stripe: pitch < cols");
@@ -507,11 +508,12 @@ int32_t nz_check_stripe(const nz_stripe *st, int halo) {
     NZ_REQUIRE(st->own0 + st->grow0 >= 0 && st->own1 + st->grow0 <= st->grows,
                "stripe: owned rows outside the global grid");
     // every row within `halo` of the owned rows must be in the buffer unless it is beyond the border
-    int need_lo = st->own0 - halo, need_hi = st->own1 - 1 + halo;
+    int need_lo = st->own0 - halo, need_hi = st->own1 - 1 + halo_below;
     int dom_lo = -st->grow0, dom_hi = st->grows - 1 - st->grow0;
     if (need_lo < dom_lo) need_lo = dom_lo;
     if (need_hi > dom_hi) need_hi = dom_hi;
-    NZ_REQUIRE(need_lo >= 0 && need_hi <= st->rows - 1, "stripe: %d ghost rows required", halo);
+    NZ_REQUIRE(need_lo >= 0 && need_hi <= st->rows - 1, "stripe: %d ghost rows required above, %d below", halo,
+               halo_below);
     return NZ_OK;
 }
 
@@ -917,7 +919,7 @@ extern "C" int32_t nz_erosion_stripe(nz_ctx *ctx, const float *src, float *dst, 
     NZ_BEGIN(ctx, dep);
     NZ_REQUIRE(src && dst && src != dst, "src/dst must be two distinct planes");
     NZ_REQUIRE(iterations >= 1 && iterations <= nz_erosion_max_fused(), "iterations %d cannot be fused", iterations);
-    NZ_TRY(nz_check_stripe(st, iterations));
+    NZ_TRY(nz_check_stripe(st, iterations, 0));  // the min window reaches upwards only
     NZ_TRY(nz_launch_erosion_fused(ctx->stream, src, dst, nz_geom_from_stripe(*st), iterations));
     return nz_ctx_finish(ctx, out);
 }

@@ -117,7 +117,7 @@ inline nz_geom nz_geom_from_stripe(const nz_stripe &s) {
 
 inline nz_geom nz_geom_tile(int res) { return nz_geom{res, res, res, 0, res - 1, 0, res}; }
 
-int32_t nz_check_stripe(const nz_stripe *st, int halo);
+int32_t nz_check_stripe(const nz_stripe *st, int halo, int halo_below = -1);  // rows needed above / below the owned ones
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------------
 int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, int cols, int pitch,

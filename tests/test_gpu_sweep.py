@@ -1,0 +1,152 @@
+"""Seeded random sweep: every stencil stage against the oracle over many tile sizes, iteration counts
+and (for the stripe entry points) random stripe geometry with a row pitch wider than the row.  All
+comparisons are bit-exact.  Sizes straddle the kernels' tile shapes (64 x 128 / 48 x 128 / 32 x 128
+workgroup tiles, 4-cell vectors) so interior, edge and unaligned paths are all taken."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+SIZES = [4, 7, 16, 31, 33, 63, 64, 65, 100, 127, 128, 129, 131, 191, 200, 257, 300, 385]
+
+
+def _run(nj, stage, d):
+    stage.ReceiveHandledInput(nj.PipelineWorkItem(d), nj.JobHandle())
+    stage.jobHandle.Complete()
+    stage.OnDestroy()
+    out = d.data.ToArray((d.resolution, d.resolution))
+    d.data.Dispose()
+    return out
+
+
+def _tile(rng, res):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        return rng.random((res, res), dtype=f32)
+    if kind == 1:  # large dynamic range, both signs
+        return ((rng.random((res, res), dtype=f32) - f32(0.5)) * f32(10.0) ** rng.integers(-3, 4)).astype(f32)
+    if kind == 2:  # plateaus: ties for the min filter, zero slopes for the flow
+        return np.round(rng.random((res, res), dtype=f32) * f32(4.0)).astype(f32) * f32(0.25)
+    t = np.zeros((res, res), f32)  # sparse impulses incl. the corners
+    t[0, 0] = t[-1, -1] = t[0, -1] = 1.0
+    t[rng.integers(0, res), rng.integers(0, res)] = -2.0
+    return t
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_filters_erosion_flow_random_sizes(nj, ctx, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(7):
+        res = int(rng.choice(SIZES))
+        t = _tile(rng, res)
+        ft = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13]))
+        it = int(rng.integers(1, 12))
+        got = _run(nj, nj.KernelFilterStage(ctx, nj.KernelFilterType(ft), it), nj.GeneratorData("k", ctx.from_host(t), res))
+        assert np.array_equal(got, oracle.kernel_filter(t, ft, it)), ("filter", res, ft, it)
+        width, sigma, it = int(rng.integers(1, 27)), int(rng.integers(0, 16)), int(rng.integers(1, 4))
+        got = _run(nj, nj.StageGaussianBlur(ctx, it, nj.GaussSigma(sigma), width), nj.GeneratorData("g", ctx.from_host(t), res))
+        assert np.array_equal(got, oracle.gauss(t, oracle.limit_width(width), sigma, it)), ("gauss", res, width, sigma, it)
+        width, it = int(rng.integers(1, 26)), int(rng.integers(1, 4))
+        got = _run(nj, nj.StageSmoothBlur(ctx, it, width), nj.GeneratorData("s", ctx.from_host(t), res))
+        assert np.array_equal(got, oracle.smooth(t, oracle.limit_width(width), it)), ("smooth", res, width, it)  # the stage passes limitWidth(width)
+        it = int(rng.integers(1, 14))
+        got = _run(nj, nj.ErosionStage(ctx, it), nj.GeneratorData("e", ctx.from_host(t), res))
+        assert np.array_equal(got, oracle.erosion_min(t, it)), ("erosion", res, it)
+        it = int(rng.integers(1, 13))
+        lo, hi = [(0.0, 0.005), (-0.1, 0.1), (0.0, 0.0)][int(rng.integers(0, 3))]
+        got = _run(nj, nj.FlowMapStage(ctx, it, lo, hi), nj.GeneratorData("f", ctx.from_host(t), res))
+        # a zero range divides 0 by 0 (NormalizeMap, FlowMapComponents.cs:157-165): NaN planes on both sides
+        assert np.array_equal(got, oracle.flowmap(t, it, lo, hi), equal_nan=True), ("flow", res, it, lo, hi)
+        it = int(rng.integers(1, 4))
+        if res >= 4:
+            got = _run(nj, nj.StageThermalErosion(ctx, it, 45, 0.5, 0.75), nj.GeneratorData("t", ctx.from_host(t), res))
+            assert np.array_equal(got, oracle.thermal_erosion(t, 45.0, 0.5, 0.75, it)), ("thermal", res, it)
+
+
+@pytest.mark.parametrize("basis", range(1, 8))
+def test_noise_random_parameters(nj, ctx, oracle, basis):
+    # every basis but Sin (device sinf) is bit-exact: random fBm parameters, positions of both signs around the
+    # lattice cells where fp32 mod289 misbehaves, small and negative noise sizes, one tile beyond the table range
+    rng = np.random.default_rng(4000 + basis)
+    for k in range(10):
+        res = int(rng.choice([17, 64, 96, 130]))
+        octv = int(rng.integers(1, 14))
+        hurst = float(f32(rng.random()))
+        amp = float(f32(rng.random() * 3.0 + 0.1))
+        step = float(f32(rng.choice([2.0, 1.9168, 2.5, 1.5, 0.7])))
+        det = float(f32(rng.choice([0.0, 0.0, 0.0317])))
+        ns = int(rng.choice([1, 2, 7, 100, 658, 1700, -13]))
+        span = 20000 * abs(ns) if k < 9 else 3000000 * abs(ns)
+        xp, zp = int(rng.integers(-span, span)), int(rng.integers(-span, span))
+        st = nj.NoiseStage(ctx, nj.FractalNoise(basis), hurst, amp, octv, step, det, ns)
+        d = nj.GeneratorData("n", ctx.alloc(res * res), res, xp, zp)
+        got = _run(nj, st, d)
+        want = oracle.fractal(basis, res, res, hurst, amp, step, det, octv, xp, zp, ns)
+        assert np.array_equal(got, want, equal_nan=True), (basis, res, octv, hurst, amp, step, det, ns, xp, zp,
+                                                            int((got != want).sum()))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_mesh_random_shapes(nj, ctx, oracle, seed):
+    rng = np.random.default_rng(2000 + seed)
+    for _ in range(6):
+        res = int(rng.choice([2, 3, 7, 16, 33, 64, 100, 255, 256, 300]))
+        margin = int(rng.integers(2, 6))  # overshoot with margin 1 reads past the row end in the reference (B17)
+        mesh_type = int(rng.integers(0, 2))
+        in_res = res + 2 * margin if mesh_type == 1 else res + int(rng.choice([1, 2, 2 * margin]))
+        h = rng.random((in_res, in_res), dtype=f32)
+        height, size = float(rng.choice([1.0, 10.0, 1000.0])), float(rng.choice([1.0, 512.0, 1000.0]))
+        md = nj.MeshStageData("m", ctx.from_host(h), res, in_res, margin, size, height)
+        st = nj.MeshTileStage(ctx, nj.MeshType(mesh_type))
+        st.ReceiveHandledInput(nj.PipelineWorkItem(md), nj.JobHandle())
+        st.jobHandle.Complete()
+        vtx, idx = oracle.mesh_heightmap(mesh_type, h, res, margin, height, size)
+        assert np.array_equal(md.mesh.index_array(), idx), (mesh_type, res, in_res)
+        assert np.array_equal(md.mesh.vertices.ToArray().reshape(-1, 12), vtx), (mesh_type, res, in_res)
+        md.data.Dispose()
+        md.mesh.vertices.Dispose()
+        md.mesh.indices.Dispose()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_stripe_entry_points_random_geometry_and_pitch(nj, ctx, oracle, seed):
+    # a stripe of a larger grid: buffer rows [grow0, grow0 + rows), produced rows [own0, own1), row pitch >= cols
+    rng = np.random.default_rng(3000 + seed)
+    for _ in range(6):
+        cols = int(rng.choice([5, 33, 64, 130, 200, 257]))
+        grows = int(rng.choice([40, 97, 150, 260]))
+        pitch = cols + int(rng.choice([0, 0, 1, 4, 13]))
+        ft = int(rng.choice([0, 1, 2, 3, 8]))
+        T = int(rng.integers(1, 1 + nj._native.lib.nz_kernel_filter_max_fused(ft)))
+        halo = nj._native.lib.nz_kernel_filter_halo_rows(ft, T)
+        grid = rng.random((grows, cols), dtype=f32)
+        want = oracle.kernel_filter(grid, ft, T)
+        g0 = int(rng.integers(0, grows - 1))
+        g1 = int(rng.integers(g0 + 1, grows + 1))
+        b0, b1 = max(0, g0 - halo - int(rng.integers(0, 3))), min(grows, g1 + halo + int(rng.integers(0, 3)))
+        rows = b1 - b0
+        buf = np.full((rows, pitch), np.nan, f32)
+        buf[:, :cols] = grid[b0:b1]
+        src, dst = ctx.from_host(buf), ctx.from_host(np.full((rows, pitch), np.nan, f32))
+        st = nj.Stripe(cols, rows, b0, grows, g0 - b0, g1 - b0, pitch)
+        ctx.call("nz_kernel_filter_stripe", src.ptr, dst.ptr, C.byref(st), ft, T).Complete()
+        out = dst.ToArray((rows, pitch))
+        assert np.array_equal(out[g0 - b0:g1 - b0, :cols], want[g0:g1]), ("conv", cols, grows, pitch, ft, T, g0, g1)
+        assert np.isnan(out[:g0 - b0]).all() and np.isnan(out[g1 - b0:]).all() and np.isnan(out[:, cols:]).all()
+        # erosion: E applications reach E rows upwards only
+        E = int(rng.integers(1, 1 + nj._native.lib.nz_erosion_max_fused_iterations()))
+        want = oracle.erosion_min(grid, E)
+        b0 = max(0, g0 - E)
+        rows = g1 - b0
+        buf = np.full((rows, pitch), np.nan, f32)
+        buf[:, :cols] = grid[b0:g1]
+        src.Dispose(); dst.Dispose()
+        src, dst = ctx.from_host(buf), ctx.from_host(np.full((rows, pitch), np.nan, f32))
+        st = nj.Stripe(cols, rows, b0, grows, g0 - b0, g1 - b0, pitch)
+        ctx.call("nz_erosion_stripe", src.ptr, dst.ptr, C.byref(st), E).Complete()
+        out = dst.ToArray((rows, pitch))
+        assert np.array_equal(out[g0 - b0:, :cols], want[g0:g1]), ("erosion", cols, grows, pitch, E, g0, g1)
+        src.Dispose(); dst.Dispose()
