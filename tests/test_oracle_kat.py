@@ -402,3 +402,37 @@ def test_crop_takes_the_top_left_corner_and_clamps(oracle):
     assert np.array_equal(oracle.crop(a, 4), a[:4, :4])
     big = oracle.crop(a, 8)
     assert np.array_equal(big[:6, :6], a) and np.array_equal(big[7], big[5]) and np.array_equal(big[:, 7], big[:, 5])
+
+
+# ---- second formulation of the 2-D noise bases (tests/np_noise.py, float4 form of SURVEY.md Appendix A) ----
+@pytest.mark.parametrize("scale", [20.0, 3000.0, 60000.0, 3.0e6])
+def test_noise_bases_equal_the_vectorised_numpy_restatement(oracle, scale):
+    import np_noise as N
+    rng = np.random.default_rng(int(scale))
+    n = 3000
+    x = ((rng.random(n, dtype=f32) - f32(0.5)) * f32(scale)).astype(f32)
+    y = ((rng.random(n, dtype=f32) - f32(0.5)) * f32(scale)).astype(f32)
+    x[:8] = [-8959.0, -8959.5, -17629.25, 8959.0, 0.0, -0.0, 289.0, -289.0]   # lattice cells where fp32 mod289 is 289
+    y[:8] = [-18207.0, 0.5, -8959.0, -8959.75, 0.0, -1.0, -289.0, 578.0]
+    pts = list(zip(x.tolist(), y.tolist()))
+    assert np.array_equal(np.array([oracle.cnoise2(u, v) for u, v in pts], f32), N.cnoise2(x, y))
+    assert np.array_equal(np.array([oracle.snoise2(u, v) for u, v in pts], f32), N.snoise2(x, y))
+    c = np.array([oracle.cellular2(u, v) for u, v in pts], f32)
+    F1, F2 = N.cellular2(x, y)
+    assert np.array_equal(c[:, 0], F1) and np.array_equal(c[:, 1], F2)
+    # psrnoise: the gradient hash (bit-exact) and the value (cos/sin from a different libm: 1e-6)
+    iu, yw, d = N.psrnoise2_parts(x, y)
+    for k in range(3):
+        h = np.array([oracle.psr_hash(a, b) for a, b in zip(iu[k].tolist(), yw[k].tolist())], f32)
+        assert np.array_equal(h, N.permute(N.permute(iu[k]) + yw[k]))
+    for rot in (0.0, 0.62):
+        w, t4 = [], []
+        for k in range(3):
+            gx, gy, _ = N.rgrad2(iu[k], yw[k], f32(rot))
+            w.append(gx * d[k][0] + gy * d[k][1])
+            t = np.maximum(f32(0.8) - (d[k][0] * d[k][0] + d[k][1] * d[k][1]), f32(0.0))
+            t2 = t * t
+            t4.append(t2 * t2)
+        want = f32(11.0) * (t4[0] * w[0] + t4[1] * w[1] + t4[2] * w[2])
+        got = np.array([oracle.psrnoise2(u, v, 1010.0, 102.0, rot) for u, v in pts], f32)
+        assert np.allclose(got, want, rtol=0, atol=2e-6)
