@@ -651,9 +651,9 @@ static int conv_tcap(int ksize) {
     } else {
         switch (ksize) {  // default fusion depth per launch (tuned on MI355X)
             case 3: cap = 6; break;
-            case 5: cap = 3; break;
+            case 5: cap = 5; break;
             case 7: cap = 3; break;
-            default: cap = 2; break;
+            default: cap = 3; break;
         }
     }
     return cap < hw ? cap : hw;

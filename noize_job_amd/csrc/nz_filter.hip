@@ -35,7 +35,7 @@ __device__ __forceinline__ void tile_origin(const nz_geom &g, int OW, int OH, in
 }
 
 // ---- register-resident fused kernel ------------------------------------------------------------------
-// T applications of X pass + Z pass on a 64 x 128 tile (halo included).  The tile never sits in LDS: each of the 256 threads keeps a 4-column x 8-row block in
+// T applications of X pass + Z pass on a (NT/4) x 128 tile (halo included; 64 rows for 3 taps, 128 rows otherwise).  The tile never sits in LDS: each of the 256 threads keeps a 4-column x 8-row block in
 // registers for the whole launch.  The X pass takes its (K-1)/2 west / east neighbours from the
 // adjacent lanes with wave-shift DPP moves; the Z pass needs (K-1)/2 rows from the thread above and
 // below, and only those boundary rows travel through LDS (16-byte accesses, double buffered: one
@@ -437,13 +437,16 @@ int32_t launch_wide(hipStream_t s, const float *src, float *dst, const nz_geom &
 #ifndef NZ_CONV_NT
 #define NZ_CONV_NT 256
 #endif
+#ifndef NZ_CONV_NT_WIDE
+#define NZ_CONV_NT_WIDE 512  // threads per workgroup for the 5-, 7- and 9-tap kernels: 128-row tiles (rows = NT / 4)
+#endif
 
 template <int KS>
 int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T) {
     constexpr int O = (KS - 1) / 2;
     int H = T * O, HX = (H + 3) & ~3;
     {
-        constexpr int NT = NZ_CONV_NT, RTH = NT / 32 * RB;  // register tile: RTH rows x 128 columns
+        constexpr int NT = KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT, RTH = NT / 32 * RB;  // register tile: RTH rows x 128 columns
         int OW = TW - 2 * HX, OH = RTH - 2 * H;
         long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
         int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
