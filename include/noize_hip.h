@@ -200,6 +200,26 @@ int32_t nz_flow_fused_stripe(nz_ctx *ctx, const float *height, const float *cons
                              float *dst, const nz_stripe *st, int32_t iterations, int32_t first, int32_t last,
                              float normMin, float normMax, nz_handle dep, nz_handle *out);
 
+/* ---- batched stage bodies (new-framework feature) ------------------------------------------------
+ * `count` independent tiles of resolution^2 cells stored back to back (tile k at data + k * resolution^2) go
+ * through one launch sequence: the reference runs one BasePipeline per tile request
+ * (Scripts/MeshTileGenerator.cs:181-211, default resolution 512), and a 512^2 tile alone cannot fill 256 CUs.
+ * Every tile is clamped at its own border exactly as in the single-tile entry points; results are identical.
+ * `positions` = DEVICE array of 2 * count int32 {xpos, zpos} (GeneratorData.xpos/zpos per tile).
+ * Flow-map work buffer: count * nz_flowmap_stage_work_floats(resolution) floats, plane-major. */
+int32_t nz_fractal_batch(nz_ctx *ctx, int32_t noiseType, float *data, int32_t resolution, int32_t count,
+                         const int32_t *positions, float hurst, float startingAmplitude, float stepdown,
+                         float detuneRate, int32_t octaves, int32_t noiseSize, nz_handle dep, nz_handle *out);
+int32_t nz_kernel_filter_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t filter, int32_t iterations,
+                                     int32_t resolution, int32_t count, nz_handle dep, nz_handle *out);
+int32_t nz_gauss_blur_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t sigma,
+                                  int32_t iterations, int32_t resolution, int32_t count, nz_handle dep,
+                                  nz_handle *out);
+int32_t nz_erosion_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t iterations, int32_t resolution,
+                               int32_t count, nz_handle dep, nz_handle *out);
+int32_t nz_flowmap_stage_batch(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
+                               float normMax, int32_t resolution, int32_t count, nz_handle dep, nz_handle *out);
+
 /* ---- mesh: HeightMapMeshJobScheduleDelegate, Mesh/Job/HeightMapMeshJob.cs:55-65 -------------- */
 /* (Mesh, MeshData) -> device vertex stream of (resolution+1)^2 records
  * {float3 position; float3 normal; float4 tangent; float2 texCoord0} = 48 B

@@ -8,7 +8,7 @@ from . import _native
 from ._native import NoizeError, Stripe
 from .runtime import Context, DeviceTile, JobHandle
 from .pipeline import (BasePipeline, BlurHelper, ConstantOperationType, ConstantStage, CropStage, CurveStage, DownsampleData, ErosionStage, FlowMapStage, FractalNoise, GaussSigma,
-                       GeneratorData, KernelFilterStage, KernelFilterType, MeshBuffers, MeshStageData,
+                       GeneratorData, GeneratorDataBatch, KernelFilterStage, KernelFilterType, MeshBuffers, MeshStageData,
                        MeshTileStage, MeshType, NoiseStage, PipelineJoint, PipelineStage, PipelineWorkItem, ReduceData,
                        ReducePipeline, ReduceStage, Upstream,
                        ReductionType, StageGaussianBlur, StageThermalErosion,

@@ -83,6 +83,11 @@ SIGNATURES = {
     "nz_crop_job": (_i, [ctx_p, dev_ptr, _i, dev_ptr, _i] + _tail),
     "nz_curve_job": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, _i, _i] + _tail),
     "nz_thermal_erosion": (_i, [ctx_p, dev_ptr, _f, _f, _f, _i, _i] + _tail),
+    "nz_fractal_batch": (_i, [ctx_p, _i, dev_ptr, _i, _i, dev_ptr, _f, _f, _f, _f, _i, _i] + _tail),
+    "nz_kernel_filter_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _i] + _tail),
+    "nz_gauss_blur_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _i, _i] + _tail),
+    "nz_erosion_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
+    "nz_flowmap_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _f, _f, _i, _i] + _tail),
     "nz_mesh_vertex_count": (_sz, [_i]),
     "nz_mesh_index_count": (_sz, [_i]),
     "nz_heightmap_mesh": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _i, _i, _i, _f, _f, dev_ptr] + _tail),

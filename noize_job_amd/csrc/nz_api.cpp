@@ -312,7 +312,7 @@ int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out) {
 template <class F>
 static int32_t banded_launch(nz_ctx *ctx, const nz_geom &g, bool stagger, F launch) {
     int rows = g.or1 - g.or0;
-    if (ctx->nbands <= 1 || rows < 128 * ctx->nbands) {
+    if (ctx->nbands <= 1 || rows < 128 * ctx->nbands || g.count > 1) {
         int32_t rc = bands_join(ctx);
         if (rc) return rc;
         return launch(ctx->stream, g);
@@ -536,7 +536,7 @@ static float calc_fractal_norm(float hurst, int octaves) {
 static int32_t fractal_impl(nz_ctx *ctx, hipStream_t stream, int noiseType, float *dst, int rows, int cols, int pitch,
                             float hurst,
                             float amp, float stepdown, float detune, int octaves, int xpos, int zpos_first_row,
-                            int noiseSize) {
+                            int noiseSize, int count = 1, size_t bstride = 0, const int32_t *positions = nullptr) {
     NZ_REQUIRE(dst, "src is NULL");
     NZ_REQUIRE(noiseType >= 0 && noiseType <= NZ_NOISE_DOMAIN_ROTATED_SIMPLEX, "unknown noise type %d", noiseType);
     NZ_REQUIRE(octaves >= 0, "octaves < 0");
@@ -560,7 +560,8 @@ static int32_t fractal_impl(nz_ctx *ctx, hipStream_t stream, int noiseType, floa
         det += detune;
         f *= (stepdown - det);
     }
-    return nz_launch_fractal(stream, noiseType, dst, rows, cols, pitch, p, ctx->d_rgrad, ctx->d_simplex);
+    return nz_launch_fractal(stream, noiseType, dst, rows, cols, pitch, p, ctx->d_rgrad, ctx->d_simplex, count, bstride,
+                             positions);
 }
 
 // SeparableKernelFilter tables, Filter/Kernel/KernelJob.cs:97-136.  Gaussian bodies are
@@ -677,7 +678,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         if (cur != src) {
             NZ_TRY_(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
                 size_t off = (size_t)gb.or0 * gb.pitch;
-                return nz_launch_copy(st, src + off, tmp + off, (size_t)(gb.or1 - gb.or0) * gb.pitch);
+                return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
             }));
         }
         return NZ_OK;
@@ -688,10 +689,18 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         }));
         return banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
-            return nz_launch_copy(st, src + off, tmp + off, (size_t)(gb.or1 - gb.or0) * gb.pitch);
+            return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
         });
     }
     if (cap == 0) {  // even or out-of-table sizes: the two passes as launched by the reference
+        if (g.count > 1) {  // no batched form of the generic passes: grid by grid
+            nz_geom one = g;
+            one.count = 1;
+            one.bstride = 0;
+            for (int b = 0; b < g.count; b++)
+                NZ_TRY_(conv_iterations(ctx, src + b * g.bstride, tmp + b * g.bstride, one, t, iterations));
+            return NZ_OK;
+        }
         for (int i = 0; i < iterations; i++) {
             int32_t rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
                 return nz_launch_conv_pass_x(st, src, tmp, gb, t);
@@ -730,7 +739,7 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
         }));
         return banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
-            return nz_launch_copy(st, src + off, tmp + off, (size_t)(gb.or1 - gb.or0) * gb.pitch);
+            return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
         });
     }
     int cap = nz_erosion_max_fused();
@@ -999,14 +1008,16 @@ extern "C" size_t nz_flowmap_stage_work_floats(int32_t resolution) {
     return resolution > 0 ? (size_t)11 * resolution * resolution : 0;  // the reference stage's 11 planes
 }
 
-extern "C" int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
-                                    float normMax, int32_t resolution, nz_handle dep, nz_handle *out) {
+static int32_t flowmap_stage_impl(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
+                                  float normMax, int32_t resolution, int32_t count, nz_handle dep, nz_handle *out) {
     NZ_BEGIN_BANDED(ctx, dep);
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(src && work, "src/work is NULL");
     NZ_REQUIRE(iterations >= 1, "iterations < 1");
-    size_t n = (size_t)resolution * resolution;
-    nz_geom g = nz_geom_tile(resolution);
+    NZ_REQUIRE(count >= 1 && count <= 65535, "count %d out of range [1,65535]", count);
+    // a batch keeps plane p of all its tiles together: plane p = work + p * count * res^2
+    size_t n = (size_t)resolution * resolution * count;
+    nz_geom g = count > 1 ? nz_geom_batch(resolution, count) : nz_geom_tile(resolution);
     float *A[5], *B[5];  // {water, fN, fS, fE, fW} x {READ, WRITE}, FlowMapStage.cs:52-62
     for (int i = 0; i < 5; i++) {
         A[i] = work + (size_t)i * n;
@@ -1038,13 +1049,76 @@ extern "C" int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_
     if (launches == 1) {
         NZ_TRY(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
-            return nz_launch_copy(st, src + off, hcopy + off, (size_t)(gb.or1 - gb.or0) * gb.pitch);
+            return nz_launch_copy(st, src + off, hcopy + off, nz_geom_span(gb));
         }));
     }
     return nz_ctx_finish(ctx, out);
 }
 
+extern "C" int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
+                                    float normMax, int32_t resolution, nz_handle dep, nz_handle *out) {
+    return flowmap_stage_impl(ctx, src, work, iterations, normMin, normMax, resolution, 1, dep, out);
+}
+
 extern "C" int32_t nz_flow_fused_max_iterations(void) { return nz_flow_fused_max(); }
+
+// ---------------------------------------------------------------------------------------------
+// batched stage bodies: `count` independent tiles of resolution^2 cells stored back to back, one launch
+// sequence for all of them (new-framework feature: the reference runs one BasePipeline per tile request,
+// Scripts/MeshTileGenerator.cs:181-211; small tiles cannot fill 256 CUs one at a time)
+// ---------------------------------------------------------------------------------------------
+static int32_t check_batch(int32_t resolution, int32_t count) {
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(count >= 1 && count <= 65535, "count %d out of range [1,65535]", count);
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_fractal_batch(nz_ctx *ctx, int32_t noiseType, float *data, int32_t resolution, int32_t count,
+                                    const int32_t *positions, float hurst, float startingAmplitude, float stepdown,
+                                    float detuneRate, int32_t octaves, int32_t noiseSize, nz_handle dep,
+                                    nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_batch(resolution, count));
+    NZ_REQUIRE(positions, "positions is NULL");
+    NZ_TRY(fractal_impl(ctx, ctx->stream, noiseType, data, resolution, resolution, resolution, hurst, startingAmplitude,
+                        stepdown, detuneRate, octaves, 0, 0, noiseSize, count, (size_t)resolution * resolution, positions));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_kernel_filter_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t filter, int32_t iterations,
+                                                int32_t resolution, int32_t count, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_batch(resolution, count));
+    nz_kernel_taps t;
+    NZ_TRY(filter_taps(filter, &t));
+    NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_batch(resolution, count), t, iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_gauss_blur_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t sigma,
+                                             int32_t iterations, int32_t resolution, int32_t count, nz_handle dep,
+                                             nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_batch(resolution, count));
+    nz_kernel_taps t;
+    NZ_TRY(gauss_taps(width, sigma, &t));
+    NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_batch(resolution, count), t, iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_erosion_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t iterations, int32_t resolution,
+                                          int32_t count, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_batch(resolution, count));
+    NZ_TRY(erosion_iterations(ctx, src, tmp, nz_geom_batch(resolution, count), iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_flowmap_stage_batch(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
+                                          float normMax, int32_t resolution, int32_t count, nz_handle dep,
+                                          nz_handle *out) {
+    return flowmap_stage_impl(ctx, src, work, iterations, normMin, normMax, resolution, count, dep, out);
+}
 
 extern "C" int32_t nz_flow_fused_stripe(nz_ctx *ctx, const float *height, const float *const *state_in,
                                         float *const *state_out, float *dst, const nz_stripe *st, int32_t iterations,

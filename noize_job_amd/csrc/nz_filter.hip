@@ -67,6 +67,8 @@ __global__ __launch_bounds__(NT) void conv_reg_kernel(const float *__restrict__ 
     const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
     const int H = T * O, HX = (H + 3) & ~3;
     const int OW = TW - 2 * HX, OH = TH - 2 * H;
+    src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
+    dst += blockIdx.y * g.bstride;
     int ox0, oz0;
     tile_origin(g, OW, OH, ox0, oz0);
     const int lx0 = ox0 - HX, lz0 = oz0 - H;
@@ -210,6 +212,8 @@ __global__ __launch_bounds__(CT) void erosion_reg_kernel(const float *__restrict
     constexpr int HX = 4;
     const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
     const int OW = TW - HX, OH = TH - E;
+    src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
+    dst += blockIdx.y * g.bstride;
     int ox0, oz0;
     tile_origin(g, OW, OH, ox0, oz0);
     const int lx0 = ox0 - HX, lz0 = oz0 - E;
@@ -338,6 +342,8 @@ __global__ __launch_bounds__(CT) void conv_wide_kernel(const float *__restrict__
     __shared__ float4 s_a[NR * WD_AP / 4];
     __shared__ float4 s_b[NR * WD_W / 4];
     const int tid = threadIdx.x;
+    src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
+    dst += blockIdx.y * g.bstride;
     const int tiles_x = (g.cols + WD_W - 1) / WD_W;
     const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
     const int x0 = bx * WD_W, z0 = g.or0 + by * WD_H;
@@ -427,9 +433,9 @@ int32_t launch_wide(hipStream_t s, const float *src, float *dst, const nz_geom &
     long long blocks = (long long)((g.cols + WD_W - 1) / WD_W) * ((g.or1 - g.or0 + WD_H - 1) / WD_H);
     int aligned = (g.pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     if (k.factor == 1.0f)
-        hipLaunchKernelGGL((conv_wide_kernel<O, true>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, aligned);
+        hipLaunchKernelGGL((conv_wide_kernel<O, true>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, k, aligned);
     else
-        hipLaunchKernelGGL((conv_wide_kernel<O, false>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, k, aligned);
+        hipLaunchKernelGGL((conv_wide_kernel<O, false>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, k, aligned);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -451,9 +457,9 @@ int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom 
         long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
         int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
         if (k.factor == 1.0f)
-            hipLaunchKernelGGL((conv_reg_kernel<KS, true, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, src, dst, g, k, T, aligned);
+            hipLaunchKernelGGL((conv_reg_kernel<KS, true, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
         else
-            hipLaunchKernelGGL((conv_reg_kernel<KS, false, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, src, dst, g, k, T, aligned);
+            hipLaunchKernelGGL((conv_reg_kernel<KS, false, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
     }
     NZ_HIP(hipGetLastError());
     return NZ_OK;
@@ -537,10 +543,10 @@ int32_t nz_launch_erosion_fused(hipStream_t s, const float *src, float *dst, con
     long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
     int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
     switch (E) {
-        case 1: hipLaunchKernelGGL((erosion_reg_kernel<1>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, aligned); break;
-        case 2: hipLaunchKernelGGL((erosion_reg_kernel<2>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, aligned); break;
-        case 3: hipLaunchKernelGGL((erosion_reg_kernel<3>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, aligned); break;
-        default: hipLaunchKernelGGL((erosion_reg_kernel<4>), dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 1: hipLaunchKernelGGL((erosion_reg_kernel<1>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 2: hipLaunchKernelGGL((erosion_reg_kernel<2>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 3: hipLaunchKernelGGL((erosion_reg_kernel<3>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        default: hipLaunchKernelGGL((erosion_reg_kernel<4>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
     }
     NZ_HIP(hipGetLastError());
     return NZ_OK;

@@ -400,12 +400,20 @@ __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__r
     const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
     const int lx0 = bx * OW - HX, lz0 = g.or0 + by * OH - H;
     const bool inner = lx0 > 0 && lx0 + FT_TW < g.cols && lz0 > g.zc0 && lz0 + FT_TH - 1 < g.zc1;
+    // batched launch: one independent grid per blockIdx.y, every plane shifted by the same stride
+    const size_t off = blockIdx.y * g.bstride;
+#define NZ_SH(p) ((p) ? (p) + off : (p))
     if (inner)
-        flow_fused_body<FIRST, LAST, false>(s_tot, s_fn, s_fs, blockIdx.x, h, w_in, fN_in, fS_in, fE_in, fW_in, w_out,
-                                            fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n, nmin, nrange, aligned);
+        flow_fused_body<FIRST, LAST, false>(s_tot, s_fn, s_fs, blockIdx.x, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
+                                            NZ_SH(fE_in), NZ_SH(fW_in), NZ_SH(w_out), NZ_SH(fN_out), NZ_SH(fS_out),
+                                            NZ_SH(fE_out), NZ_SH(fW_out), NZ_SH(dst), NZ_SH(h_out), g, n, nmin, nrange,
+                                            aligned);
     else
-        flow_fused_body<FIRST, LAST, true>(s_tot, s_fn, s_fs, blockIdx.x, h, w_in, fN_in, fS_in, fE_in, fW_in, w_out,
-                                           fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n, nmin, nrange, aligned);
+        flow_fused_body<FIRST, LAST, true>(s_tot, s_fn, s_fs, blockIdx.x, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
+                                           NZ_SH(fE_in), NZ_SH(fW_in), NZ_SH(w_out), NZ_SH(fN_out), NZ_SH(fS_out),
+                                           NZ_SH(fE_out), NZ_SH(fW_out), NZ_SH(dst), NZ_SH(h_out), g, n, nmin, nrange,
+                                           aligned);
+#undef NZ_SH
 }
 
 }  // namespace
@@ -444,11 +452,11 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
 #define NZ_FF(F, L)                                                                                                  \
     do {                                                                                                             \
         if (occ >= 4)                                                                                                \
-            hipLaunchKernelGGL((flow_fused_kernel<F, L, NZ_FT_OCC>), dim3((unsigned)blocks), dim3(FT_NT), 0, s, h, w_in,     \
+            hipLaunchKernelGGL((flow_fused_kernel<F, L, NZ_FT_OCC>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, \
                                fN_in, fS_in, fE_in, fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n,   \
                                nmin, nrange, aligned);                                                                     \
         else                                                                                                         \
-            hipLaunchKernelGGL((flow_fused_kernel<F, L, 2>), dim3((unsigned)blocks), dim3(FT_NT), 0, s, h, w_in,     \
+            hipLaunchKernelGGL((flow_fused_kernel<F, L, 2>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, \
                                fN_in, fS_in, fE_in, fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n,   \
                                nmin, nrange, aligned);                                                                     \
     } while (0)

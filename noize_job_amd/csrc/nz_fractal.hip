@@ -464,6 +464,15 @@ __device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1
     return 130.0f * (m0 * q0 + m1 * q1 + m2 * q2);
 }
 
+// batched launch: grid blockIdx.y of the batch has its own world position and output plane
+__device__ __forceinline__ void fractal_batch_enter(nz_fractal_params &p, float *__restrict__ &dst) {
+    if (p.positions) {
+        p.posx = (float)p.positions[2 * blockIdx.y];
+        p.posz = (float)p.positions[2 * blockIdx.y + 1];
+    }
+    dst += blockIdx.y * p.bstride;
+}
+
 #ifndef NZ_FT_ROWS
 #define NZ_FT_ROWS 8
 #endif
@@ -479,6 +488,7 @@ __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restr
     for (int i = threadIdx.x; i < NZ_T1_N; i += 256) s_t1[i] = t1g[i];
     for (int i = threadIdx.x; i < NZ_T2_N; i += 256) s_t2[i] = t2g[i];
     __syncthreads();
+    fractal_batch_enter(p, dst);
     int by = blockIdx.x / blocks_per_row;
     int bx = blockIdx.x - by * blocks_per_row;
     int x0 = (bx * 256 + threadIdx.x) * VEC;
@@ -630,6 +640,7 @@ __global__ __launch_bounds__(256) void fractal_tab2_kernel(float *__restrict__ d
     for (int i = threadIdx.x; i < NZ_TB1_N; i += 256) s_t1[i] = t1g[i];
     for (int i = threadIdx.x; i < NZ_TB2_N; i += 256) s_t2[i] = t2g[i];
     __syncthreads();
+    fractal_batch_enter(p, dst);
     int by = blockIdx.x / blocks_per_row;
     int bx = blockIdx.x - by * blocks_per_row;
     int x0 = (bx * 256 + threadIdx.x) * VEC;
@@ -786,6 +797,7 @@ __global__ __launch_bounds__(256) void fractal_tab3_kernel(float *__restrict__ d
     for (int i = threadIdx.x; i < NZ_P3_N; i += 256) s_p[i] = p3g[i];
     for (int i = threadIdx.x; i < NZ_G3_N; i += 256) s_g[i] = g3g[i];
     __syncthreads();
+    fractal_batch_enter(p, dst);
     int by = blockIdx.x / blocks_per_row;
     int bx = blockIdx.x - by * blocks_per_row;
     int x0 = bx * 256 + threadIdx.x;
@@ -839,6 +851,7 @@ __global__ __launch_bounds__(FR_THREADS) void fractal_kernel(float *__restrict__
         __syncthreads();
     }
     const psr_tables tabs{s_t1, s_tab};
+    fractal_batch_enter(p, dst);
     int by = blockIdx.x / blocks_per_row;
     int bx = blockIdx.x - by * blocks_per_row;
     int x0 = (bx * FR_THREADS + threadIdx.x) * VEC;
@@ -888,7 +901,7 @@ __global__ __launch_bounds__(FR_THREADS) void fractal_kernel(float *__restrict__
 
 template <int BASIS, int VEC>
 int32_t launch_basis(hipStream_t s, float *dst, int rows, int cols, int pitch, const nz_fractal_params &p,
-                     const float *d_rgrad) {
+                     const float *d_rgrad, int count) {
     int per_block = FR_THREADS * VEC;
     int bpr = (cols + per_block - 1) / per_block;
     long long blocks = (long long)bpr * ((rows + FR_ROWS - 1) / FR_ROWS);
@@ -896,7 +909,7 @@ int32_t launch_basis(hipStream_t s, float *dst, int rows, int cols, int pitch, c
         nz_set_error("fractal grid too large");
         return NZ_ERR_INVALID;
     }
-    hipLaunchKernelGGL((fractal_kernel<BASIS, VEC>), dim3((unsigned)blocks), dim3(FR_THREADS), 0, s, dst, rows,
+    hipLaunchKernelGGL((fractal_kernel<BASIS, VEC>), dim3((unsigned)blocks, count), dim3(FR_THREADS), 0, s, dst, rows,
                        cols, pitch, bpr, p, reinterpret_cast<const float2 *>(d_rgrad));
     NZ_HIP(hipGetLastError());
     return NZ_OK;
@@ -905,7 +918,12 @@ int32_t launch_basis(hipStream_t s, float *dst, int rows, int cols, int pitch, c
 }  // namespace
 
 int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, int cols, int pitch,
-                          const nz_fractal_params &p, const float *d_rgrad, const void *d_simplex) {
+                          const nz_fractal_params &p_in, const float *d_rgrad, const void *d_simplex, int count,
+                          size_t bstride, const int32_t *positions) {
+    if (count < 1) return NZ_OK;
+    nz_fractal_params p = p_in;
+    p.positions = positions;
+    p.bstride = count > 1 || positions ? bstride : 0;
     static const int use_tab = getenv("NZ_NOISE_TAB") ? atoi(getenv("NZ_NOISE_TAB")) : 1;
     if (noiseType == NZ_NOISE_SIMPLEX && use_tab && d_simplex) {
 #ifndef NZ_FT_VEC
@@ -916,7 +934,7 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         long long blocks = (long long)bpr * ((rows + FT_ROWS - 1) / FT_ROWS);
         const int *t1 = reinterpret_cast<const int *>(d_simplex);
         const float4 *t2 = reinterpret_cast<const float4 *>(t1 + NZ_T1_N);
-        hipLaunchKernelGGL((fractal_simplex_tab_kernel<VEC>), dim3((unsigned)blocks), dim3(256), 0, s, dst, rows, cols,
+        hipLaunchKernelGGL((fractal_simplex_tab_kernel<VEC>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows, cols,
                            pitch, bpr, p, t1, t2);
         NZ_HIP(hipGetLastError());
         return NZ_OK;
@@ -930,10 +948,10 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         int bpr = (cols + 255) / 256;
         long long blocks = (long long)bpr * ((rows + 7) / 8);
         if (noiseType == NZ_NOISE_PERLIN)
-            hipLaunchKernelGGL((fractal_tab2_kernel<NZ_NOISE_PERLIN, 1>), dim3((unsigned)blocks), dim3(256), 0, s, dst, rows,
+            hipLaunchKernelGGL((fractal_tab2_kernel<NZ_NOISE_PERLIN, 1>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows,
                                cols, pitch, bpr, p, t1, t2);
         else
-            hipLaunchKernelGGL((fractal_tab2_kernel<NZ_NOISE_CELLULAR, 1>), dim3((unsigned)blocks), dim3(256), 0, s, dst,
+            hipLaunchKernelGGL((fractal_tab2_kernel<NZ_NOISE_CELLULAR, 1>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst,
                                rows, cols, pitch, bpr, p, t1, t2);
         NZ_HIP(hipGetLastError());
         return NZ_OK;
@@ -947,30 +965,30 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         int bpr = (cols + 255) / 256;
         long long blocks = (long long)bpr * ((rows + 7) / 8);
         if (noiseType == NZ_NOISE_DOMAIN_ROTATED_PERLIN)
-            hipLaunchKernelGGL((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_PERLIN>), dim3((unsigned)blocks), dim3(256), 0,
+            hipLaunchKernelGGL((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_PERLIN>), dim3((unsigned)blocks, count), dim3(256), 0,
                                s, dst, rows, cols, pitch, bpr, p, p3, g3);
         else
-            hipLaunchKernelGGL((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_SIMPLEX>), dim3((unsigned)blocks), dim3(256), 0,
+            hipLaunchKernelGGL((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_SIMPLEX>), dim3((unsigned)blocks, count), dim3(256), 0,
                                s, dst, rows, cols, pitch, bpr, p, p3, g3 + NZ_G3_N);
         NZ_HIP(hipGetLastError());
         return NZ_OK;
     }
     switch (noiseType) {
-        case NZ_NOISE_SIN: return launch_basis<NZ_NOISE_SIN, 4>(s, dst, rows, cols, pitch, p, d_rgrad);
-        case NZ_NOISE_PERLIN: return launch_basis<NZ_NOISE_PERLIN, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
+        case NZ_NOISE_SIN: return launch_basis<NZ_NOISE_SIN, 4>(s, dst, rows, cols, pitch, p, d_rgrad, count);
+        case NZ_NOISE_PERLIN: return launch_basis<NZ_NOISE_PERLIN, 2>(s, dst, rows, cols, pitch, p, d_rgrad, count);
         case NZ_NOISE_PERIODIC_PERLIN:
-            return launch_basis<NZ_NOISE_PERIODIC_PERLIN, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
+            return launch_basis<NZ_NOISE_PERIODIC_PERLIN, 2>(s, dst, rows, cols, pitch, p, d_rgrad, count);
 #ifndef NZ_FR_VEC
 #define NZ_FR_VEC 2
 #endif
-        case NZ_NOISE_SIMPLEX: return launch_basis<NZ_NOISE_SIMPLEX, NZ_FR_VEC>(s, dst, rows, cols, pitch, p, d_rgrad);
+        case NZ_NOISE_SIMPLEX: return launch_basis<NZ_NOISE_SIMPLEX, NZ_FR_VEC>(s, dst, rows, cols, pitch, p, d_rgrad, count);
         case NZ_NOISE_ROTATED_SIMPLEX:
-            return launch_basis<NZ_NOISE_ROTATED_SIMPLEX, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
-        case NZ_NOISE_CELLULAR: return launch_basis<NZ_NOISE_CELLULAR, 2>(s, dst, rows, cols, pitch, p, d_rgrad);
+            return launch_basis<NZ_NOISE_ROTATED_SIMPLEX, 2>(s, dst, rows, cols, pitch, p, d_rgrad, count);
+        case NZ_NOISE_CELLULAR: return launch_basis<NZ_NOISE_CELLULAR, 2>(s, dst, rows, cols, pitch, p, d_rgrad, count);
         case NZ_NOISE_DOMAIN_ROTATED_PERLIN:
-            return launch_basis<NZ_NOISE_DOMAIN_ROTATED_PERLIN, 1>(s, dst, rows, cols, pitch, p, d_rgrad);
+            return launch_basis<NZ_NOISE_DOMAIN_ROTATED_PERLIN, 1>(s, dst, rows, cols, pitch, p, d_rgrad, count);
         case NZ_NOISE_DOMAIN_ROTATED_SIMPLEX:
-            return launch_basis<NZ_NOISE_DOMAIN_ROTATED_SIMPLEX, 1>(s, dst, rows, cols, pitch, p, d_rgrad);
+            return launch_basis<NZ_NOISE_DOMAIN_ROTATED_SIMPLEX, 1>(s, dst, rows, cols, pitch, p, d_rgrad, count);
     }
     nz_set_error("unknown noise type %d", noiseType);
     return NZ_ERR_INVALID;

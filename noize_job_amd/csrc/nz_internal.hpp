@@ -90,6 +90,9 @@ struct nz_fractal_params {
     float norm;           // CalcFractalNormValue
     float fmax;           // max over the octaves of |frequency| (same fp32 recurrence as the kernels; NaN if it overflows)
     int octaves;
+    // batched launch (one grid per blockIdx.y): grids `bstride` floats apart, {xpos, zpos} of grid b at positions[2b]
+    const int32_t *positions = nullptr;
+    size_t bstride = 0;
 };
 
 // plane geometry handed to every stencil kernel: clamp rows are the global border seen from the
@@ -100,7 +103,22 @@ struct nz_geom {
     int rows;      // rows in the buffer
     int zc0, zc1;  // inclusive clamp range for row reads (buffer coordinates)
     int or0, or1;  // rows to produce [or0, or1)
+    // batched launches: `count` independent grids of this geometry, `bstride` floats apart in every plane;
+    // the kernels take the grid index from blockIdx.y
+    int count = 1;
+    size_t bstride = 0;
 };
+
+inline nz_geom nz_geom_batch(int res, int count) {
+    nz_geom g{res, res, res, 0, res - 1, 0, res};
+    g.count = count;
+    g.bstride = (size_t)res * res;
+    return g;
+}
+// floats covered by rows [or0, or1) of every grid of the batch when the grids are stored back to back
+inline size_t nz_geom_span(const nz_geom &g) {
+    return g.count > 1 ? (size_t)g.count * g.bstride : (size_t)(g.or1 - g.or0) * g.pitch;
+}
 
 inline nz_geom nz_geom_from_stripe(const nz_stripe &s) {
     nz_geom g;
@@ -120,8 +138,10 @@ inline nz_geom nz_geom_tile(int res) { return nz_geom{res, res, res, 0, res - 1,
 int32_t nz_check_stripe(const nz_stripe *st, int halo, int halo_below = -1);  // rows needed above / below the owned ones
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------------
+// `positions` (nullable, device): {xpos, zpos} per grid of a batched launch of `count` grids `bstride` floats apart
 int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, int cols, int pitch,
-                          const nz_fractal_params &p, const float *d_rgrad, const void *d_simplex);
+                          const nz_fractal_params &p, const float *d_rgrad, const void *d_simplex, int count = 1,
+                          size_t bstride = 0, const int32_t *positions = nullptr);
 
 int nz_conv_max_fused(int ksize);
 // T fused applications of (X pass, Z pass) src -> dst on rows [or0, or1)

@@ -114,6 +114,28 @@ class GeneratorData(StageIO):  # StageIOTypes/GeneratorData.cs:9-15
         self.zpos = zpos
 
 
+class GeneratorDataBatch(GeneratorData):
+    """New-framework payload: `count` independent tiles of `resolution`^2 cells stored back to back in `data`
+    (tile k at offset k * resolution^2), world positions in `positions` (device int32 array {xpos, zpos} per
+    tile).  The noise / filter / blur / erosion / flow-map stages run such a batch through one launch
+    sequence (nz_*_batch); every tile comes out exactly as it would alone."""
+
+    def __init__(self, uuid="", data=None, resolution=512, positions=None, count=1):
+        super().__init__(uuid, data, resolution, 0, 0)
+        self.positions = positions
+        self.count = count
+
+    @classmethod
+    def create(cls, ctx, uuid, resolution, positions):
+        """positions: sequence of (xpos, zpos); allocates the stacked planes and uploads the positions."""
+        pos = np.ascontiguousarray(positions, np.int32).reshape(-1, 2)
+        return cls(uuid, ctx.alloc(len(pos) * resolution * resolution), resolution, ctx.from_host(pos), len(pos))
+
+    def tile(self, k):
+        n = self.resolution * self.resolution
+        return self.data.offset(k * n, n)
+
+
 class MeshStageData(StageIO):  # StageIOTypes/MeshStageData.cs:9-21
     def __init__(self, uuid="", data=None, resolution=512, inputResolution=512, marginPix=5, tileSize=512.0,
                  tileHeight=512.0, xpos=0, zpos=0, mesh=None):
@@ -243,6 +265,11 @@ class NoiseStage(PipelineStage):  # Noise/NoiseStage.cs:13-61
     def Schedule(self, requirements, dependency):
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
+        if isinstance(d, GeneratorDataBatch):
+            self.jobHandle = self.ctx.call("nz_fractal_batch", int(self.noiseType), d.data.ptr, d.resolution, d.count,
+                                           d.positions.ptr, self.hurst, self.startingAmplitude, self.stepdown,
+                                           self.detuneRate, self.octaves, self.noiseSize, dep=dependency)
+            return
         # jobs[(int)noiseType](d.data, d.resolution, hurst, startingAmplitude, stepdown, detuneRate, octaves, ...)
         self.jobHandle = self.ctx.call("nz_fractal", int(self.noiseType), d.data.ptr, d.resolution, self.hurst,
                                        self.startingAmplitude, self.stepdown, self.detuneRate, self.octaves, d.xpos,
@@ -262,6 +289,10 @@ class KernelFilterStage(PipelineStage):  # Filter/KernelFilterStage.cs:13-51
     def Schedule(self, requirements, dependency):
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
+        if isinstance(d, GeneratorDataBatch):
+            self.jobHandle = self.ctx.call("nz_kernel_filter_stage_batch", d.data.ptr, self.tmp.ptr, int(self.filter),
+                                           self.iterations, d.resolution, d.count, dep=dependency)
+            return
         # the reference chains `iterations` SeparableKernelFilter.Schedule calls (:35-41); the
         # library fuses the chain into as few launches as halo growth allows
         self.jobHandle = self.ctx.call("nz_kernel_filter_stage", d.data.ptr, self.tmp.ptr, int(self.filter),
@@ -287,6 +318,10 @@ class StageGaussianBlur(PipelineStage):  # Filter/Kernel/Blur/StageGaussianBlur.
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
         width_ = BlurHelper.limitWidth(self.width)
+        if isinstance(d, GeneratorDataBatch):
+            self.jobHandle = self.ctx.call("nz_gauss_blur_stage_batch", d.data.ptr, self.tmp.ptr, width_, int(self.sigma),
+                                           self.iterations, d.resolution, d.count, dep=dependency)
+            return
         self.jobHandle = self.ctx.call("nz_gauss_blur_stage", d.data.ptr, self.tmp.ptr, width_, int(self.sigma),
                                        self.iterations, d.resolution, dep=dependency)
 
@@ -332,6 +367,10 @@ class ErosionStage(PipelineStage):
     def Schedule(self, requirements, dependency):
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
+        if isinstance(d, GeneratorDataBatch):
+            self.jobHandle = self.ctx.call("nz_erosion_stage_batch", d.data.ptr, self.tmp.ptr, self.iterations,
+                                           d.resolution, d.count, dep=dependency)
+            return
         self.jobHandle = self.ctx.call("nz_erosion_stage", d.data.ptr, self.tmp.ptr, self.iterations, d.resolution,
                                        dep=dependency)
 
@@ -466,7 +505,8 @@ class FlowMapStage(PipelineStage):  # Geologic/Stage/FlowMapStage.cs:16-220
 
     def ResizeNativeContainers(self, size):
         self.DisposeArrays()
-        self.work = self.ctx.alloc(N.lib.nz_flowmap_stage_work_floats(self.resolution))
+        # 11 planes per tile (nz_flowmap_stage_work_floats); a batch stacks its tiles inside every plane
+        self.work = self.ctx.alloc(11 * self.dataLength)
 
     def Schedule(self, requirements, dependency):
         d = requirements.data
@@ -475,6 +515,10 @@ class FlowMapStage(PipelineStage):  # Geologic/Stage/FlowMapStage.cs:16-220
         if self.resolution != d.resolution:
             self.resolution = d.resolution
         self.CheckRequirements(GeneratorData, requirements)
+        if isinstance(d, GeneratorDataBatch):
+            self.jobHandle = self.ctx.call("nz_flowmap_stage_batch", d.data.ptr, self.work.ptr, self.iterations,
+                                           self.normMin, self.normMax, d.resolution, d.count, dep=dependency)
+            return
         self.jobHandle = self.ctx.call("nz_flowmap_stage", d.data.ptr, self.work.ptr, self.iterations, self.normMin,
                                        self.normMax, d.resolution, dep=dependency)
 

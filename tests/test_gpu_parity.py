@@ -451,6 +451,51 @@ def test_crop_stage(nj, ctx, oracle):
         nj.CropStage(ctx).Schedule(nj.PipelineWorkItem(gen(nj, ctx, 8)), nj.JobHandle())
 
 
+@pytest.mark.parametrize("res,count", [(100, 5), (128, 9), (37, 3), (256, 2)])
+def test_batched_tiles_equal_single_tiles(nj, ctx, oracle, res, count):
+    # `count` independent tiles through ONE launch sequence (nz_*_batch): each tile must come out exactly as it
+    # does alone -- clamped at its own border, its own world position
+    rng = np.random.default_rng(res)
+    positions = [(int(rng.integers(-5000, 5000)), int(rng.integers(-5000, 5000))) for _ in range(count)]
+    batch = nj.GeneratorDataBatch.create(ctx, "b", res, positions)
+    stages = [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 9, 2.0, 0.0, 300),
+              nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 7), nj.FlowMapStage(ctx, 5, 0.0, 0.005),
+              nj.ErosionStage(ctx, 5)]
+    pipe = nj.BasePipeline(stages, "batched")
+    done = []
+    pipe.Enqueue(batch, completeAction=lambda d: done.append(d.count))
+    pipe.RunToCompletion()
+    assert done == [count]
+    for k, (xp, zp) in enumerate(positions):
+        want = oracle.pipeline(res, res, octaves=9, noise_size=300, gauss_iterations=7, xpos=xp, zpos=zp)
+        assert np.array_equal(batch.tile(k).ToArray((res, res)), want), (k, xp, zp)
+    pipe.Destroy()
+    # other stage bodies: every basis, a wide blur, the even-width quirk (grid-by-grid fallback), one application
+    t = rng.random((count, res, res), dtype=f32)
+    for basis in (1, 2, 5, 6):
+        _ = run_batch(nj, nj.NoiseStage(ctx, nj.FractalNoise(basis), 0.5, 1.0, 4, 2.0, 0.0, 50), batch)
+        for k, (xp, zp) in enumerate(positions):
+            assert np.array_equal(batch.tile(k).ToArray((res, res)),
+                                  oracle.fractal(basis, res, res, 0.5, 1.0, 2.0, 0.0, 4, xp, zp, 50)), (basis, k)
+    for stage, fn in ((nj.StageGaussianBlur(ctx, 2, nj.GaussSigma(5), 13), lambda a: oracle.gauss(a, 13, 5, 2)),
+                      (nj.StageGaussianBlur(ctx, 1, nj.GaussSigma(3), 5), lambda a: oracle.gauss(a, 5, 3, 1)),
+                      (nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss9_S2, 4), lambda a: oracle.kernel_filter(a, 4, 4)),
+                      (nj.ErosionStage(ctx, 1), lambda a: oracle.erosion_min(a, 1)),
+                      (nj.FlowMapStage(ctx, 7, -0.1, 0.1), lambda a: oracle.flowmap(a, 7, -0.1, 0.1))):
+        batch.data.CopyFrom(t)
+        run_batch(nj, stage, batch)
+        for k in range(count):
+            assert np.array_equal(batch.tile(k).ToArray((res, res)), fn(t[k])), (type(stage).__name__, k)
+        stage.OnDestroy()
+    batch.data.Dispose()
+    batch.positions.Dispose()
+
+
+def run_batch(nj, stage, batch):
+    stage.ReceiveHandledInput(nj.PipelineWorkItem(batch), nj.JobHandle())
+    stage.jobHandle.Complete()
+
+
 def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):
     # BasicDemo "ParallelFlowMap": Perlin fBm -> Invert (curve) -> FlowMapStage -> CurveBoostContrast
     res = 128
