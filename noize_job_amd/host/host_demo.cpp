@@ -2,6 +2,7 @@
 // Writes the resulting plane as raw little-endian fp32 so the test suite can compare it with the oracle.
 //   usage: host_demo <resolution> <out.f32> [gauss_iterations flow_iterations erosion_iterations]
 //          host_demo <resolution> <out.f32> reduce      (ReducePipeline: simplex x cellular, MULTIPLY)
+//          host_demo <resolution> <out.f32> batch <n>   (n tiles at xpos = k * resolution through the batched stage bodies)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,11 +19,48 @@ int main(int argc, char **argv) {
     }
     int res = std::atoi(argv[1]);
     const bool reduce = argc > 3 && std::strcmp(argv[3], "reduce") == 0;
+    const int batch = argc > 4 && std::strcmp(argv[3], "batch") == 0 ? std::atoi(argv[4]) : 0;
     int G = argc > 3 ? std::atoi(argv[3]) : 17, F = argc > 4 ? std::atoi(argv[4]) : 5, E = argc > 5 ? std::atoi(argv[5]) : 5;
     try {
         nz_ctx *ctx = nullptr;
         check(nz_ctx_create(0, &ctx), "nz_ctx_create");
-        if (reduce) {
+        if (batch > 0) {
+            const size_t n = (size_t)res * res;
+            DeviceTile tiles(ctx, n * batch);
+            std::vector<int32_t> pos(2 * batch);
+            for (int k = 0; k < batch; k++) pos[2 * k] = k * res, pos[2 * k + 1] = -3 * k;
+            DeviceTile dpos(ctx, (2 * batch * sizeof(int32_t) + 3) / 4);
+            dpos.CopyFrom(reinterpret_cast<const float *>(pos.data()));
+            NoiseStage noise(ctx);
+            noise.noiseType = FractalNoise::Simplex;
+            noise.hurst = 0.4f;
+            noise.octaves = 13;
+            noise.noiseSize = 1700;
+            KernelFilterStage gauss(ctx);
+            gauss.filter = NZ_GAUSS5_S1;
+            gauss.iterations = 17;
+            FlowMapStage flow(ctx);
+            flow.normMin = 0.0f;
+            flow.normMax = 0.005f;
+            ErosionStage erosion(ctx);
+            erosion.iterations = 5;
+            BasePipeline pipe({&noise, &gauss, &flow, &erosion});
+            GeneratorDataBatch gd;
+            gd.uuid = "host-demo-batch";
+            gd.data = &tiles;
+            gd.resolution = res;
+            gd.count = batch;
+            gd.positions = reinterpret_cast<const int32_t *>(dpos.ptr);
+            pipe.Enqueue(&gd);
+            pipe.RunToCompletion();
+            std::vector<float> host(n * batch);
+            tiles.CopyTo(host.data());
+            FILE *f = std::fopen(argv[2], "wb");
+            if (!f) throw std::runtime_error("cannot open output");
+            std::fwrite(host.data(), sizeof(float), host.size(), f);
+            std::fclose(f);
+            pipe.Destroy();
+        } else if (reduce) {
             DeviceTile tile(ctx, (size_t)res * res);
             NoiseStage nl(ctx), nr(ctx);
             nl.noiseType = FractalNoise::Simplex;

@@ -85,6 +85,13 @@ struct GeneratorData : StageIO {
     int resolution = 512, xpos = 0, zpos = 0;
 };
 
+// New-framework payload: `count` independent tiles of resolution^2 cells stored back to back in `data`,
+// world positions {xpos, zpos} per tile in the device int32 array `positions` (see nz_*_batch).
+struct GeneratorDataBatch : GeneratorData {
+    int count = 1;
+    const int32_t *positions = nullptr;
+};
+
 struct MeshBuffers {  // stands in for UnityEngine.Mesh + Mesh.MeshData (PositionStream32 layout)
     std::unique_ptr<DeviceTile> vertices, indices;
     size_t vertexCount = 0, indexCount = 0;
@@ -152,6 +159,13 @@ class NoiseStage : public PipelineStage {
     void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
         auto *d = CheckRequirements<GeneratorData>(requirements);
         nz_handle h = 0;
+        if (auto *b = dynamic_cast<GeneratorDataBatch *>(d)) {
+            check(nz_fractal_batch(ctx, (int)noiseType, b->data->ptr, b->resolution, b->count, b->positions, hurst,
+                                   startingAmplitude, stepdown, detuneRate, octaves, noiseSize, dependency.id, &h),
+                  "nz_fractal_batch");
+            jobHandle = done(h);
+            return;
+        }
         check(nz_fractal(ctx, (int)noiseType, d->data->ptr, d->resolution, hurst, startingAmplitude, stepdown,
                          detuneRate, octaves, d->xpos, d->zpos, noiseSize, dependency.id, &h), "nz_fractal");
         jobHandle = done(h);
@@ -176,6 +190,12 @@ class KernelFilterStage : public TmpStage {
     void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
         auto *d = CheckRequirements<GeneratorData>(requirements);
         nz_handle h = 0;
+        if (auto *b = dynamic_cast<GeneratorDataBatch *>(d)) {
+            check(nz_kernel_filter_stage_batch(ctx, b->data->ptr, tmp->ptr, filter, iterations, b->resolution, b->count,
+                                               dependency.id, &h), "nz_kernel_filter_stage_batch");
+            jobHandle = done(h);
+            return;
+        }
         check(nz_kernel_filter_stage(ctx, d->data->ptr, tmp->ptr, filter, iterations, d->resolution, dependency.id, &h),
               "nz_kernel_filter_stage");
         jobHandle = done(h);
@@ -221,6 +241,12 @@ class ErosionStage : public TmpStage {  // ErosionKernelJob x iterations (no sta
     void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
         auto *d = CheckRequirements<GeneratorData>(requirements);
         nz_handle h = 0;
+        if (auto *b = dynamic_cast<GeneratorDataBatch *>(d)) {
+            check(nz_erosion_stage_batch(ctx, b->data->ptr, tmp->ptr, iterations, b->resolution, b->count, dependency.id,
+                                         &h), "nz_erosion_stage_batch");
+            jobHandle = done(h);
+            return;
+        }
         check(nz_erosion_stage(ctx, d->data->ptr, tmp->ptr, iterations, d->resolution, dependency.id, &h),
               "nz_erosion_stage");
         jobHandle = done(h);
@@ -321,7 +347,7 @@ class FlowMapStage : public PipelineStage {
     int iterations = 5;
     float normMin = -.1f, normMax = .1f;
     void ResizeNativeContainers(size_t) override {
-        work.reset(new DeviceTile(ctx, nz_flowmap_stage_work_floats(resolution)));
+        work.reset(new DeviceTile(ctx, 11 * dataLength));  // nz_flowmap_stage_work_floats per tile of the payload
     }
     void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
         auto *g = dynamic_cast<GeneratorData *>(requirements.data);
@@ -329,6 +355,12 @@ class FlowMapStage : public PipelineStage {
         resolution = g->resolution;
         auto *d = CheckRequirements<GeneratorData>(requirements);
         nz_handle h = 0;
+        if (auto *b = dynamic_cast<GeneratorDataBatch *>(d)) {
+            check(nz_flowmap_stage_batch(ctx, b->data->ptr, work->ptr, iterations, normMin, normMax, b->resolution,
+                                         b->count, dependency.id, &h), "nz_flowmap_stage_batch");
+            jobHandle = done(h);
+            return;
+        }
         check(nz_flowmap_stage(ctx, d->data->ptr, work->ptr, iterations, normMin, normMax, d->resolution,
                                dependency.id, &h), "nz_flowmap_stage");
         jobHandle = done(h);
