@@ -219,6 +219,11 @@ int32_t nz_erosion_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t iter
                                int32_t count, nz_handle dep, nz_handle *out);
 int32_t nz_flowmap_stage_batch(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
                                float normMax, int32_t resolution, int32_t count, nz_handle dep, nz_handle *out);
+/* `count` meshes from height planes stored back to back (inputResolution^2 floats each); mesh k is written at
+ * vertices + k * nz_mesh_vertex_count(resolution) * 48 bytes and indices + k * nz_mesh_index_count(resolution) */
+int32_t nz_heightmap_mesh_batch(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_t *indices,
+                                int32_t resolution, int32_t inputResolution, int32_t marginPix, float tileHeight,
+                                float tileSize, const float *heights, int32_t count, nz_handle dep, nz_handle *out);
 
 /* ---- mesh: HeightMapMeshJobScheduleDelegate, Mesh/Job/HeightMapMeshJob.cs:55-65 -------------- */
 /* (Mesh, MeshData) -> device vertex stream of (resolution+1)^2 records

@@ -1152,10 +1152,9 @@ extern "C" size_t nz_mesh_index_count(int32_t resolution) {  // IndexCount, Over
     return resolution > 0 ? (size_t)6 * resolution * resolution : 0;
 }
 
-extern "C" int32_t nz_heightmap_mesh(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_t *indices,
-                                     int32_t resolution, int32_t inputResolution, int32_t marginPix,
-                                     float tileHeight, float tileSize, const float *heights, nz_handle dep,
-                                     nz_handle *out) {
+static int32_t heightmap_mesh_impl(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_t *indices,
+                                   int32_t resolution, int32_t inputResolution, int32_t marginPix, float tileHeight,
+                                   float tileSize, const float *heights, int32_t count, nz_handle dep, nz_handle *out) {
     NZ_BEGIN(ctx, dep);
     (void)marginPix;  // MarginScale is commented out of the vertex path (Overshoot :64)
     NZ_REQUIRE(vertices && indices && heights, "buffer is NULL");
@@ -1175,8 +1174,27 @@ extern "C" int32_t nz_heightmap_mesh(nz_ctx *ctx, int32_t meshType, void *vertic
         return NZ_ERR_INVALID;
     }
     NZ_TRY(nz_launch_mesh(ctx->stream, meshType, vertices, indices, resolution, inputResolution, tileHeight, tileSize,
-                          heights));
+                          heights, count));
     return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_heightmap_mesh(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_t *indices,
+                                     int32_t resolution, int32_t inputResolution, int32_t marginPix,
+                                     float tileHeight, float tileSize, const float *heights, nz_handle dep,
+                                     nz_handle *out) {
+    return heightmap_mesh_impl(ctx, meshType, vertices, indices, resolution, inputResolution, marginPix, tileHeight,
+                               tileSize, heights, 1, dep, out);
+}
+
+// `count` meshes from `count` height planes stored back to back; mesh k at vertices + k * vertex_count * 48 bytes
+// and indices + k * index_count
+extern "C" int32_t nz_heightmap_mesh_batch(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_t *indices,
+                                           int32_t resolution, int32_t inputResolution, int32_t marginPix,
+                                           float tileHeight, float tileSize, const float *heights, int32_t count,
+                                           nz_handle dep, nz_handle *out) {
+    NZ_REQUIRE(count >= 1 && count <= 65535, "count %d out of range [1,65535]", count);
+    return heightmap_mesh_impl(ctx, meshType, vertices, indices, resolution, inputResolution, marginPix, tileHeight,
+                               tileSize, heights, count, dep, out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -20,6 +20,9 @@ constexpr int CT = 256;
 struct mesh_params {
     int res, in_res, off, type;
     float height, tile_size, normal_strength;
+    // batched launch: mesh blockIdx.y reads the height plane hstride floats on and writes vstride float4s /
+    // istride indices on
+    size_t hstride, vstride, istride;
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -49,6 +52,8 @@ __device__ __forceinline__ float interpolate_edge(float a, float b) { return a -
 __global__ __launch_bounds__(CT) void mesh_vertex_kernel(float4 *__restrict__ vtx, const float *__restrict__ heights,
                                                         mesh_params g) {
     __shared__ float4 s_rec[CT * 3];
+    heights += blockIdx.y * g.hstride;
+    vtx += blockIdx.y * g.vstride;
     const int R = g.res;
     const size_t base = (size_t)blockIdx.x * CT;
     size_t vi = base + threadIdx.x;
@@ -119,7 +124,8 @@ __device__ __forceinline__ uint32_t mesh_index(uint32_t i, uint32_t R) {
     return corner == 0 ? a : (corner == 1 ? b : c);
 }
 
-__global__ __launch_bounds__(CT) void mesh_index_kernel(uint32_t *__restrict__ idx, uint32_t R, size_t n) {
+__global__ __launch_bounds__(CT) void mesh_index_kernel(uint32_t *__restrict__ idx, uint32_t R, size_t n, size_t istride) {
+    idx += blockIdx.y * istride;
     size_t i = ((size_t)blockIdx.x * CT + threadIdx.x) * 4;
     if (i >= n) return;
     if (i + 4 <= n && ((reinterpret_cast<uintptr_t>(idx) & 15) == 0)) {
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(CT) void mesh_index_kernel(uint32_t *__restrict__ i
 }  // namespace
 
 int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *indices, int res, int in_res,
-                       float tile_height, float tile_size, const float *heights) {
+                       float tile_height, float tile_size, const float *heights, int count) {
     mesh_params g;
     g.res = res;
     g.in_res = in_res;
@@ -148,6 +154,9 @@ int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *in
     g.normal_strength = 8.0f;  // HeightMapMeshJob.cs:41
     size_t nv = (size_t)(res + 1) * (res + 1);
     size_t ni = (size_t)6 * res * res;
+    g.hstride = (size_t)in_res * in_res;
+    g.vstride = nv * 3;
+    g.istride = ni;
     if (ni > 0xffffffffULL) {
         nz_set_error("mesh index count overflows uint32");
         return NZ_ERR_INVALID;
@@ -156,12 +165,16 @@ int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *in
         nz_set_error("vertex buffer must be 16-byte aligned");
         return NZ_ERR_INVALID;
     }
-    hipLaunchKernelGGL(mesh_vertex_kernel, dim3((unsigned)((nv + CT - 1) / CT)), dim3(CT), 0, s,
+    if ((count > 1 && (nv * 48) % 16 != 0) || count < 1 || count > 65535) {
+        nz_set_error("mesh batch: count %d unsupported", count);
+        return NZ_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(mesh_vertex_kernel, dim3((unsigned)((nv + CT - 1) / CT), count), dim3(CT), 0, s,
                        reinterpret_cast<float4 *>(vertices), heights, g);
     NZ_HIP(hipGetLastError());
     size_t nthreads = (ni + 3) / 4;
-    hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT)), dim3(CT), 0, s, indices,
-                       (uint32_t)res, ni);
+    hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT), count), dim3(CT), 0, s, indices,
+                       (uint32_t)res, ni, ni);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

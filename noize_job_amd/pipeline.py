@@ -138,8 +138,9 @@ class GeneratorDataBatch(GeneratorData):
 
 class MeshStageData(StageIO):  # StageIOTypes/MeshStageData.cs:9-21
     def __init__(self, uuid="", data=None, resolution=512, inputResolution=512, marginPix=5, tileSize=512.0,
-                 tileHeight=512.0, xpos=0, zpos=0, mesh=None):
+                 tileHeight=512.0, xpos=0, zpos=0, mesh=None, count=1):
         super().__init__(uuid, data)
+        self.count = count  # new-framework: `count` height planes stored back to back -> `count` meshes
         self.resolution = resolution
         self.inputResolution = inputResolution
         self.marginPix = marginPix
@@ -539,11 +540,17 @@ class MeshTileStage(PipelineStage):  # Mesh/Stage/MeshTileStage.cs:28-61
         self.currentMesh = d.mesh if d.mesh is not None else MeshBuffers()
         d.mesh = self.currentMesh
         m = self.currentMesh
-        nv, ni = N.lib.nz_mesh_vertex_count(d.resolution), N.lib.nz_mesh_index_count(d.resolution)
+        count = getattr(d, "count", 1)
+        nv, ni = N.lib.nz_mesh_vertex_count(d.resolution) * count, N.lib.nz_mesh_index_count(d.resolution) * count
         if m.vertexCount != nv or m.vertices is None:  # Mesh.AllocateWritableMeshData(1)
             m.vertices = self.ctx.alloc(nv * 12)
             m.indices = self.ctx.alloc(ni, dtype=np.uint32)
             m.vertexCount, m.indexCount = nv, ni
+        if count > 1:
+            self.jobHandle = self.ctx.call("nz_heightmap_mesh_batch", int(self.meshType), m.vertices.ptr, m.indices.ptr,
+                                           d.resolution, d.inputResolution, d.marginPix, d.tileHeight, d.tileSize,
+                                           d.data.ptr, count, dep=dependency)
+            return
         self.jobHandle = self.ctx.call("nz_heightmap_mesh", int(self.meshType), m.vertices.ptr, m.indices.ptr,
                                        d.resolution, d.inputResolution, d.marginPix, d.tileHeight, d.tileSize,
                                        d.data.ptr, dep=dependency)

@@ -496,6 +496,22 @@ def test_batched_tiles_equal_single_tiles(nj, ctx, oracle, res, count):
     batch.positions.Dispose()
 
 
+@pytest.mark.parametrize("mesh_type,res,in_res,margin", [(1, 64, 72, 4), (0, 33, 35, 1), (1, 127, 131, 2)])
+def test_batched_meshes_equal_single_meshes(nj, ctx, oracle, mesh_type, res, in_res, margin):
+    count = 4
+    h = np.random.default_rng(res).random((count, in_res, in_res), dtype=f32)
+    md = nj.MeshStageData("m", ctx.from_host(h), res, in_res, margin, 100.0, 25.0, count=count)
+    st = nj.MeshTileStage(ctx, nj.MeshType(mesh_type))
+    st.ReceiveHandledInput(nj.PipelineWorkItem(md), nj.JobHandle())
+    st.jobHandle.Complete()
+    vtx = md.mesh.vertices.ToArray().reshape(count, -1, 12)
+    idx = md.mesh.index_array().reshape(count, -1)
+    for k in range(count):
+        v, i = oracle.mesh_heightmap(mesh_type, h[k], res, margin, 25.0, 100.0)
+        assert np.array_equal(idx[k], i), k
+        assert np.array_equal(vtx[k], v), k
+
+
 def run_batch(nj, stage, batch):
     stage.ReceiveHandledInput(nj.PipelineWorkItem(batch), nj.JobHandle())
     stage.jobHandle.Complete()
