@@ -266,9 +266,14 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
     }
 
     for (int it = 0; it < n; it++) {
+        // Rows within 2*it of the tile's top / bottom edge already hold values no interior cell depends on (each
+        // iteration's clamped-neighbour error creeps 2 rows inwards), so interior tiles skip them: a wave owns the
+        // row pairs (2w, 2w+1) + 16j and the bounds are even, which keeps the skip wave-uniform.
+        const int dead = EDGE ? 0 : 2 * it;
         // ---- 1. publish water + height
 #pragma unroll
         for (int j = 0; j < FT_G; j++) {
+            if (grow[j] < dead || grow[j] >= FT_TH - dead) continue;
             float tot[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) tot[e] = ww[j][e] + hh[j][e];
@@ -279,6 +284,7 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
 #pragma unroll
         for (int j = 0; j < FT_G; j++) {
             int r = grow[j];
+            if (r < dead || r >= FT_TH - dead) continue;
             f4 tS = lds_load4(&s_tot[(r > 0 ? r - 1 : r) * FT_LP + gcol[j]]);
             f4 tN = lds_load4(&s_tot[(r < FT_TH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);
             float tot[4];  // recomputed rather than kept live across the barrier (same value)
@@ -310,6 +316,7 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
 #pragma unroll
         for (int j = 0; j < FT_G; j++) {
             int r = grow[j];
+            if (!EDGE && (r < dead + 2 || r >= FT_TH - dead - 2)) continue;  // the water of the next iteration's dead rows
             f4 nS = lds_load4(&s_fn[(r > 0 ? r - 1 : r) * FT_LP + gcol[j]]);            // fN of row z-1
             f4 sN = lds_load4(&s_fs[(r < FT_TH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);    // fS of row z+1
             float eW = wave_from_prev_lane(fE[j][3]), wE = wave_from_next_lane(fW[j][0]);
