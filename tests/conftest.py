@@ -19,6 +19,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The built artefacts are kept out of git: a fresh checkout builds them once (the same
+    __graft_entry__.build() the driver calls; hipcc cross-compiles gfx950 without a GPU).  The product
+    package itself never builds or falls back -- importing it without the library raises."""
+    built = [os.path.join(ROOT, "noize_job_amd", "libnoize_hip.so"), os.path.join(ROOT, "oracle", "libnoize_oracle.so"),
+             os.path.join(ROOT, "noize_job_amd", "host", "host_demo")]
+    if not all(os.path.exists(p) for p in built):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def assert_parity(got, want, what=""):
     got, want = np.asarray(got), np.asarray(want)
     assert got.shape == want.shape, "%s: shape %s vs %s" % (what, got.shape, want.shape)
