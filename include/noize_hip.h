@@ -33,7 +33,7 @@ typedef uint64_t nz_handle;
 enum nz_status {
     NZ_OK = 0,
     NZ_ERR_INVALID = -1,     /* bad argument (reference: undefined behaviour or C# exception) */
-    NZ_ERR_UNSUPPORTED = -2, /* enum value outside the hot path (e.g. Sobel3_2D) */
+    NZ_ERR_UNSUPPORTED = -2, /* combination without an implementation (e.g. Sobel3_2D in a batched launch) */
     NZ_ERR_HIP = -3,         /* HIP runtime error */
     NZ_ERR_NOMEM = -4,
     NZ_ERR_NO_DEVICE = -5    /* no gfx950 device / HIP runtime unavailable */

@@ -604,7 +604,7 @@ static int32_t filter_taps(int32_t filter, nz_kernel_taps *t) {
         case NZ_PREWITT3_HORIZONTAL: set3(1, 0, -1, 1, 1, 1, 1.0f); return NZ_OK;     // :124-130
         case NZ_PREWITT3_VERTICAL: set3(1, 1, 1, -1, 0, 1, 1.0f); return NZ_OK;       // :131-136
         case NZ_SOBEL3_2D:
-            nz_set_error("Sobel3_2D runs through ScheduleReduce (KernelJob.cs:187-215), outside the hot path");
+            nz_set_error("Sobel3_2D is not a single separable pass (ScheduleReduce, KernelJob.cs:187-215)");
             return NZ_ERR_UNSUPPORTED;
     }
     nz_set_error("unknown KernelFilterType %d", filter);
@@ -814,10 +814,40 @@ extern "C" int32_t nz_fractal_stripe(nz_ctx *ctx, int32_t noiseType, float *buf,
 // ---------------------------------------------------------------------------------------------
 // separable filters
 // ---------------------------------------------------------------------------------------------
+// SeparableKernelFilter.ScheduleReduce<RootSumSquaresTiles> (KernelJob.cs:187-215) for Sobel3_2D: the horizontal
+// filter on src, the vertical filter on a copy of the ORIGINAL plane, then src = sqrt(src^2 + copy^2); both with
+// kernelFactor 1.  (The reference takes its copy on the host at schedule time, i.e. before `dependency` has run --
+// the README lists the filter as broken; here the copy is ordered after `dep` like every other job.)
+static int32_t sobel_2d(nz_ctx *ctx, float *src, float *tmp, int resolution, int iterations) {
+    NZ_REQUIRE(src && tmp && src != tmp, "src/tmp must be two distinct planes");
+    NZ_REQUIRE(iterations >= 1, "iterations < 1");
+    size_t n = (size_t)resolution * resolution;
+    float *original = nullptr;
+    NZ_TRY(nz_ctx_scratch(ctx, n, &original));
+    nz_kernel_taps th, tv;
+    NZ_TRY(filter_taps(NZ_SOBEL3_HORIZONTAL, &th));
+    NZ_TRY(filter_taps(NZ_SOBEL3_VERTICAL, &tv));
+    th.factor = tv.factor = 1.0f;
+    nz_geom g = nz_geom_tile(resolution);
+    for (int i = 0; i < iterations; i++) {
+        NZ_TRY(bands_join(ctx));
+        NZ_TRY(nz_launch_copy(ctx->stream, original, src, n));
+        NZ_TRY(conv_iterations(ctx, src, tmp, g, th, 1));
+        NZ_TRY(conv_iterations(ctx, original, tmp, g, tv, 1));
+        NZ_TRY(bands_join(ctx));
+        NZ_TRY(nz_launch_reduce(ctx->stream, 2 /* ROOTSUMSQUARES */, src, original, n));
+    }
+    return NZ_OK;
+}
+
 extern "C" int32_t nz_kernel_filter_stage(nz_ctx *ctx, float *src, float *tmp, int32_t filter, int32_t iterations,
                                           int32_t resolution, nz_handle dep, nz_handle *out) {
     NZ_BEGIN_BANDED(ctx, dep);
     NZ_TRY(check_res(resolution));
+    if (filter == NZ_SOBEL3_2D) {
+        NZ_TRY(sobel_2d(ctx, src, tmp, resolution, iterations));
+        return nz_ctx_finish(ctx, out);
+    }
     nz_kernel_taps t;
     NZ_TRY(filter_taps(filter, &t));
     NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_tile(resolution), t, iterations));

@@ -188,6 +188,14 @@ def pass_sample_z(a, ksize, k, factor):
 
 def kernel_filter(a, filter_type, iterations=1):
     a = _plane(a).copy()
+    if filter_type == SOBEL3_2D:
+        # SeparableKernelFilter.ScheduleReduce<RootSumSquaresTiles>, Filter/Kernel/KernelJob.cs:187-215: horizontal
+        # filter on the plane, vertical filter on a copy of the original, reduce; both with kernelFactor 1
+        hx, hz, _, _ = kernel_filter_table(SOBEL3_H)
+        vx, vz, _, _ = kernel_filter_table(SOBEL3_V)
+        for _ in range(iterations):
+            a = reduce(separable(a, 3, hx, hz, 1.0), separable(a, 3, vx, vz, 1.0), RED_ROOTSUMSQUARES)
+        return a
     tmp = np.empty_like(a)
     for _ in range(iterations):
         rc = lib().nzo_kernel_filter(_p(a), _p(tmp), filter_type, a.shape[0], a.shape[1])

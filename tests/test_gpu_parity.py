@@ -123,11 +123,15 @@ def test_kernel_filter_stage_iterations(nj, ctx, oracle, ft, iters):
             d.data.Dispose()
 
 
-def test_sobel_2d_is_rejected(nj, ctx):
-    d = gen(nj, ctx, 16)
-    with pytest.raises(nj.NoizeError) as e:
-        run(nj.KernelFilterStage(ctx, nj.KernelFilterType.Sobel3_2D, 1), nj, d)
-    assert e.value.status == nj._native.NZ_ERR_UNSUPPORTED
+@pytest.mark.parametrize("res,iters", [(16, 1), (90, 1), (257, 2)])
+def test_sobel_2d_runs_both_filters_and_reduces(nj, ctx, oracle, res, iters):
+    # SeparableKernelFilter.ScheduleReduce<RootSumSquaresTiles> (KernelJob.cs:187-215)
+    t = np.random.default_rng(res).random((res, res), dtype=f32)
+    got = run(nj.KernelFilterStage(ctx, nj.KernelFilterType.Sobel3_2D, iters), nj, gen(nj, ctx, res, host=t))
+    assert np.array_equal(got, oracle.kernel_filter(t, oracle.SOBEL3_2D, iters))
+    flat = np.full((res, res), 0.25, f32)       # no gradient anywhere, clamped borders included
+    got = run(nj.KernelFilterStage(ctx, nj.KernelFilterType.Sobel3_2D, 1), nj, gen(nj, ctx, res, host=flat))
+    assert np.array_equal(got, np.zeros((res, res), f32))
 
 
 @pytest.mark.parametrize("sigma,width,iters", [(0, 3, 1), (1, 5, 3), (3, 9, 2), (7, 13, 1), (15, 25, 2), (5, 4, 1),
