@@ -124,6 +124,14 @@ int32_t nz_fractal_stripe(nz_ctx *ctx, int32_t noiseType, float *buf, const nz_s
 /* SeperableKernelFilterDelegate, Filter/Kernel/KernelJob.cs:308-314 (one X+Z application) */
 int32_t nz_kernel_filter(nz_ctx *ctx, float *src, float *tmp, int32_t filter, int32_t resolution,
                          nz_handle dep, nz_handle *out);
+/* Edge1DFilterDelegate(src, tmp, EdgeAlgorithm algo, EdgeDirection dir, resolution, dep) and
+ * Edge2DFilterDelegate(src, tmp, algo, resolution, dep), Filter/Kernel/Edge/EdgeJob.cs:22-43.
+ * algo: 0 SOBEL, 1 PREWITT; dir: 0 HORIZONTAL, 1 VERTICAL (EdgeDetection.cs:13-21).  The 2-D form is
+ * ScheduleReduce<RootSumSquaresTiles>: sqrt(horizontal^2 + vertical^2). */
+int32_t nz_edge_1d_filter(nz_ctx *ctx, float *src, float *tmp, int32_t algo, int32_t dir, int32_t resolution,
+                          nz_handle dep, nz_handle *out);
+int32_t nz_edge_2d_filter(nz_ctx *ctx, float *src, float *tmp, int32_t algo, int32_t resolution, nz_handle dep,
+                          nz_handle *out);
 /* GaussFilter.GaussFilterDelegate, Filter/Kernel/Blur/BlurJob.cs:23-30 (sigma = GaussSigma enum 0..15) */
 int32_t nz_gauss_filter(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t sigma,
                         int32_t resolution, nz_handle dep, nz_handle *out);

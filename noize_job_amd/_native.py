@@ -55,6 +55,8 @@ SIGNATURES = {
     "nz_fractal": (_i, [ctx_p, _i, dev_ptr, _i, _f, _f, _f, _f, _i, _i, _i, _i] + _tail),
     "nz_fractal_stripe": (_i, [ctx_p, _i, dev_ptr, stripe_p, _f, _f, _f, _f, _i, _i, _i, _i] + _tail),
     "nz_kernel_filter": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
+    "nz_edge_1d_filter": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
+    "nz_edge_2d_filter": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
     "nz_gauss_filter": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
     "nz_smooth_filter": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
     "nz_separable_series": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, f32p, f32p, _f] + _tail),

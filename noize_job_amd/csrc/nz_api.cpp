@@ -818,15 +818,15 @@ extern "C" int32_t nz_fractal_stripe(nz_ctx *ctx, int32_t noiseType, float *buf,
 // filter on src, the vertical filter on a copy of the ORIGINAL plane, then src = sqrt(src^2 + copy^2); both with
 // kernelFactor 1.  (The reference takes its copy on the host at schedule time, i.e. before `dependency` has run --
 // the README lists the filter as broken; here the copy is ordered after `dep` like every other job.)
-static int32_t sobel_2d(nz_ctx *ctx, float *src, float *tmp, int resolution, int iterations) {
+static int32_t edge_2d(nz_ctx *ctx, float *src, float *tmp, int resolution, int iterations, int filterH, int filterV) {
     NZ_REQUIRE(src && tmp && src != tmp, "src/tmp must be two distinct planes");
     NZ_REQUIRE(iterations >= 1, "iterations < 1");
     size_t n = (size_t)resolution * resolution;
     float *original = nullptr;
     NZ_TRY(nz_ctx_scratch(ctx, n, &original));
     nz_kernel_taps th, tv;
-    NZ_TRY(filter_taps(NZ_SOBEL3_HORIZONTAL, &th));
-    NZ_TRY(filter_taps(NZ_SOBEL3_VERTICAL, &tv));
+    NZ_TRY(filter_taps(filterH, &th));
+    NZ_TRY(filter_taps(filterV, &tv));
     th.factor = tv.factor = 1.0f;
     nz_geom g = nz_geom_tile(resolution);
     for (int i = 0; i < iterations; i++) {
@@ -845,12 +845,33 @@ extern "C" int32_t nz_kernel_filter_stage(nz_ctx *ctx, float *src, float *tmp, i
     NZ_BEGIN_BANDED(ctx, dep);
     NZ_TRY(check_res(resolution));
     if (filter == NZ_SOBEL3_2D) {
-        NZ_TRY(sobel_2d(ctx, src, tmp, resolution, iterations));
+        NZ_TRY(edge_2d(ctx, src, tmp, resolution, iterations, NZ_SOBEL3_HORIZONTAL, NZ_SOBEL3_VERTICAL));
         return nz_ctx_finish(ctx, out);
     }
     nz_kernel_taps t;
     NZ_TRY(filter_taps(filter, &t));
     NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_tile(resolution), t, iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
+// Edge1DFilter.Schedule / Edge2DFilter.Schedule, Filter/Kernel/Edge/EdgeJob.cs:11-44 (kernels: EdgeDetection.cs:23-84,
+// the same numbers as the Sobel / Prewitt entries of KernelFilterType), kernelFactor 1
+extern "C" int32_t nz_edge_1d_filter(nz_ctx *ctx, float *src, float *tmp, int32_t algo, int32_t dir, int32_t resolution,
+                                     nz_handle dep, nz_handle *out) {
+    NZ_REQUIRE((algo == 0 || algo == 1) && (dir == 0 || dir == 1), "EdgeAlgorithm %d / EdgeDirection %d out of range",
+               algo, dir);
+    int filter = algo == 0 ? (dir == 0 ? NZ_SOBEL3_HORIZONTAL : NZ_SOBEL3_VERTICAL)
+                           : (dir == 0 ? NZ_PREWITT3_HORIZONTAL : NZ_PREWITT3_VERTICAL);
+    return nz_kernel_filter_stage(ctx, src, tmp, filter, 1, resolution, dep, out);
+}
+
+extern "C" int32_t nz_edge_2d_filter(nz_ctx *ctx, float *src, float *tmp, int32_t algo, int32_t resolution,
+                                     nz_handle dep, nz_handle *out) {
+    NZ_BEGIN_BANDED(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(algo == 0 || algo == 1, "EdgeAlgorithm %d out of range", algo);
+    NZ_TRY(edge_2d(ctx, src, tmp, resolution, 1, algo == 0 ? NZ_SOBEL3_HORIZONTAL : NZ_PREWITT3_HORIZONTAL,
+                   algo == 0 ? NZ_SOBEL3_VERTICAL : NZ_PREWITT3_VERTICAL));
     return nz_ctx_finish(ctx, out);
 }
 

@@ -134,6 +134,26 @@ def test_sobel_2d_runs_both_filters_and_reduces(nj, ctx, oracle, res, iters):
     assert np.array_equal(got, np.zeros((res, res), f32))
 
 
+def test_edge_filter_delegates(nj, ctx, oracle):
+    # Edge1DFilter / Edge2DFilter (Filter/Kernel/Edge/EdgeJob.cs): the Sobel / Prewitt kernels with kernelFactor 1
+    res = 75
+    t = np.random.default_rng(9).random((res, res), dtype=f32)
+    for algo, (fh, fv) in enumerate(((oracle.SOBEL3_H, oracle.SOBEL3_V), (oracle.PREWITT3_H, oracle.PREWITT3_V))):
+        for dirn, ft in enumerate((fh, fv)):
+            src, tmp = ctx.from_host(t), ctx.alloc(res * res)
+            ctx.call("nz_edge_1d_filter", src.ptr, tmp.ptr, algo, dirn, res).Complete()
+            kx, kz, _, _ = oracle.kernel_filter_table(ft)
+            assert np.array_equal(src.ToArray((res, res)), oracle.separable(t, 3, kx, kz, 1.0)), (algo, dirn)
+        src, tmp = ctx.from_host(t), ctx.alloc(res * res)
+        ctx.call("nz_edge_2d_filter", src.ptr, tmp.ptr, algo, res).Complete()
+        hx, hz, _, _ = oracle.kernel_filter_table(fh)
+        vx, vz, _, _ = oracle.kernel_filter_table(fv)
+        want = oracle.reduce(oracle.separable(t, 3, hx, hz, 1.0), oracle.separable(t, 3, vx, vz, 1.0), 2)
+        assert np.array_equal(src.ToArray((res, res)), want), algo
+    with pytest.raises(nj.NoizeError):
+        ctx.call("nz_edge_2d_filter", src.ptr, tmp.ptr, 2, res)
+
+
 @pytest.mark.parametrize("sigma,width,iters", [(0, 3, 1), (1, 5, 3), (3, 9, 2), (7, 13, 1), (15, 25, 2), (5, 4, 1),
                                                (2, 40, 1)])
 def test_gaussian_blur_stage(nj, ctx, oracle, sigma, width, iters):
