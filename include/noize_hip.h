@@ -258,6 +258,13 @@ int32_t nz_reduction_job(nz_ctx *ctx, int32_t operation, float *srcL, const floa
 int32_t nz_curve_job(nz_ctx *ctx, float *src, float *tmp, const float *curve, int32_t curveSize,
                      int32_t resolution, nz_handle dep, nz_handle *out);
 
+/* MeshJobScheduleDelegate with G = SharedSquareGridPosition (Mesh/Job/MeshJob.cs:37-60,
+ * Mesh/Generators/SharedSquareGridPosition.cs:20-50; MeshHelper.makeSquarePlanarMesh): the flat unit-square grid,
+ * same vertex / index layout and counts as nz_heightmap_mesh.  TileSize / Height of the delegate only set
+ * mesh.bounds and are not needed here. */
+int32_t nz_square_grid_mesh(nz_ctx *ctx, void *vertices, uint32_t *indices, int32_t resolution, nz_handle dep,
+                            nz_handle *out);
+
 /* CropJobDelegate(input, inputResolution, output, outputResolution, dep), Filter/Sample/CropJob.cs:62-68.
  * As in the reference, Offset stays 0 (ScheduleParallel :43-59 never sets it): the top-left
  * outputResolution^2 corner, reads clamped to the input plane. */

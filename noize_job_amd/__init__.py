@@ -14,7 +14,7 @@ from .pipeline import (BasePipeline, BlurHelper, ConstantOperationType, Constant
                        ReductionType, StageGaussianBlur, StageThermalErosion,
                        StageIO, StageSmoothBlur)
 
-from .pipeline_state import (HandleLock, PipelineStateManager, ReadGeneratorContextStage,
+from .pipeline_state import (HandleLock, MeshTileReferenceDataStage, PipelineStateManager, ReadGeneratorContextStage,
                              WriteGeneratorContextStage)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

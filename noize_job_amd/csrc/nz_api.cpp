@@ -1237,6 +1237,17 @@ extern "C" int32_t nz_heightmap_mesh(nz_ctx *ctx, int32_t meshType, void *vertic
                                tileSize, heights, 1, dep, out);
 }
 
+// MeshJobScheduleDelegate(Mesh, MeshData, resolution, dep, TileSize, Height), Mesh/Job/MeshJob.cs:37-60, with
+// G = SharedSquareGridPosition: TileSize and Height only set mesh.bounds, the vertices span the unit square
+extern "C" int32_t nz_square_grid_mesh(nz_ctx *ctx, void *vertices, uint32_t *indices, int32_t resolution, nz_handle dep,
+                                       nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(vertices && indices, "buffer is NULL");
+    NZ_REQUIRE(resolution >= 1 && resolution <= 26754, "resolution %d out of range", resolution);
+    NZ_TRY(nz_launch_mesh_planar(ctx->stream, vertices, indices, resolution));
+    return nz_ctx_finish(ctx, out);
+}
+
 // `count` meshes from `count` height planes stored back to back; mesh k at vertices + k * vertex_count * 48 bytes
 // and indices + k * index_count
 extern "C" int32_t nz_heightmap_mesh_batch(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_t *indices,

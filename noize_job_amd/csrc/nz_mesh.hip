@@ -111,6 +111,25 @@ __global__ __launch_bounds__(CT) void mesh_vertex_kernel(float4 *__restrict__ vt
     }
 }
 
+// MeshJob<SharedSquareGridPosition, PositionStream32> (Mesh/Generators/SharedSquareGridPosition.cs:20-50): the flat
+// unit-square grid.  The reference reuses one Vertex along a row, so column 0 keeps position.x = -0.5 (a literal)
+// and texCoord0.x = 0 (never assigned).
+__global__ __launch_bounds__(CT) void mesh_planar_vertex_kernel(float4 *__restrict__ vtx, int R) {
+    size_t vi = (size_t)blockIdx.x * CT + threadIdx.x;
+    size_t nv = (size_t)(R + 1) * (R + 1);
+    if (vi >= nv) return;
+    int z = (int)(vi / (R + 1));
+    int x = (int)(vi - (size_t)z * (R + 1));
+    float px = x == 0 ? -0.5f : (float)x / (float)R - 0.5f;
+    float pz = (float)z / (float)R - 0.5f;
+    float u = x == 0 ? 0.0f : ((float)x) / ((float)R + 1.0f);
+    float v = ((float)z) / ((float)R + 1.0f);
+    float4 *o = vtx + vi * 3;
+    nt_store(o + 0, make_float4(px, 0.0f, pz, 0.0f));     // position, normal.x
+    nt_store(o + 1, make_float4(0.0f, -1.0f, 1.0f, 0.0f));  // normal.yz, tangent.xy
+    nt_store(o + 2, make_float4(0.0f, -1.0f, u, v));      // tangent.zw, texCoord0
+}
+
 // flat index i -> triangle i/3 (ti), corner i%3.  ti = 2R(z-1) + 2(x-1) + s, s in {0,1}:
 //   s=0: vi + (-R-2, -1, -R-1);  s=1: vi + (-R-1, -1, 0);  vi = (R+1) z + x
 __device__ __forceinline__ uint32_t mesh_index(uint32_t i, uint32_t R) {
@@ -175,6 +194,27 @@ int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *in
     size_t nthreads = (ni + 3) / 4;
     hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT), count), dim3(CT), 0, s, indices,
                        (uint32_t)res, ni, ni);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_mesh_planar(hipStream_t s, void *vertices, uint32_t *indices, int res) {
+    size_t nv = (size_t)(res + 1) * (res + 1);
+    size_t ni = (size_t)6 * res * res;
+    if (ni > 0xffffffffULL) {
+        nz_set_error("mesh index count overflows uint32");
+        return NZ_ERR_INVALID;
+    }
+    if ((reinterpret_cast<uintptr_t>(vertices) & 15) != 0) {
+        nz_set_error("vertex buffer must be 16-byte aligned");
+        return NZ_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(mesh_planar_vertex_kernel, dim3((unsigned)((nv + CT - 1) / CT)), dim3(CT), 0, s,
+                       reinterpret_cast<float4 *>(vertices), res);
+    NZ_HIP(hipGetLastError());
+    size_t nthreads = (ni + 3) / 4;
+    hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT)), dim3(CT), 0, s, indices,
+                       (uint32_t)res, ni, (size_t)0);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

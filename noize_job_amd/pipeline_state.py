@@ -10,7 +10,7 @@ pipeline (WriteGeneratorContextStage) stays in HBM for the pipelines that read i
 import numpy as np
 
 from .persistence import PipelineSerdeManager
-from .pipeline import GeneratorData, PipelineStage
+from .pipeline import GeneratorData, MeshStageData, MeshTileStage, MeshType, PipelineStage
 from .runtime import JobHandle
 
 
@@ -159,3 +159,34 @@ class WriteGeneratorContextStage(PipelineStage):  # .../WriteGeneratorContextSta
         h1 = self.ctx.call("nz_flush_write_slice", buffer.ptr, gd.data.ptr, res, dep=dependency)
         self.jobHandle = self.ctx.record()  # LockJob: a no-op marker scheduled after the copy
         requirements.stageManager.TrySetLock(name, h1, self.jobHandle)
+
+
+class MeshTileReferenceDataStage(MeshTileStage):  # Mesh/Stage/MeshTileReferenceDataStage.cs:22-84
+    """MeshTileStage whose heights come from the context buffer `{xpos}_{zpos}__{inputResolution}__{contextAlias}`
+    instead of the work item's own data; schedulable once that buffer exists and is not being written."""
+
+    def __init__(self, ctx, meshType=MeshType.OvershootSquareGridHeightMap, contextAlias=""):
+        super().__init__(ctx, meshType)
+        self.contextAlias = contextAlias
+
+    def getBufferName(self, d):
+        return "%d_%d__%d__%s" % (d.xpos, d.zpos, d.inputResolution, self.contextAlias)
+
+    def IsSchedulable(self, job):
+        if job.stageManager is None:
+            return False
+        name = self.getBufferName(job.data)
+        if not job.stageManager.BufferExists(name):
+            return False
+        return not job.stageManager.IsLocked(name)
+
+    def Schedule(self, requirements, dependency):
+        d = requirements.data
+        if not isinstance(d, MeshStageData):
+            raise Exception("Unhandled stageio %s" % type(d).__name__)
+        buffer = requirements.stageManager.GetBuffer(self.getBufferName(d), d.inputResolution * d.inputResolution)
+        own, d.data = d.data, buffer          # the mesh job reads the context buffer (:62-64)
+        try:
+            super().Schedule(requirements, dependency)
+        finally:
+            d.data = own

@@ -75,6 +75,7 @@ def lib():
         L.nzo_normalize.argtypes = [f32p, f32p, f32p, i, i]
         L.nzo_flowmap.argtypes = [f32p, i, i, i, f, f]
         L.nzo_mesh_heightmap.argtypes = [i, f32p, i, i, i, f, f, f32p, u32p]
+        L.nzo_mesh_square_grid.argtypes = [i, f32p, u32p]
         L.nzo_constant.argtypes = [f32p, f32p, i, f, i, i]
         L.nzo_reduce.argtypes = [f32p, f32p, f32p, i, i, i]
         L.nzo_curve.argtypes = [f32p, f32p, f32p, i, i, i]
@@ -277,6 +278,14 @@ def flowmap(a, iterations=5, norm_min=-0.1, norm_max=0.1):
 
 
 # ---- mesh -----------------------------------------------------------------------------------
+def mesh_square_grid(resolution):
+    vtx = np.zeros(((resolution + 1) ** 2, 12), np.float32)
+    idx = np.zeros(6 * resolution * resolution, np.uint32)
+    if lib().nzo_mesh_square_grid(resolution, _p(vtx), idx.ctypes.data_as(u32p)):
+        raise ValueError("bad resolution")
+    return vtx, idx
+
+
 def mesh_heightmap(mesh_type, heights, resolution, margin_pix, tile_height, tile_size):
     heights = _plane(heights)
     in_res = heights.shape[0]

@@ -861,6 +861,38 @@ static void mesh_vertex_values(const mesh_gen *g, float *v, int x, int z) {
     }
 }
 
+/* MeshJob<SharedSquareGridPosition, PositionStream32>, Mesh/Generators/SharedSquareGridPosition.cs:20-50: the flat
+ * unit-square grid of MeshHelper.makeSquarePlanarMesh (Mesh/Helpers/Helper.cs:47-58).  The vertex is reused along
+ * a row, so texCoord0.x of column 0 is the default 0 and position.x of column 0 is the literal -0.5. */
+int nzo_mesh_square_grid(int resolution, float *vtx, uint32_t *idx) {
+    if (resolution < 1) return -1;
+    int R = resolution;
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z <= R; z++) {
+        int vi = (R + 1) * z, ti = 2 * R * (z - 1);
+        float v[12] = {0};
+        v[5] = -1.0f;              /* normal.z */
+        v[6] = 1.0f; v[9] = -1.0f; /* tangent.xw */
+        v[0] = -0.5f;
+        v[2] = (float)z / (float)R - 0.5f;
+        v[1] = 0.0f;
+        v[11] = ((float)z) / ((float)R + 1.0f);
+        memcpy(vtx + (size_t)vi * 12, v, sizeof v);
+        vi += 1;
+        for (int x = 1; x <= R; x++, vi++, ti += 2) {
+            v[0] = (float)x / (float)R - 0.5f;
+            v[10] = ((float)x) / ((float)R + 1.0f);
+            memcpy(vtx + (size_t)vi * 12, v, sizeof v);
+            if (z > 0) {
+                uint32_t *t0 = idx + (size_t)(ti + 0) * 3, *t1 = idx + (size_t)(ti + 1) * 3;
+                t0[0] = (uint32_t)(vi - R - 2); t0[1] = (uint32_t)(vi - 1); t0[2] = (uint32_t)(vi - R - 1);
+                t1[0] = (uint32_t)(vi - R - 1); t1[1] = (uint32_t)(vi - 1); t1[2] = (uint32_t)vi;
+            }
+        }
+    }
+    return 0;
+}
+
 int nzo_mesh_heightmap(int meshType, const float *heights, int resolution, int inputResolution,
                        int marginPix, float tileHeight, float tileSize, float *vtx,
                        uint32_t *idx) {

@@ -126,6 +126,7 @@ int nzo_flowmap(float *src, int rows, int cols, int iterations, float normMin, f
 /* ---- mesh ---- */
 /* HeightMapMeshJob.ScheduleParallel HeightMapMeshJob.cs:24-52.
  * vtx: (res+1)^2 records of 12 floats {pos3, normal3, tangent4, uv2}; idx: 6*res*res uint32. */
+int nzo_mesh_square_grid(int resolution, float *vtx, uint32_t *idx); /* Mesh/Generators/SharedSquareGridPosition.cs */
 int nzo_mesh_heightmap(int meshType, const float *heights, int resolution, int inputResolution,
                        int marginPix, float tileHeight, float tileSize, float *vtx,
                        uint32_t *idx);

@@ -541,6 +541,41 @@ def run_batch(nj, stage, batch):
     stage.jobHandle.Complete()
 
 
+@pytest.mark.parametrize("res", [1, 2, 17, 255, 256])
+def test_square_planar_mesh(nj, ctx, oracle, res):
+    # MeshJob<SharedSquareGridPosition, PositionStream32> (MeshHelper.makeSquarePlanarMesh)
+    nv, ni = nj._native.lib.nz_mesh_vertex_count(res), nj._native.lib.nz_mesh_index_count(res)
+    v, i = ctx.alloc(nv * 12), ctx.alloc(ni, dtype=np.uint32)
+    ctx.call("nz_square_grid_mesh", v.ptr, i.ptr, res).Complete()
+    vtx, idx = oracle.mesh_square_grid(res)
+    assert np.array_equal(i.ToArray(), idx)
+    assert np.array_equal(v.ToArray().reshape(-1, 12), vtx)
+    v.Dispose()
+    i.Dispose()
+
+
+def test_mesh_from_a_context_buffer(nj, ctx, oracle):
+    # MeshTileReferenceDataStage: heights come from the state manager's buffer named after the tile, not from the
+    # work item; the stage waits until that buffer exists
+    res, in_res, margin = 56, 64, 4
+    mgr = nj.PipelineStateManager(ctx)
+    h = np.random.default_rng(2).random((in_res, in_res), dtype=f32)
+    mesher = nj.BasePipeline([nj.MeshTileReferenceDataStage(ctx, nj.MeshType.OvershootSquareGridHeightMap, "height")],
+                             "mesher", contextManager=mgr)
+    md = nj.MeshStageData("m", ctx.alloc(4), res, in_res, margin, 100.0, 30.0, xpos=7, zpos=-3)
+    mesher.Enqueue(md)
+    mesher.Update()
+    assert not mesher.pipelineRunning and len(mesher.dependencyHell) == 1      # no buffer yet
+    writer = nj.BasePipeline([nj.WriteGeneratorContextStage(ctx, "height")], "writer", contextManager=mgr)
+    writer.Enqueue(nj.GeneratorData("h", ctx.from_host(h), in_res, 7, -3))
+    writer.RunToCompletion()
+    mesher.RunToCompletion()
+    vtx, idx = oracle.mesh_heightmap(oracle.MESH_OVERSHOOT, h, res, margin, 30.0, 100.0)
+    assert np.array_equal(md.mesh.index_array(), idx)
+    assert np.array_equal(md.mesh.vertices.ToArray().reshape(-1, 12), vtx)
+    mgr.OnDestroy()
+
+
 def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):
     # BasicDemo "ParallelFlowMap": Perlin fBm -> Invert (curve) -> FlowMapStage -> CurveBoostContrast
     res = 128

@@ -436,3 +436,16 @@ def test_noise_bases_equal_the_vectorised_numpy_restatement(oracle, scale):
         want = f32(11.0) * (t4[0] * w[0] + t4[1] * w[1] + t4[2] * w[2])
         got = np.array([oracle.psrnoise2(u, v, 1010.0, 102.0, rot) for u, v in pts], f32)
         assert np.allclose(got, want, rtol=0, atol=2e-6)
+
+
+def test_square_planar_mesh_by_hand(oracle):
+    # SharedSquareGridPosition.cs:20-50 at resolution 2: 9 vertices, 8 triangles
+    vtx, idx = oracle.mesh_square_grid(2)
+    assert vtx.shape == (9, 12) and idx.shape == (24,)
+    assert np.array_equal(vtx[:, 3:10], np.tile(np.array([0, 0, -1, 1, 0, 0, -1], f32), (9, 1)))  # normal, tangent
+    assert np.array_equal(vtx[:, 0].reshape(3, 3), np.tile(np.array([-0.5, 0.0, 0.5], f32), (3, 1)))
+    assert np.array_equal(vtx[:, 2].reshape(3, 3), np.tile(np.array([[-0.5], [0.0], [0.5]], f32), (1, 3)))
+    assert np.array_equal(vtx[:, 1], np.zeros(9, f32))
+    third = f32(1.0) / f32(3.0)
+    assert np.array_equal(vtx[:, 10].reshape(3, 3)[0], np.array([0.0, third, f32(2.0) / f32(3.0)], f32))
+    assert np.array_equal(idx[:6], np.array([0, 3, 1, 1, 3, 4], np.uint32))   # vi=4: (4-4, 4-1, 4-3), (4-3, 4-1, 4)
