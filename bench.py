@@ -110,6 +110,10 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
+    local_rank %= ndev  # a launcher that narrows HIP_VISIBLE_DEVICES per rank leaves one device, index 0
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.sharded or args.as_rank is not None
     if args.as_rank is not None and (world != 1 or args.halo != "recompute"):
