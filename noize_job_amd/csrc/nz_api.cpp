@@ -714,7 +714,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         return NZ_OK;
     }
     int L = (iterations + cap - 1) / cap;
-    if (L & 1) L += 1;
+    if ((L & 1) && L + 1 <= iterations) L += 1;  // an even count leaves the result in src
     int base = iterations / L, rem = iterations % L;
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
@@ -724,6 +724,12 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         });
         if (rc) return rc;
         float *s = cur; cur = other; other = s;
+    }
+    if (cur != src) {  // odd count (only when cap == 1): copy back
+        return banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            size_t off = (size_t)gb.or0 * gb.pitch;
+            return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
+        });
     }
     return NZ_OK;
 }
