@@ -323,18 +323,19 @@ __global__ __launch_bounds__(CT) void conv_pass_z_kernel(const float *__restrict
 
 // ---- wide separable kernels (odd kernelSize 11..25): both passes of one application in one launch -----
 // Used by the Gaussian / box blur stages (StageGaussianBlur / StageSmoothBlur, width <= 25,
-// Filter/Kernel/Blur/BlurJob.cs:11-52).  A workgroup produces a 32 x 128 output tile.  Source rows
+// Filter/Kernel/Blur/BlurJob.cs:11-52).  A workgroup of NT threads produces an (NT/8) x 128 output tile.  Source rows
 // [z0-O, z0+32+O) x columns [x0-16, x0+144), clamped to the grid (RWTileData.GetData), are staged in LDS
 // as 160-float rows: 16-byte loads, five whole 128-byte lines per row.  The X pass runs on all 32+2O rows
 // into a second LDS plane, 8 consecutive outputs per thread from one register window; the Z pass reads
 // that plane column-wise, 4 columns x 4 rows per thread, and stores 16 bytes per lane.  Clamped source
 // rows give the X-pass value of the clamped row, which is what the reference's Z pass reads after the flush.
-constexpr int WD_H = 32, WD_W = 128, WD_XH = 16, WD_AP = WD_W + 2 * WD_XH;
+constexpr int WD_W = 128, WD_XH = 16, WD_AP = WD_W + 2 * WD_XH;
 
-template <int O, bool UNIT>
-__global__ __launch_bounds__(CT) void conv_wide_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
+template <int O, bool UNIT, int WD_NT>
+__global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
                                                       nz_kernel_taps taps, int aligned) {
     constexpr int KS = 2 * O + 1;
+    constexpr int WD_H = WD_NT / 8;           // output rows: 4 per 32 threads
     constexpr int NR = WD_H + 2 * O;          // staged rows
     constexpr int OFF = WD_XH - O;            // first window column of output column 0
     constexpr int OFA = OFF & ~3, SH = OFF & 3;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(CT) void conv_wide_kernel(const float *__restrict__
 
     const bool inside = aligned && x0 - WD_XH >= 0 && x0 + WD_W + WD_XH <= g.cols && z0 - O >= g.zc0 &&
                         z0 + WD_H + O - 1 <= g.zc1;
-    for (int i = tid; i < NR * (WD_AP / 4); i += CT) {
+    for (int i = tid; i < NR * (WD_AP / 4); i += WD_NT) {
         int r = i / (WD_AP / 4), c4 = i - r * (WD_AP / 4);
         int gx = x0 - WD_XH + 4 * c4;
         float4 t;
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(CT) void conv_wide_kernel(const float *__restrict__
     // ---- X pass (KernelSampleXOperator: taps k ascending)
     {
         const int tx = tid & 15, ry = tid >> 4;
-        for (int r = ry; r < NR; r += CT / 16) {
+        for (int r = ry; r < NR; r += WD_NT / 16) {
             float w[NF * 4];
             const float4 *a = s_a + (r * WD_AP + OFA + 8 * tx) / 4;
 #pragma unroll
@@ -428,16 +429,28 @@ __global__ __launch_bounds__(CT) void conv_wide_kernel(const float *__restrict__
     }
 }
 
-template <int O>
-int32_t launch_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k) {
+template <int O, int NT>
+int32_t launch_wide_nt(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k) {
+    constexpr int WD_H = NT / 8;
     long long blocks = (long long)((g.cols + WD_W - 1) / WD_W) * ((g.or1 - g.or0 + WD_H - 1) / WD_H);
     int aligned = (g.pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     if (k.factor == 1.0f)
-        hipLaunchKernelGGL((conv_wide_kernel<O, true>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, k, aligned);
+        hipLaunchKernelGGL((conv_wide_kernel<O, true, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k,
+                           aligned);
     else
-        hipLaunchKernelGGL((conv_wide_kernel<O, false>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, k, aligned);
+        hipLaunchKernelGGL((conv_wide_kernel<O, false, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k,
+                           aligned);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
+}
+
+// 32-row tiles (256 threads) up to NZ_WIDE_BIG_FROM taps, 64-row tiles (512 threads) beyond: the taller tile stages
+// fewer halo rows per output row, which pays once the halo (kernelSize - 1 rows) is a large part of the tile
+template <int O>
+int32_t launch_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k) {
+    static const int big_from = getenv("NZ_WIDE_BIG_FROM") ? atoi(getenv("NZ_WIDE_BIG_FROM")) : 17;
+    if (2 * O + 1 >= big_from) return launch_wide_nt<O, 512>(s, src, dst, g, k);
+    return launch_wide_nt<O, 256>(s, src, dst, g, k);
 }
 
 #ifndef NZ_CONV_NT

@@ -1,14 +1,31 @@
 #!/bin/bash
-# rebuilds nz_filter.hip with each flag set on the GPU box and times the metric's Gauss5 x17 stage per fusion cap
-set -e
-cd "$(dirname "$0")/../noize_job_amd/csrc"
-BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -fno-slp-vectorize"
-mkdir -p build
-for extra in "-DNZ_CONV_NT=256" "-DNZ_CONV_NT=512"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE $extra -c nz_filter.hip -o build/nz_filter.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libnoize_hip.so
-  for cap in 3 4 5 6; do
-    echo "== flags: [$extra] NZ_CONV_TCAP=$cap"
-    NZ_CONV_TCAP=$cap python3 ../../tools/bench_stage.py gauss --reps 30 2>/dev/null
-  done
+# wide blurs: 32-row (256 threads) vs 64-row (512 threads) tiles per kernel width
+cd "$(dirname "$0")/.."
+for big in 99 11; do
+  echo "== NZ_WIDE_BIG_FROM=$big"
+  NZ_WIDE_BIG_FROM=$big python3 - <<'PY'
+import os, sys
+sys.path.insert(0, ".")
+import noize_job_amd as nj
+res = 4096
+with nj.Context(0) as ctx:
+    data = ctx.alloc(res * res)
+    gd = nj.GeneratorData("b", data, res, 0, 0)
+    nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700).Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+    for width in (11, 13, 15, 17, 19, 21, 23, 25):
+        st = nj.StageGaussianBlur(ctx, 2, nj.GaussSigma.s2d00, width)
+        wi = nj.PipelineWorkItem(gd)
+        for _ in range(3):
+            st.Schedule(wi, nj.JobHandle())
+        ctx.synchronize()
+        best = 1e9
+        for _ in range(3):
+            h0 = ctx.record()
+            for _ in range(10):
+                st.Schedule(wi, nj.JobHandle())
+            h1 = ctx.record(); h1.Complete()
+            best = min(best, ctx.elapsed_ms(h0, h1) / 10)
+        print("width %2d x2: %.4f ms" % (width, best))
+        st.OnDestroy()
+PY
 done
