@@ -45,6 +45,24 @@ def main():
         v, i = O.mesh_heightmap(mt, hm, 16, 2, 1000.0, 1000.0)
         out["mesh_%s_vtx" % name], out["mesh_%s_idx" % name] = v, i
     out["pipeline_64"] = O.pipeline(64, 64)
+    # lattice cells where fp32 mod289 returns 289 (negative multiples of 289), every basis
+    for b in range(8):
+        out["fractal_neg_%d" % b] = O.fractal(b, 64, 64, 0.5, 1.0, 2.0, 0.0, 2, -8990, -18230, 1)
+    # stages either side of the metric path
+    other = rng.random((64, 64), dtype=np.float32)
+    out["other"] = other
+    out["constant_mul"] = O.constant(tile, O.CONST_MULTIPLY, 0.37)
+    out["constant_bin"] = O.constant(tile, O.CONST_BINARIZE, 0.37)
+    for op in range(5):
+        out["reduce_%d" % op] = O.reduce(tile, other, op)
+    lut = np.array([1.0 - np.float32(i) / np.float32(256) for i in range(256)], np.float32)
+    out["curve_lut"] = lut
+    out["curve_invert"] = O.curve(tile, lut)
+    out["thermal_x2"] = O.thermal_erosion(tile, 45.0, 0.5, 0.75, 2)
+    out["crop_40"] = O.crop(tile, 40)
+    out["sobel_2d"] = O.kernel_filter(tile, O.SOBEL3_2D)
+    v, i = O.mesh_square_grid(5)
+    out["mesh_planar_vtx"], out["mesh_planar_idx"] = v, i
     np.savez_compressed(os.path.join(HERE, "fixtures.npz"), **out)
     print("wrote fixtures.npz with %d arrays, %.1f KiB" %
           (len(out), os.path.getsize(os.path.join(HERE, "fixtures.npz")) / 1024))
