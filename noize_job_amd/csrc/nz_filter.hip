@@ -4,9 +4,11 @@
 // (Filter/Kernel/KernelJob.cs:18-54,165-185; operators Filter/Kernel/KernelOperators.cs:18-67) and
 // the KernelMin{X,Z}Operator pair of ErosionKernelJob (KernelJob.cs:317-347, KernelOperators.cs:69-118).
 //
-// conv_reg_kernel / erosion_reg_kernel: one workgroup owns a 64 x 128 tile (rows x cols, halo included)
+// conv_reg_kernel / erosion_reg_kernel: one workgroup owns a TH x 128 tile (rows x cols, halo included;
+// TH = 128 rows with 512 threads for 5..9 taps, 64 rows with 256 threads for 3 taps and the min filter)
 // held entirely in registers, runs T applications of (X pass, Z pass) on it without touching HBM and
-// stores the (64-2H) x (128-2HX) interior, H = T*(K-1)/2.  HBM traffic per launch is one read and one
+// stores the (TH-2H) x (128-2HX) interior, H = T*(K-1)/2.  conv_wide_kernel (11..25 taps) runs one
+// application per launch through two LDS planes.  HBM traffic per launch is one read and one
 // write of the plane for T filter applications (the reference moves 32 B/cell per application: two
 // passes + two serial flush copies).  The FlushWriteSlice copies (Pipeline/Tiles/TileData.cs:15-40) do
 // not exist here: launches ping-pong between `src` and `tmp`.

@@ -6,12 +6,15 @@
 // multiply coordinates by up to 2^12, so the skew/unskew steps cancel catastrophically and any
 // re-association or FMA contraction moves the result by more than the 1e-5 tolerance.  Every
 // operation is an IEEE-754 binary32 add/mul/div/floor, which makes the result bit-identical to the
-// CPU restatement.  psrnoise's cos/sin come from a 290-entry table built by the host libm
-// (its hash is an exact small integer), so no device trig is involved except for the Sin basis.
+// CPU restatement.  psrnoise's cos/sin come from a table built by the host libm (its hash is an exact
+// small integer), so no device trig is involved except for the Sin basis.  The lattice hashes of the
+// other bases are exact small-integer arithmetic as well: the default kernels read them (and the decoded
+// corner gradients) from host-built tables in LDS and fall back to the direct evaluation below wherever a
+// coordinate leaves the range the tables are exact for.
 //
 // VALU-bound (~1.1 k fp32 ops per cell for 13 simplex octaves against 4 B written): one thread
 // produces VEC consecutive cells of a row so the octave chains of different cells interleave, and
-// stores them with one 8/16-byte coalesced write.
+// stores them with one 8/16-byte coalesced write.  Batched launches take the tile from blockIdx.y.
 #include <cstdlib>
 
 #include "nz_internal.hpp"
