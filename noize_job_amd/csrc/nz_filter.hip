@@ -28,10 +28,26 @@ constexpr int TH = 64;       // LDS tile height, rows
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Workgroups are dealt round-robin to the 8 XCDs (blockIdx.x % 8), each with its own L2.  Giving XCD x the x-th
+// contiguous eighth of the tiles keeps tiles that share halo rows / columns on one L2 (NZ_XCD_REMAP=0: identity).
+#ifndef NZ_XCD_REMAP
+#define NZ_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_tile_index() {
+    int bid = blockIdx.x;
+#if NZ_XCD_REMAP
+    int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+    int x = bid & 7, k = bid >> 3;
+    bid = x * q + (x < r ? x : r) + k;
+#endif
+    return bid;
+}
+
 __device__ __forceinline__ void tile_origin(const nz_geom &g, int OW, int OH, int &ox0, int &oz0) {
     int tiles_x = (g.cols + OW - 1) / OW;
-    int by = blockIdx.x / tiles_x;
-    int bx = blockIdx.x - by * tiles_x;
+    int bid = xcd_tile_index();
+    int by = bid / tiles_x;
+    int bx = bid - by * tiles_x;
     ox0 = bx * OW;
     oz0 = g.or0 + by * OH;
 }
@@ -348,7 +364,8 @@ __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restric
     src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
     dst += blockIdx.y * g.bstride;
     const int tiles_x = (g.cols + WD_W - 1) / WD_W;
-    const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    const int bid = xcd_tile_index();
+    const int by = bid / tiles_x, bx = bid - by * tiles_x;
     const int x0 = bx * WD_W, z0 = g.or0 + by * WD_H;
 
     const bool inside = aligned && x0 - WD_XH >= 0 && x0 + WD_W + WD_XH <= g.cols && z0 - O >= g.zc0 &&

@@ -404,19 +404,26 @@ __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__r
     const int H = 2 * n, HX = (H + 3) & ~3;
     const int OW = FT_TW - 2 * HX, OH = FT_TH - 2 * H;
     const int tiles_x = (g.cols + OW - 1) / OW;
-    const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    // XCD-aware tile order (workgroups go round-robin to the 8 XCDs): XCD x takes the x-th contiguous eighth of
+    // the tiles, so tiles that share halo rows / columns meet in one L2
+    int tile = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = tile & 7, k = tile >> 3;
+        tile = x * q + (x < r ? x : r) + k;
+    }
+    const int by = tile / tiles_x, bx = tile - by * tiles_x;
     const int lx0 = bx * OW - HX, lz0 = g.or0 + by * OH - H;
     const bool inner = lx0 > 0 && lx0 + FT_TW < g.cols && lz0 > g.zc0 && lz0 + FT_TH - 1 < g.zc1;
     // batched launch: one independent grid per blockIdx.y, every plane shifted by the same stride
     const size_t off = blockIdx.y * g.bstride;
 #define NZ_SH(p) ((p) ? (p) + off : (p))
     if (inner)
-        flow_fused_body<FIRST, LAST, false>(s_tot, s_fn, s_fs, blockIdx.x, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
+        flow_fused_body<FIRST, LAST, false>(s_tot, s_fn, s_fs, tile, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
                                             NZ_SH(fE_in), NZ_SH(fW_in), NZ_SH(w_out), NZ_SH(fN_out), NZ_SH(fS_out),
                                             NZ_SH(fE_out), NZ_SH(fW_out), NZ_SH(dst), NZ_SH(h_out), g, n, nmin, nrange,
                                             aligned);
     else
-        flow_fused_body<FIRST, LAST, true>(s_tot, s_fn, s_fs, blockIdx.x, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
+        flow_fused_body<FIRST, LAST, true>(s_tot, s_fn, s_fs, tile, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
                                            NZ_SH(fE_in), NZ_SH(fW_in), NZ_SH(w_out), NZ_SH(fN_out), NZ_SH(fS_out),
                                            NZ_SH(fE_out), NZ_SH(fW_out), NZ_SH(dst), NZ_SH(h_out), g, n, nmin, nrange,
                                            aligned);

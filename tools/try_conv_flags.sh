@@ -1,31 +1,25 @@
 #!/bin/bash
-# wide blurs: 32-row (256 threads) vs 64-row (512 threads) tiles per kernel width
-cd "$(dirname "$0")/.."
-for big in 99 11; do
-  echo "== NZ_WIDE_BIG_FROM=$big"
-  NZ_WIDE_BIG_FROM=$big python3 - <<'PY'
-import os, sys
-sys.path.insert(0, ".")
-import noize_job_amd as nj
-res = 4096
-with nj.Context(0) as ctx:
-    data = ctx.alloc(res * res)
-    gd = nj.GeneratorData("b", data, res, 0, 0)
-    nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700).Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
-    for width in (11, 13, 15, 17, 19, 21, 23, 25):
-        st = nj.StageGaussianBlur(ctx, 2, nj.GaussSigma.s2d00, width)
-        wi = nj.PipelineWorkItem(gd)
-        for _ in range(3):
-            st.Schedule(wi, nj.JobHandle())
-        ctx.synchronize()
-        best = 1e9
-        for _ in range(3):
-            h0 = ctx.record()
-            for _ in range(10):
-                st.Schedule(wi, nj.JobHandle())
-            h1 = ctx.record(); h1.Complete()
-            best = min(best, ctx.elapsed_ms(h0, h1) / 10)
-        print("width %2d x2: %.4f ms" % (width, best))
-        st.OnDestroy()
+# XCD-aware tile order for the register conv / erosion kernels: time + HBM fetch per launch
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd "$ROOT/noize_job_amd/csrc"
+BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -fno-slp-vectorize"
+mkdir -p build
+for extra in "-DNZ_XCD_REMAP=0" "-DNZ_XCD_REMAP=1"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE $extra -c nz_filter.hip -o build/nz_filter.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libnoize_hip.so
+  echo "== flags: [$extra]"
+  python3 "$ROOT/tools/bench_stage.py" gauss --reps 40 2>/dev/null
+  python3 "$ROOT/tools/bench_stage.py" erosion --reps 40 2>/dev/null
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pf && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o run -- python3 "$ROOT/tools/bench_stage.py" gauss --reps 2 > /dev/null 2>&1; python3 - <<'PY'
+import csv, glob, collections
+d = collections.defaultdict(list)
+for f in glob.glob("/tmp/pf/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            d[r["Kernel_Name"][:40]].append(float(r["Counter_Value"]))
+for k, v in d.items():
+    print("   fetch %-40s %7.1f MB per launch (x2 corrected)" % (k, 2 * 1024 * sum(v) / len(v) / 1e6))
 PY
+  )
 done
