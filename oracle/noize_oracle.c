@@ -59,8 +59,10 @@ static void flush_write_slice(float *write, const float *read, size_t n) {
 static inline float fracf_(float x) { return x - floorf(x); }              /* math.frac */
 static inline float lerpf_(float a, float b, float s) { return a + s * (b - a); } /* math.lerp */
 static inline float stepf_(float y, float x) { return x >= y ? 1.0f : 0.0f; }     /* math.step(y,x) */
-static inline float minf_(float a, float b) { return a < b ? a : b; }
-static inline float maxf_(float a, float b) { return a > b ? a : b; }
+/* Unity.Mathematics math.min / math.max (1.2.x): `float.IsNaN(y) || x < y ? x : y` -- a NaN operand loses,
+ * like C fminf / fmaxf and the GPU's v_min_f32 / v_max_f32 */
+static inline float minf_(float a, float b) { return (b != b) || a < b ? a : b; }
+static inline float maxf_(float a, float b) { return (b != b) || a > b ? a : b; }
 
 /* noise/common.cs */
 static inline float mod289f(float x) { return x - floorf(x * (1.0f / 289.0f)) * 289.0f; }
