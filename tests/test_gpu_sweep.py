@@ -66,6 +66,32 @@ def test_filters_erosion_flow_random_sizes(nj, ctx, oracle, seed):
             assert np.array_equal(got, oracle.thermal_erosion(t, 45.0, 0.5, 0.75, it)), ("thermal", res, it)
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_non_finite_cells_propagate_like_the_oracle(nj, ctx, oracle, seed):
+    # NaN / +-inf cells: sums and products spread them the IEEE way, min / max drop a NaN operand
+    # (Unity.Mathematics math.min / math.max, C fminf / fmaxf, v_min_f32 / v_max_f32)
+    rng = np.random.default_rng(5000 + seed)
+    for res in (33, 130, 200):
+        t = rng.random((res, res), dtype=f32)
+        for v in (np.nan, np.inf, -np.inf, np.nan):
+            t[rng.integers(0, res), rng.integers(0, res)] = v
+        t[0, 0] = np.nan
+        t[-1, -1] = np.inf
+        eq = lambda a, b: np.array_equal(a, b, equal_nan=True)  # noqa: E731
+        got = _run(nj, nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 4), nj.GeneratorData("k", ctx.from_host(t), res))
+        assert eq(got, oracle.kernel_filter(t, 2, 4)), ("filter", res)
+        got = _run(nj, nj.StageGaussianBlur(ctx, 1, nj.GaussSigma(3), 21), nj.GeneratorData("g", ctx.from_host(t), res))
+        assert eq(got, oracle.gauss(t, 21, 3, 1)), ("wide blur", res)
+        for it in (1, 3, 6):
+            got = _run(nj, nj.ErosionStage(ctx, it), nj.GeneratorData("e", ctx.from_host(t), res))
+            assert eq(got, oracle.erosion_min(t, it)), ("erosion", res, it)
+        for it in (1, 5, 7):
+            got = _run(nj, nj.FlowMapStage(ctx, it, 0.0, 0.005), nj.GeneratorData("f", ctx.from_host(t), res))
+            assert eq(got, oracle.flowmap(t, it, 0.0, 0.005)), ("flow", res, it)
+        got = _run(nj, nj.StageThermalErosion(ctx, 2, 45, 0.5, 0.75), nj.GeneratorData("t", ctx.from_host(t), res))
+        assert eq(got, oracle.thermal_erosion(t, 45.0, 0.5, 0.75, 2)), ("thermal", res)
+
+
 @pytest.mark.parametrize("basis", range(1, 8))
 def test_noise_random_parameters(nj, ctx, oracle, basis):
     # every basis but Sin (device sinf) is bit-exact: random fBm parameters, positions of both signs around the
