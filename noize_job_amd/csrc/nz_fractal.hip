@@ -476,10 +476,6 @@ __device__ __forceinline__ void fractal_batch_enter(nz_fractal_params &p, float 
     dst += blockIdx.y * p.bstride;
 }
 
-#ifndef NZ_FT_ROWS
-#define NZ_FT_ROWS 8
-#endif
-constexpr int FT_ROWS = NZ_FT_ROWS;  // rows per workgroup: amortises the 10 KB table copy
 
 template <int VEC>
 __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restrict__ dst, int rows, int cols, int pitch,
@@ -499,8 +495,8 @@ __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restr
     float xi[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; c++) xi[c] = ((float)(x0 + c) + p.posx) / p.noise_size;
-    int zend = min(rows, (by + 1) * FT_ROWS);
-    for (int z = by * FT_ROWS; z < zend; z++) {
+    int zend = min(rows, (by + 1) * p.rows_per_wg);
+    for (int z = by * p.rows_per_wg; z < zend; z++) {
         float zi = ((float)z + p.posz) / p.noise_size;
         float t[VEC];
 #pragma unroll
@@ -651,8 +647,8 @@ __global__ __launch_bounds__(256) void fractal_tab2_kernel(float *__restrict__ d
     float xi[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; c++) xi[c] = ((float)(x0 + c) + p.posx) / p.noise_size;
-    int zend = min(rows, (by + 1) * 8);
-    for (int z = by * 8; z < zend; z++) {
+    int zend = min(rows, (by + 1) * p.rows_per_wg);
+    for (int z = by * p.rows_per_wg; z < zend; z++) {
         float zi = ((float)z + p.posz) / p.noise_size;
         float t[VEC];
 #pragma unroll
@@ -806,8 +802,8 @@ __global__ __launch_bounds__(256) void fractal_tab3_kernel(float *__restrict__ d
     int x0 = bx * 256 + threadIdx.x;
     if (x0 >= cols) return;
     float xi = ((float)x0 + p.posx) / p.noise_size;
-    int zend = min(rows, (by + 1) * 8);
-    for (int z = by * 8; z < zend; z++) {
+    int zend = min(rows, (by + 1) * p.rows_per_wg);
+    for (int z = by * p.rows_per_wg; z < zend; z++) {
         float zi = ((float)z + p.posz) / p.noise_size;
         float t = 0.0f, detune = 0.0f, f = 1.0f, a = p.amp;
         // the rotation shrinks |x|, |z| (factor <= 1.16 on x + z), so the 2-D limit keeps the lattice in range
@@ -834,7 +830,6 @@ __global__ __launch_bounds__(256) void fractal_tab3_kernel(float *__restrict__ d
 }
 
 constexpr int FR_THREADS = 256;
-constexpr int FR_ROWS = 8;
 
 // FractalGenerator.NoiseValue (Fractal.cs:114-131) for VEC consecutive cells of one row.
 template <int BASIS, int VEC>
@@ -862,9 +857,9 @@ __global__ __launch_bounds__(FR_THREADS) void fractal_kernel(float *__restrict__
     float xi[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; c++) xi[c] = ((float)(x0 + c) + p.posx) / p.noise_size;
-    // FR_ROWS rows per workgroup: amortises the table fill of the periodic bases
-    int zend = min(rows, (by + 1) * FR_ROWS);
-    for (int z = by * FR_ROWS; z < zend; z++) {
+    // p.rows_per_wg rows per workgroup: 8 amortise the table fill of the periodic bases on big grids
+    int zend = min(rows, (by + 1) * p.rows_per_wg);
+    for (int z = by * p.rows_per_wg; z < zend; z++) {
         float zi = ((float)z + p.posz) / p.noise_size;
         float t[VEC];
 #pragma unroll
@@ -907,7 +902,7 @@ int32_t launch_basis(hipStream_t s, float *dst, int rows, int cols, int pitch, c
                      const float *d_rgrad, int count) {
     int per_block = FR_THREADS * VEC;
     int bpr = (cols + per_block - 1) / per_block;
-    long long blocks = (long long)bpr * ((rows + FR_ROWS - 1) / FR_ROWS);
+    long long blocks = (long long)bpr * ((rows + p.rows_per_wg - 1) / p.rows_per_wg);
     if (blocks > 0x7fffffffLL) {
         nz_set_error("fractal grid too large");
         return NZ_ERR_INVALID;
@@ -927,6 +922,13 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
     nz_fractal_params p = p_in;
     p.positions = positions;
     p.bstride = count > 1 || positions ? bstride : 0;
+    // 8 rows per workgroup amortise the table staging on big grids; a small grid gets more, shorter workgroups
+    // (the launch lasts as long as one workgroup's rows)
+    p.rows_per_wg = 8;
+    {
+        long long wg_per_row = (cols + 511) / 512;
+        while (p.rows_per_wg > 1 && wg_per_row * ((rows + p.rows_per_wg - 1) / p.rows_per_wg) * count < 2048) p.rows_per_wg >>= 1;
+    }
     static const int use_tab = getenv("NZ_NOISE_TAB") ? atoi(getenv("NZ_NOISE_TAB")) : 1;
     if (noiseType == NZ_NOISE_SIMPLEX && use_tab && d_simplex) {
 #ifndef NZ_FT_VEC
@@ -934,7 +936,7 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
 #endif
         constexpr int VEC = NZ_FT_VEC;
         int bpr = (cols + 256 * VEC - 1) / (256 * VEC);
-        long long blocks = (long long)bpr * ((rows + FT_ROWS - 1) / FT_ROWS);
+        long long blocks = (long long)bpr * ((rows + p.rows_per_wg - 1) / p.rows_per_wg);
         const int *t1 = reinterpret_cast<const int *>(d_simplex);
         const float4 *t2 = reinterpret_cast<const float4 *>(t1 + NZ_T1_N);
         hipLaunchKernelGGL((fractal_simplex_tab_kernel<VEC>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows, cols,
@@ -949,7 +951,7 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         const int *t1 = reinterpret_cast<const int *>(base);
         const float2 *t2 = reinterpret_cast<const float2 *>(base + NZ_TB1_N * 4);
         int bpr = (cols + 255) / 256;
-        long long blocks = (long long)bpr * ((rows + 7) / 8);
+        long long blocks = (long long)bpr * ((rows + p.rows_per_wg - 1) / p.rows_per_wg);
         if (noiseType == NZ_NOISE_PERLIN)
             hipLaunchKernelGGL((fractal_tab2_kernel<NZ_NOISE_PERLIN, 1>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows,
                                cols, pitch, bpr, p, t1, t2);
@@ -966,7 +968,7 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         const int *p3 = reinterpret_cast<const int *>(base);
         const float4 *g3 = reinterpret_cast<const float4 *>(base + NZ_P3_N * 4);
         int bpr = (cols + 255) / 256;
-        long long blocks = (long long)bpr * ((rows + 7) / 8);
+        long long blocks = (long long)bpr * ((rows + p.rows_per_wg - 1) / p.rows_per_wg);
         if (noiseType == NZ_NOISE_DOMAIN_ROTATED_PERLIN)
             hipLaunchKernelGGL((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_PERLIN>), dim3((unsigned)blocks, count), dim3(256), 0,
                                s, dst, rows, cols, pitch, bpr, p, p3, g3);

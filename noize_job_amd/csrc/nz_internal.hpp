@@ -93,6 +93,7 @@ struct nz_fractal_params {
     // batched launch (one grid per blockIdx.y): grids `bstride` floats apart, {xpos, zpos} of grid b at positions[2b]
     const int32_t *positions = nullptr;
     size_t bstride = 0;
+    int rows_per_wg = 8;  // rows one workgroup walks through (8 amortises the table staging; fewer for small grids)
 };
 
 // plane geometry handed to every stencil kernel: clamp rows are the global border seen from the
