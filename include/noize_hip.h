@@ -258,6 +258,20 @@ int32_t nz_reduction_job(nz_ctx *ctx, int32_t operation, float *srcL, const floa
 int32_t nz_curve_job(nz_ctx *ctx, float *src, float *tmp, const float *curve, int32_t curveSize,
                      int32_t resolution, nz_handle dep, nz_handle *out);
 
+/* ---- live erosion: the deterministic grid jobs (planes indexed x * resolution + z, WorldTile.getIdx,
+ * Geologic/ParticleErosion/LiveErosionDataTypes.cs:608-610) ------------------------------------------------
+ * UpdateFlowFromTrackJob.Schedule(pool, flow, track, ep, tm, res, deps), MultiThreadErosionJob.cs:240-261:
+ * ep.FLOW_LOSS_RATE, ep.SURFACE_EVAPORATION_RATE and tm.HEIGHT are passed as scalars. */
+int32_t nz_update_flow_from_track(nz_ctx *ctx, float *pool, float *flow, float *track, float flowLossRate,
+                                  float surfaceEvaporationRate, float tileHeight, int32_t resolution,
+                                  nz_handle dep, nz_handle *out);
+/* PoolAutomataJob.Schedule(pool, height, particleQueue, ep, tm, iterations, res, drainParticles, deps),
+ * MultiThreadErosionJob.cs:289-325, with drainParticles == false: `iterations` x four colour passes of
+ * WorldTile.SpreadPool (LiveErosionDataTypes.cs:938-1010).  The neighbour order comes from NativeArray.Sort() of
+ * com.unity.collections 1.4.0 (not in the reference tree; restated: insertion sort for 4 elements). */
+int32_t nz_pool_automata(nz_ctx *ctx, float *pool, const float *height, int32_t iterations, int32_t resolution,
+                         nz_handle dep, nz_handle *out);
+
 /* MeshJobScheduleDelegate with G = SharedSquareGridPosition (Mesh/Job/MeshJob.cs:37-60,
  * Mesh/Generators/SharedSquareGridPosition.cs:20-50; MeshHelper.makeSquarePlanarMesh): the flat unit-square grid,
  * same vertex / index layout and counts as nz_heightmap_mesh.  TileSize / Height of the delegate only set

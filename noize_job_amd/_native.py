@@ -82,6 +82,8 @@ SIGNATURES = {
                                   _f, _f] + _tail),
     "nz_constant_job": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _f, _i] + _tail),
     "nz_reduction_job": (_i, [ctx_p, _i, dev_ptr, dev_ptr, dev_ptr, _i] + _tail),
+    "nz_update_flow_from_track": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, _f, _f, _f, _i] + _tail),
+    "nz_pool_automata": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
     "nz_crop_job": (_i, [ctx_p, dev_ptr, _i, dev_ptr, _i] + _tail),
     "nz_curve_job": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, _i, _i] + _tail),
     "nz_thermal_erosion": (_i, [ctx_p, dev_ptr, _f, _f, _f, _i, _i] + _tail),

@@ -1299,6 +1299,34 @@ extern "C" int32_t nz_curve_job(nz_ctx *ctx, float *src, float *tmp, const float
     return nz_ctx_finish(ctx, out);
 }
 
+// ---- live erosion: the deterministic grid jobs ----------------------------------------
+// UpdateFlowFromTrackJob.Schedule, Geologic/ParticleErosion/MultiThreadErosionJob.cs:240-261
+extern "C" int32_t nz_update_flow_from_track(nz_ctx *ctx, float *pool, float *flow, float *track, float flowLossRate,
+                                             float surfaceEvaporationRate, float tileHeight, int32_t resolution,
+                                             nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(pool && flow && track, "pool/flow/track is NULL");
+    NZ_TRY(nz_launch_flow_from_track(ctx->stream, pool, flow, track, (size_t)resolution * resolution, flowLossRate,
+                                     surfaceEvaporationRate / tileHeight));
+    return nz_ctx_finish(ctx, out);
+}
+
+// PoolAutomataJob.Schedule, MultiThreadErosionJob.cs:289-325, with drainParticles == false (the other setting feeds
+// the particle queue, which is outside the deterministic part)
+extern "C" int32_t nz_pool_automata(nz_ctx *ctx, float *pool, const float *height, int32_t iterations, int32_t resolution,
+                                    nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(pool && height && pool != height, "pool/height must be two distinct planes");
+    NZ_REQUIRE(resolution >= 2 && iterations >= 0, "resolution < 2 or iterations < 0");
+    for (int i = 0; i < iterations; i++)
+        for (int xoff = 0; xoff < 2; xoff++)
+            for (int zoff = 0; zoff < 2; zoff++)
+                NZ_TRY(nz_launch_pool_automata_pass(ctx->stream, pool, height, resolution, xoff, zoff));
+    return nz_ctx_finish(ctx, out);
+}
+
 // CropJobDelegate, Filter/Sample/CropJob.cs:62-68
 extern "C" int32_t nz_crop_job(nz_ctx *ctx, const float *input, int32_t inputResolution, float *output,
                                int32_t outputResolution, nz_handle dep, nz_handle *out) {

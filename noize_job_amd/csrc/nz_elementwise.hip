@@ -82,6 +82,112 @@ __global__ __launch_bounds__(CT) void curve_kernel(float *data, size_t n, const 
     }
 }
 
+// ---- live erosion: the deterministic grid jobs (planes indexed x * res + z, LiveErosionDataTypes.cs:608-610) -------
+// WorldTile.UpdateFlowMapFromTrack, LiveErosionDataTypes.cs:869-886 (UpdateFlowFromTrackJob)
+__global__ __launch_bounds__(CT) void flow_from_track_kernel(float *__restrict__ pool, float *__restrict__ flow,
+                                                            float *__restrict__ track, size_t n, float flowLossRate,
+                                                            float evaporation /* SURFACE_EVAPORATION_RATE / tm.HEIGHT */) {
+    size_t i = (size_t)blockIdx.x * CT + threadIdx.x;
+    if (i >= n) return;
+    const float MINFLOWPOOL = .00005f;
+    float pv = flow[i], tv = track[i], poolV = pool[i];
+    float f;
+    if (poolV > MINFLOWPOOL) {
+        f = ((1.0f - 0.1f * flowLossRate) * pv);
+    } else if (tv > 0.0f) {
+        f = ((1.0f - flowLossRate) * pv) + (flowLossRate * 50.0f * tv) / (1.0f + 50.0f * tv);
+    } else {
+        f = (1.0f - flowLossRate) * pv;
+    }
+    flow[i] = f;
+    track[i] = 0.0f;
+    pool[i] = fmaxf(poolV - evaporation, 0.0f);
+}
+
+// FloodedNeighbor ordering (LiveErosionDataTypes.cs:1013-1050): by the hash of height + water = the float's bits as a
+// signed int (+-0 -> 0); the same cell compares equal.
+struct flooded {
+    int idx;
+    float height, water;
+};
+__device__ __forceinline__ int float_hash(float f) { return f == 0.0f ? 0 : __builtin_bit_cast(int, f); }
+__device__ __forceinline__ int flooded_cmp(const flooded &a, const flooded &b) {
+    if (a.idx == b.idx) return 0;
+    return float_hash(a.height + a.water) > float_hash(b.height + b.water) ? 1 : -1;
+}
+
+// One colour pass of PoolAutomataJob (MultiThreadErosionJob.cs:264-327, drainParticles == false): thread k walks row
+// z = 2k + zoff over x = xoff (+1 for odd k), step 2, calling WorldTile.SpreadPool (LiveErosionDataTypes.cs:938-1010)
+// wherever water stands.  The walk along a row is sequential in the reference too (a cell's right-hand neighbour is
+// the next cell's left-hand one); rows of one pass share no cell.  z is the fast index of the planes, so the lanes
+// of a wave touch neighbouring addresses at every step.
+__global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *__restrict__ pool, const float *__restrict__ height,
+                                                               int res, int xoff, int zoff) {
+    int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= res / 2) return;
+    int z = 2 * k + zoff;
+    for (int x = xoff + ((k & 1) ? 1 : 0); x < res; x += 2) {
+        size_t idx = (size_t)x * res + z;
+        float hWater = pool[idx];
+        if (!(hWater > 0.0f)) continue;
+        float hLand = height[idx];
+        float tHeight = hLand + hWater;
+        flooded b[4];
+        const int dx[4] = {0, 1, 0, -1}, dz[4] = {1, 0, -1, 0};  // up, right, down, left; SafeIdx clamps (:585-589)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int nx = min(max(x + dx[e], 0), res - 1), nz = min(max(z + dz[e], 0), res - 1);
+            b[e].idx = nx * res + nz;
+            b[e].height = height[b[e].idx];
+            b[e].water = pool[b[e].idx];
+        }
+        // NativeArray.Sort() of com.unity.collections 1.4.0 on 4 elements: insertion sort, element i+1 moves left
+        // while it compares < 0 -- written out with fixed positions so that b[] stays in registers
+        {
+            flooded t = b[1];
+            if (flooded_cmp(t, b[0]) < 0) { b[1] = b[0]; b[0] = t; }
+            t = b[2];
+            if (flooded_cmp(t, b[1]) < 0) {
+                b[2] = b[1];
+                if (flooded_cmp(t, b[0]) < 0) { b[1] = b[0]; b[0] = t; } else { b[1] = t; }
+            }
+            t = b[3];
+            if (flooded_cmp(t, b[2]) < 0) {
+                b[3] = b[2];
+                if (flooded_cmp(t, b[1]) < 0) {
+                    b[2] = b[1];
+                    if (flooded_cmp(t, b[0]) < 0) { b[1] = b[0]; b[0] = t; } else { b[1] = t; }
+                } else {
+                    b[2] = t;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float diffV = tHeight - (b[e].height + b[e].water);
+            if (hWater < 1E-3f) continue;
+            if (b[e].water <= 0.0f && hLand >= b[e].height) {
+                pool[b[e].idx] = b[e].water + hWater;
+                hWater = 0.0f;
+                tHeight = hLand;
+            } else if (diffV > 0.0f) {
+                if (hWater <= 0.0f) continue;
+                float fill = fminf(0.25f * hWater, 0.25f * diffV);
+                hWater -= fill;
+                tHeight = hLand + hWater;
+                pool[b[e].idx] = b[e].water + fill;
+            } else if (diffV < 0.0f) {
+                if (b[e].water <= 0.0f) continue;
+                float fill = fminf(0.25f * b[e].water, -0.25f * diffV);
+                hWater += fill;
+                tHeight = hLand + hWater;
+                pool[b[e].idx] = b[e].water + (-1.0f * fill);
+            }
+        }
+        pool[idx] = hWater;
+    }
+}
+
 // CropJob (Filter/Sample/CropJob.cs:34-41): out(x,z) = in(clamp(x + Offset), clamp(z + Offset)); the reference never
 // sets Offset, so it is 0 (top-left crop).  One thread per output cell; rows of different pitch on either side.
 __global__ __launch_bounds__(CT) void crop_kernel(const float *__restrict__ in, int in_res, float *__restrict__ out,
@@ -166,6 +272,24 @@ int32_t nz_launch_curve(hipStream_t s, float *data, size_t n, const float *curve
     int aligned = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
     hipLaunchKernelGGL(curve_kernel, dim3(blocks_for(n)), dim3(CT), (size_t)curveSize * sizeof(float), s, data, n, curve,
                        curveSize, aligned);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_flow_from_track(hipStream_t s, float *pool, float *flow, float *track, size_t n, float flowLossRate,
+                                  float evaporation) {
+    if (n == 0) return NZ_OK;
+    hipLaunchKernelGGL(flow_from_track_kernel, dim3((unsigned)((n + CT - 1) / CT)), dim3(CT), 0, s, pool, flow, track, n,
+                       flowLossRate, evaporation);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *height, int res, int xoff, int zoff) {
+    int jobs = res / 2;
+    if (jobs <= 0) return NZ_OK;
+    hipLaunchKernelGGL(pool_automata_pass_kernel, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, s, pool, height, res,
+                       xoff, zoff);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

@@ -80,6 +80,8 @@ def lib():
         L.nzo_reduce.argtypes = [f32p, f32p, f32p, i, i, i]
         L.nzo_curve.argtypes = [f32p, f32p, f32p, i, i, i]
         L.nzo_crop.argtypes = [f32p, i, f32p, i]
+        L.nzo_update_flow_from_track.argtypes = [f32p, f32p, f32p, i, f, f, f]
+        L.nzo_pool_automata.argtypes = [f32p, f32p, i, i]
         L.nzo_thermal_erosion.argtypes = [f32p, i, f, f, f, i]
         L.nzo_pipeline.argtypes = [f32p, f32p, i, i, i, f, f, f, f, i, i, i, i, i, i, i, f, f, i]
         # the GPU box grants a CPU share, not the whole host: size the OpenMP team to the affinity mask
@@ -348,6 +350,22 @@ def crop(a, out_res):
     out = np.empty((out_res, out_res), np.float32)
     lib().nzo_crop(_p(a), a.shape[0], _p(out), out_res)
     return out
+
+
+def update_flow_from_track(pool, flow, track, flow_loss_rate=0.05, evaporation_rate=0.1, tile_height=1000.0):
+    """Planes indexed [x, z] (x-major, LiveErosionDataTypes.cs:608-610).  Returns (pool, flow, track)."""
+    pool, flow, track = _plane(pool).copy(), _plane(flow).copy(), _plane(track).copy()
+    lib().nzo_update_flow_from_track(_p(pool), _p(flow), _p(track), pool.shape[0], flow_loss_rate, evaporation_rate,
+                                     tile_height)
+    return pool, flow, track
+
+
+def pool_automata(pool, height, iterations=1):
+    """Planes indexed [x, z].  Returns the new pool plane."""
+    pool, height = _plane(pool).copy(), _plane(height)
+    if lib().nzo_pool_automata(_p(pool), _p(height), pool.shape[0], iterations):
+        raise ValueError("bad resolution")
+    return pool
 
 
 def thermal_erosion(a, talus=45.0, increment=0.5, ratio=0.75, iterations=1):

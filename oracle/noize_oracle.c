@@ -985,6 +985,124 @@ int nzo_reduce(float *srcL, const float *srcR, float *tmp, int op, int rows, int
     return 0;
 }
 
+/* ---- live erosion: the deterministic grid jobs -----------------------------------------
+ * WorldTile planes are indexed x * res + z (LiveErosionDataTypes.cs:608-610), not z * res + x. */
+
+/* WorldTile.UpdateFlowMapFromTrack, LiveErosionDataTypes.cs:869-886 (UpdateFlowFromTrackJob, MultiThreadErosionJob.cs:
+ * 226-262): flow decays, gains from the particle track where no pool stands, the track is cleared, pools evaporate */
+int nzo_update_flow_from_track(float *pool, float *flow, float *track, int res, float flowLossRate,
+                               float surfaceEvaporationRate, float tileHeight) {
+    const float MINFLOWPOOL = .00005f; /* :440 */
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z < res; z++) {
+        for (int x = 0; x < res; x++) {
+            size_t i = (size_t)x * res + z;
+            float pv = flow[i], tv = track[i], poolV = pool[i];
+            if (poolV > MINFLOWPOOL) {
+                flow[i] = ((1.0f - 0.1f * flowLossRate) * pv);
+            } else if (tv > 0.0f) {
+                flow[i] = ((1.0f - flowLossRate) * pv) + (flowLossRate * 50.0f * tv) / (1.0f + 50.0f * tv);
+            } else {
+                flow[i] = (1.0f - flowLossRate) * pv;
+            }
+            track[i] = 0.0f;
+            pool[i] = maxf_(poolV - (surfaceEvaporationRate / tileHeight), 0.0f);
+        }
+    }
+    return 0;
+}
+
+/* FloodedNeighbor (LiveErosionDataTypes.cs:1013-1050): ordered by the HASH of height + water, i.e. by the bit
+ * pattern of the float as a signed int (float.GetHashCode: the bits, +-0 -> 0); same idx compares equal. */
+typedef struct { int idx; float height, water; } nzo_flooded;
+static inline int nzo_float_hash(float f) {
+    if (f == 0.0f) return 0;
+    int v;
+    memcpy(&v, &f, sizeof v);
+    return v;
+}
+static inline int nzo_flooded_cmp(const nzo_flooded *a, const nzo_flooded *b) { /* a.CompareTo(b) */
+    if (a->idx == b->idx) return 0;
+    return nzo_float_hash(a->height + a->water) > nzo_float_hash(b->height + b->water) ? 1 : -1;
+}
+/* NativeArray<T>.Sort() of com.unity.collections 1.4.0 (package.json:17; not in the reference tree, restated from
+ * the published source): partitions of <= 16 elements are insertion-sorted, element i+1 moving left while it
+ * compares < 0 -- for 4 elements that is the whole sort. */
+static inline void nzo_flooded_sort4(nzo_flooded *a) {
+    for (int i = 0; i < 3; i++) {
+        int j = i;
+        nzo_flooded t = a[i + 1];
+        while (j >= 0 && nzo_flooded_cmp(&t, &a[j]) < 0) {
+            a[j + 1] = a[j];
+            j--;
+        }
+        a[j + 1] = t;
+    }
+}
+
+/* WorldTile.SpreadPool with drainParticles == false, LiveErosionDataTypes.cs:938-1010 */
+static void nzo_spread_pool(float *pool, const float *height, int res, int x, int z) {
+    size_t idx = (size_t)x * res + z;
+    float hLand = height[idx], hWater = pool[idx];
+    if (hWater <= 0.0f) return;
+    float tHeight = hLand + hWater;
+    /* up (0,1), right (1,0), down (0,-1), left (-1,0); SafeIdx clamps at the border (:585-589), so a border cell can
+     * be its own neighbour */
+    const int dx[4] = {0, 1, 0, -1}, dz[4] = {1, 0, -1, 0};
+    nzo_flooded b[4];
+    for (int e = 0; e < 4; e++) {
+        int nx = x + dx[e], nz = z + dz[e];
+        nx = nx < 0 ? 0 : (nx > res - 1 ? res - 1 : nx);
+        nz = nz < 0 ? 0 : (nz > res - 1 ? res - 1 : nz);
+        b[e].idx = nx * res + nz;
+        b[e].height = height[b[e].idx];
+        b[e].water = pool[b[e].idx];
+    }
+    nzo_flooded_sort4(b);
+    for (int e = 0; e < 4; e++) {
+        float fill = 0.0f;
+        float diffV = tHeight - (b[e].height + b[e].water);
+        if (hWater < 1E-3f) continue;
+        if (b[e].water <= 0.0f && hLand >= b[e].height) { /* found a drain: all of the water goes there */
+            pool[b[e].idx] = b[e].water + hWater;
+            hWater = 0.0f;
+            tHeight = hLand;
+        } else if (diffV > 0.0f) {
+            if (hWater <= 0.0f) continue;
+            fill = minf_(0.25f * hWater, 0.25f * diffV);
+            hWater -= fill;
+            tHeight = hLand + hWater;
+            pool[b[e].idx] = b[e].water + fill;
+        } else if (diffV < 0.0f) {
+            if (b[e].water <= 0.0f) continue;
+            fill = minf_(0.25f * b[e].water, -0.25f * diffV);
+            hWater += fill;
+            tHeight = hLand + hWater;
+            pool[b[e].idx] = b[e].water + (-1.0f * fill);
+        }
+    }
+    pool[idx] = hWater;
+}
+
+/* PoolAutomataJob.Schedule / Execute, MultiThreadErosionJob.cs:264-327, drainParticles == false: per iteration four
+ * colour passes (xoff, zoff); job k of a pass walks row z = 2k + zoff over x = xoff (+1 for odd k), step 2.  Rows of
+ * one pass never touch a common cell, so the pass is deterministic however its jobs are scheduled. */
+int nzo_pool_automata(float *pool, const float *height, int res, int iterations) {
+    if (res < 2) return -1;
+    for (int it = 0; it < iterations; it++)
+        for (int xoff = 0; xoff < 2; xoff++)
+            for (int zoff = 0; zoff < 2; zoff++) {
+#pragma omp parallel for schedule(static)
+                for (int k = 0; k < res / 2; k++) {
+                    int offset = xoff + ((k % 2 != 0) ? 1 : 0);
+                    int z = 2 * k + zoff;
+                    for (int x = offset; x < res; x += 2)
+                        if (pool[(size_t)x * res + z] > 0.0f) nzo_spread_pool(pool, height, res, x, z);
+                }
+            }
+    return 0;
+}
+
 /* CropJob<ReadTileData,WriteTileData>.Execute, Filter/Sample/CropJob.cs:34-41.  ScheduleParallel (:43-59)
  * never assigns `Offset`, so the "centre crop" takes the top-left corner: out(x,z) = in(x+0, z+0) with the
  * read tile's clamp-to-edge (an output larger than the input repeats the last row / column). */

@@ -134,6 +134,9 @@ int nzo_mesh_heightmap(int meshType, const float *heights, int resolution, int i
 /* ---- element-wise stages ---- */
 int nzo_constant(float *src, float *tmp, int op, float value, int rows, int cols);      /* Filter/ConstantJob.cs */
 int nzo_reduce(float *srcL, const float *srcR, float *tmp, int op, int rows, int cols); /* Filter/ReductionJob.cs */
+int nzo_update_flow_from_track(float *pool, float *flow, float *track, int res, float flowLossRate,
+                               float surfaceEvaporationRate, float tileHeight); /* LiveErosionDataTypes.cs:869-886 */
+int nzo_pool_automata(float *pool, const float *height, int res, int iterations); /* MultiThreadErosionJob.cs:264-327 */
 int nzo_crop(const float *input, int inputResolution, float *output, int outputResolution); /* Filter/Sample/CropJob.cs */
 int nzo_curve(float *src, float *tmp, const float *curve, int curveSize, int rows, int cols); /* Filter/Curve/CurveJob.cs */
 

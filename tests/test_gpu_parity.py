@@ -576,6 +576,28 @@ def test_mesh_from_a_context_buffer(nj, ctx, oracle):
     mgr.OnDestroy()
 
 
+@pytest.mark.parametrize("res", [2, 9, 64, 255])
+def test_live_erosion_grid_jobs(nj, ctx, oracle, res):
+    # UpdateFlowFromTrackJob and PoolAutomataJob (drainParticles == false): the deterministic part of the live erosion
+    rng = np.random.default_rng(res)
+    height = rng.random((res, res), dtype=f32)
+    pool = np.where(rng.random((res, res)) < 0.35, rng.random((res, res), dtype=f32) * f32(0.3), 0).astype(f32)
+    pool[0, :] = f32(0.05)          # border cells: a clamped neighbour is the cell itself
+    flow = rng.random((res, res), dtype=f32)
+    track = np.where(rng.random((res, res)) < 0.5, rng.random((res, res), dtype=f32), 0).astype(f32)
+    d_pool, d_flow, d_track = ctx.from_host(pool), ctx.from_host(flow), ctx.from_host(track)
+    ctx.call("nz_update_flow_from_track", d_pool.ptr, d_flow.ptr, d_track.ptr, 0.05, 0.1, 700.0, res).Complete()
+    p, fl, tr = oracle.update_flow_from_track(pool, flow, track, 0.05, 0.1, 700.0)
+    assert np.array_equal(d_pool.ToArray((res, res)), p) and np.array_equal(d_flow.ToArray((res, res)), fl)
+    assert np.array_equal(d_track.ToArray((res, res)), tr)
+    for iters in (1, 3):
+        d_pool, d_h = ctx.from_host(pool), ctx.from_host(height)
+        ctx.call("nz_pool_automata", d_pool.ptr, d_h.ptr, iters, res).Complete()
+        assert np.array_equal(d_pool.ToArray((res, res)), oracle.pool_automata(pool, height, iters)), iters
+    with pytest.raises(nj.NoizeError):
+        ctx.call("nz_pool_automata", d_pool.ptr, d_pool.ptr, 1, res)
+
+
 def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):
     # BasicDemo "ParallelFlowMap": Perlin fBm -> Invert (curve) -> FlowMapStage -> CurveBoostContrast
     res = 128

@@ -449,3 +449,52 @@ def test_square_planar_mesh_by_hand(oracle):
     third = f32(1.0) / f32(3.0)
     assert np.array_equal(vtx[:, 10].reshape(3, 3)[0], np.array([0.0, third, f32(2.0) / f32(3.0)], f32))
     assert np.array_equal(idx[:6], np.array([0, 3, 1, 1, 3, 4], np.uint32))   # vi=4: (4-4, 4-1, 4-3), (4-3, 4-1, 4)
+
+
+# ---- live erosion grid jobs (planes indexed [x, z]) ---------------------------------------------------------------
+def test_update_flow_from_track_known_answers(oracle):
+    # LiveErosionDataTypes.cs:869-886
+    pool = np.array([[0.0, 0.001], [0.00004, 0.0]], f32)
+    flow = np.array([[0.5, 0.5], [0.5, 0.0]], f32)
+    track = np.array([[0.0, 3.0], [0.02, 0.0]], f32)
+    p, fl, tr = oracle.update_flow_from_track(pool, flow, track, 0.05, 0.1, 1000.0)
+    assert np.array_equal(tr, np.zeros((2, 2), f32))
+    assert fl[0, 0] == f32(f32(1.0) - f32(0.05)) * f32(0.5)                       # no pool, no track: decay
+    assert fl[0, 1] == f32(f32(1.0) - f32(0.1) * f32(0.05)) * f32(0.5)              # pool: slow decay, track ignored
+    want = f32(f32(f32(1.0) - f32(0.05)) * f32(0.5)) + f32(f32(f32(0.05) * f32(50.0)) * f32(0.02)) / f32(f32(1.0) + f32(f32(50.0) * f32(0.02)))
+    assert fl[1, 0] == f32(want)                                                   # track feeds the flow
+    evap = f32(0.1) / f32(1000.0)
+    assert p[0, 1] == f32(0.001) - evap and p[1, 0] == 0.0 and p[0, 0] == 0.0      # evaporation, floored at 0
+
+
+def test_pool_automata_known_answers(oracle):
+    # MultiThreadErosionJob.cs:264-327 + WorldTile.SpreadPool (LiveErosionDataTypes.cs:938-1010)
+    res = 8
+    # (1) two wet cells in a walled basin exchange a quarter of their level difference per visit:
+    #     A = (3,3) is visited in colour pass (xoff 0, zoff 1), B = (4,3) in pass (1, 1)
+    walls = np.full((res, res), 10.0, f32)
+    walls[3, 3] = walls[4, 3] = 0.0
+    pool = np.zeros((res, res), f32)
+    pool[3, 3], pool[4, 3] = 1.0, 0.2
+    out = oracle.pool_automata(pool, walls, 1)
+    assert out[3, 3] == pytest.approx(0.7, abs=1e-6) and out[4, 3] == pytest.approx(0.5, abs=1e-6)
+    assert (out > 0).sum() == 2
+    level = oracle.pool_automata(pool, walls, 60)
+    assert abs(level[3, 3] - level[4, 3]) < 1e-3 and level.sum() == pytest.approx(1.2, abs=1e-5)
+    # (2) next to dry land that is not higher, the whole pool "drains" into the first such neighbour: on flat
+    #     land a lone pool hops around as a unit, on a slope it runs downhill
+    flat = np.zeros((res, res), f32)
+    pool = np.zeros((res, res), f32)
+    pool[4, 4] = 1.0
+    one = oracle.pool_automata(pool, flat, 1)
+    assert one.sum() == 1.0 and (one > 0).sum() == 1
+    slope = np.tile(np.arange(res, dtype=f32)[:, None], (1, res))           # height grows with x
+    pool = np.zeros((res, res), f32)
+    pool[5, 3] = 0.5
+    out = oracle.pool_automata(pool, slope, 1)
+    assert out[5, 3] == 0.0 and out[:5, :].sum() == pytest.approx(0.5)     # everything ran to lower x
+    assert not oracle.pool_automata(np.zeros((res, res), f32), slope, 3).any()
+    # (3) less than 1e-3 of water never moves
+    pool = np.zeros((res, res), f32)
+    pool[2, 2] = 5e-4
+    assert np.array_equal(oracle.pool_automata(pool, flat, 4), pool)

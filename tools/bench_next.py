@@ -91,6 +91,28 @@ def main():
         run("mesh Overshoot %d^2" % (res - 8), nj.MeshTileStage(ctx, nj.MeshType.OvershootSquareGridHeightMap), md, vb,
             "write-only streams")
         run("mesh SquareGrid %d^2" % (res - 8), nj.MeshTileStage(ctx, nj.MeshType.SquareGridHeightMap), md, vb)
+        # live erosion grid jobs (not PipelineStages: timed through the C ABI)
+        import numpy as np
+        rng = np.random.default_rng(0)
+        pool = ctx.from_host(np.where(rng.random((res, res)) < 0.3, rng.random((res, res), dtype=np.float32) * 0.3, 0).astype(np.float32))
+        flow, track = ctx.alloc(cells), ctx.alloc(cells)
+        for name, fn, bpc, note in (
+                ("live erosion: flow from track", lambda: ctx.call("nz_update_flow_from_track", pool.ptr, flow.ptr, track.ptr, 0.05, 0.1, 1000.0, res), 24, ""),
+                ("live erosion: pool automaton x1 (4 colour passes)", lambda: ctx.call("nz_pool_automata", pool.ptr, data.ptr, 1, res), 4 * 8,
+                 "sequential along every row, as in the reference: res/2 threads per pass")):
+            fn()
+            ctx.synchronize()
+            h0 = ctx.record()
+            for _ in range(3):
+                fn()
+            h1 = ctx.record()
+            h1.Complete()
+            ms = ctx.elapsed_ms(h0, h1) / 3
+            gbs = bpc * cells / (ms * 1e-3) / 1e9
+            rows.append({"stage": name, "ms": round(ms, 4), "Mcells/s": round(cells / ms / 1e3), "algorithmic_B_per_cell": bpc,
+                         "algorithmic_GB/s": round(gbs, 1), "frac_hbm": round(gbs / HBM, 3), "note": note})
+            print("%-44s %8.4f ms %9.0f Mcells/s  %6.0f B/cell  %7.0f GB/s (%5.1f %% of 8 TB/s) %s" % (
+                name, ms, cells / ms / 1e3, bpc, gbs, 100 * gbs / HBM, note))
     if a.json:
         json.dump({"res": res, "rows": rows}, open(a.json, "w"), indent=1)
 
