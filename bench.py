@@ -16,7 +16,6 @@ every stage; both come from HIP events recorded on the kernels' stream inside th
 box's host cores on one full 4096^2 pass.
 """
 import argparse
-import ctypes as C
 import glob
 import json
 import os

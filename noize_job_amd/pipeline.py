@@ -13,13 +13,12 @@ Filter/Kernel/Blur/Stage{Gaussian,Smooth}Blur.cs, Geologic/Stage/FlowMapStage.cs
 Mesh/Stage/MeshTileStage.cs.
 """
 import collections
-import ctypes as C
 import enum
 
 import numpy as np
 
 from . import _native as N
-from .runtime import Context, DeviceTile, JobHandle
+from .runtime import JobHandle
 
 
 # ---- enums (values are the C# enum values) ----------------------------------------------------

@@ -7,11 +7,8 @@ A context buffer is a DeviceTile owned by the manager and keyed by a string, so 
 pipeline (WriteGeneratorContextStage) stays in HBM for the pipelines that read it
 (ReadGeneratorContextStage); `SetSavePath` adds the reference's on-disk form (persistence.py).
 """
-import numpy as np
-
 from .persistence import PipelineSerdeManager
 from .pipeline import GeneratorData, MeshStageData, MeshTileStage, MeshType, PipelineStage
-from .runtime import JobHandle
 
 
 class HandleLock:  # PipelineStateLock.cs:12-27

@@ -2,8 +2,6 @@
 seeded inputs.  Bar: 1e-5 relative (abs floor 1e-6) for float planes, bit-exact for mesh indices
 (BASELINE.json); where the kernels reproduce the oracle's operation order the planes are
 additionally required to be equal bit for bit."""
-import ctypes as C
-
 import numpy as np
 import pytest
 
