@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--cols", type=int, default=16384, help="grid columns at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="run the row-stripe path even with one rank (rehearsal)")
-    ap.add_argument("--halo", choices=("recompute", "exchange"), default="recompute",
+    ap.add_argument("--halo", choices=("recompute", "exchange", "exchange_once"), default="recompute",
                     help="N>1: ghost rows recomputed from the closed-form noise (no data-path communication) or "
                          "exchanged with the neighbour ranks over RCCL before every launch")
     ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "P"), default=None,
@@ -160,13 +160,13 @@ def main():
         halo = sh.halo_rows_needed(ops, p)
         prank, pworld = args.as_rank if args.as_rank is not None else (rank, world)
         plan = sh.StripePlan(prank, pworld, args.stripe_rows * pworld, args.cols, halo,
-                             neighbours_own_halo=args.halo == "exchange")
+                             neighbours_own_halo=args.halo != "recompute")
         cells = plan.nown * world * plan.cols  # every rank owns stripe_rows rows
         bufs = (torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
                 torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
                 torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
                 torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"))
-        comm = sh.TorchComm(dist) if args.halo == "exchange" else sh.NoComm()
+        comm = sh.NoComm() if args.halo == "recompute" else sh.TorchComm(dist)
 
         def step(record):
             if record:  # stream markers where the stages begin (exchanges of a stage are charged to it)
@@ -176,8 +176,10 @@ def main():
             else:
                 sh.run_pipeline(ops, comm, plan, p, bufs)
 
-        how = "ghost rows exchanged over RCCL before every launch" if args.halo == "exchange" else \
-            "%d ghost rows per side recomputed from the closed-form noise, no data-path communication" % halo
+        how = {"exchange": "ghost rows exchanged over RCCL before every launch",
+               "exchange_once": "%d ghost rows per side of the source plane exchanged once over RCCL" % halo,
+               "recompute": "%d ghost rows per side recomputed from the closed-form noise, no data-path "
+                            "communication" % halo}[args.halo]
         workload = "%dx%d grid as %d row stripes of %dx%d (%s): simplex-13oct -> Gauss5_S1 x%d " \
                    "-> FlowMap x%d -> ValueErosion x%d" % (plan.grows, plan.cols, pworld, args.stripe_rows, plan.cols,
                                                             how, G_IT, F_IT, E_IT)

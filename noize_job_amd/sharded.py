@@ -13,6 +13,9 @@ stage is a small-radius stencil.  Two ways of feeding the stencils their ghost r
   * haloMode "exchange": before each launch the ranks exchange the ghost rows that launch consumes
     with their two neighbours (rank-1 / rank+1 only) -- the form a pipeline needs whose source plane
     is not recomputable (an uploaded height map).
+  * haloMode "exchange_once": the source plane is produced on the owned rows only, its ghost rows for
+    the WHOLE pipeline (49 rows) are exchanged once, and everything after runs like "recompute" -- one
+    latency-bound exchange instead of one per launch, for the price of the same redundant rows.
 
 Because the kernels compute each cell with the same operations wherever it sits, either way the
 sharded result equals the single-GPU monolithic result bit for bit; the only clamps are at the
@@ -84,7 +87,7 @@ class PipelineParams:
     def __init__(self, noiseType=3, hurst=0.4, startingAmplitude=1.0, stepdown=2.0, detuneRate=0.0, octaves=13,
                  xpos=0, zpos=0, noiseSize=1700, filter=2, gaussIterations=17, flowIterations=5, normMin=0.0,
                  normMax=0.005, erosionIterations=5, haloMode="exchange"):
-        assert haloMode in ("exchange", "recompute")
+        assert haloMode in ("exchange", "recompute", "exchange_once")
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -115,14 +118,15 @@ def halo_rows_needed(ops, p):
     """Ghost rows every plane buffer needs on each side: the widest single launch when ghost rows are
     exchanged before each launch, the whole pipeline's radius when they are recomputed."""
     radii = _launch_radii(ops, p)
-    if p.haloMode == "recompute":
+    if p.haloMode in ("recompute", "exchange_once"):
         return max(sum(r[2] for r in radii), sum(r[3] for r in radii), 1)
     return max([max(r[2], r[3]) for r in radii] + [1])
 
 
 def pipeline_steps(ops, plan, p, bufs, result, on_stage=None):
     """The sharded metric pipeline as a generator: yields (planes, up_rows, down_rows) wherever the
-    ranks must exchange ghost rows (never in haloMode "recompute"), runs the stripe kernels in between.
+    ranks must exchange ghost rows (never in haloMode "recompute", once in "exchange_once"), runs the stripe
+    kernels in between.
     bufs = (A, B, S0, S1): two height planes [plan.rows, cols] and two flow-state buffers
     [5, plan.rows, cols].  The plane whose owned rows hold the result is appended to `result`.
     `on_stage(name)` (optional) is called where a stage begins ("noise", "gauss", "flow", "erosion") and
@@ -134,11 +138,15 @@ def pipeline_steps(ops, plan, p, bufs, result, on_stage=None):
     cur, nxt = A, B
     s_cur, s_nxt = S0, S1
     radii = _launch_radii(ops, p)
-    recompute = p.haloMode == "recompute"
+    recompute = p.haloMode in ("recompute", "exchange_once")   # launches produce shrinking windows, no per-launch exchange
     # rows beyond the owned ones that the remaining launches will still consume
     need_up = sum(r[2] for r in radii) if recompute else 0
     need_down = sum(r[3] for r in radii) if recompute else 0
-    ops.fractal(cur, plan.widened(need_up, need_down), p)
+    if p.haloMode == "exchange_once":
+        ops.fractal(cur, plan, p)                 # stands for any source plane, e.g. an uploaded height map
+        yield [cur], need_up, need_down           # its ghost rows for the whole pipeline, once
+    else:
+        ops.fractal(cur, plan.widened(need_up, need_down), p)
     flow_launches = [i for i, r in enumerate(radii) if r[0] == "flow"]
     for i, (stage, n, up, down) in enumerate(radii):
         if stage != current:

@@ -15,7 +15,7 @@ def _run_lockstep(nj, world, grows, cols, p):
         ctx = nj.Context(0, stream=stream.cuda_stream)
         ops = sh.HipStripeOps(ctx)
         halo = sh.halo_rows_needed(ops, p)
-        plans = [sh.StripePlan(r, world, grows, cols, halo, neighbours_own_halo=p.haloMode == "exchange")
+        plans = [sh.StripePlan(r, world, grows, cols, halo, neighbours_own_halo=p.haloMode != "recompute")
                  for r in range(world)]
         nan = float("nan")
         bufs = [(torch.full((pl.rows, cols), nan, device="cuda"), torch.full((pl.rows, cols), nan, device="cuda"),
@@ -33,7 +33,8 @@ def _run_lockstep(nj, world, grows, cols, p):
 
 
 @pytest.mark.parametrize("world,mode", [(1, "exchange"), (2, "exchange"), (4, "exchange"), (8, "exchange"),
-                                        (1, "recompute"), (2, "recompute"), (8, "recompute"), (16, "recompute")])
+                                        (1, "recompute"), (2, "recompute"), (8, "recompute"), (16, "recompute"),
+                                        (2, "exchange_once"), (8, "exchange_once")])
 def test_sharded_equals_monolithic_and_oracle(nj, ctx, oracle, world, mode):
     # "recompute" at 16 ranks: 32-row stripes with 49 ghost rows, so a rank recomputes rows of two neighbours
     from noize_job_amd import sharded as sh

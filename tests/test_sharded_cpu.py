@@ -31,10 +31,10 @@ def _worker(rank, world, port, grows, cols, pkw, out_path):
     ops = OracleStripeOps()
     p = sh.PipelineParams(**pkw)
     plan = sh.StripePlan(rank, world, grows, cols, sh.halo_rows_needed(ops, p),
-                         neighbours_own_halo=p.haloMode == "exchange")
+                         neighbours_own_halo=p.haloMode != "recompute")
     bufs = (torch.full((plan.rows, cols), float("nan")), torch.full((plan.rows, cols), float("nan")),
             torch.full((5, plan.rows, cols), float("nan")), torch.full((5, plan.rows, cols), float("nan")))
-    comm = sh.TorchComm(dist) if p.haloMode == "exchange" else sh.NoComm()  # "recompute" never communicates
+    comm = sh.NoComm() if p.haloMode == "recompute" else sh.TorchComm(dist)  # "recompute" never communicates
     res = sh.run_pipeline(ops, comm, plan, p, bufs)
     mine = res[plan.own0:plan.own1].contiguous()
     parts = [None] * world
@@ -47,7 +47,8 @@ def _worker(rank, world, port, grows, cols, pkw, out_path):
 
 
 @pytest.mark.parametrize("world,grows,cols,mode", [(2, 64, 48, "exchange"), (3, 70, 33, "exchange"),
-                                                    (2, 64, 48, "recompute"), (3, 70, 33, "recompute")])
+                                                    (2, 64, 48, "recompute"), (3, 70, 33, "recompute"),
+                                                    (2, 64, 48, "exchange_once")])
 def test_sharded_schedule_equals_monolithic(oracle, tmp_path, world, grows, cols, mode):
     pkw = dict(octaves=6, noiseSize=40, gaussIterations=7, flowIterations=3, erosionIterations=4, xpos=11, zpos=5,
                haloMode=mode)
@@ -112,7 +113,7 @@ def test_recompute_mode_needs_the_whole_pipeline_radius():
     assert all(a[0] <= b[0] and a[1] >= b[1] for a, b in zip(calls, calls[1:]))
 
 
-@pytest.mark.parametrize("mode", ["exchange", "recompute"])
+@pytest.mark.parametrize("mode", ["exchange", "recompute", "exchange_once"])
 def test_lockstep_driver_equals_monolithic(oracle, mode):
     # the same schedule with all ranks in one process (the driver the single-GPU rehearsal uses)
     import sys
@@ -124,7 +125,7 @@ def test_lockstep_driver_equals_monolithic(oracle, mode):
                           haloMode=mode)
     ops = OracleStripeOps()
     halo = sh.halo_rows_needed(ops, p)
-    plans = [sh.StripePlan(r, world, grows, cols, halo, neighbours_own_halo=mode == "exchange")
+    plans = [sh.StripePlan(r, world, grows, cols, halo, neighbours_own_halo=mode != "recompute")
              for r in range(world)]
     bufs = [(torch.full((pl.rows, cols), float("nan")), torch.full((pl.rows, cols), float("nan")),
              torch.full((5, pl.rows, cols), float("nan")), torch.full((5, pl.rows, cols), float("nan")))
