@@ -2,6 +2,7 @@
 // Writes the resulting plane as raw little-endian fp32 so the test suite can compare it with the oracle.
 //   usage: host_demo <resolution> <out.f32> [gauss_iterations flow_iterations erosion_iterations]
 //          host_demo <resolution> <out.f32> reduce      (ReducePipeline: simplex x cellular, MULTIPLY)
+//          host_demo <resolution> <out.f32> context     (producer -> context buffer -> consumer, parked until written)
 //          host_demo <resolution> <out.f32> batch <n>   (n tiles at xpos = k * resolution through the batched stage bodies)
 #include <cstdio>
 #include <cstdlib>
@@ -19,12 +20,54 @@ int main(int argc, char **argv) {
     }
     int res = std::atoi(argv[1]);
     const bool reduce = argc > 3 && std::strcmp(argv[3], "reduce") == 0;
+    const bool context = argc > 3 && std::strcmp(argv[3], "context") == 0;
     const int batch = argc > 4 && std::strcmp(argv[3], "batch") == 0 ? std::atoi(argv[4]) : 0;
     int G = argc > 3 ? std::atoi(argv[3]) : 17, F = argc > 4 ? std::atoi(argv[4]) : 5, E = argc > 5 ? std::atoi(argv[5]) : 5;
     try {
         nz_ctx *ctx = nullptr;
         check(nz_ctx_create(0, &ctx), "nz_ctx_create");
-        if (batch > 0) {
+        if (context) {
+            PipelineStateManager mgr(ctx);
+            DeviceTile src(ctx, (size_t)res * res), dst(ctx, (size_t)res * res);
+            NoiseStage noise(ctx);
+            noise.noiseType = FractalNoise::Simplex;
+            noise.hurst = 0.4f;
+            noise.octaves = 8;
+            noise.noiseSize = 200;
+            WriteGeneratorContextStage wr(ctx);
+            wr.contextAlias = "height";
+            ReadGeneratorContextStage rd(ctx);
+            rd.contextAlias = "height";
+            KernelFilterStage gauss(ctx);
+            gauss.filter = NZ_GAUSS5_S1;
+            gauss.iterations = 3;
+            BasePipeline producer({&noise, &wr}), consumer({&rd, &gauss});
+            producer.contextManager = consumer.contextManager = &mgr;
+            GeneratorData in, out;
+            in.uuid = "src";
+            in.data = &src;
+            out.uuid = "out";
+            out.data = &dst;
+            in.resolution = out.resolution = res;
+            in.xpos = out.xpos = 64;
+            in.zpos = out.zpos = 32;
+            consumer.Enqueue(&out);
+            consumer.RunToCompletion();  // nothing to read yet: the item is parked
+            if (consumer.Parked() != 1) throw std::runtime_error("consumer should wait for the context buffer");
+            producer.Enqueue(&in);
+            producer.RunToCompletion();
+            consumer.RunToCompletion();
+            if (consumer.Parked() != 0) throw std::runtime_error("consumer did not run");
+            std::vector<float> host((size_t)res * res);
+            dst.CopyTo(host.data());
+            FILE *f = std::fopen(argv[2], "wb");
+            if (!f) throw std::runtime_error("cannot open output");
+            std::fwrite(host.data(), sizeof(float), host.size(), f);
+            std::fclose(f);
+            producer.Destroy();
+            consumer.Destroy();
+            mgr.OnDestroy();
+        } else if (batch > 0) {
             const size_t n = (size_t)res * res;
             DeviceTile tiles(ctx, n * batch);
             std::vector<int32_t> pos(2 * batch);

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -104,11 +105,52 @@ struct MeshStageData : StageIO {
     MeshBuffers *mesh = nullptr;
 };
 
+class PipelineStateManager;
+
 struct PipelineWorkItem {
     StageIO *data = nullptr;
     std::function<void(StageIO *)> completeAction;
     std::function<void(StageIO *, JobHandle)> scheduledAction;
     JobHandle dependency;
+    PipelineStateManager *stageManager = nullptr;  // Pipeline/Stage/PipelineDefinition.cs:18-25
+};
+
+struct DownsampleData : StageIO {  // StageIOTypes/DownsampleData.cs:9-17
+    int resolution = 512, inputResolution = 512;
+    DeviceTile *inputData = nullptr;
+};
+
+// ---- PipelineStateManager, NativeArray<float> part (Pipeline/PipelineState/PipelineStateManager.cs:13-189,
+//      PipelineState.cs:230-349) with the job-fence lock of PipelineStateLock.cs:12-27: named device buffers shared
+//      between pipelines, locked while a scheduled write to them has not completed ------------------------------
+class PipelineStateManager {
+  public:
+    explicit PipelineStateManager(nz_ctx *c) : ctx(c) {}
+    DeviceTile *GetBuffer(const std::string &name, long size = -1) {
+        auto it = buffers.find(name);
+        if (it == buffers.end()) {
+            if (size < 0) throw std::invalid_argument("No allocated buffer named " + name);
+            it = buffers.emplace(name, std::unique_ptr<DeviceTile>(new DeviceTile(ctx, (size_t)size))).first;
+        }
+        return it->second.get();
+    }
+    bool BufferExists(const std::string &name) const { return buffers.count(name) != 0; }
+    bool ReleaseBuffer(const std::string &name) { return buffers.erase(name) != 0; }
+    bool IsLocked(const std::string &key) const {
+        auto it = locks.find(key);
+        return it != locks.end() && !it->second.IsCompleted();  // HandleLock.isLocked
+    }
+    bool TrySetLock(const std::string &key, JobHandle handle, JobHandle /*spyHandle*/) {
+        if (IsLocked(key)) return false;  // a completed handle is an open lock
+        locks[key] = handle;
+        return true;
+    }
+    void OnDestroy() { buffers.clear(); }
+
+  private:
+    nz_ctx *ctx;
+    std::map<std::string, std::unique_ptr<DeviceTile>> buffers;
+    std::map<std::string, JobHandle> locks;
 };
 
 // ---- PipelineStage ---------------------------------------------------------------------------
@@ -395,18 +437,108 @@ class MeshTileStage : public PipelineStage {
     }
 };
 
+// ---- CropStage (Filter/Sample/CropStage.cs:11-19; the job's offset stays 0 as in CropJob.cs:43-59) -----------
+class CropStage : public PipelineStage {
+  public:
+    using PipelineStage::PipelineStage;
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = dynamic_cast<DownsampleData *>(requirements.data);
+        if (!d) throw std::runtime_error("Unhandled stageio");
+        nz_handle h = 0;
+        check(nz_crop_job(ctx, d->inputData->ptr, d->inputResolution, d->data->ptr, d->resolution, dependency.id, &h),
+              "nz_crop_job");
+        jobHandle = done(h);
+    }
+};
+
+// ---- context stages (Pipeline/PipelineState/Stage/*.cs, Mesh/Stage/MeshTileReferenceDataStage.cs) -----------
+inline std::string contextBufferName(int xpos, int zpos, int resolution, const std::string &alias) {
+    return std::to_string(xpos) + "_" + std::to_string(zpos) + "__" + std::to_string(resolution) + "__" + alias;
+}
+
+class ReadGeneratorContextStage : public PipelineStage {  // ReadGeneratorContextStage.cs:13-46
+  public:
+    using PipelineStage::PipelineStage;
+    std::string contextAlias;
+    bool IsSchedulable(const PipelineWorkItem &job) override {
+        auto *gd = dynamic_cast<GeneratorData *>(job.data);
+        if (!job.stageManager || !gd) return false;
+        std::string name = contextBufferName(gd->xpos, gd->zpos, gd->resolution, contextAlias);
+        return job.stageManager->BufferExists(name) && !job.stageManager->IsLocked(name);
+    }
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *gd = CheckRequirements<GeneratorData>(requirements);
+        size_t res = (size_t)gd->resolution * gd->resolution;
+        DeviceTile *buffer = requirements.stageManager->GetBuffer(
+            contextBufferName(gd->xpos, gd->zpos, gd->resolution, contextAlias), (long)res);
+        nz_handle h = 0;
+        check(nz_flush_write_slice(ctx, gd->data->ptr, buffer->ptr, res, dependency.id, &h), "nz_flush_write_slice");
+        jobHandle = done(h);
+    }
+};
+
+class WriteGeneratorContextStage : public PipelineStage {  // WriteGeneratorContextStage.cs:13-46
+  public:
+    using PipelineStage::PipelineStage;
+    std::string contextAlias;
+    bool IsSchedulable(const PipelineWorkItem &job) override {
+        auto *gd = dynamic_cast<GeneratorData *>(job.data);
+        if (!job.stageManager || !gd) return false;
+        return !job.stageManager->IsLocked(contextBufferName(gd->xpos, gd->zpos, gd->resolution, contextAlias));
+    }
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *gd = CheckRequirements<GeneratorData>(requirements);
+        size_t res = (size_t)gd->resolution * gd->resolution;
+        std::string name = contextBufferName(gd->xpos, gd->zpos, gd->resolution, contextAlias);
+        DeviceTile *buffer = requirements.stageManager->GetBuffer(name, (long)res);
+        nz_handle h1 = 0, h2 = 0;
+        check(nz_flush_write_slice(ctx, buffer->ptr, gd->data->ptr, res, dependency.id, &h1), "nz_flush_write_slice");
+        check(nz_handle_record(ctx, &h2), "nz_handle_record");  // LockJob: a no-op marker after the copy
+        jobHandle = done(h2);
+        requirements.stageManager->TrySetLock(name, done(h1), jobHandle);
+    }
+};
+
+class MeshTileReferenceDataStage : public MeshTileStage {  // Mesh/Stage/MeshTileReferenceDataStage.cs:22-84
+  public:
+    using MeshTileStage::MeshTileStage;
+    std::string contextAlias;
+    bool IsSchedulable(const PipelineWorkItem &job) override {
+        auto *d = dynamic_cast<MeshStageData *>(job.data);
+        if (!job.stageManager || !d) return false;
+        std::string name = contextBufferName(d->xpos, d->zpos, d->inputResolution, contextAlias);
+        return job.stageManager->BufferExists(name) && !job.stageManager->IsLocked(name);
+    }
+    void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
+        auto *d = dynamic_cast<MeshStageData *>(requirements.data);
+        if (!d) throw std::runtime_error("Unhandled stageio");
+        DeviceTile *own = d->data;
+        d->data = requirements.stageManager->GetBuffer(contextBufferName(d->xpos, d->zpos, d->inputResolution, contextAlias),
+                                                       (long)d->inputResolution * d->inputResolution);
+        try {
+            MeshTileStage::Schedule(requirements, dependency);  // the mesh job reads the context buffer (:62-64)
+        } catch (...) {
+            d->data = own;
+            throw;
+        }
+        d->data = own;
+    }
+};
+
 // ---- BasePipeline (Pipeline/Executable/Pipeline.cs) --------------------------------------------
 class BasePipeline {
   public:
     std::string alias = "Unnamed Pipeline";
+    PipelineStateManager *contextManager = nullptr;  // handed to every work item (Pipeline.cs:76-104)
     explicit BasePipeline(std::vector<PipelineStage *> stages) : stage_instances(std::move(stages)) { Setup(); }
     virtual ~BasePipeline() = default;
     virtual std::vector<BasePipeline *> GetDependencies() { return {this}; }  // Pipeline.cs:63-65
-    bool Idle() const { return queue.empty() && !pipelineRunning && !pipelineBeingScheduled; }
+    bool Idle() const { return queue.empty() && dependencyHell.empty() && !pipelineRunning && !pipelineBeingScheduled; }
+    size_t Parked() const { return dependencyHell.size(); }
 
     void Enqueue(StageIO *input, std::function<void(StageIO *, JobHandle)> scheduleAction = nullptr,
                  std::function<void(StageIO *)> completeAction = nullptr, JobHandle dependency = JobHandle()) {
-        queue.push_back(PipelineWorkItem{input, completeAction, scheduleAction, dependency});
+        queue.push_back(PipelineWorkItem{input, completeAction, scheduleAction, dependency, contextManager});
     }
     void Schedule(PipelineWorkItem wi) {
         activeItem = std::move(wi);
@@ -414,11 +546,33 @@ class BasePipeline {
         pipelineBeingScheduled = true;
         stage_instances[0]->ReceiveHandledInput(activeItem, activeItem.dependency);
     }
-    virtual void Update() {
-        if (!pipelineRunning && !pipelineBeingScheduled && !queue.empty()) {
+    bool WorkIsSchedulable(const PipelineWorkItem &item) {  // Pipeline.cs:256-265
+        bool ready = true;
+        for (auto *s : stage_instances) ready = s->IsSchedulable(item) && ready;
+        return ready;
+    }
+    bool GetNextJob(PipelineWorkItem &out) {  // Pipeline.cs:183-214: parked items first, then the queue
+        for (size_t i = 0; i < dependencyHell.size(); i++)
+            if (WorkIsSchedulable(dependencyHell[i])) {
+                out = dependencyHell[i];
+                dependencyHell.erase(dependencyHell.begin() + i);
+                return true;
+            }
+        while (!queue.empty()) {
             PipelineWorkItem wi = queue.front();
             queue.pop_front();
-            Schedule(wi);
+            if (WorkIsSchedulable(wi)) {
+                out = wi;
+                return true;
+            }
+            dependencyHell.push_back(wi);
+        }
+        return false;
+    }
+    virtual void Update() {
+        if (!pipelineRunning && !pipelineBeingScheduled) {
+            PipelineWorkItem wi;
+            if (GetNextJob(wi)) Schedule(wi);
         }
     }
     bool LateUpdate() {
@@ -431,12 +585,14 @@ class BasePipeline {
         }
         return false;
     }
-    void RunToCompletion() {
-        while (!queue.empty() || pipelineRunning) {
+    void RunToCompletion() {  // until the queue is drained or only unschedulable items are left
+        while (!queue.empty() || !dependencyHell.empty() || pipelineRunning) {
             Update();
             if (pipelineRunning) {
                 pipelineHandle.Complete();
                 LateUpdate();
+            } else if (queue.empty()) {
+                break;  // everything left is parked on a dependency another pipeline has to satisfy
             }
         }
     }
@@ -463,6 +619,7 @@ class BasePipeline {
     }
     std::vector<PipelineStage *> stage_instances;
     std::deque<PipelineWorkItem> queue;
+    std::vector<PipelineWorkItem> dependencyHell;
     PipelineWorkItem activeItem;
     JobHandle pipelineHandle;
     bool pipelineBeingScheduled = false, pipelineRunning = false;
@@ -532,7 +689,7 @@ class ReducePipeline : public BasePipeline {
         joined.rightData = rightIO.data;
         joined.xpos = d->xpos;
         joined.zpos = d->zpos;
-        Schedule(PipelineWorkItem{&joined, action, nullptr, JobHandle()});
+        Schedule(PipelineWorkItem{&joined, action, nullptr, JobHandle(), contextManager});
     }
     nz_ctx *ctx;
     BasePipeline *upstreamPipelineLeft, *upstreamPipelineRight;

@@ -374,6 +374,11 @@ def test_cpp_host_mirror_runs_the_metric_pipeline(oracle, tmp_path):
     a = oracle.fractal(oracle.SIMPLEX, 200, 200, 0.4, 1.0, 2.0, 0.0, 6, 37, 11, 300)
     b = oracle.fractal(oracle.CELLULAR, 200, 200, 0.5, 1.0, 2.0, 0.0, 3, 37, 11, 90)
     assert np.array_equal(got, oracle.reduce(a, b, 1))
+    # context stages of the C++ mirror: the consumer waits for the producer's buffer, then reads it
+    subprocess.check_call([exe, "128", out, "context"])
+    got = np.fromfile(out, dtype=np.float32).reshape(128, 128)
+    noise = oracle.fractal(oracle.SIMPLEX, 128, 128, 0.4, 1.0, 2.0, 0.0, 8, 64, 32, 200)
+    assert np.array_equal(got, oracle.kernel_filter(noise, 2, 3))
     # batched stage bodies from the C++ mirror: 3 tiles of 96^2 at (k * 96, -3 k)
     subprocess.check_call([exe, "96", out, "batch", "3"])
     got = np.fromfile(out, dtype=np.float32).reshape(3, 96, 96)
