@@ -103,6 +103,7 @@ struct MeshStageData : StageIO {
     float tileSize = 512.f, tileHeight = 512.f;
     int xpos = 0, zpos = 0;
     MeshBuffers *mesh = nullptr;
+    int count = 1;  // new-framework: `count` height planes stored back to back -> `count` meshes (nz_heightmap_mesh_batch)
 };
 
 class PipelineStateManager;
@@ -257,6 +258,12 @@ class StageGaussianBlur : public TmpStage {
     void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
         auto *d = CheckRequirements<GeneratorData>(requirements);
         nz_handle h = 0;
+        if (auto *b = dynamic_cast<GeneratorDataBatch *>(d)) {
+            check(nz_gauss_blur_stage_batch(ctx, b->data->ptr, tmp->ptr, limitWidth(width), sigma, iterations, b->resolution,
+                                            b->count, dependency.id, &h), "nz_gauss_blur_stage_batch");
+            jobHandle = done(h);
+            return;
+        }
         check(nz_gauss_blur_stage(ctx, d->data->ptr, tmp->ptr, limitWidth(width), sigma, iterations, d->resolution,
                                   dependency.id, &h), "nz_gauss_blur_stage");
         jobHandle = done(h);
@@ -422,7 +429,7 @@ class MeshTileStage : public PipelineStage {
         auto *d = dynamic_cast<MeshStageData *>(requirements.data);
         if (!d || !d->mesh) throw std::runtime_error("Unhandled stageio");
         MeshBuffers &m = *d->mesh;
-        size_t nv = nz_mesh_vertex_count(d->resolution), ni = nz_mesh_index_count(d->resolution);
+        size_t nv = nz_mesh_vertex_count(d->resolution) * d->count, ni = nz_mesh_index_count(d->resolution) * d->count;
         if (m.vertexCount != nv) {  // Mesh.AllocateWritableMeshData(1)
             m.vertices.reset(new DeviceTile(ctx, nv * 12));
             m.indices.reset(new DeviceTile(ctx, ni));
@@ -430,6 +437,13 @@ class MeshTileStage : public PipelineStage {
             m.indexCount = ni;
         }
         nz_handle h = 0;
+        if (d->count > 1) {
+            check(nz_heightmap_mesh_batch(ctx, meshType, m.vertices->ptr, reinterpret_cast<uint32_t *>(m.indices->ptr),
+                                          d->resolution, d->inputResolution, d->marginPix, d->tileHeight, d->tileSize,
+                                          d->data->ptr, d->count, dependency.id, &h), "nz_heightmap_mesh_batch");
+            jobHandle = done(h);
+            return;
+        }
         check(nz_heightmap_mesh(ctx, meshType, m.vertices->ptr, reinterpret_cast<uint32_t *>(m.indices->ptr),
                                 d->resolution, d->inputResolution, d->marginPix, d->tileHeight, d->tileSize,
                                 d->data->ptr, dependency.id, &h), "nz_heightmap_mesh");
