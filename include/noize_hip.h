@@ -81,11 +81,6 @@ int32_t nz_device_count(int32_t *count);
 int32_t nz_ctx_create(int32_t device, nz_ctx **out);
 /* borrow an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL = default) */
 int32_t nz_ctx_create_on_stream(int32_t device, void *hip_stream, nz_ctx **out);
-/* Banded asynchronous execution of the stage-level calls (nz_fractal, nz_*_stage): the tile is split into
- * `bands` row bands, one HIP stream each; a band's launch waits only for the previous launch of its two
- * neighbours, so compute-bound and memory-bound stages overlap on the GPU.  Results are unchanged (same
- * kernels, same cells).  1 = off (default; env NZ_BANDS overrides at context creation). */
-int32_t nz_ctx_set_bands(nz_ctx *ctx, int32_t bands);
 int32_t nz_ctx_destroy(nz_ctx *ctx);
 int32_t nz_ctx_synchronize(nz_ctx *ctx);
 void *nz_ctx_stream(nz_ctx *ctx);

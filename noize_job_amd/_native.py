@@ -38,7 +38,6 @@ SIGNATURES = {
     "nz_device_count": (_i, [C.POINTER(_i)]),
     "nz_ctx_create": (_i, [_i, C.POINTER(ctx_p)]),
     "nz_ctx_create_on_stream": (_i, [_i, C.c_void_p, C.POINTER(ctx_p)]),
-    "nz_ctx_set_bands": (_i, [ctx_p, _i]),
     "nz_ctx_destroy": (_i, [ctx_p]),
     "nz_ctx_synchronize": (_i, [ctx_p]),
     "nz_ctx_stream": (C.c_void_p, [ctx_p]),

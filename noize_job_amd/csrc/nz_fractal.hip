@@ -945,7 +945,7 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         return NZ_OK;
     }
     if ((noiseType == NZ_NOISE_PERLIN || noiseType == NZ_NOISE_CELLULAR) && use_tab && d_simplex) {
-        // table block layout: see build_lattice_tables() in nz_api.cpp
+        // table block layout: see build_simplex_tables() in nz_runtime.cpp
         const char *base = reinterpret_cast<const char *>(d_simplex) + (NZ_T1_N * 4 + NZ_T2_N * 16);
         if (noiseType == NZ_NOISE_CELLULAR) base += NZ_TB1_N * 4 + NZ_TB2_N * 8;
         const int *t1 = reinterpret_cast<const int *>(base);

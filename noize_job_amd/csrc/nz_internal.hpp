@@ -43,25 +43,18 @@ struct nz_ctx {
     float *d_rgrad = nullptr;
     // snoise lattice tables: int T1[292] (16*permute(i)) followed by float4 T2[580] (gradient of permute(j))
     void *d_simplex = nullptr;
-    // Banded asynchronous execution (nz_ctx_set_bands): the stage-level calls split a tile into row bands,
-    // one HIP stream per band; a band's launch waits only for the previous launch of its two neighbours, so
-    // compute-bound and memory-bound stages of different bands overlap on the GPU.
-    int nbands = 1;
-    std::vector<hipStream_t> bstreams;
-    std::vector<hipEvent_t> bev[2];   // [set][band]: events of the previous / current launch
-    std::vector<char> bev_valid;      // previous-launch event recorded since the last fork?
-    int bev_prev = 0;
-    bool bands_active = false;        // band streams hold work the main stream has not joined
-    int band_or0 = -1, band_or1 = -1; // row range the current partition was made for
-    hipEvent_t fork_ev = nullptr;
-    hipStream_t hstream = nullptr;    // carries the JobHandle markers of banded calls
     // stage scratch owned by the ctx (grown on demand)
     float *scratch = nullptr;
     size_t scratch_floats = 0;
 };
 
-int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep);           // set device, honour `dep`, join the band streams
-int32_t nz_ctx_begin_banded(nz_ctx *ctx, nz_handle dep);    // same, but leaves the band streams running
+#define NZ_TRY_(expr)             \
+    do {                          \
+        int32_t rc_t_ = (expr);    \
+        if (rc_t_) return rc_t_;    \
+    } while (0)
+
+int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep);           // set device, check `dep`
 int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out);         // record the JobHandle marker
 int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out);
 
@@ -135,6 +128,12 @@ inline nz_geom nz_geom_from_stripe(const nz_stripe &s) {
 }
 
 inline nz_geom nz_geom_tile(int res) { return nz_geom{res, res, res, 0, res - 1, 0, res}; }
+
+// every stage launch goes through here: one place that knows which stream a context's work runs on
+template <class F>
+inline int32_t launch_on_ctx(nz_ctx *ctx, const nz_geom &g, F launch) {
+    return launch(ctx->stream, g);
+}
 
 int32_t nz_check_stripe(const nz_stripe *st, int halo, int halo_below = -1);  // rows needed above / below the owned ones
 

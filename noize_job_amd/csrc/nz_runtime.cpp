@@ -1,0 +1,386 @@
+// nz_runtime.cpp -- the runtime half of libnoize_hip.so: errors, contexts (one HIP stream each), the host-built
+// noise tables, JobHandle markers and device tiles.  The stage entry points are in nz_stages.cpp; see
+// include/noize_hip.h for the reference interface each entry replaces.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "nz_internal.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void nz_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *nz_last_error(void) { return g_err; }
+extern "C" int32_t nz_version(void) { return NZ_VERSION; }
+
+extern "C" int32_t nz_device_count(int32_t *count) {
+    NZ_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        nz_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return NZ_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return NZ_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+static constexpr size_t NZ_EVENT_RING = 4096;
+static int32_t ctx_sync_all(nz_ctx *ctx);
+
+
+static float h_mod289(float x);
+static float h_permute(float x);
+
+static int32_t build_rgrad_table(nz_ctx *ctx) {
+    // noise.psrnoise.  Every hash argument is an integer-valued float, so both
+    // permutes are pure functions of small integers and are tabulated with the reference's own fp32
+    // operations (the first one overflows 2^24 and rounds; the table reproduces that rounding because it is
+    // computed the same way).  (cos u, sin u) of rgrad2 come from the host libm the CPU restatement calls.
+    std::vector<int32_t> buf(NZ_PSR_T1 + 2 * NZ_PSR_T2 * 2);
+    for (int i = 0; i < NZ_PSR_T1; i++) buf[i] = 8 * ((int32_t)h_permute((float)(i - NZ_PSR_O1)) + NZ_PSR_O2);
+    float *t2 = reinterpret_cast<float *>(buf.data() + NZ_PSR_T1);
+    const float rots[2] = {0.0f, 0.62f};  // PeriodicPerlinGetter / RotatedSimplexGetter, Fractal.cs:184,201
+    for (int t = 0; t < 2; t++) {
+        for (int j = 0; j < NZ_PSR_T2; j++) {
+            float h = h_permute((float)(j - NZ_PSR_O2));
+            float u = h * 0.0243902439f + rots[t];
+            u = (u - floorf(u)) * 6.28318530718f;
+            t2[(t * NZ_PSR_T2 + j) * 2 + 0] = cosf(u);
+            t2[(t * NZ_PSR_T2 + j) * 2 + 1] = sinf(u);
+        }
+    }
+    NZ_HIP(hipMalloc((void **)&ctx->d_rgrad, buf.size() * sizeof(int32_t)));
+    NZ_HIP(hipMemcpy(ctx->d_rgrad, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return NZ_OK;
+}
+
+// Host copies of the reference's hash helpers; plain IEEE fp32, no contraction.
+static float h_mod289(float x) { return x - floorf(x * (1.0f / 289.0f)) * 289.0f; }
+static float h_permute(float x) { return h_mod289((34.0f * x + 1.0f) * x); }
+
+static float h_mod7(float x) { return x - floorf(x * (1.0f / 7.0f)) * 7.0f; }
+
+static int32_t build_simplex_tables(nz_ctx *ctx) {
+    // Lattice tables of nz_fractal.hip (snoise2_tab, cnoise2_tab, cellular_rect_tab), every entry computed
+    // with exactly the operations of the corresponding Unity.Mathematics.noise function:
+    //   simplex : T1[292] int = 16*permute(i);      T2[580] float4 = {a0, h, 1.79284291400159 - 0.85373472095314*(a0*a0+h*h), 0}
+    //   perlin  : P1[292] int = 8*permute(i);       P2[584] float2 = {gx*norm, gy*norm} of permute(j)
+    //   cellular: C1[292] int = 8*permute(i-1);     C2[584] float2 = {ox, oy} of permute(a-1)
+    //   3-D     : P3[580] int = permute(j);           G3c[292] / G3s[292] float4 = normalised corner gradient of
+    //             noise.cnoise(float3) / noise.snoise(float3) for the final hash value 0..288
+    constexpr int T1 = 292, T2 = 580, B1 = 292, B2 = 584, P3 = 580, G3 = 292;
+    std::vector<int32_t> buf(T1 + T2 * 4 + 2 * (B1 + B2 * 2) + P3 + 2 * G3 * 4);
+    for (int i = 0; i < T1; i++) buf[i] = 16 * (int32_t)h_permute((float)i);
+    float *t2 = reinterpret_cast<float *>(buf.data() + T1);
+    for (int j = 0; j < T2; j++) {
+        float p = h_permute((float)j);
+        float y = p * 0.024390243902439f;
+        float x = 2.0f * (y - floorf(y)) - 1.0f;
+        float h = fabsf(x) - 0.5f;
+        float ox = floorf(x + 0.5f);
+        float a0 = x - ox;
+        float nrm = 1.79284291400159f - 0.85373472095314f * (a0 * a0 + h * h);
+        t2[4 * j + 0] = a0;
+        t2[4 * j + 1] = h;
+        t2[4 * j + 2] = nrm;
+        t2[4 * j + 3] = 0.0f;
+    }
+    int32_t *p1 = buf.data() + T1 + T2 * 4;
+    float *p2 = reinterpret_cast<float *>(p1 + B1);
+    for (int i = 0; i < B1; i++) p1[i] = 8 * (int32_t)h_permute((float)i);
+    for (int j = 0; j < B2; j++) {  // noise.cnoise: gradient of i = permute(permute(ix) + iy), normalised
+        float i = h_permute((float)j);
+        float y = i * (1.0f / 41.0f);
+        float g = (y - floorf(y)) * 2.0f - 1.0f;
+        float gy = fabsf(g) - 0.5f;
+        float tx = floorf(g + 0.5f);
+        float gx = g - tx;
+        float nrm = 1.79284291400159f - 0.85373472095314f * (gx * gx + gy * gy);
+        p2[2 * j + 0] = gx * nrm;
+        p2[2 * j + 1] = gy * nrm;
+    }
+    int32_t *c1 = p1 + B1 + B2 * 2;
+    float *c2 = reinterpret_cast<float *>(c1 + B1);
+    const float K = 0.142857142857f, Ko = 0.428571428571f;
+    for (int i = 0; i < B1; i++) c1[i] = 8 * (int32_t)h_permute((float)(i - 1));
+    for (int a = 0; a < B2; a++) {  // noise.cellular: ox = frac(p*K) - Ko; oy = mod7(floor(p*K))*K - Ko
+        float p = h_permute((float)(a - 1));
+        float pk = p * K;
+        c2[2 * a + 0] = (pk - floorf(pk)) - Ko;
+        c2[2 * a + 1] = h_mod7(floorf(pk)) * K - Ko;
+    }
+    int32_t *p3 = c1 + B1 + B2 * 2;
+    for (int j = 0; j < P3; j++) p3[j] = (int32_t)h_permute((float)j);
+    float *g3c = reinterpret_cast<float *>(p3 + P3), *g3s = g3c + G3 * 4;
+    auto step = [](float y, float x) { return x >= y ? 1.0f : 0.0f; };  // math.step(y, x)
+    for (int h = 0; h < G3; h++) {
+        {  // noise.cnoise(float3): gradient decode of ixy0 / ixy1
+            float gx = (float)h * (1.0f / 7.0f);
+            float t = floorf(gx) * (1.0f / 7.0f);
+            float gy = (t - floorf(t)) - 0.5f;
+            gx = gx - floorf(gx);
+            float gz = 0.5f - fabsf(gx) - fabsf(gy);
+            float sz = step(gz, 0.0f);
+            gx -= sz * (step(0.0f, gx) - 0.5f);
+            gy -= sz * (step(0.0f, gy) - 0.5f);
+            float nr = 1.79284291400159f - 0.85373472095314f * (gx * gx + gy * gy + gz * gz);
+            g3c[4 * h + 0] = gx * nr;
+            g3c[4 * h + 1] = gy * nr;
+            g3c[4 * h + 2] = gz * nr;
+            g3c[4 * h + 3] = 0.0f;
+        }
+        {  // noise.snoise(float3): p -> (x, y, h) on the 7x7 grid, octahedron fold, normalisation
+            const float n_ = 0.142857142857f;
+            const float nsx = n_ * 2.0f - 0.0f, nsy = n_ * 0.5f - 1.0f, nsz = n_ * 1.0f - 0.0f;
+            float pp = (float)h;
+            float j = pp - 49.0f * floorf(pp * nsz * nsz);
+            float x_ = floorf(j * nsz);
+            float y_ = floorf(j - 7.0f * x_);
+            float X = x_ * nsx + nsy, Y = y_ * nsx + nsy;
+            float H = 1.0f - fabsf(X) - fabsf(Y);
+            float sx = floorf(X) * 2.0f + 1.0f, sy = floorf(Y) * 2.0f + 1.0f;
+            float sh = -step(H, 0.0f);
+            float ax = X + sx * sh, ay = Y + sy * sh;
+            float nr = 1.79284291400159f - 0.85373472095314f * (ax * ax + ay * ay + H * H);
+            g3s[4 * h + 0] = ax * nr;
+            g3s[4 * h + 1] = ay * nr;
+            g3s[4 * h + 2] = H * nr;
+            g3s[4 * h + 3] = 0.0f;
+        }
+    }
+    NZ_HIP(hipMalloc(&ctx->d_simplex, buf.size() * sizeof(int32_t)));
+    NZ_HIP(hipMemcpy(ctx->d_simplex, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return NZ_OK;
+}
+
+static int32_t ctx_create(int32_t device, hipStream_t stream, bool own, nz_ctx **out) {
+    NZ_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        nz_set_error("no HIP device available (%s)", e != hipSuccess ? hipGetErrorString(e) : "count 0");
+        return NZ_ERR_NO_DEVICE;
+    }
+    NZ_REQUIRE(device >= 0 && device < n, "device %d out of range [0,%d)", device, n);
+    NZ_HIP(hipSetDevice(device));
+    nz_ctx *ctx = new nz_ctx();
+    ctx->device = device;
+    if (own) {
+        hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete ctx;
+            nz_set_error("hipStreamCreate: %s", hipGetErrorString(se));
+            return NZ_ERR_HIP;
+        }
+        ctx->owns_stream = true;
+    } else {
+        ctx->stream = stream;
+    }
+    int32_t rc = build_rgrad_table(ctx);
+    if (rc == NZ_OK) rc = build_simplex_tables(ctx);
+    if (rc != NZ_OK) {
+        if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_ctx_create(int32_t device, nz_ctx **out) { return ctx_create(device, nullptr, true, out); }
+
+extern "C" int32_t nz_ctx_create_on_stream(int32_t device, void *hip_stream, nz_ctx **out) {
+    return ctx_create(device, (hipStream_t)hip_stream, false, out);
+}
+
+extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
+    if (!ctx) return NZ_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t ev : ctx->events)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->d_rgrad) (void)hipFree(ctx->d_rgrad);
+    if (ctx->d_simplex) (void)hipFree(ctx->d_simplex);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_ctx_synchronize(nz_ctx *ctx) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    NZ_HIP(hipSetDevice(ctx->device));
+    return ctx_sync_all(ctx);
+}
+
+extern "C" void *nz_ctx_stream(nz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+static int32_t ctx_sync_all(nz_ctx *ctx) {
+    NZ_HIP(hipStreamSynchronize(ctx->stream));
+    return NZ_OK;
+}
+
+int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    NZ_HIP(hipSetDevice(ctx->device));
+    // all work of a ctx is ordered on its stream, so a dependency on one of its own handles is
+    // already satisfied by that order; anything else is a caller error
+    NZ_REQUIRE(dep <= ctx->last_handle, "dependency handle %llu was not issued by this context",
+               (unsigned long long)dep);
+    return NZ_OK;
+}
+
+static int32_t handle_new_event(nz_ctx *ctx, hipEvent_t **ev, uint64_t *h) {
+    if (ctx->events.empty()) ctx->events.assign(NZ_EVENT_RING, nullptr);
+    *h = ctx->last_handle + 1;
+    *ev = &ctx->events[*h % NZ_EVENT_RING];
+    if (!**ev) NZ_HIP(hipEventCreate(*ev));
+    return NZ_OK;
+}
+
+int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out) {
+    if (!out) return NZ_OK;
+    hipEvent_t *ev;
+    uint64_t h;
+    int32_t rc = handle_new_event(ctx, &ev, &h);
+    if (rc) return rc;
+    NZ_HIP(hipEventRecord(*ev, ctx->stream));
+    ctx->last_handle = h;
+    *out = h;
+    return NZ_OK;
+}
+
+int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out) {
+    if (floats > ctx->scratch_floats) {
+        if (ctx->scratch) {
+            NZ_TRY_(ctx_sync_all(ctx));
+            NZ_HIP(hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_floats = 0;
+        }
+        hipError_t e = hipMalloc((void **)&ctx->scratch, floats * sizeof(float));
+        if (e != hipSuccess) {
+            nz_set_error("hipMalloc(%zu floats): %s", floats, hipGetErrorString(e));
+            return NZ_ERR_NOMEM;
+        }
+        ctx->scratch_floats = floats;
+    }
+    *out = ctx->scratch;
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_handle_record(nz_ctx *ctx, nz_handle *out) {
+    NZ_REQUIRE(ctx && out, "ctx/out is NULL");
+    NZ_HIP(hipSetDevice(ctx->device));
+    return nz_ctx_finish(ctx, out);
+}
+
+static bool handle_live(nz_ctx *ctx, nz_handle h) {
+    return h != 0 && h <= ctx->last_handle && h + NZ_EVENT_RING > ctx->last_handle;
+}
+
+extern "C" int32_t nz_handle_query(nz_ctx *ctx, nz_handle h, int32_t *is_completed) {
+    NZ_REQUIRE(ctx && is_completed, "ctx/is_completed is NULL");
+    NZ_REQUIRE(h <= ctx->last_handle, "unknown handle");
+    NZ_HIP(hipSetDevice(ctx->device));
+    if (h == 0) {
+        *is_completed = 1;  // default(JobHandle).IsCompleted == true
+        return NZ_OK;
+    }
+    hipError_t e = handle_live(ctx, h) ? hipEventQuery(ctx->events[h % NZ_EVENT_RING])
+                                      : hipStreamQuery(ctx->stream);
+    if (e == hipSuccess) {
+        *is_completed = 1;
+    } else if (e == hipErrorNotReady) {
+        *is_completed = 0;
+        (void)hipGetLastError();
+    } else {
+        nz_set_error("handle query: %s", hipGetErrorString(e));
+        return NZ_ERR_HIP;
+    }
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_handle_wait(nz_ctx *ctx, nz_handle h) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    NZ_REQUIRE(h <= ctx->last_handle, "unknown handle");
+    NZ_HIP(hipSetDevice(ctx->device));
+    if (h == 0) return NZ_OK;
+    if (handle_live(ctx, h)) {
+        NZ_HIP(hipEventSynchronize(ctx->events[h % NZ_EVENT_RING]));
+    } else {
+        NZ_TRY_(ctx_sync_all(ctx));
+    }
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_handle_elapsed_ms(nz_ctx *ctx, nz_handle start, nz_handle stop, float *ms) {
+    NZ_REQUIRE(ctx && ms, "ctx/ms is NULL");
+    NZ_REQUIRE(handle_live(ctx, start) && handle_live(ctx, stop), "handle expired or unknown");
+    NZ_HIP(hipSetDevice(ctx->device));
+    NZ_HIP(hipEventElapsedTime(ms, ctx->events[start % NZ_EVENT_RING], ctx->events[stop % NZ_EVENT_RING]));
+    return NZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tiles
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t nz_tile_alloc(nz_ctx *ctx, size_t n_floats, float **out_dev) {
+    NZ_REQUIRE(ctx && out_dev, "ctx/out is NULL");
+    NZ_HIP(hipSetDevice(ctx->device));
+    *out_dev = nullptr;
+    hipError_t e = hipMalloc((void **)out_dev, (n_floats ? n_floats : 1) * sizeof(float));
+    if (e != hipSuccess) {
+        nz_set_error("hipMalloc(%zu floats): %s", n_floats, hipGetErrorString(e));
+        return NZ_ERR_NOMEM;
+    }
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_tile_free(nz_ctx *ctx, float *dev) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    if (!dev) return NZ_OK;
+    NZ_HIP(hipSetDevice(ctx->device));
+    NZ_TRY_(ctx_sync_all(ctx));  // Dispose(handle): free after the work that uses it
+    NZ_HIP(hipFree(dev));
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_tile_upload(nz_ctx *ctx, float *dev, const float *host, size_t n_floats, nz_handle dep,
+                                  nz_handle *out) {
+    int32_t rc = nz_ctx_begin(ctx, dep);
+    if (rc) return rc;
+    NZ_REQUIRE(dev && host, "dev/host is NULL");
+    NZ_HIP(hipMemcpyAsync(dev, host, n_floats * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_bytes_download(nz_ctx *ctx, const void *dev, void *host, size_t n_bytes, nz_handle dep,
+                                     nz_handle *out) {
+    int32_t rc = nz_ctx_begin(ctx, dep);
+    if (rc) return rc;
+    NZ_REQUIRE(dev && host, "dev/host is NULL");
+    NZ_HIP(hipMemcpyAsync(host, dev, n_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_tile_download(nz_ctx *ctx, const float *dev, float *host, size_t n_floats, nz_handle dep,
+                                    nz_handle *out) {
+    return nz_bytes_download(ctx, dev, host, n_floats * sizeof(float), dep, out);
+}

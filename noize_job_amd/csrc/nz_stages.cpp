@@ -1,500 +1,10 @@
-// nz_api.cpp -- runtime (context, device tiles, JobHandle markers) and the extern "C" entry points
-// of libnoize_hip.so.  See include/noize_hip.h for the reference interface each entry replaces.
+// nz_stages.cpp -- the extern "C" stage entry points of libnoize_hip.so (one per reference job delegate or
+// PipelineStage.Schedule body, include/noize_hip.h) and the launch planners behind them.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 
 #include "nz_internal.hpp"
-
-// ---------------------------------------------------------------------------------------------
-// errors
-// ---------------------------------------------------------------------------------------------
-static thread_local char g_err[1024] = "";
-
-void nz_set_error(const char *fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-}
-
-extern "C" const char *nz_last_error(void) { return g_err; }
-extern "C" int32_t nz_version(void) { return NZ_VERSION; }
-
-extern "C" int32_t nz_device_count(int32_t *count) {
-    NZ_REQUIRE(count, "count is NULL");
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) {
-        *count = 0;
-        nz_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
-        return NZ_ERR_NO_DEVICE;
-    }
-    *count = n;
-    return NZ_OK;
-}
-
-#define NZ_TRY_(expr)             \
-    do {                          \
-        int32_t rc__ = (expr);    \
-        if (rc__) return rc__;    \
-    } while (0)
-
-// ---------------------------------------------------------------------------------------------
-// context
-// ---------------------------------------------------------------------------------------------
-static constexpr size_t NZ_EVENT_RING = 4096;
-
-static int32_t ctx_sync_all(nz_ctx *ctx);
-extern "C" int32_t nz_ctx_set_bands(nz_ctx *ctx, int32_t bands);
-
-static float h_mod289(float x);
-static float h_permute(float x);
-
-static int32_t build_rgrad_table(nz_ctx *ctx) {
-    // noise.psrnoise.  Every hash argument is an integer-valued float, so both
-    // permutes are pure functions of small integers and are tabulated with the reference's own fp32
-    // operations (the first one overflows 2^24 and rounds; the table reproduces that rounding because it is
-    // computed the same way).  (cos u, sin u) of rgrad2 come from the host libm the CPU restatement calls.
-    std::vector<int32_t> buf(NZ_PSR_T1 + 2 * NZ_PSR_T2 * 2);
-    for (int i = 0; i < NZ_PSR_T1; i++) buf[i] = 8 * ((int32_t)h_permute((float)(i - NZ_PSR_O1)) + NZ_PSR_O2);
-    float *t2 = reinterpret_cast<float *>(buf.data() + NZ_PSR_T1);
-    const float rots[2] = {0.0f, 0.62f};  // PeriodicPerlinGetter / RotatedSimplexGetter, Fractal.cs:184,201
-    for (int t = 0; t < 2; t++) {
-        for (int j = 0; j < NZ_PSR_T2; j++) {
-            float h = h_permute((float)(j - NZ_PSR_O2));
-            float u = h * 0.0243902439f + rots[t];
-            u = (u - floorf(u)) * 6.28318530718f;
-            t2[(t * NZ_PSR_T2 + j) * 2 + 0] = cosf(u);
-            t2[(t * NZ_PSR_T2 + j) * 2 + 1] = sinf(u);
-        }
-    }
-    NZ_HIP(hipMalloc((void **)&ctx->d_rgrad, buf.size() * sizeof(int32_t)));
-    NZ_HIP(hipMemcpy(ctx->d_rgrad, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    return NZ_OK;
-}
-
-// Host copies of the reference's hash helpers; plain IEEE fp32, no contraction.
-static float h_mod289(float x) { return x - floorf(x * (1.0f / 289.0f)) * 289.0f; }
-static float h_permute(float x) { return h_mod289((34.0f * x + 1.0f) * x); }
-
-static float h_mod7(float x) { return x - floorf(x * (1.0f / 7.0f)) * 7.0f; }
-
-static int32_t build_simplex_tables(nz_ctx *ctx) {
-    // Lattice tables of nz_fractal.hip (snoise2_tab, cnoise2_tab, cellular_rect_tab), every entry computed
-    // with exactly the operations of the corresponding Unity.Mathematics.noise function:
-    //   simplex : T1[292] int = 16*permute(i);      T2[580] float4 = {a0, h, 1.79284291400159 - 0.85373472095314*(a0*a0+h*h), 0}
-    //   perlin  : P1[292] int = 8*permute(i);       P2[584] float2 = {gx*norm, gy*norm} of permute(j)
-    //   cellular: C1[292] int = 8*permute(i-1);     C2[584] float2 = {ox, oy} of permute(a-1)
-    //   3-D     : P3[580] int = permute(j);           G3c[292] / G3s[292] float4 = normalised corner gradient of
-    //             noise.cnoise(float3) / noise.snoise(float3) for the final hash value 0..288
-    constexpr int T1 = 292, T2 = 580, B1 = 292, B2 = 584, P3 = 580, G3 = 292;
-    std::vector<int32_t> buf(T1 + T2 * 4 + 2 * (B1 + B2 * 2) + P3 + 2 * G3 * 4);
-    for (int i = 0; i < T1; i++) buf[i] = 16 * (int32_t)h_permute((float)i);
-    float *t2 = reinterpret_cast<float *>(buf.data() + T1);
-    for (int j = 0; j < T2; j++) {
-        float p = h_permute((float)j);
-        float y = p * 0.024390243902439f;
-        float x = 2.0f * (y - floorf(y)) - 1.0f;
-        float h = fabsf(x) - 0.5f;
-        float ox = floorf(x + 0.5f);
-        float a0 = x - ox;
-        float nrm = 1.79284291400159f - 0.85373472095314f * (a0 * a0 + h * h);
-        t2[4 * j + 0] = a0;
-        t2[4 * j + 1] = h;
-        t2[4 * j + 2] = nrm;
-        t2[4 * j + 3] = 0.0f;
-    }
-    int32_t *p1 = buf.data() + T1 + T2 * 4;
-    float *p2 = reinterpret_cast<float *>(p1 + B1);
-    for (int i = 0; i < B1; i++) p1[i] = 8 * (int32_t)h_permute((float)i);
-    for (int j = 0; j < B2; j++) {  // noise.cnoise: gradient of i = permute(permute(ix) + iy), normalised
-        float i = h_permute((float)j);
-        float y = i * (1.0f / 41.0f);
-        float g = (y - floorf(y)) * 2.0f - 1.0f;
-        float gy = fabsf(g) - 0.5f;
-        float tx = floorf(g + 0.5f);
-        float gx = g - tx;
-        float nrm = 1.79284291400159f - 0.85373472095314f * (gx * gx + gy * gy);
-        p2[2 * j + 0] = gx * nrm;
-        p2[2 * j + 1] = gy * nrm;
-    }
-    int32_t *c1 = p1 + B1 + B2 * 2;
-    float *c2 = reinterpret_cast<float *>(c1 + B1);
-    const float K = 0.142857142857f, Ko = 0.428571428571f;
-    for (int i = 0; i < B1; i++) c1[i] = 8 * (int32_t)h_permute((float)(i - 1));
-    for (int a = 0; a < B2; a++) {  // noise.cellular: ox = frac(p*K) - Ko; oy = mod7(floor(p*K))*K - Ko
-        float p = h_permute((float)(a - 1));
-        float pk = p * K;
-        c2[2 * a + 0] = (pk - floorf(pk)) - Ko;
-        c2[2 * a + 1] = h_mod7(floorf(pk)) * K - Ko;
-    }
-    int32_t *p3 = c1 + B1 + B2 * 2;
-    for (int j = 0; j < P3; j++) p3[j] = (int32_t)h_permute((float)j);
-    float *g3c = reinterpret_cast<float *>(p3 + P3), *g3s = g3c + G3 * 4;
-    auto step = [](float y, float x) { return x >= y ? 1.0f : 0.0f; };  // math.step(y, x)
-    for (int h = 0; h < G3; h++) {
-        {  // noise.cnoise(float3): gradient decode of ixy0 / ixy1
-            float gx = (float)h * (1.0f / 7.0f);
-            float t = floorf(gx) * (1.0f / 7.0f);
-            float gy = (t - floorf(t)) - 0.5f;
-            gx = gx - floorf(gx);
-            float gz = 0.5f - fabsf(gx) - fabsf(gy);
-            float sz = step(gz, 0.0f);
-            gx -= sz * (step(0.0f, gx) - 0.5f);
-            gy -= sz * (step(0.0f, gy) - 0.5f);
-            float nr = 1.79284291400159f - 0.85373472095314f * (gx * gx + gy * gy + gz * gz);
-            g3c[4 * h + 0] = gx * nr;
-            g3c[4 * h + 1] = gy * nr;
-            g3c[4 * h + 2] = gz * nr;
-            g3c[4 * h + 3] = 0.0f;
-        }
-        {  // noise.snoise(float3): p -> (x, y, h) on the 7x7 grid, octahedron fold, normalisation
-            const float n_ = 0.142857142857f;
-            const float nsx = n_ * 2.0f - 0.0f, nsy = n_ * 0.5f - 1.0f, nsz = n_ * 1.0f - 0.0f;
-            float pp = (float)h;
-            float j = pp - 49.0f * floorf(pp * nsz * nsz);
-            float x_ = floorf(j * nsz);
-            float y_ = floorf(j - 7.0f * x_);
-            float X = x_ * nsx + nsy, Y = y_ * nsx + nsy;
-            float H = 1.0f - fabsf(X) - fabsf(Y);
-            float sx = floorf(X) * 2.0f + 1.0f, sy = floorf(Y) * 2.0f + 1.0f;
-            float sh = -step(H, 0.0f);
-            float ax = X + sx * sh, ay = Y + sy * sh;
-            float nr = 1.79284291400159f - 0.85373472095314f * (ax * ax + ay * ay + H * H);
-            g3s[4 * h + 0] = ax * nr;
-            g3s[4 * h + 1] = ay * nr;
-            g3s[4 * h + 2] = H * nr;
-            g3s[4 * h + 3] = 0.0f;
-        }
-    }
-    NZ_HIP(hipMalloc(&ctx->d_simplex, buf.size() * sizeof(int32_t)));
-    NZ_HIP(hipMemcpy(ctx->d_simplex, buf.data(), buf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    return NZ_OK;
-}
-
-static int32_t ctx_create(int32_t device, hipStream_t stream, bool own, nz_ctx **out) {
-    NZ_REQUIRE(out, "out is NULL");
-    *out = nullptr;
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        nz_set_error("no HIP device available (%s)", e != hipSuccess ? hipGetErrorString(e) : "count 0");
-        return NZ_ERR_NO_DEVICE;
-    }
-    NZ_REQUIRE(device >= 0 && device < n, "device %d out of range [0,%d)", device, n);
-    NZ_HIP(hipSetDevice(device));
-    nz_ctx *ctx = new nz_ctx();
-    ctx->device = device;
-    if (own) {
-        hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-        if (se != hipSuccess) {
-            delete ctx;
-            nz_set_error("hipStreamCreate: %s", hipGetErrorString(se));
-            return NZ_ERR_HIP;
-        }
-        ctx->owns_stream = true;
-    } else {
-        ctx->stream = stream;
-    }
-    int32_t rc = build_rgrad_table(ctx);
-    if (rc == NZ_OK) rc = build_simplex_tables(ctx);
-    if (rc != NZ_OK) {
-        if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
-        delete ctx;
-        return rc;
-    }
-    *out = ctx;
-    if (const char *env = getenv("NZ_BANDS")) {
-        int nb = atoi(env);
-        if (nb > 1) return nz_ctx_set_bands(ctx, nb);
-    }
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_ctx_create(int32_t device, nz_ctx **out) { return ctx_create(device, nullptr, true, out); }
-
-extern "C" int32_t nz_ctx_create_on_stream(int32_t device, void *hip_stream, nz_ctx **out) {
-    return ctx_create(device, (hipStream_t)hip_stream, false, out);
-}
-
-extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
-    if (!ctx) return NZ_OK;
-    (void)hipSetDevice(ctx->device);
-    (void)ctx_sync_all(ctx);
-    for (hipStream_t bs : ctx->bstreams) (void)hipStreamDestroy(bs);
-    for (int k = 0; k < 2; k++)
-        for (hipEvent_t ev : ctx->bev[k]) (void)hipEventDestroy(ev);
-    if (ctx->hstream) (void)hipStreamDestroy(ctx->hstream);
-    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
-    for (hipEvent_t ev : ctx->events)
-        if (ev) (void)hipEventDestroy(ev);
-    if (ctx->d_rgrad) (void)hipFree(ctx->d_rgrad);
-    if (ctx->d_simplex) (void)hipFree(ctx->d_simplex);
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_ctx_synchronize(nz_ctx *ctx) {
-    NZ_REQUIRE(ctx, "ctx is NULL");
-    NZ_HIP(hipSetDevice(ctx->device));
-    return ctx_sync_all(ctx);
-}
-
-extern "C" void *nz_ctx_stream(nz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
-
-static int32_t bands_join(nz_ctx *ctx) {
-    // the main stream catches up with every band: needed before any call that is not band-aware
-    if (!ctx->bands_active) return NZ_OK;
-    for (int b = 0; b < ctx->nbands; b++)
-        if (ctx->bev_valid[b]) NZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->bev[ctx->bev_prev][b], 0));
-    ctx->bands_active = false;
-    return NZ_OK;
-}
-
-static int32_t ctx_sync_all(nz_ctx *ctx) {
-    NZ_HIP(hipStreamSynchronize(ctx->stream));
-    for (hipStream_t bs : ctx->bstreams) NZ_HIP(hipStreamSynchronize(bs));
-    if (ctx->hstream) NZ_HIP(hipStreamSynchronize(ctx->hstream));
-    return NZ_OK;
-}
-
-int32_t nz_ctx_begin_banded(nz_ctx *ctx, nz_handle dep) {
-    NZ_REQUIRE(ctx, "ctx is NULL");
-    NZ_HIP(hipSetDevice(ctx->device));
-    // all work of a ctx is ordered on its streams, so a dependency on one of its own handles is
-    // already satisfied by that order; anything else is a caller error
-    NZ_REQUIRE(dep <= ctx->last_handle, "dependency handle %llu was not issued by this context",
-               (unsigned long long)dep);
-    return NZ_OK;
-}
-
-int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep) {
-    int32_t rc = nz_ctx_begin_banded(ctx, dep);
-    if (rc) return rc;
-    return bands_join(ctx);
-}
-
-static int32_t handle_new_event(nz_ctx *ctx, hipEvent_t **ev, uint64_t *h) {
-    if (ctx->events.empty()) ctx->events.assign(NZ_EVENT_RING, nullptr);
-    *h = ctx->last_handle + 1;
-    *ev = &ctx->events[*h % NZ_EVENT_RING];
-    if (!**ev) NZ_HIP(hipEventCreate(*ev));
-    return NZ_OK;
-}
-
-int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out) {
-    if (!out) return NZ_OK;
-    hipEvent_t *ev;
-    uint64_t h;
-    int32_t rc = handle_new_event(ctx, &ev, &h);
-    if (rc) return rc;
-    if (ctx->bands_active) {
-        // marker = all bands done, recorded on a side stream so that neither the main stream nor the
-        // band streams wait for it
-        for (int b = 0; b < ctx->nbands; b++)
-            if (ctx->bev_valid[b]) NZ_HIP(hipStreamWaitEvent(ctx->hstream, ctx->bev[ctx->bev_prev][b], 0));
-        NZ_HIP(hipEventRecord(*ev, ctx->hstream));
-    } else {
-        NZ_HIP(hipEventRecord(*ev, ctx->stream));
-    }
-    ctx->last_handle = h;
-    *out = h;
-    return NZ_OK;
-}
-
-// Runs `launch(stream, geom)` once per row band of [g.or0, g.or1).  Band b waits for the previous
-// launch of bands b-1 and b+1 (read-after-write of their halo rows and write-after-read of the plane
-// they may still be reading); with `stagger` it also waits for band b-1 of THIS launch, which
-// serialises a halo-free stage band by band so that later stages of early bands can start under it.
-template <class F>
-static int32_t banded_launch(nz_ctx *ctx, const nz_geom &g, bool stagger, F launch) {
-    int rows = g.or1 - g.or0;
-    if (ctx->nbands <= 1 || rows < 128 * ctx->nbands || g.count > 1) {
-        int32_t rc = bands_join(ctx);
-        if (rc) return rc;
-        return launch(ctx->stream, g);
-    }
-    const int B = ctx->nbands;
-    if (ctx->bands_active && (ctx->band_or0 != g.or0 || ctx->band_or1 != g.or1)) {
-        int32_t rc = bands_join(ctx);  // a different partition: start over from a full barrier
-        if (rc) return rc;
-    }
-    if (!ctx->bands_active) {
-        NZ_HIP(hipEventRecord(ctx->fork_ev, ctx->stream));
-        for (int b = 0; b < B; b++) {
-            NZ_HIP(hipStreamWaitEvent(ctx->bstreams[b], ctx->fork_ev, 0));
-            ctx->bev_valid[b] = 0;
-        }
-        ctx->bands_active = true;
-        ctx->band_or0 = g.or0;
-        ctx->band_or1 = g.or1;
-    }
-    const int prev = ctx->bev_prev, cur = prev ^ 1;
-    for (int b = 0; b < B; b++) {
-        nz_geom gb = g;
-        gb.or0 = g.or0 + (int)(((long long)rows * b / B) & ~7LL);
-        gb.or1 = b == B - 1 ? g.or1 : g.or0 + (int)(((long long)rows * (b + 1) / B) & ~7LL);
-        hipStream_t bs = ctx->bstreams[b];
-        if (b > 0 && ctx->bev_valid[b - 1]) NZ_HIP(hipStreamWaitEvent(bs, ctx->bev[prev][b - 1], 0));
-        if (b + 1 < B && ctx->bev_valid[b + 1]) NZ_HIP(hipStreamWaitEvent(bs, ctx->bev[prev][b + 1], 0));
-        if (stagger && b > 0) NZ_HIP(hipStreamWaitEvent(bs, ctx->bev[cur][b - 1], 0));
-        int32_t rc = launch(bs, gb);
-        if (rc) return rc;
-        NZ_HIP(hipEventRecord(ctx->bev[cur][b], bs));
-    }
-    for (int b = 0; b < B; b++) ctx->bev_valid[b] = 1;
-    ctx->bev_prev = cur;
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_ctx_set_bands(nz_ctx *ctx, int32_t bands) {
-    NZ_REQUIRE(ctx, "ctx is NULL");
-    NZ_REQUIRE(bands >= 1 && bands <= 64, "bands %d out of range [1,64]", bands);
-    NZ_HIP(hipSetDevice(ctx->device));
-    int32_t rc = bands_join(ctx);
-    if (rc) return rc;
-    rc = ctx_sync_all(ctx);
-    if (rc) return rc;
-    while ((int)ctx->bstreams.size() < bands) {
-        hipStream_t st;
-        NZ_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        ctx->bstreams.push_back(st);
-        for (int k = 0; k < 2; k++) {
-            hipEvent_t ev;
-            NZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            ctx->bev[k].push_back(ev);
-        }
-        ctx->bev_valid.push_back(0);
-    }
-    if (bands > 1 && !ctx->hstream) {
-        NZ_HIP(hipStreamCreateWithFlags(&ctx->hstream, hipStreamNonBlocking));
-        NZ_HIP(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
-    }
-    ctx->nbands = bands;
-    return NZ_OK;
-}
-
-int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out) {
-    if (floats > ctx->scratch_floats) {
-        if (ctx->scratch) {
-            NZ_TRY_(ctx_sync_all(ctx));
-            NZ_HIP(hipFree(ctx->scratch));
-            ctx->scratch = nullptr;
-            ctx->scratch_floats = 0;
-        }
-        hipError_t e = hipMalloc((void **)&ctx->scratch, floats * sizeof(float));
-        if (e != hipSuccess) {
-            nz_set_error("hipMalloc(%zu floats): %s", floats, hipGetErrorString(e));
-            return NZ_ERR_NOMEM;
-        }
-        ctx->scratch_floats = floats;
-    }
-    *out = ctx->scratch;
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_handle_record(nz_ctx *ctx, nz_handle *out) {
-    NZ_REQUIRE(ctx && out, "ctx/out is NULL");
-    NZ_HIP(hipSetDevice(ctx->device));
-    return nz_ctx_finish(ctx, out);
-}
-
-static bool handle_live(nz_ctx *ctx, nz_handle h) {
-    return h != 0 && h <= ctx->last_handle && h + NZ_EVENT_RING > ctx->last_handle;
-}
-
-extern "C" int32_t nz_handle_query(nz_ctx *ctx, nz_handle h, int32_t *is_completed) {
-    NZ_REQUIRE(ctx && is_completed, "ctx/is_completed is NULL");
-    NZ_REQUIRE(h <= ctx->last_handle, "unknown handle");
-    NZ_HIP(hipSetDevice(ctx->device));
-    if (h == 0) {
-        *is_completed = 1;  // default(JobHandle).IsCompleted == true
-        return NZ_OK;
-    }
-    hipError_t e = handle_live(ctx, h) ? hipEventQuery(ctx->events[h % NZ_EVENT_RING])
-                                      : (ctx->bands_active ? hipErrorNotReady : hipStreamQuery(ctx->stream));
-    if (e == hipSuccess) {
-        *is_completed = 1;
-    } else if (e == hipErrorNotReady) {
-        *is_completed = 0;
-        (void)hipGetLastError();
-    } else {
-        nz_set_error("handle query: %s", hipGetErrorString(e));
-        return NZ_ERR_HIP;
-    }
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_handle_wait(nz_ctx *ctx, nz_handle h) {
-    NZ_REQUIRE(ctx, "ctx is NULL");
-    NZ_REQUIRE(h <= ctx->last_handle, "unknown handle");
-    NZ_HIP(hipSetDevice(ctx->device));
-    if (h == 0) return NZ_OK;
-    if (handle_live(ctx, h)) {
-        NZ_HIP(hipEventSynchronize(ctx->events[h % NZ_EVENT_RING]));
-    } else {
-        NZ_TRY_(ctx_sync_all(ctx));
-    }
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_handle_elapsed_ms(nz_ctx *ctx, nz_handle start, nz_handle stop, float *ms) {
-    NZ_REQUIRE(ctx && ms, "ctx/ms is NULL");
-    NZ_REQUIRE(handle_live(ctx, start) && handle_live(ctx, stop), "handle expired or unknown");
-    NZ_HIP(hipSetDevice(ctx->device));
-    NZ_HIP(hipEventElapsedTime(ms, ctx->events[start % NZ_EVENT_RING], ctx->events[stop % NZ_EVENT_RING]));
-    return NZ_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// tiles
-// ---------------------------------------------------------------------------------------------
-extern "C" int32_t nz_tile_alloc(nz_ctx *ctx, size_t n_floats, float **out_dev) {
-    NZ_REQUIRE(ctx && out_dev, "ctx/out is NULL");
-    NZ_HIP(hipSetDevice(ctx->device));
-    *out_dev = nullptr;
-    hipError_t e = hipMalloc((void **)out_dev, (n_floats ? n_floats : 1) * sizeof(float));
-    if (e != hipSuccess) {
-        nz_set_error("hipMalloc(%zu floats): %s", n_floats, hipGetErrorString(e));
-        return NZ_ERR_NOMEM;
-    }
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_tile_free(nz_ctx *ctx, float *dev) {
-    NZ_REQUIRE(ctx, "ctx is NULL");
-    if (!dev) return NZ_OK;
-    NZ_HIP(hipSetDevice(ctx->device));
-    NZ_TRY_(ctx_sync_all(ctx));  // Dispose(handle): free after the work that uses it
-    NZ_HIP(hipFree(dev));
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_tile_upload(nz_ctx *ctx, float *dev, const float *host, size_t n_floats, nz_handle dep,
-                                  nz_handle *out) {
-    int32_t rc = nz_ctx_begin(ctx, dep);
-    if (rc) return rc;
-    NZ_REQUIRE(dev && host, "dev/host is NULL");
-    NZ_HIP(hipMemcpyAsync(dev, host, n_floats * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    return nz_ctx_finish(ctx, out);
-}
-
-extern "C" int32_t nz_bytes_download(nz_ctx *ctx, const void *dev, void *host, size_t n_bytes, nz_handle dep,
-                                     nz_handle *out) {
-    int32_t rc = nz_ctx_begin(ctx, dep);
-    if (rc) return rc;
-    NZ_REQUIRE(dev && host, "dev/host is NULL");
-    NZ_HIP(hipMemcpyAsync(host, dev, n_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    return nz_ctx_finish(ctx, out);
-}
-
-extern "C" int32_t nz_tile_download(nz_ctx *ctx, const float *dev, float *host, size_t n_floats, nz_handle dep,
-                                    nz_handle *out) {
-    return nz_bytes_download(ctx, dev, host, n_floats * sizeof(float), dep, out);
-}
 
 // ---------------------------------------------------------------------------------------------
 // helpers shared by the stage entry points
@@ -670,13 +180,13 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     if (nz_conv_has_wide(t.ksize)) {  // one launch per application, ping-pong, copy back after an odd count
         float *cur = src, *other = tmp;
         for (int i = 0; i < iterations; i++) {
-            NZ_TRY_(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
                 return nz_launch_conv_wide(st, cur, other, gb, t);
             }));
             float *s = cur; cur = other; other = s;
         }
         if (cur != src) {
-            NZ_TRY_(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
                 size_t off = (size_t)gb.or0 * gb.pitch;
                 return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
             }));
@@ -684,10 +194,10 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         return NZ_OK;
     }
     if (cap > 0 && iterations == 1) {  // the delegate's single application: one launch into tmp, copy back
-        NZ_TRY_(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+        NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_conv_fused(st, src, tmp, gb, t, 1);
         }));
-        return banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+        return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
             return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
         });
@@ -702,11 +212,11 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
             return NZ_OK;
         }
         for (int i = 0; i < iterations; i++) {
-            int32_t rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            int32_t rc = launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
                 return nz_launch_conv_pass_x(st, src, tmp, gb, t);
             });
             if (rc) return rc;
-            rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+            rc = launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
                 return nz_launch_conv_pass_z(st, tmp, src, gb, t);
             });
             if (rc) return rc;
@@ -719,14 +229,14 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
         int T = base + (i < rem ? 1 : 0);
-        int32_t rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+        int32_t rc = launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_conv_fused(st, cur, other, gb, t, T);
         });
         if (rc) return rc;
         float *s = cur; cur = other; other = s;
     }
     if (cur != src) {  // odd count (only when cap == 1): copy back
-        return banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+        return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
             return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
         });
@@ -740,10 +250,10 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
     if (iterations == 1) {
         // ErosionKernelJob.ScheduleSeries KernelJob.cs:318-335: min-X then min-Z (size 3) = the min over
         // {x-1,x} x {z-1,z}; one launch into tmp, then the copy back that stands for the flush
-        NZ_TRY_(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+        NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_erosion_fused(st, src, tmp, gb, 1);
         }));
-        return banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+        return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
             return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
         });
@@ -756,7 +266,7 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
         int E = base + (i < rem ? 1 : 0);
-        int32_t rc = banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+        int32_t rc = launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_erosion_fused(st, cur, other, gb, E);
         });
         if (rc) return rc;
@@ -771,12 +281,6 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
         if (rc_) return rc_;                 \
     } while (0)
 
-#define NZ_BEGIN_BANDED(ctx, dep)                    \
-    do {                                             \
-        int32_t rc_ = nz_ctx_begin_banded(ctx, dep); \
-        if (rc_) return rc_;                         \
-    } while (0)
-
 #define NZ_TRY(expr)              \
     do {                          \
         int32_t rc_ = (expr);     \
@@ -789,15 +293,10 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
 extern "C" int32_t nz_fractal(nz_ctx *ctx, int32_t noiseType, float *src, int32_t resolution, float hurst,
                               float startingAmplitude, float stepdown, float detuneRate, int32_t octaves,
                               int32_t xpos, int32_t zpos, int32_t noiseSize, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN_BANDED(ctx, dep);
+    NZ_BEGIN(ctx, dep);
     NZ_TRY(check_res(resolution));
-    // no halo: bands are serialised (stagger) so that the filters of the first bands can start under the
-    // noise of the later ones
-    NZ_TRY(banded_launch(ctx, nz_geom_tile(resolution), true, [&](hipStream_t st, const nz_geom &gb) {
-        return fractal_impl(ctx, st, noiseType, src ? src + (size_t)gb.or0 * resolution : nullptr, gb.or1 - gb.or0,
-                            resolution, resolution, hurst, startingAmplitude, stepdown, detuneRate, octaves, xpos,
-                            zpos + gb.or0, noiseSize);
-    }));
+    NZ_TRY(fractal_impl(ctx, ctx->stream, noiseType, src, resolution, resolution, resolution, hurst, startingAmplitude,
+                        stepdown, detuneRate, octaves, xpos, zpos, noiseSize));
     return nz_ctx_finish(ctx, out);
 }
 
@@ -836,11 +335,9 @@ static int32_t edge_2d(nz_ctx *ctx, float *src, float *tmp, int resolution, int 
     th.factor = tv.factor = 1.0f;
     nz_geom g = nz_geom_tile(resolution);
     for (int i = 0; i < iterations; i++) {
-        NZ_TRY(bands_join(ctx));
         NZ_TRY(nz_launch_copy(ctx->stream, original, src, n));
         NZ_TRY(conv_iterations(ctx, src, tmp, g, th, 1));
         NZ_TRY(conv_iterations(ctx, original, tmp, g, tv, 1));
-        NZ_TRY(bands_join(ctx));
         NZ_TRY(nz_launch_reduce(ctx->stream, 2 /* ROOTSUMSQUARES */, src, original, n));
     }
     return NZ_OK;
@@ -848,7 +345,7 @@ static int32_t edge_2d(nz_ctx *ctx, float *src, float *tmp, int resolution, int 
 
 extern "C" int32_t nz_kernel_filter_stage(nz_ctx *ctx, float *src, float *tmp, int32_t filter, int32_t iterations,
                                           int32_t resolution, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN_BANDED(ctx, dep);
+    NZ_BEGIN(ctx, dep);
     NZ_TRY(check_res(resolution));
     if (filter == NZ_SOBEL3_2D) {
         NZ_TRY(edge_2d(ctx, src, tmp, resolution, iterations, NZ_SOBEL3_HORIZONTAL, NZ_SOBEL3_VERTICAL));
@@ -873,7 +370,7 @@ extern "C" int32_t nz_edge_1d_filter(nz_ctx *ctx, float *src, float *tmp, int32_
 
 extern "C" int32_t nz_edge_2d_filter(nz_ctx *ctx, float *src, float *tmp, int32_t algo, int32_t resolution,
                                      nz_handle dep, nz_handle *out) {
-    NZ_BEGIN_BANDED(ctx, dep);
+    NZ_BEGIN(ctx, dep);
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(algo == 0 || algo == 1, "EdgeAlgorithm %d out of range", algo);
     NZ_TRY(edge_2d(ctx, src, tmp, resolution, 1, algo == 0 ? NZ_SOBEL3_HORIZONTAL : NZ_PREWITT3_HORIZONTAL,
@@ -888,7 +385,7 @@ extern "C" int32_t nz_kernel_filter(nz_ctx *ctx, float *src, float *tmp, int32_t
 
 extern "C" int32_t nz_gauss_blur_stage(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t sigma,
                                        int32_t iterations, int32_t resolution, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN_BANDED(ctx, dep);
+    NZ_BEGIN(ctx, dep);
     NZ_TRY(check_res(resolution));
     nz_kernel_taps t;
     NZ_TRY(gauss_taps(width, sigma, &t));
@@ -903,7 +400,7 @@ extern "C" int32_t nz_gauss_filter(nz_ctx *ctx, float *src, float *tmp, int32_t 
 
 extern "C" int32_t nz_smooth_blur_stage(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t iterations,
                                         int32_t resolution, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN_BANDED(ctx, dep);
+    NZ_BEGIN(ctx, dep);
     NZ_TRY(check_res(resolution));
     nz_kernel_taps t;
     NZ_TRY(smooth_taps(width, &t));
@@ -936,7 +433,7 @@ extern "C" int32_t nz_separable_series(nz_ctx *ctx, float *src, float *tmp, int3
 
 extern "C" int32_t nz_erosion_stage(nz_ctx *ctx, float *src, float *tmp, int32_t iterations, int32_t resolution,
                                     nz_handle dep, nz_handle *out) {
-    NZ_BEGIN_BANDED(ctx, dep);
+    NZ_BEGIN(ctx, dep);
     NZ_TRY(check_res(resolution));
     NZ_TRY(erosion_iterations(ctx, src, tmp, nz_geom_tile(resolution), iterations));
     return nz_ctx_finish(ctx, out);
@@ -1067,7 +564,7 @@ extern "C" size_t nz_flowmap_stage_work_floats(int32_t resolution) {
 
 static int32_t flowmap_stage_impl(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
                                   float normMax, int32_t resolution, int32_t count, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN_BANDED(ctx, dep);
+    NZ_BEGIN(ctx, dep);
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(src && work, "src/work is NULL");
     NZ_REQUIRE(iterations >= 1, "iterations < 1");
@@ -1096,7 +593,7 @@ static int32_t flowmap_stage_impl(nz_ctx *ctx, float *src, float *work, int32_t 
         int first = i == 0, last = i == launches - 1;
         const float *hsrc = first ? src : hcopy;
         float *dst = !last ? nullptr : (launches == 1 ? hcopy : src);
-        NZ_TRY(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+        NZ_TRY(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_flow_fused(st, hsrc, first ? nullptr : cur, last ? nullptr : nxt, dst,
                                         (first && !last) ? hcopy : nullptr, gb, nit, first, last, normMin,
                                         normMax - normMin);
@@ -1104,7 +601,7 @@ static int32_t flowmap_stage_impl(nz_ctx *ctx, float *src, float *work, int32_t 
         float **s = cur; cur = nxt; nxt = s;
     }
     if (launches == 1) {
-        NZ_TRY(banded_launch(ctx, g, false, [&](hipStream_t st, const nz_geom &gb) {
+        NZ_TRY(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
             return nz_launch_copy(st, src + off, hcopy + off, nz_geom_span(gb));
         }));

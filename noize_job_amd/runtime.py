@@ -118,10 +118,6 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
-    def set_bands(self, bands):
-        """Banded asynchronous execution of the stage-level calls (see nz_ctx_set_bands)."""
-        N.check(N.lib.nz_ctx_set_bands(self._h, int(bands)), "nz_ctx_set_bands")
-
     def synchronize(self):
         N.check(N.lib.nz_ctx_synchronize(self._h), "nz_ctx_synchronize")
 
