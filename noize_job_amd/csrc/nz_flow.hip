@@ -39,7 +39,7 @@ __device__ __forceinline__ flux4 compute_flow(float totalHt, float water_0, floa
     f.e = fmaxf(0.0f, old.e + dE);
     f.s = fmaxf(0.0f, old.s + dS);
     f.n = fmaxf(0.0f, old.n + dN);
-    float sum_ = f.w + f.e + f.s + f.n;
+    float sum_ = (f.w + f.e) + (f.s + f.n);  // math.csum(float4) = (x.x + x.y) + (x.z + x.w)
     if (sum_ > 0.0f) {
         float K = water_0 / (sum_ * TIMESTEP);
         K = fmaxf(0.0f, fminf(1.0f, K));

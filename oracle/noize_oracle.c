@@ -699,7 +699,7 @@ void nzo_flow_step(const float *height, const float *water, float *fN, float *fN
             float flE = maxf_(0.0f, fE[c] + dE);
             float flS = maxf_(0.0f, fS[c] + dS);
             float flN = maxf_(0.0f, fN[c] + dN);
-            float sum_ = flW + flE + flS + flN; /* csum(float4) = ((x+y)+z)+w */
+            float sum_ = (flW + flE) + (flS + flN); /* math.csum(float4) = (x.x + x.y) + (x.z + x.w), Unity.Mathematics 1.2.1 */
             if (sum_ > 0.0f) {
                 float K = water_0 / (sum_ * TIMESTEP);
                 K = K < 0.0f ? 0.0f : (K > 1.0f ? 1.0f : K); /* clamp(K,0,1) = max(0,min(1,K)) */

@@ -51,7 +51,7 @@ def np_flow_step(h, w, fN, fS, fE, fW):
     z = f32(0)
     flW, flE, flS, flN = (np.maximum(z, fW + dW), np.maximum(z, fE + dE), np.maximum(z, fS + dS),
                           np.maximum(z, fN + dN))
-    s = ((flW + flE) + flS) + flN
+    s = (flW + flE) + (flS + flN)   # math.csum(float4): pairwise
     with np.errstate(divide="ignore", invalid="ignore"):
         K = np.clip(w / (s * f32(0.2)), f32(0), f32(1))
     pos = s > 0
