@@ -1,0 +1,45 @@
+"""bench.py keeps its contract: ONE JSON line on stdout with the metric, the roofline of the dominant
+kernel (measured with HIP events inside the timed steps) and the CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one line, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    d = _run("--steps", "6", "--warmup", "2", "--res", "1024", "--cpu-res", "512")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["unit"] == "Mcells/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(d["config"]["cells"] / (d["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3) and "traffic" in r
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=2e-2)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mcells/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert set(d["stages"]) == {"noise", "gauss", "flow", "erosion"}
+
+
+def test_stripe_rehearsal_line():
+    d = _run("--steps", "4", "--warmup", "1", "--as-rank", "1", "4", "--stripe-rows", "256", "--cols", "1024")
+    assert d["n_gpus"] == 1 and "cpu_baseline" not in d and "roofline" in d
+    assert "rehearsal of rank 1 of 4" in d["config"]["parallelism"] and d["config"]["cells"] == 256 * 1024
