@@ -18,7 +18,7 @@ minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
 deadline = time.time() + 60 * minutes
 ctx = nj.Context(0)
 f32 = np.float32
-seed, fails, runs = 10_000, 0, 0
+seed, fails, runs = int(os.environ.get("SOAK_SEED", "10000")), 0, 0
 orig_rng = np.random.default_rng
 while time.time() < deadline:
     seed += 1
