@@ -69,17 +69,26 @@ __device__ __forceinline__ float dpp_next(float v) {  // lane i <- lane i+1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+// Register budget per tap count (waves per SIMD the allocator is asked to fit): the 5-tap kernel runs three
+// 512-thread workgroups per CU (6 waves per SIMD, 80 VGPRs, one edge buffer of 32 KB each) so one workgroup's
+// load/store phase overlaps the others' VALU phases: 5 % faster than two workgroups at 121 VGPRs; the 7- and
+// 9-tap windows do not fit 80 registers without spilling and stay at two.
+#ifndef NZ_CONV5_WAVES
+#define NZ_CONV5_WAVES 6
+#endif
+constexpr int conv_waves(int ks, int nt) { return ks == 5 ? NZ_CONV5_WAVES : nt >= 512 ? 4 : 6; }
+
 template <int KS, bool UNIT, int NT>
-__global__ __launch_bounds__(NT) void conv_reg_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(KS, NT)))) void conv_reg_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
                                                      nz_kernel_taps taps, int T, int aligned) {
     constexpr int O = (KS - 1) / 2;
     constexpr int WN = 4 + 2 * O;   // X window
     constexpr int ZN = RB + 2 * O;  // Z window
     constexpr int TH = NT / 32 * RB;  // tile rows: one 8-row block per 32 threads (shadows the file-level TH)
     // boundary rows of every 8-row block: [parity][block][top|bottom][o][column group].  Double buffered
-    // (one barrier per application) while that fits 4 workgroups per CU; 7- and 9-tap kernels keep one
-    // buffer and pay a second barrier instead of halving the occupancy.
-    constexpr int NBUF = O >= 3 ? 1 : 2;
+    // (one barrier per application) for the 3-tap kernel; the others keep one buffer and pay a second barrier
+    // instead of giving up a resident workgroup (5 taps: 3 x 32 KB; 7/9 taps: 2 x 48/64 KB).
+    constexpr int NBUF = O >= 2 ? 1 : 2;
     __shared__ float4 s_edge[NBUF][TH / RB][2][O][TW / 4];
 
     const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
