@@ -228,15 +228,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
 }
 
 // E applications of the {-1,0} min window fused as one window min over [x-E,x] x [z-E,z], register
-// resident like conv_reg_kernel: the X pass reaches E <= 4 cells into the lane on the left (DPP), the Z
-// pass E rows into the block above (LDS).  Cells outside the grid are loaded as +FLT_MAX: the clamped
-// tap they stand for duplicates a cell that is already inside the window, so they must not win a min.
+// resident like conv_reg_kernel: the X pass reaches E <= 8 cells into the one or two lanes on the left
+// (DPP), the Z pass E <= 8 rows into the block above (LDS).  Cells outside the grid are loaded as +FLT_MAX:
+// the clamped tap they stand for duplicates a cell that is already inside the window, so they must not win
+// a min.  The default five iterations are one launch (one read and one write of the plane).
 template <int E>
 __global__ __launch_bounds__(CT) void erosion_reg_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                         nz_geom g, int aligned) {
     __shared__ float4 s_edge[TH / RB][E][TW / 4];
     constexpr float BIG = 3.40282347e+38f;
-    constexpr int HX = 4;
+    constexpr int HX = E > 4 ? 8 : 4;
+    static_assert(E >= 1 && E <= RB, "the window reaches one 8-row block / two lanes back at most");
     const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
     const int OW = TW - HX, OH = TH - E;
     src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
@@ -267,11 +269,32 @@ __global__ __launch_bounds__(CT) void erosion_reg_kernel(const float *__restrict
 #pragma unroll
     for (int r = 0; r < RB; r++) {
         float w[4 + E];
+        if constexpr (E <= 4) {
 #pragma unroll
-        for (int o = 0; o < E; o++) w[o] = dpp_prev(v[r][4 - E + o]);
-        if (cg == 0) {  // no lane to the left inside this tile row: halo garbage, keep it neutral
+            for (int o = 0; o < E; o++) w[o] = dpp_prev(v[r][4 - E + o]);
+            if (cg == 0) {  // no lane to the left inside this tile row: halo garbage, keep it neutral
 #pragma unroll
-            for (int o = 0; o < E; o++) w[o] = BIG;
+                for (int o = 0; o < E; o++) w[o] = BIG;
+            }
+        } else {  // cells x-E..x-5 sit two lanes to the left
+            // every lane must execute the shifts (a lane masked off would hand its neighbour the DPP `old`
+            // value): the empty asm pins each result before the select, which the compiler otherwise turns
+            // into a branch around the move
+            float p1[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float t = dpp_prev(v[r][e]);
+                asm volatile("" : "+v"(t));
+                p1[e] = cg == 0 ? BIG : t;
+            }
+#pragma unroll
+            for (int o = 0; o < E - 4; o++) {
+                float t = dpp_prev(p1[8 - E + o]);
+                asm volatile("" : "+v"(t));
+                w[o] = cg == 0 ? BIG : t;  // lane 1 receives lane 0's BIG through p1
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) w[E - 4 + e] = p1[e];
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) w[E + e] = v[r][e];
@@ -572,7 +595,10 @@ int32_t nz_launch_conv_pass_z(hipStream_t s, const float *src, float *dst, const
     return NZ_OK;
 }
 
-int nz_erosion_max_fused() { return 4; }
+int nz_erosion_max_fused() {
+    static const int cap = getenv("NZ_EROSION_EMAX") ? atoi(getenv("NZ_EROSION_EMAX")) : 8;
+    return cap < 1 ? 1 : (cap > 8 ? 8 : cap);
+}
 
 int32_t nz_launch_erosion_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g, int E) {
     if (E < 1 || E > nz_erosion_max_fused()) {
@@ -580,14 +606,18 @@ int32_t nz_launch_erosion_fused(hipStream_t s, const float *src, float *dst, con
         return NZ_ERR_INVALID;
     }
     if (g.or1 <= g.or0) return NZ_OK;
-    int OW = TW - 4, OH = TH - E;
+    int OW = TW - (E > 4 ? 8 : 4), OH = TH - E;
     long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
     int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
     switch (E) {
         case 1: hipLaunchKernelGGL((erosion_reg_kernel<1>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
         case 2: hipLaunchKernelGGL((erosion_reg_kernel<2>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
         case 3: hipLaunchKernelGGL((erosion_reg_kernel<3>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
-        default: hipLaunchKernelGGL((erosion_reg_kernel<4>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 4: hipLaunchKernelGGL((erosion_reg_kernel<4>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 5: hipLaunchKernelGGL((erosion_reg_kernel<5>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 6: hipLaunchKernelGGL((erosion_reg_kernel<6>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 7: hipLaunchKernelGGL((erosion_reg_kernel<7>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        default: hipLaunchKernelGGL((erosion_reg_kernel<8>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
     }
     NZ_HIP(hipGetLastError());
     return NZ_OK;
