@@ -118,73 +118,118 @@ __device__ __forceinline__ int flooded_cmp(const flooded &a, const flooded &b) {
 
 // One colour pass of PoolAutomataJob (MultiThreadErosionJob.cs:264-327, drainParticles == false): thread k walks row
 // z = 2k + zoff over x = xoff (+1 for odd k), step 2, calling WorldTile.SpreadPool (LiveErosionDataTypes.cs:938-1010)
-// wherever water stands.  The walk along a row is sequential in the reference too (a cell's right-hand neighbour is
-// the next cell's left-hand one); rows of one pass share no cell.  z is the fast index of the planes, so the lanes
-// of a wave touch neighbouring addresses at every step.
-__global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *__restrict__ pool, const float *__restrict__ height,
-                                                               int res, int xoff, int zoff) {
+// wherever water stands.  The walk along a row is sequential in the reference too; rows of one pass share no cell.
+// z is the fast index of the planes, so the lanes of a wave touch neighbouring addresses at every step.
+//
+// What one step leaves for a later step of the same walk is a single cell: the right-hand neighbour (x+1, z) of
+// step x is the left-hand neighbour of step x+2; every other cell a step reads (itself, (x, z+-1), (x+1, z)) is
+// written by no earlier step of the walk and by no other walk of the pass.  So the loads of PU consecutive steps are
+// issued together, ahead of the arithmetic, and the one carried cell travels in a register: the walk pays one
+// memory round trip per PU steps instead of a store -> load round trip per step.
+constexpr int PU = 8;
+
+__global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *pool, const float *__restrict__ height, int res,
+                                                               int xoff, int zoff) {
     int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= res / 2) return;
-    int z = 2 * k + zoff;
-    for (int x = xoff + ((k & 1) ? 1 : 0); x < res; x += 2) {
-        size_t idx = (size_t)x * res + z;
-        float hWater = pool[idx];
-        if (!(hWater > 0.0f)) continue;
-        float hLand = height[idx];
-        float tHeight = hLand + hWater;
-        flooded b[4];
-        const int dx[4] = {0, 1, 0, -1}, dz[4] = {1, 0, -1, 0};  // up, right, down, left; SafeIdx clamps (:585-589)
+    const int z = 2 * k + zoff;
+    const int zu = min(z + 1, res - 1), zd = max(z - 1, 0);  // SafeIdx clamps (:585-589)
+    float carry = 0.0f;
+    bool have_carry = false;
+    for (int x0 = xoff + ((k & 1) ? 1 : 0); x0 < res; x0 += 2 * PU) {
+        float sw[PU], sh[PU], nh[PU][4], nw[PU][4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            int nx = min(max(x + dx[e], 0), res - 1), nz = min(max(z + dz[e], 0), res - 1);
-            b[e].idx = nx * res + nz;
-            b[e].height = height[b[e].idx];
-            b[e].water = pool[b[e].idx];
+        for (int u = 0; u < PU; u++) {
+            int x = min(x0 + 2 * u, res - 1);  // steps past the end of the row load a valid cell and are skipped below
+            int xr = min(x + 1, res - 1), xl = max(x - 1, 0);
+            size_t c = (size_t)x * res;
+            sw[u] = pool[c + z];
+            sh[u] = height[c + z];
+            nh[u][0] = height[c + zu];                 nw[u][0] = pool[c + zu];                  // up
+            nh[u][1] = height[(size_t)xr * res + z];   nw[u][1] = pool[(size_t)xr * res + z];    // right
+            nh[u][2] = height[c + zd];                 nw[u][2] = pool[c + zd];                  // down
+            nh[u][3] = height[(size_t)xl * res + z];   nw[u][3] = pool[(size_t)xl * res + z];    // left
         }
-        // NativeArray.Sort() of com.unity.collections 1.4.0 on 4 elements: insertion sort, element i+1 moves left
-        // while it compares < 0 -- written out with fixed positions so that b[] stays in registers
-        {
-            flooded t = b[1];
-            if (flooded_cmp(t, b[0]) < 0) { b[1] = b[0]; b[0] = t; }
-            t = b[2];
-            if (flooded_cmp(t, b[1]) < 0) {
-                b[2] = b[1];
-                if (flooded_cmp(t, b[0]) < 0) { b[1] = b[0]; b[0] = t; } else { b[1] = t; }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const int x = x0 + 2 * u;
+            if (x >= res) break;
+            const int xr = min(x + 1, res - 1), xl = max(x - 1, 0);
+            const int idx = x * res + z, right_idx = xr * res + z;
+            if (have_carry) nw[u][3] = carry;
+            float hWater = sw[u];
+            carry = nw[u][1];
+            have_carry = true;
+            if (!(hWater > 0.0f)) continue;
+            const float hLand = sh[u];
+            float tHeight = hLand + hWater;
+            flooded b[4];
+            b[0].idx = x * res + zu;  b[1].idx = right_idx;  b[2].idx = x * res + zd;  b[3].idx = xl * res + z;
+            int key[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                b[e].height = nh[u][e];
+                b[e].water = nw[u][e];
+                key[e] = float_hash(nh[u][e] + nw[u][e]);
             }
-            t = b[3];
-            if (flooded_cmp(t, b[2]) < 0) {
-                b[3] = b[2];
-                if (flooded_cmp(t, b[1]) < 0) {
-                    b[2] = b[1];
-                    if (flooded_cmp(t, b[0]) < 0) { b[1] = b[0]; b[0] = t; } else { b[1] = t; }
-                } else {
-                    b[2] = t;
+            // NativeArray.Sort() of com.unity.collections 1.4.0 on 4 elements: insertion sort, element i+1 moves
+            // left while it compares < 0 (flooded_cmp above: same cell -> 0, else key > key ? 1 : -1).  The same
+            // comparisons in the same order, applied with selects so that the lanes of a wave do not diverge (the
+            // walk is bound by the length of its instruction stream)
+#define NZ_LT(ti, tk, j) ((ti) != b[j].idx && !((tk) > key[j]))
+#define NZ_SEL(dst, c, src_t) do { b[dst].idx = (c) ? (src_t##i) : b[dst].idx; b[dst].height = (c) ? (src_t##h) : b[dst].height; \
+                                   b[dst].water = (c) ? (src_t##w) : b[dst].water; key[dst] = (c) ? (src_t##k) : key[dst]; } while (0)
+#define NZ_MOV(dst, c, src) do { b[dst].idx = (c) ? b[src].idx : b[dst].idx; b[dst].height = (c) ? b[src].height : b[dst].height; \
+                                 b[dst].water = (c) ? b[src].water : b[dst].water; key[dst] = (c) ? key[src] : key[dst]; } while (0)
+            {
+                int ti = b[1].idx, tk = key[1];
+                float th = b[1].height, tw = b[1].water;
+                bool c0 = NZ_LT(ti, tk, 0);
+                NZ_MOV(1, c0, 0);
+                NZ_SEL(0, c0, t);
+                ti = b[2].idx; tk = key[2]; th = b[2].height; tw = b[2].water;
+                bool c1 = NZ_LT(ti, tk, 1);
+                c0 = c1 && NZ_LT(ti, tk, 0);
+                NZ_MOV(2, c1, 1);
+                NZ_MOV(1, c0, 0);
+                NZ_SEL(1, c1 && !c0, t);
+                NZ_SEL(0, c0, t);
+                ti = b[3].idx; tk = key[3]; th = b[3].height; tw = b[3].water;
+                bool c2 = NZ_LT(ti, tk, 2);
+                c1 = c2 && NZ_LT(ti, tk, 1);
+                c0 = c1 && NZ_LT(ti, tk, 0);
+                NZ_MOV(3, c2, 2);
+                NZ_MOV(2, c1, 1);
+                NZ_MOV(1, c0, 0);
+                NZ_SEL(2, c2 && !c1, t);
+                NZ_SEL(1, c1 && !c0, t);
+                NZ_SEL(0, c0, t);
+            }
+#undef NZ_LT
+#undef NZ_SEL
+#undef NZ_MOV
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float bw = b[e].water, bh = b[e].height;
+                const float diffV = tHeight - (bh + bw);
+                const bool go = !(hWater < 1E-3f);
+                const bool spill = bw <= 0.0f && hLand >= bh;                       // the dry neighbour takes it all
+                const bool give = !spill && diffV > 0.0f && !(hWater <= 0.0f);
+                const bool take = !spill && !(diffV > 0.0f) && diffV < 0.0f && !(bw <= 0.0f);
+                const float fill_give = fminf(0.25f * hWater, 0.25f * diffV);
+                const float fill_take = fminf(0.25f * bw, -0.25f * diffV);
+                const float put = spill ? bw + hWater : (give ? bw + fill_give : bw + (-1.0f * fill_take));
+                const float w_new = spill ? 0.0f : (give ? hWater - fill_give : hWater + fill_take);
+                if (go && (spill || give || take)) {
+                    pool[b[e].idx] = put;
+                    hWater = w_new;
+                    tHeight = spill ? hLand : hLand + w_new;
+                    if (b[e].idx == right_idx) carry = put;
                 }
             }
+            pool[idx] = hWater;
+            if (idx == right_idx) carry = hWater;  // last column: the right-hand neighbour is the cell itself
         }
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            float diffV = tHeight - (b[e].height + b[e].water);
-            if (hWater < 1E-3f) continue;
-            if (b[e].water <= 0.0f && hLand >= b[e].height) {
-                pool[b[e].idx] = b[e].water + hWater;
-                hWater = 0.0f;
-                tHeight = hLand;
-            } else if (diffV > 0.0f) {
-                if (hWater <= 0.0f) continue;
-                float fill = fminf(0.25f * hWater, 0.25f * diffV);
-                hWater -= fill;
-                tHeight = hLand + hWater;
-                pool[b[e].idx] = b[e].water + fill;
-            } else if (diffV < 0.0f) {
-                if (b[e].water <= 0.0f) continue;
-                float fill = fminf(0.25f * b[e].water, -0.25f * diffV);
-                hWater += fill;
-                tHeight = hLand + hWater;
-                pool[b[e].idx] = b[e].water + (-1.0f * fill);
-            }
-        }
-        pool[idx] = hWater;
     }
 }
 

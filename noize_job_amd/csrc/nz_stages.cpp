@@ -258,10 +258,12 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
             return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
         });
     }
+    // an even number of launches ends in src; when every launch already holds its one iteration and the
+    // count is odd, the last result is copied back instead
     int cap = nz_erosion_max_fused();
     int L = (iterations + cap - 1) / cap;
     if (L < 2) L = 2;
-    if (L & 1) L += 1;
+    if ((L & 1) && L + 1 <= iterations) L += 1;
     int base = iterations / L, rem = iterations % L;
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
@@ -272,6 +274,11 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
         if (rc) return rc;
         float *s = cur; cur = other; other = s;
     }
+    if (cur != src)
+        return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
+            size_t off = (size_t)gb.or0 * gb.pitch;
+            return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
+        });
     return NZ_OK;
 }
 
