@@ -58,6 +58,9 @@ def parse():
                          "exchanged with the neighbour ranks over RCCL before every launch")
     ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "P"), default=None,
                     help="one-process rehearsal of rank R of a P-rank job (needs --halo recompute)")
+    ap.add_argument("--flush", choices=("swap", "copy"), default="swap",
+                    help="N=1: the tile is a READ / WRITE plane pair and TileHelpers.SWAP_RWTILE is a pointer swap "
+                         "(nz_*_rw entries), or one plane with the in-place entries and their flush copies")
     ap.add_argument("--cpu-res", type=int, default=4096)
     return ap.parse_args()
 
@@ -135,13 +138,15 @@ def main():
         cells = res * res
         data = torch.empty(cells, dtype=torch.float32, device="cuda")
         tile = ctx.wrap(data.data_ptr(), cells)
+        swap = args.flush == "swap"
+        data_w = torch.empty(cells, dtype=torch.float32, device="cuda") if swap else None
         stages = [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, p.hurst, p.startingAmplitude, p.octaves, p.stepdown,
                                 p.detuneRate, p.noiseSize),
                   nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, G_IT),
                   nj.FlowMapStage(ctx, F_IT, p.normMin, p.normMax),
                   nj.ErosionStage(ctx, E_IT)]
         pipe = nj.BasePipeline(stages, "metric")
-        gd = nj.GeneratorData("bench", tile, res, 0, 0)
+        gd = nj.GeneratorData("bench", tile, res, 0, 0, write=ctx.wrap(data_w.data_ptr(), cells) if swap else None)
 
         def step(record):
             if record:
@@ -157,7 +162,10 @@ def main():
         workload = "%dx%d tile: simplex-13oct(h0.4,size1700) -> Gauss5_S1 x%d -> FlowMap x%d (norm 0/0.005) -> " \
                    "ValueErosion x%d" % (res, res, G_IT, F_IT, E_IT)
         parallelism = "single tile"
+        flush_note = ("READ/WRITE plane pair, SWAP_RWTILE = pointer swap (nz_*_rw entries)" if swap else
+                      "one plane, in-place entries with flush copies")
     else:
+        swap, flush_note = False, "stripe entries (explicit src / dst planes)"
         ops = sh.HipStripeOps(ctx)
         halo = sh.halo_rows_needed(ops, p)
         prank, pworld = args.as_rank if args.as_rank is not None else (rank, world)
@@ -223,7 +231,7 @@ def main():
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload, "cells": cells, "parallelism": parallelism, "preheat_steps": preheat,
-                          "algorithmic_bytes_per_cell": total_bytes},
+                          "algorithmic_bytes_per_cell": total_bytes, "flush": flush_note},
                "pipeline_hbm": {"achieved": round(total_bytes * cells / (dt / args.steps) / 1e9 / world, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
                                 "frac": round(total_bytes * cells / (dt / args.steps) / 1e9 / world / HBM_PEAK_GBS, 4)}}
@@ -232,8 +240,12 @@ def main():
             flow_cap = nj._native.lib.nz_flow_fused_max_iterations()
             flow_launches = len(sh.split_iterations(F_IT, flow_cap))
             # the tile API ends a one-launch flow stage with a copy back into the caller's plane; stripes ping-pong
+            pingpong = sharded or swap  # explicit src / dst: no copy back, no even-launch-count rule
+            ero_cap = nj._native.lib.nz_erosion_max_fused_iterations()
             launches = {"noise": 1, "gauss": None,
-                        "flow": flow_launches + (1 if flow_launches == 1 and not sharded else 0), "erosion": 2}
+                        "flow": flow_launches + (1 if flow_launches == 1 and not pingpong else 0),
+                        "erosion": len(sh.split_iterations(E_IT, ero_cap)) if pingpong else 2}
+            KERNEL_OF["erosion"] = "erosion_reg_kernel<%d>" % (sh.split_iterations(E_IT, ero_cap)[0] if pingpong else 3)
             rcells = cells // world  # rank 0's own cells: the stage figures are per GPU
             acc = {n: 0.0 for n in names}
             for hs in marks:
@@ -249,13 +261,13 @@ def main():
                                                        (stages_out["noise"]["ms"] * 1e-3) / 1e9, 1)
             stages_out["noise"]["frac_valu"] = round(stages_out["noise"]["valu_Gops/s"] / VALU_PEAK_GOPS, 4)
             stages_out["gauss"]["launches"] = N_gauss = len(sh.split_iterations(G_IT, nj._native.lib.nz_kernel_filter_max_fused(2)))
-            if N_gauss & 1 and not sharded:  # the tile API keeps the launch count even (result back in `src`)
+            if N_gauss & 1 and not pingpong:  # the tile API keeps the launch count even (result back in `src`)
                 stages_out["gauss"]["launches"] = N_gauss + 1
             out["stages"] = stages_out
             # The tile API's one-launch flow stage ends with a plane copy back into the caller's buffer: time
             # that copy on its own (outside the timed steps) so the flow KERNEL's launch time is known
             kernel_ms = {n: stages_out[n]["ms"] for n in names}
-            if not sharded and flow_launches == 1:
+            if not pingpong and flow_launches == 1:
                 scratch = ctx.alloc(rcells)
                 hc0 = ctx.record()
                 for _ in range(20):

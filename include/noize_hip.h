@@ -72,6 +72,21 @@ typedef struct nz_stripe {
     int32_t pitch; /* floats between consecutive rows; 0 = cols */
 } nz_stripe;
 
+/* The READ / WRITE slice pair of one tile, device resident: the reference's RWTileData
+ * (Pipeline/Tiles/TileData.cs:49-93: `src` is read with a clamp, `dst` is written) together with
+ * TileHelpers.SWAP_RWTILE (TileData.cs:42-45), which the reference implements as a copy job WRITE -> READ after
+ * every job.  Here the swap is a swap: an `_rw` stage entry reads `read`, may use `write` as its ping-pong plane,
+ * and RETURNS WITH `read` POINTING AT THE PLANE THAT HOLDS THE RESULT (the two pointers exchanged, or not) -- no
+ * flush copy, and no constraint on the number of launches.  The struct is updated when the call returns (enqueue
+ * time); both planes belong to the caller and stay valid until the returned handle has completed.
+ * `count` tiles of resolution^2 floats stored back to back form a batch (1 = a single tile). */
+typedef struct nz_rw_tile {
+    float *read;
+    float *write;
+    int32_t resolution;
+    int32_t count;
+} nz_rw_tile;
+
 /* ---- runtime ---------------------------------------------------------------------------- */
 int32_t nz_version(void);
 const char *nz_last_error(void);
@@ -154,6 +169,17 @@ int32_t nz_smooth_blur_stage(nz_ctx *ctx, float *src, float *tmp, int32_t width,
 int32_t nz_erosion_stage(nz_ctx *ctx, float *src, float *tmp, int32_t iterations, int32_t resolution,
                          nz_handle dep, nz_handle *out);
 
+/* The same stage bodies on a READ / WRITE pair (nz_rw_tile above): the result is in tile->read when the call
+ * returns; the flush copies of the in-place forms are gone and the launch count is free (five erosion iterations
+ * are one launch, a single filter application is one launch without a copy). */
+int32_t nz_kernel_filter_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, int32_t filter, int32_t iterations, nz_handle dep,
+                                  nz_handle *out);
+int32_t nz_gauss_blur_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, int32_t width, int32_t sigma, int32_t iterations,
+                               nz_handle dep, nz_handle *out);
+int32_t nz_smooth_blur_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, int32_t width, int32_t iterations, nz_handle dep,
+                                nz_handle *out);
+int32_t nz_erosion_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, int32_t iterations, nz_handle dep, nz_handle *out);
+
 /* stripe forms: one launch that advances `iterations` applications on rows [own0, own1); the filter needs
  * nz_kernel_filter_halo_rows(...) valid ghost rows on each side, the min erosion `iterations` rows ABOVE only
  * (its window is {-1, 0}); rows beyond the global border are never needed.  Reads `src`, writes `dst`
@@ -192,6 +218,13 @@ int32_t nz_map_normalize_values(nz_ctx *ctx, float *src, float *tmp, const float
 size_t nz_flowmap_stage_work_floats(int32_t resolution);
 int32_t nz_flowmap_stage(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,
                          float normMax, int32_t resolution, nz_handle dep, nz_handle *out);
+
+/* FlowMapStage.Schedule on a READ / WRITE pair: heights are read from tile->read, the normalised flow map is
+ * written to tile->write and the pair is swapped; `work` = nz_flowmap_stage_rw_work_floats(resolution, count) floats
+ * (the two sets of five state planes; no private copy of the heights is needed). */
+size_t nz_flowmap_stage_rw_work_floats(int32_t resolution, int32_t count);
+int32_t nz_flowmap_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, float *work, int32_t iterations, float normMin,
+                            float normMax, nz_handle dep, nz_handle *out);
 
 /* stripe forms for sharded runs: state = {water, fN, fS, fE, fW} planes of the stripe's shape. */
 /* `iterations` (<= nz_flow_fused_max_iterations()) whole iterations in one launch on an on-chip tile; needs

@@ -26,6 +26,14 @@ class Stripe(C.Structure):
 
 stripe_p = C.POINTER(Stripe)
 
+
+class RWTile(C.Structure):
+    """nz_rw_tile (include/noize_hip.h): the READ / WRITE slice pair of a tile (RWTileData, TileData.cs:49-93)."""
+    _fields_ = [("read", C.c_void_p), ("write", C.c_void_p), ("resolution", C.c_int32), ("count", C.c_int32)]
+
+
+rw_tile_p = C.POINTER(RWTile)
+
 NZ_OK, NZ_ERR_INVALID, NZ_ERR_UNSUPPORTED, NZ_ERR_HIP, NZ_ERR_NOMEM, NZ_ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 
 _i, _f, _sz = C.c_int32, C.c_float, C.c_size_t
@@ -89,6 +97,12 @@ SIGNATURES = {
     "nz_fractal_batch": (_i, [ctx_p, _i, dev_ptr, _i, _i, dev_ptr, _f, _f, _f, _f, _i, _i] + _tail),
     "nz_kernel_filter_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _i] + _tail),
     "nz_gauss_blur_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _i, _i] + _tail),
+    "nz_kernel_filter_stage_rw": (_i, [ctx_p, rw_tile_p, _i, _i] + _tail),
+    "nz_gauss_blur_stage_rw": (_i, [ctx_p, rw_tile_p, _i, _i, _i] + _tail),
+    "nz_smooth_blur_stage_rw": (_i, [ctx_p, rw_tile_p, _i, _i] + _tail),
+    "nz_erosion_stage_rw": (_i, [ctx_p, rw_tile_p, _i] + _tail),
+    "nz_flowmap_stage_rw_work_floats": (_sz, [_i, _i]),
+    "nz_flowmap_stage_rw": (_i, [ctx_p, rw_tile_p, dev_ptr, _i, _f, _f] + _tail),
     "nz_erosion_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
     "nz_flowmap_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _f, _f, _i, _i] + _tail),
     "nz_mesh_vertex_count": (_sz, [_i]),

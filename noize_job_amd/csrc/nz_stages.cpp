@@ -170,12 +170,15 @@ static int conv_tcap(int ksize) {
     return cap < hw ? cap : hw;
 }
 
-// `iterations` applications of (X pass, Z pass) with the result back in `src`: the applications are
-// grouped into an even number of fused launches that ping-pong src <-> tmp.
+// `iterations` applications of (X pass, Z pass).  swapped == nullptr: the result must be back in `src`, so the
+// applications are grouped into an even number of fused launches that ping-pong src <-> tmp (or an odd number and a
+// copy).  Otherwise (READ / WRITE pair, nz_rw_tile) the launch count is free and *swapped tells whether the result
+// is in `tmp`.
 static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geom &g, const nz_kernel_taps &t,
-                               int iterations) {
+                               int iterations, bool *swapped = nullptr) {
     NZ_REQUIRE(src && tmp && src != tmp, "src/tmp must be two distinct planes");
     NZ_REQUIRE(iterations >= 1, "iterations < 1");
+    if (swapped) *swapped = false;
     int cap = (t.ksize & 1) ? conv_tcap(t.ksize) : 0;
     if (nz_conv_has_wide(t.ksize)) {  // one launch per application, ping-pong, copy back after an odd count
         float *cur = src, *other = tmp;
@@ -185,7 +188,9 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
             }));
             float *s = cur; cur = other; other = s;
         }
-        if (cur != src) {
+        if (cur != src && swapped) {
+            *swapped = true;
+        } else if (cur != src) {
             NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
                 size_t off = (size_t)gb.or0 * gb.pitch;
                 return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
@@ -197,6 +202,10 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_conv_fused(st, src, tmp, gb, t, 1);
         }));
+        if (swapped) {
+            *swapped = true;
+            return NZ_OK;
+        }
         return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
             return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
@@ -208,7 +217,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
             one.count = 1;
             one.bstride = 0;
             for (int b = 0; b < g.count; b++)
-                NZ_TRY_(conv_iterations(ctx, src + b * g.bstride, tmp + b * g.bstride, one, t, iterations));
+                NZ_TRY_(conv_iterations(ctx, src + b * g.bstride, tmp + b * g.bstride, one, t, iterations, nullptr));
             return NZ_OK;
         }
         for (int i = 0; i < iterations; i++) {
@@ -224,7 +233,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         return NZ_OK;
     }
     int L = (iterations + cap - 1) / cap;
-    if ((L & 1) && L + 1 <= iterations) L += 1;  // an even count leaves the result in src
+    if (!swapped && (L & 1) && L + 1 <= iterations) L += 1;  // an even count leaves the result in src
     int base = iterations / L, rem = iterations % L;
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
@@ -235,6 +244,10 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         if (rc) return rc;
         float *s = cur; cur = other; other = s;
     }
+    if (cur != src && swapped) {
+        *swapped = true;
+        return NZ_OK;
+    }
     if (cur != src) {  // odd count (only when cap == 1): copy back
         return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
@@ -244,10 +257,12 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     return NZ_OK;
 }
 
-static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geom &g, int iterations) {
+static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geom &g, int iterations,
+                                  bool *swapped = nullptr) {
     NZ_REQUIRE(src && tmp && src != tmp, "src/tmp must be two distinct planes");
     NZ_REQUIRE(iterations >= 1, "iterations < 1");
-    if (iterations == 1) {
+    if (swapped) *swapped = false;
+    if (iterations == 1 && !swapped) {
         // ErosionKernelJob.ScheduleSeries KernelJob.cs:318-335: min-X then min-Z (size 3) = the min over
         // {x-1,x} x {z-1,z}; one launch into tmp, then the copy back that stands for the flush
         NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
@@ -262,8 +277,10 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
     // count is odd, the last result is copied back instead
     int cap = nz_erosion_max_fused();
     int L = (iterations + cap - 1) / cap;
-    if (L < 2) L = 2;
-    if ((L & 1) && L + 1 <= iterations) L += 1;
+    if (!swapped) {
+        if (L < 2) L = 2;
+        if ((L & 1) && L + 1 <= iterations) L += 1;
+    }
     int base = iterations / L, rem = iterations % L;
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
@@ -273,6 +290,10 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
         });
         if (rc) return rc;
         float *s = cur; cur = other; other = s;
+    }
+    if (cur != src && swapped) {
+        *swapped = true;
+        return NZ_OK;
     }
     if (cur != src)
         return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
@@ -679,6 +700,108 @@ extern "C" int32_t nz_flowmap_stage_batch(nz_ctx *ctx, float *src, float *work, 
                                           float normMax, int32_t resolution, int32_t count, nz_handle dep,
                                           nz_handle *out) {
     return flowmap_stage_impl(ctx, src, work, iterations, normMin, normMax, resolution, count, dep, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// READ / WRITE pair forms (nz_rw_tile): TileHelpers.SWAP_RWTILE (Pipeline/Tiles/TileData.cs:42-45) as a swap of the
+// two pointers instead of a copy job
+// ---------------------------------------------------------------------------------------------
+static int32_t check_rw(const nz_rw_tile *t) {
+    NZ_REQUIRE(t, "tile is NULL");
+    NZ_TRY(check_batch(t->resolution, t->count));
+    NZ_REQUIRE(t->read && t->write && t->read != t->write, "read/write must be two distinct planes");
+    return NZ_OK;
+}
+static nz_geom rw_geom(const nz_rw_tile *t) {
+    return t->count > 1 ? nz_geom_batch(t->resolution, t->count) : nz_geom_tile(t->resolution);
+}
+static void rw_swap(nz_rw_tile *t, bool swapped) {
+    if (swapped) {
+        float *r = t->read;
+        t->read = t->write;
+        t->write = r;
+    }
+}
+
+static int32_t conv_rw(nz_ctx *ctx, nz_rw_tile *tile, const nz_kernel_taps &t, int32_t iterations, nz_handle *out) {
+    bool swapped = false;
+    NZ_TRY(conv_iterations(ctx, tile->read, tile->write, rw_geom(tile), t, iterations, &swapped));
+    rw_swap(tile, swapped);
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_kernel_filter_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, int32_t filter, int32_t iterations,
+                                             nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_rw(tile));
+    NZ_REQUIRE(filter != NZ_SOBEL3_2D, "Sobel3_2D keeps a third plane: use nz_kernel_filter_stage");
+    nz_kernel_taps t;
+    NZ_TRY(filter_taps(filter, &t));
+    return conv_rw(ctx, tile, t, iterations, out);
+}
+
+extern "C" int32_t nz_gauss_blur_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, int32_t width, int32_t sigma,
+                                          int32_t iterations, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_rw(tile));
+    nz_kernel_taps t;
+    NZ_TRY(gauss_taps(width, sigma, &t));
+    return conv_rw(ctx, tile, t, iterations, out);
+}
+
+extern "C" int32_t nz_smooth_blur_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, int32_t width, int32_t iterations,
+                                           nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_rw(tile));
+    nz_kernel_taps t;
+    NZ_TRY(smooth_taps(width, &t));
+    return conv_rw(ctx, tile, t, iterations, out);
+}
+
+extern "C" int32_t nz_erosion_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, int32_t iterations, nz_handle dep,
+                                       nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_rw(tile));
+    bool swapped = false;
+    NZ_TRY(erosion_iterations(ctx, tile->read, tile->write, rw_geom(tile), iterations, &swapped));
+    rw_swap(tile, swapped);
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" size_t nz_flowmap_stage_rw_work_floats(int32_t resolution, int32_t count) {
+    return resolution > 0 && count > 0 ? (size_t)10 * resolution * resolution * count : 0;
+}
+
+extern "C" int32_t nz_flowmap_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, float *work, int32_t iterations, float normMin,
+                                       float normMax, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_rw(tile));
+    NZ_REQUIRE(work, "work is NULL");
+    NZ_REQUIRE(iterations >= 1, "iterations < 1");
+    size_t n = (size_t)tile->resolution * tile->resolution * tile->count;
+    nz_geom g = rw_geom(tile);
+    float *A[5], *B[5];  // {water, fN, fS, fE, fW} x {READ, WRITE}, FlowMapStage.cs:52-62
+    for (int i = 0; i < 5; i++) {
+        A[i] = work + (size_t)i * n;
+        B[i] = work + (size_t)(5 + i) * n;
+    }
+    int cap = nz_flow_fused_max();
+    int launches = (iterations + cap - 1) / cap;
+    int base = iterations / launches, rem = iterations % launches;
+    float **cur = A, **nxt = B;
+    // every launch reads the heights from the READ plane, which nothing overwrites; the last one writes the WRITE plane
+    for (int i = 0; i < launches; i++) {
+        int nit = base + (i < rem ? 1 : 0);
+        int first = i == 0, last = i == launches - 1;
+        NZ_TRY(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
+            return nz_launch_flow_fused(st, tile->read, first ? nullptr : cur, last ? nullptr : nxt,
+                                        last ? tile->write : nullptr, nullptr, gb, nit, first, last, normMin,
+                                        normMax - normMin);
+        }));
+        float **s = cur; cur = nxt; nxt = s;
+    }
+    rw_swap(tile, true);
+    return nz_ctx_finish(ctx, out);
 }
 
 extern "C" int32_t nz_flow_fused_stripe(nz_ctx *ctx, const float *height, const float *const *state_in,

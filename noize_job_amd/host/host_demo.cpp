@@ -22,6 +22,9 @@ int main(int argc, char **argv) {
     const bool reduce = argc > 3 && std::strcmp(argv[3], "reduce") == 0;
     const bool context = argc > 3 && std::strcmp(argv[3], "context") == 0;
     const int batch = argc > 4 && std::strcmp(argv[3], "batch") == 0 ? std::atoi(argv[4]) : 0;
+    // `rw`: the tile is a READ / WRITE plane pair and the stencil stages swap it instead of flushing (nz_*_rw)
+    const bool rw = argc > 3 && std::strcmp(argv[3], "rw") == 0;
+    if (rw) argc = 3;
     int G = argc > 3 ? std::atoi(argv[3]) : 17, F = argc > 4 ? std::atoi(argv[4]) : 5, E = argc > 5 ? std::atoi(argv[5]) : 5;
     try {
         nz_ctx *ctx = nullptr;
@@ -158,12 +161,17 @@ int main(int argc, char **argv) {
             gd.uuid = "host-demo";
             gd.data = &tile;
             gd.resolution = res;
+            std::unique_ptr<DeviceTile> wtile;
+            if (rw) {
+                wtile.reset(new DeviceTile(ctx, (size_t)res * res));
+                gd.write = wtile.get();
+            }
             int completed = 0;
             pipe.Enqueue(&gd, nullptr, [&](StageIO *) { completed++; });
             pipe.RunToCompletion();
             if (completed != 1) throw std::runtime_error("completeAction did not fire");
             std::vector<float> host((size_t)res * res);
-            tile.CopyTo(host.data());
+            gd.data->CopyTo(host.data());  // with a pair, `data` is whichever plane the last stage left the result in
             FILE *f = std::fopen(argv[2], "wb");
             if (!f) throw std::runtime_error("cannot open output");
             std::fwrite(host.data(), sizeof(float), host.size(), f);

@@ -84,7 +84,18 @@ struct StageIO {
 
 struct GeneratorData : StageIO {
     int resolution = 512, xpos = 0, zpos = 0;
+    // optional WRITE slice of the tile's RWTileData pair (Pipeline/Tiles/TileData.cs:49-93; new-framework): with it
+    // the stencil stages run their nz_*_rw forms and TileHelpers.SWAP_RWTILE swaps `data` and `write` instead of
+    // copying, so after a stage `data` is whichever of the two planes holds the result
+    DeviceTile *write = nullptr;
 };
+
+struct GeneratorDataBatch;
+// the payload's READ / WRITE pair as nz_rw_tile, and back (adopts the pair as the call left it)
+inline nz_rw_tile rw_pair(GeneratorData *d, int count) { return nz_rw_tile{d->data->ptr, d->write->ptr, d->resolution, count}; }
+inline void rw_adopt(GeneratorData *d, const nz_rw_tile &t) {
+    if (t.read != d->data->ptr) std::swap(d->data, d->write);
+}
 
 // New-framework payload: `count` independent tiles of resolution^2 cells stored back to back in `data`,
 // world positions {xpos, zpos} per tile in the device int32 array `positions` (see nz_*_batch).
@@ -92,6 +103,11 @@ struct GeneratorDataBatch : GeneratorData {
     int count = 1;
     const int32_t *positions = nullptr;
 };
+
+inline int tile_count(GeneratorData *d) {
+    auto *b = dynamic_cast<GeneratorDataBatch *>(d);
+    return b ? b->count : 1;
+}
 
 struct MeshBuffers {  // stands in for UnityEngine.Mesh + Mesh.MeshData (PositionStream32 layout)
     std::unique_ptr<DeviceTile> vertices, indices;
@@ -233,6 +249,13 @@ class KernelFilterStage : public TmpStage {
     void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
         auto *d = CheckRequirements<GeneratorData>(requirements);
         nz_handle h = 0;
+        if (d->write && filter != NZ_SOBEL3_2D) {
+            nz_rw_tile t = rw_pair(d, tile_count(d));
+            check(nz_kernel_filter_stage_rw(ctx, &t, filter, iterations, dependency.id, &h), "nz_kernel_filter_stage_rw");
+            rw_adopt(d, t);
+            jobHandle = done(h);
+            return;
+        }
         if (auto *b = dynamic_cast<GeneratorDataBatch *>(d)) {
             check(nz_kernel_filter_stage_batch(ctx, b->data->ptr, tmp->ptr, filter, iterations, b->resolution, b->count,
                                                dependency.id, &h), "nz_kernel_filter_stage_batch");
@@ -258,6 +281,14 @@ class StageGaussianBlur : public TmpStage {
     void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
         auto *d = CheckRequirements<GeneratorData>(requirements);
         nz_handle h = 0;
+        if (d->write) {
+            nz_rw_tile t = rw_pair(d, tile_count(d));
+            check(nz_gauss_blur_stage_rw(ctx, &t, limitWidth(width), sigma, iterations, dependency.id, &h),
+                  "nz_gauss_blur_stage_rw");
+            rw_adopt(d, t);
+            jobHandle = done(h);
+            return;
+        }
         if (auto *b = dynamic_cast<GeneratorDataBatch *>(d)) {
             check(nz_gauss_blur_stage_batch(ctx, b->data->ptr, tmp->ptr, limitWidth(width), sigma, iterations, b->resolution,
                                             b->count, dependency.id, &h), "nz_gauss_blur_stage_batch");
@@ -277,6 +308,14 @@ class StageSmoothBlur : public TmpStage {
     void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
         auto *d = CheckRequirements<GeneratorData>(requirements);
         nz_handle h = 0;
+        if (d->write && tile_count(d) == 1) {
+            nz_rw_tile t = rw_pair(d, 1);
+            check(nz_smooth_blur_stage_rw(ctx, &t, limitWidth(width), iterations, dependency.id, &h),
+                  "nz_smooth_blur_stage_rw");
+            rw_adopt(d, t);
+            jobHandle = done(h);
+            return;
+        }
         check(nz_smooth_blur_stage(ctx, d->data->ptr, tmp->ptr, limitWidth(width), iterations, d->resolution,
                                    dependency.id, &h), "nz_smooth_blur_stage");
         jobHandle = done(h);
@@ -290,6 +329,13 @@ class ErosionStage : public TmpStage {  // ErosionKernelJob x iterations (no sta
     void Schedule(PipelineWorkItem &requirements, JobHandle dependency) override {
         auto *d = CheckRequirements<GeneratorData>(requirements);
         nz_handle h = 0;
+        if (d->write) {
+            nz_rw_tile t = rw_pair(d, tile_count(d));
+            check(nz_erosion_stage_rw(ctx, &t, iterations, dependency.id, &h), "nz_erosion_stage_rw");
+            rw_adopt(d, t);
+            jobHandle = done(h);
+            return;
+        }
         if (auto *b = dynamic_cast<GeneratorDataBatch *>(d)) {
             check(nz_erosion_stage_batch(ctx, b->data->ptr, tmp->ptr, iterations, b->resolution, b->count, dependency.id,
                                          &h), "nz_erosion_stage_batch");
@@ -404,6 +450,14 @@ class FlowMapStage : public PipelineStage {
         resolution = g->resolution;
         auto *d = CheckRequirements<GeneratorData>(requirements);
         nz_handle h = 0;
+        if (d->write) {
+            nz_rw_tile t = rw_pair(d, tile_count(d));
+            check(nz_flowmap_stage_rw(ctx, &t, work->ptr, iterations, normMin, normMax, dependency.id, &h),
+                  "nz_flowmap_stage_rw");
+            rw_adopt(d, t);
+            jobHandle = done(h);
+            return;
+        }
         if (auto *b = dynamic_cast<GeneratorDataBatch *>(d)) {
             check(nz_flowmap_stage_batch(ctx, b->data->ptr, work->ptr, iterations, normMin, normMax, b->resolution,
                                          b->count, dependency.id, &h), "nz_flowmap_stage_batch");

@@ -13,6 +13,7 @@ Filter/Kernel/Blur/Stage{Gaussian,Smooth}Blur.cs, Geologic/Stage/FlowMapStage.cs
 Mesh/Stage/MeshTileStage.cs.
 """
 import collections
+import ctypes as C
 import enum
 
 import numpy as np
@@ -106,11 +107,26 @@ class StageIO:  # Pipeline/Stage/StageIO.cs:8-11
 
 
 class GeneratorData(StageIO):  # StageIOTypes/GeneratorData.cs:9-15
-    def __init__(self, uuid="", data=None, resolution=512, xpos=0, zpos=0):
+    """`write` (optional, new-framework): a second plane of the same size, the WRITE slice of the tile's RWTileData
+    pair (Pipeline/Tiles/TileData.cs:49-93).  With it the stencil stages (kernel filter, blurs, erosion, flow map)
+    run their nz_*_rw forms: TileHelpers.SWAP_RWTILE is a swap of `data` and `write` instead of a flush copy, so
+    after a stage `data` is whichever of the two planes holds the result."""
+
+    def __init__(self, uuid="", data=None, resolution=512, xpos=0, zpos=0, write=None):
         super().__init__(uuid, data)
         self.resolution = resolution
         self.xpos = xpos
         self.zpos = zpos
+        self.write = write
+
+
+def _call_rw(ctx, name, d, *args, dep=None):
+    """Runs an nz_*_rw entry on the payload's READ / WRITE pair and adopts the pair as the call left it."""
+    t = N.RWTile(d.data.ptr, d.write.ptr, d.resolution, getattr(d, "count", 1))
+    handle = ctx.call(name, C.byref(t), *args, dep=dep)
+    if t.read != d.data.ptr:
+        d.data, d.write = d.write, d.data
+    return handle
 
 
 class GeneratorDataBatch(GeneratorData):
@@ -119,8 +135,8 @@ class GeneratorDataBatch(GeneratorData):
     tile).  The noise / filter / blur / erosion / flow-map stages run such a batch through one launch
     sequence (nz_*_batch); every tile comes out exactly as it would alone."""
 
-    def __init__(self, uuid="", data=None, resolution=512, positions=None, count=1):
-        super().__init__(uuid, data, resolution, 0, 0)
+    def __init__(self, uuid="", data=None, resolution=512, positions=None, count=1, write=None):
+        super().__init__(uuid, data, resolution, 0, 0, write)
         self.positions = positions
         self.count = count
 
@@ -289,6 +305,10 @@ class KernelFilterStage(PipelineStage):  # Filter/KernelFilterStage.cs:13-51
     def Schedule(self, requirements, dependency):
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
+        if d.write is not None and self.filter != KernelFilterType.Sobel3_2D:
+            self.jobHandle = _call_rw(self.ctx, "nz_kernel_filter_stage_rw", d, int(self.filter), self.iterations,
+                                      dep=dependency)
+            return
         if isinstance(d, GeneratorDataBatch):
             self.jobHandle = self.ctx.call("nz_kernel_filter_stage_batch", d.data.ptr, self.tmp.ptr, int(self.filter),
                                            self.iterations, d.resolution, d.count, dep=dependency)
@@ -318,6 +338,10 @@ class StageGaussianBlur(PipelineStage):  # Filter/Kernel/Blur/StageGaussianBlur.
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
         width_ = BlurHelper.limitWidth(self.width)
+        if d.write is not None:
+            self.jobHandle = _call_rw(self.ctx, "nz_gauss_blur_stage_rw", d, width_, int(self.sigma), self.iterations,
+                                      dep=dependency)
+            return
         if isinstance(d, GeneratorDataBatch):
             self.jobHandle = self.ctx.call("nz_gauss_blur_stage_batch", d.data.ptr, self.tmp.ptr, width_, int(self.sigma),
                                            self.iterations, d.resolution, d.count, dep=dependency)
@@ -344,6 +368,9 @@ class StageSmoothBlur(PipelineStage):  # Filter/Kernel/Blur/StageSmoothBlur.cs:1
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
         width_ = BlurHelper.limitWidth(self.width)
+        if d.write is not None and not isinstance(d, GeneratorDataBatch):
+            self.jobHandle = _call_rw(self.ctx, "nz_smooth_blur_stage_rw", d, width_, self.iterations, dep=dependency)
+            return
         self.jobHandle = self.ctx.call("nz_smooth_blur_stage", d.data.ptr, self.tmp.ptr, width_, self.iterations,
                                        d.resolution, dep=dependency)
 
@@ -367,6 +394,9 @@ class ErosionStage(PipelineStage):
     def Schedule(self, requirements, dependency):
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
+        if d.write is not None:
+            self.jobHandle = _call_rw(self.ctx, "nz_erosion_stage_rw", d, self.iterations, dep=dependency)
+            return
         if isinstance(d, GeneratorDataBatch):
             self.jobHandle = self.ctx.call("nz_erosion_stage_batch", d.data.ptr, self.tmp.ptr, self.iterations,
                                            d.resolution, d.count, dep=dependency)
@@ -515,6 +545,10 @@ class FlowMapStage(PipelineStage):  # Geologic/Stage/FlowMapStage.cs:16-220
         if self.resolution != d.resolution:
             self.resolution = d.resolution
         self.CheckRequirements(GeneratorData, requirements)
+        if d.write is not None:
+            self.jobHandle = _call_rw(self.ctx, "nz_flowmap_stage_rw", d, self.work.ptr, self.iterations, self.normMin,
+                                      self.normMax, dep=dependency)
+            return
         if isinstance(d, GeneratorDataBatch):
             self.jobHandle = self.ctx.call("nz_flowmap_stage_batch", d.data.ptr, self.work.ptr, self.iterations,
                                            self.normMin, self.normMax, d.resolution, d.count, dep=dependency)

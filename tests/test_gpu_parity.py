@@ -2,6 +2,8 @@
 seeded inputs.  Bar: 1e-5 relative (abs floor 1e-6) for float planes, bit-exact for mesh indices
 (BASELINE.json); where the kernels reproduce the oracle's operation order the planes are
 additionally required to be equal bit for bit."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -368,6 +370,9 @@ def test_cpp_host_mirror_runs_the_metric_pipeline(oracle, tmp_path):
     subprocess.check_call([exe, "256", out, "17", "5", "5"])
     got = np.fromfile(out, dtype=np.float32).reshape(256, 256)
     assert np.array_equal(got, oracle.pipeline(256, 256))
+    # the same pipeline on a READ / WRITE plane pair (nz_*_rw entries: SWAP_RWTILE as a pointer swap)
+    subprocess.check_call([exe, "256", out, "rw"])
+    assert np.array_equal(np.fromfile(out, dtype=np.float32).reshape(256, 256), got)
     # ReducePipeline of the C++ mirror: simplex (left) x cellular (right), MULTIPLY
     subprocess.check_call([exe, "200", out, "reduce"])
     got = np.fromfile(out, dtype=np.float32).reshape(200, 200)
@@ -624,3 +629,71 @@ def test_thermal_erosion_stage(nj, ctx, oracle):
         for iters, talus, inc, ratio in ((1, 45, 0.5, 0.75), (3, 20, 0.25, 0.3), (2, 80, 0.5, 2.0)):
             got = run(nj.StageThermalErosion(ctx, iters, talus, inc, ratio), nj, gen(nj, ctx, res, host=t))
             assert np.array_equal(got, oracle.thermal_erosion(t, float(talus), inc, ratio, iters)), (res, iters)
+
+
+# ---- READ / WRITE plane pairs (nz_rw_tile): TileHelpers.SWAP_RWTILE as a swap ---------------------------------
+def _pair(nj, ctx, res, host):
+    d = nj.GeneratorData("rw", ctx.from_host(host), res, 0, 0, write=ctx.from_host(np.full((res, res), np.nan, f32)))
+    return d, {d.data.ptr, d.write.ptr}
+
+
+@pytest.mark.parametrize("res", [50, 257])
+def test_rw_pair_stages_match_the_oracle(nj, ctx, oracle, res):
+    t = adversarial_tiles(res)["uniform"]
+    cases = [(nj.KernelFilterStage(ctx, nj.KernelFilterType(ft), it), lambda a, ft=ft, it=it: oracle.kernel_filter(a, ft, it))
+             for ft, it in ((2, 1), (2, 17), (0, 3), (6, 7), (3, 4), (12, 2), (13, 1))]
+    cases += [(nj.StageGaussianBlur(ctx, it, nj.GaussSigma(4), w),
+               lambda a, w=w, it=it: oracle.gauss(a, oracle.limit_width(w), 4, it)) for w, it in ((5, 1), (13, 3), (25, 2), (8, 2))]
+    cases += [(nj.StageSmoothBlur(ctx, 3, 11), lambda a: oracle.smooth(a, oracle.limit_width(11), 3))]
+    cases += [(nj.ErosionStage(ctx, it), lambda a, it=it: oracle.erosion_min(a, it)) for it in (1, 2, 5, 8, 9, 21)]
+    cases += [(nj.FlowMapStage(ctx, it, 0.0, 0.005), lambda a, it=it: oracle.flowmap(a, it, 0.0, 0.005)) for it in (1, 5, 7, 12)]
+    for stage, want in cases:
+        d, planes = _pair(nj, ctx, res, t)
+        got = run(stage, nj, d)  # reads d.data after the stage: whichever plane holds the result
+        assert np.array_equal(got, want(t)), (type(stage).__name__, vars(stage).get("iterations"))
+        assert {d.data.ptr, d.write.ptr} == planes and d.data.ptr != d.write.ptr
+        d.data.Dispose(); d.write.Dispose()
+
+
+def test_rw_pair_pipeline_equals_the_in_place_pipeline(nj, ctx, oracle):
+    res = 600
+
+    def stages():
+        return [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700),
+                nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), nj.FlowMapStage(ctx, 5, 0.0, 0.005),
+                nj.ErosionStage(ctx, 5), nj.ConstantStage(ctx, nj.ConstantOperationType.MULTIPLY, 0.5)]
+    outs = []
+    for pair in (False, True):
+        d = nj.GeneratorData("p", ctx.alloc(res * res), res, 40, -7, write=ctx.alloc(res * res) if pair else None)
+        pipe = nj.BasePipeline(stages())
+        seen = []
+        pipe.Enqueue(d, completeAction=lambda x: seen.append(x.data.ToArray((res, res))))
+        pipe.RunToCompletion()
+        outs.append(seen[0])
+        pipe.Destroy()
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], oracle.constant(oracle.pipeline(res, res, xpos=40, zpos=-7), 0, 0.5))
+
+
+def test_rw_pair_batch_and_errors(nj, ctx, oracle):
+    res, count = 96, 3
+    b = nj.GeneratorDataBatch.create(ctx, "b", res, [(96 * k, -3 * k) for k in range(count)])
+    b.write = ctx.alloc(count * res * res)
+    pipe = nj.BasePipeline([nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700),
+                            nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17),
+                            nj.FlowMapStage(ctx, 5, 0.0, 0.005), nj.ErosionStage(ctx, 5)])
+    pipe.Enqueue(b)
+    pipe.RunToCompletion()
+    got = b.data.ToArray((count, res, res))
+    for k in range(count):
+        assert np.array_equal(got[k], oracle.pipeline(res, res, xpos=96 * k, zpos=-3 * k)), k
+    N = nj._native
+    same = N.RWTile(b.data.ptr, b.data.ptr, res, 1)
+    with pytest.raises(nj.NoizeError):
+        ctx.call("nz_erosion_stage_rw", C.byref(same), 2)
+    t = N.RWTile(b.data.ptr, b.write.ptr, res, 1)
+    with pytest.raises(nj.NoizeError):
+        ctx.call("nz_kernel_filter_stage_rw", C.byref(t), int(nj.KernelFilterType.Sobel3_2D), 1)
+    with pytest.raises(nj.NoizeError):
+        ctx.call("nz_flowmap_stage_rw", C.byref(t), None, 5, 0.0, 0.005)
+    assert (t.read, t.write) == (b.data.ptr, b.write.ptr)  # a refused call leaves the pair alone
