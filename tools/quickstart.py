@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import noize_job_amd as nj  # noqa: E402
 
 ctx = nj.Context(0)
-tile = nj.GeneratorData("t", ctx.alloc(4096 * 4096), 4096, xpos=0, zpos=0)
+tile = nj.GeneratorData("t", ctx.alloc(4096 * 4096), 4096, xpos=0, zpos=0,
+                        write=ctx.alloc(4096 * 4096))  # optional WRITE plane: stages swap the pair instead of flushing
 pipe = nj.BasePipeline([nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700),
                         nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17),
                         nj.FlowMapStage(ctx, 5, 0.0, 0.005), nj.ErosionStage(ctx, 5)])
