@@ -17,7 +17,7 @@ def make(ctx, res):
               nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), nj.FlowMapStage(ctx, 5, 0.0, 0.005),
               nj.ErosionStage(ctx, 5)]
     pipe = nj.BasePipeline(stages, "tile")
-    gd = nj.GeneratorData("t", ctx.alloc(res * res), res, 0, 0)
+    gd = nj.GeneratorData("t", ctx.alloc(res * res), res, 0, 0, write=ctx.alloc(res * res))  # READ / WRITE pair
     return pipe, gd
 
 
@@ -36,6 +36,7 @@ def main():
                           nj.FlowMapStage(ctx, 5, 0.0, 0.005), nj.ErosionStage(ctx, 5)]
                 pipe = nj.BasePipeline(stages, "batch")
                 batch = nj.GeneratorDataBatch.create(ctx, "b", res, [(res * k, 0) for k in range(B)])
+                batch.write = ctx.alloc(B * res * res)  # READ / WRITE pair: the stages swap instead of flushing
                 for _ in range(3):
                     pipe.Schedule(batch)
                     pipe.pipelineRunning = False
@@ -51,6 +52,7 @@ def main():
                     res, B, n * B / dt, n * B * res * res / dt / 1e6, dt / (n * B) * 1e3))
                 pipe.Destroy()
                 batch.data.Dispose()
+                batch.write.Dispose()
                 batch.positions.Dispose()
         for S in a.streams:
             ctxs = [nj.Context(0) for _ in range(S)]
@@ -77,6 +79,7 @@ def main():
             for p, gd in pipes:
                 p.Destroy()
                 gd.data.Dispose()
+                gd.write.Dispose()
             for c in ctxs:
                 c.close()
 
