@@ -66,6 +66,46 @@ def test_filters_erosion_flow_random_sizes(nj, ctx, oracle, seed):
             assert np.array_equal(got, oracle.thermal_erosion(t, 45.0, 0.5, 0.75, it)), ("thermal", res, it)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_rw_pair_random_stage_chains(nj, ctx, oracle, seed):
+    # chains of stencil stages on a READ / WRITE plane pair (nz_*_rw: the pair is swapped, never flushed), with an
+    # in-place element-wise stage thrown in, against the oracle's composition
+    rng = np.random.default_rng(9000 + seed)
+    for _ in range(5):
+        res = int(rng.choice(SIZES))
+        t = _tile(rng, res)
+        d = nj.GeneratorData("rw", ctx.from_host(t), res, write=ctx.from_host(np.full((res, res), np.nan, f32)))
+        planes = {d.data.ptr, d.write.ptr}
+        want, desc = t, []
+        for _ in range(int(rng.integers(1, 5))):
+            kind = int(rng.integers(0, 6))
+            if kind == 0:
+                ft = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13]))
+                it = int(rng.integers(1, 20))
+                stage, want = nj.KernelFilterStage(ctx, nj.KernelFilterType(ft), it), oracle.kernel_filter(want, ft, it)
+            elif kind == 1:
+                w, sg, it = int(rng.integers(1, 27)), int(rng.integers(0, 16)), int(rng.integers(1, 4))
+                stage, want = nj.StageGaussianBlur(ctx, it, nj.GaussSigma(sg), w), oracle.gauss(want, oracle.limit_width(w), sg, it)
+            elif kind == 2:
+                w, it = int(rng.integers(1, 26)), int(rng.integers(1, 4))
+                stage, want = nj.StageSmoothBlur(ctx, it, w), oracle.smooth(want, oracle.limit_width(w), it)
+            elif kind == 3:
+                it = int(rng.integers(1, 20))
+                stage, want = nj.ErosionStage(ctx, it), oracle.erosion_min(want, it)
+            elif kind == 4:
+                it = int(rng.integers(1, 13))
+                stage, want = nj.FlowMapStage(ctx, it, -0.1, 0.1), oracle.flowmap(want, it, -0.1, 0.1)
+            else:
+                stage, want = nj.ConstantStage(ctx, nj.ConstantOperationType.MULTIPLY, 0.75), oracle.constant(want, 0, 0.75)
+            desc.append((type(stage).__name__, vars(stage).get("iterations")))
+            stage.ReceiveHandledInput(nj.PipelineWorkItem(d), nj.JobHandle())
+            stage.jobHandle.Complete()
+            stage.OnDestroy()
+            assert {d.data.ptr, d.write.ptr} == planes
+        assert np.array_equal(d.data.ToArray((res, res)), want, equal_nan=True), (res, desc)
+        d.data.Dispose(); d.write.Dispose()
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_non_finite_cells_propagate_like_the_oracle(nj, ctx, oracle, seed):
     # NaN / +-inf cells: sums and products spread them the IEEE way, min / max drop a NaN operand
