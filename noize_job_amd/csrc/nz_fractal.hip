@@ -442,15 +442,17 @@ __device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1
     x12y -= i1y;
     int ixi = (int)mod289i(fx), iyi = (int)mod289i(fy);
     // fp32 mod289 returns 289 (not 0) for some negative multiples of 289 (-8959, -17629, ...): the tables carry
-    // that index; the clamps only guard the LDS reads, they never bind below NZ_TAB_LIMIT
-    ixi = min(max(ixi, 0), 289);
-    iyi = min(max(iyi, 0), 289);
+    // that index.  Callers guarantee |v| < NZ_TAB_LIMIT (or NaN, which converts to index 0 and poisons the result
+    // through x0 anyway), so both indices are in [0, 289] without a clamp
     int ix16 = ixi << 4;
-    int k0 = s_t1[iyi], k1 = s_t1[iyi + (gt ? 0 : 1)], k2 = s_t1[iyi + 1];
+    // corner 1 is (ix + 1, iy) or (ix, iy + 1): its T1 entry is one of the two already read, selected, not re-read
+    int k0 = s_t1[iyi], k2 = s_t1[iyi + 1];
     const char *t2 = reinterpret_cast<const char *>(s_t2);
-    float4 g0 = *reinterpret_cast<const float4 *>(t2 + (k0 + ix16));
-    float4 g1 = *reinterpret_cast<const float4 *>(t2 + (k1 + ix16 + (gt ? 16 : 0)));
-    float4 g2 = *reinterpret_cast<const float4 *>(t2 + (k2 + ix16 + 16));
+    int a0 = k0 + ix16, a2 = k2 + ix16;
+    int a1 = gt ? a0 + 16 : a2;
+    float4 g0 = *reinterpret_cast<const float4 *>(t2 + a0);
+    float4 g1 = *reinterpret_cast<const float4 *>(t2 + a1);
+    float4 g2 = *reinterpret_cast<const float4 *>(t2 + (a2 + 16));
     // keep the padding lane live: a 16-byte LDS read takes 4 LDS cycles per wave, the 12-byte form 8
     asm volatile("" ::"v"(g0.w), "v"(g1.w), "v"(g2.w));
     float m0 = fmaxf(0.5f - (x0x * x0x + x0y * x0y), 0.0f);
