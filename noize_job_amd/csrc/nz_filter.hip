@@ -73,6 +73,20 @@ __device__ __forceinline__ float dpp_next(float v) {  // lane i <- lane i+1
 // 512-thread workgroups per CU (6 waves per SIMD, 80 VGPRs, one edge buffer of 32 KB each) so one workgroup's
 // load/store phase overlaps the others' VALU phases: 5 % faster than two workgroups at 121 VGPRs; the 7- and
 // 9-tap windows do not fit 80 registers without spilling and stay at two.
+// -DNZ_CONV_PROBE: thread 0 of every workgroup stamps s_memrealtime (100 MHz) at the start, after each application and
+// at the end, plus its HW_ID / XCC_ID, into a caller-supplied buffer (tools/probe_conv_phases.py).  Never built by the Makefile.
+#ifdef NZ_CONV_PROBE
+__device__ unsigned long long *nz_probe_buf = nullptr;  // [workgroup][16]
+#define NZ_PROBE(slot, val)                                                                                   \
+    do {                                                                                                      \
+        if (threadIdx.x == 0 && nz_probe_buf) nz_probe_buf[(size_t)blockIdx.x * 16 + (slot)] = (val);        \
+    } while (0)
+#define NZ_PROBE_T(slot) NZ_PROBE(slot, __builtin_amdgcn_s_memrealtime())
+#else
+#define NZ_PROBE(slot, val)
+#define NZ_PROBE_T(slot)
+#endif
+
 #ifndef NZ_CONV5_WAVES
 #define NZ_CONV5_WAVES 6
 #endif
@@ -102,14 +116,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
     const int gx0 = lx0 + cg * 4, gzb = lz0 + rb * RB;
     const bool inside = lx0 >= 0 && lx0 + TW <= g.cols && lz0 >= g.zc0 && lz0 + TH - 1 <= g.zc1;
     const bool fast = inside && aligned;
+    NZ_PROBE_T(0);
+    NZ_PROBE(14, (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)));   // HW_ID
+    NZ_PROBE(15, (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)));  // XCC_ID
 
     float v[RB][4];
+    if (fast) {  // a real branch (the asm keeps the two forms from being merged into 4-byte accesses with selected addresses)
 #pragma unroll
-    for (int r = 0; r < RB; r++) {
-        if (fast) {
+        for (int r = 0; r < RB; r++) {
             float4 t = *reinterpret_cast<const float4 *>(src + (size_t)(gzb + r) * g.pitch + gx0);
             v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
-        } else {
+        }
+        asm volatile("; 16-byte loads issued" ::: "memory");  // after the loads: they cannot be sunk into a common tail
+    } else {
+        asm volatile("; clamped 4-byte loads of an edge tile" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
             size_t row = (size_t)clampi(gzb + r, g.zc0, g.zc1) * g.pitch;
 #pragma unroll
             for (int e = 0; e < 4; e++) v[r][e] = src[row + clampi(gx0 + e, 0, g.cols - 1)];
@@ -208,23 +230,31 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
                 v[r][e] = UNIT ? total : total * taps.factor;
             }
         }
+        NZ_PROBE_T(1 + t);
     }
 
     // ---- store the interior
+    if (fast) {  // whole tile inside the grid, 16-byte aligned rows: one 16-byte store per row
 #pragma unroll
-    for (int r = 0; r < RB; r++) {
-        int lr = rb * RB + r, gz = gzb + r;
-        bool in = lr >= H && lr < H + OH && cg * 4 >= HX && cg * 4 < HX + OW && gz < g.or1 && gx0 < g.cols;
-        if (in) {
-            if (aligned && gx0 + 4 <= g.cols) {
-                *reinterpret_cast<float4 *>(dst + (size_t)gz * g.pitch + gx0) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
-            } else {
+        for (int r = 0; r < RB; r++) {
+            int lr = rb * RB + r, gz = gzb + r;
+            bool in = lr >= H && lr < H + OH && cg * 4 >= HX && cg * 4 < HX + OW && gz < g.or1;
+            if (in) *reinterpret_cast<float4 *>(dst + (size_t)gz * g.pitch + gx0) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        }
+    } else {
+        asm volatile("; guarded stores of an edge tile" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            int lr = rb * RB + r, gz = gzb + r;
+            bool in = lr >= H && lr < H + OH && cg * 4 >= HX && cg * 4 < HX + OW && gz < g.or1 && gx0 < g.cols;
+            if (in) {
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                     if (gx0 + e < g.cols) dst[(size_t)gz * g.pitch + gx0 + e] = v[r][e];
             }
         }
     }
+    NZ_PROBE_T(12);
 }
 
 // E applications of the {-1,0} min window fused as one window min over [x-E,x] x [z-E,z], register
@@ -256,6 +286,7 @@ __global__ __launch_bounds__(CT) void erosion_reg_kernel(const float *__restrict
         if (fast) {
             float4 t = *reinterpret_cast<const float4 *>(src + (size_t)gz * g.pitch + gx0);
             v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+            asm volatile("; 16-byte load" ::: "memory");  // after the access: the two forms stay two forms
         } else {
             bool zin = gz >= g.zc0 && gz <= g.zc1;
 #pragma unroll
@@ -336,6 +367,7 @@ __global__ __launch_bounds__(CT) void erosion_reg_kernel(const float *__restrict
         if (in) {
             if (aligned && gx0 + 4 <= g.cols) {
                 *reinterpret_cast<float4 *>(dst + (size_t)gz * g.pitch + gx0) = make_float4(out[0], out[1], out[2], out[3]);
+                asm volatile("; 16-byte store" ::: "memory");
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++)
@@ -408,6 +440,7 @@ __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restric
         float4 t;
         if (inside) {
             t = *reinterpret_cast<const float4 *>(src + (size_t)(z0 - O + r) * g.pitch + gx);
+            asm volatile("; 16-byte load" ::: "memory");  // after the access: the two forms stay two forms
         } else {
             const float *row = src + (size_t)clampi(z0 - O + r, g.zc0, g.zc1) * g.pitch;
             t.x = row[clampi(gx, 0, g.cols - 1)];
@@ -470,6 +503,7 @@ __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restric
                 float *out = dst + (size_t)gz * g.pitch + gx;
                 if (aligned && gx + 4 <= g.cols) {
                     *reinterpret_cast<float4 *>(out) = make_float4(o[0], o[1], o[2], o[3]);
+                    asm volatile("; 16-byte store" ::: "memory");
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; e++)
@@ -622,3 +656,9 @@ int32_t nz_launch_erosion_fused(hipStream_t s, const float *src, float *dst, con
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
+
+#ifdef NZ_CONV_PROBE
+extern "C" int32_t nz_debug_set_conv_probe(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(nz_probe_buf), &buf, sizeof buf) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -204,6 +204,8 @@ __device__ __forceinline__ void load_group(const float *__restrict__ p, const nz
     if (fast) {
         float4 t = *reinterpret_cast<const float4 *>(p + (size_t)gz * g.pitch + gx0);
         out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+        // after the access: keeps the two forms from being sunk into one tail of 4-byte accesses with selected addresses
+        asm volatile("; 16-byte load" ::: "memory");
     } else {
         size_t row = (size_t)clampi(gz, g.zc0, g.zc1) * g.pitch;
 #pragma unroll
@@ -215,6 +217,7 @@ __device__ __forceinline__ void store_group(float *__restrict__ p, const nz_geom
                                             const float v[4]) {
     if (fast) {
         *reinterpret_cast<float4 *>(p + (size_t)gz * g.pitch + gx0) = make_float4(v[0], v[1], v[2], v[3]);
+        asm volatile("; 16-byte store" ::: "memory");
     } else {
 #pragma unroll
         for (int e = 0; e < 4; e++)
