@@ -1,11 +1,14 @@
 #!/bin/bash
+# compile-time variants of nz_flow.hip timed on the GPU box (its scratch copy of the tree):
+#   tools/try_flow_flags.sh "-DNZ_FT_NT=768 -DNZ_FT_OCC=6" ...
 set -e
-cd "$(dirname "$0")/../noize_job_amd/csrc"
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd "$ROOT/noize_job_amd/csrc"
 BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -fno-slp-vectorize"
-for extra in "-DNZ_FT_NT=512 -DNZ_FT_OCC=4" "-DNZ_FT_NT=768 -DNZ_FT_OCC=3" "-DNZ_FT_NT=768 -DNZ_FT_OCC=6" "-DNZ_FT_NT=768 -DNZ_FT_OCC=4"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE $extra -c nz_flow.hip -o build/nz_flow.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A12 "flow_fused_kernelILb1ELb1ELi" | grep -E "VGPRs:|ScratchSize|Occupancy" | sed -E 's/.*remark: +//; s/ \[-R.*//' | head -3 | paste - - -
+mkdir -p build
+for extra in "" "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE $extra -c nz_flow.hip -o build/nz_flow.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libnoize_hip.so
   echo "== flags: [$extra]"
-  python3 ../../tools/bench_stage.py flow --reps 10 2>/dev/null
+  python3 "$ROOT/tools/bench_stage.py" flow --reps 40 2>/dev/null | tail -1
 done
-cd ../.. && python3 -m pytest tests/test_gpu_parity.py -m gpu -q -k "flow" 2>&1 | tail -1
