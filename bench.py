@@ -33,7 +33,7 @@ G_IT, F_IT, E_IT = 17, 5, 5
 BYTES = {"noise": 4.0, "gauss": 8.0 * G_IT, "flow": 24.0 + 44.0 * (F_IT - 1) + 20.0, "erosion": 8.0 * E_IT}
 KERNEL_OF = {"noise": "fractal_simplex_tab_kernel<2>", "gauss": "conv_reg_kernel<5, true>",
              "flow": "flow_fused_kernel<true, true, 4>", "erosion": "erosion_reg_kernel<3>"}
-NOISE_OPS_PER_OCTAVE_CELL = 90.0  # VALU slots of the table-driven simplex octave (ISA count: 172 per 2 cells + LDS)
+NOISE_OPS_PER_OCTAVE_CELL = 83.0  # VALU instructions of the table-driven simplex octave (ISA count: 166 per 2 cells)
 
 
 CPU_PASSES = 11         # ~10 s of host work on the GPU box's 32 cores (0.9-1.0 s per 4096^2 pass)
