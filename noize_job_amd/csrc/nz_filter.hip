@@ -53,13 +53,14 @@ __device__ __forceinline__ void tile_origin(const nz_geom &g, int OW, int OH, in
 }
 
 // ---- register-resident fused kernel ------------------------------------------------------------------
-// T applications of X pass + Z pass on a (NT/4) x 128 tile (halo included; 64 rows for 3 taps, 128 rows otherwise).  The tile never sits in LDS: each of the 256 threads keeps a 4-column x 8-row block in
-// registers for the whole launch.  The X pass takes its (K-1)/2 west / east neighbours from the
-// adjacent lanes with wave-shift DPP moves; the Z pass needs (K-1)/2 rows from the thread above and
-// below, and only those boundary rows travel through LDS (16-byte accesses, double buffered: one
-// barrier per application).  Global loads and stores go register <-> HBM directly, 16 B per lane.
-// Clamp-to-edge is applied when a window is assembled: a tap beyond the grid takes the border cell's
-// current value (RWTileData.GetData, Pipeline/Tiles/TileData.cs:72-82), so no fix-up pass is needed.
+// T applications of X pass + Z pass on a (NT/4) x 128 tile (halo included; 64 rows for 3 taps, 128 rows otherwise).
+// The tile never sits in LDS: every thread keeps a 4-column x 8-row block in registers for the whole launch.  The
+// X pass takes its (K-1)/2 west / east neighbours from the adjacent lanes with wave-shift DPP moves; the Z pass needs
+// (K-1)/2 rows from the thread above and below, and only those boundary rows travel through LDS (16-byte accesses;
+// double buffered with one barrier per application for 3 taps, one buffer and two barriers otherwise).  Global loads
+// and stores go register <-> HBM directly, 16 B per lane.  Clamp-to-edge is applied when a window is assembled: a tap
+// beyond the grid takes the border cell's current value (RWTileData.GetData, Pipeline/Tiles/TileData.cs:72-82), so no
+// fix-up pass is needed.
 constexpr int RB = 8;  // rows per thread
 
 __device__ __forceinline__ float dpp_prev(float v) {  // lane i <- lane i-1
@@ -69,10 +70,6 @@ __device__ __forceinline__ float dpp_next(float v) {  // lane i <- lane i+1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-// Register budget per tap count (waves per SIMD the allocator is asked to fit): the 5-tap kernel runs three
-// 512-thread workgroups per CU (6 waves per SIMD, 80 VGPRs, one edge buffer of 32 KB each) so one workgroup's
-// load/store phase overlaps the others' VALU phases: 5 % faster than two workgroups at 121 VGPRs; the 7- and
-// 9-tap windows do not fit 80 registers without spilling and stay at two.
 // -DNZ_CONV_PROBE: thread 0 of every workgroup stamps s_memrealtime (100 MHz) at the start, after each application and
 // at the end, plus its HW_ID / XCC_ID, into a caller-supplied buffer (tools/probe_conv_phases.py).  Never built by the Makefile.
 #ifdef NZ_CONV_PROBE
@@ -87,6 +84,10 @@ __device__ unsigned long long *nz_probe_buf = nullptr;  // [workgroup][16]
 #define NZ_PROBE_T(slot)
 #endif
 
+// Register budget per tap count (waves per SIMD the allocator is asked to fit): the 5-tap kernel runs three
+// 512-thread workgroups per CU (6 waves per SIMD, 80 VGPRs, one edge buffer of 32 KB each) so one workgroup's
+// load/store phase overlaps the others' VALU phases: 5 % faster than two workgroups at 121 VGPRs; the 7- and
+// 9-tap windows do not fit 80 registers without spilling and stay at two.
 #ifndef NZ_CONV5_WAVES
 #define NZ_CONV5_WAVES 6
 #endif
