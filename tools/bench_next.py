@@ -75,19 +75,21 @@ def main():
         run("flow map x1", nj.FlowMapStage(ctx, 1, 0.0, 0.005), gd, 24 + 20)
         seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
         run("flow map x12", nj.FlowMapStage(ctx, 12, 0.0, 0.005), gd, 24 + 44 * 11 + 20)
-        # the same stage bodies on a READ / WRITE plane pair (nz_*_rw: SWAP_RWTILE is a pointer swap)
+        # the same stage bodies on a READ / WRITE plane pair (nz_*_rw: SWAP_RWTILE is a pointer swap); the pair is its
+        # own two planes, since the stages leave the result in either
         seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
-        gd.write = ctx.alloc(cells)
+        pd = nj.GeneratorData("pair", ctx.alloc(cells), res, 0, 0, write=ctx.alloc(cells))
+        pd.data.CopyFrom(data.ToArray())
         pair = "READ/WRITE pair: no flush copy"
-        run("pair: filter Gauss5_S1 x1", nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 1), gd, 8, pair)
-        run("pair: filter Gauss5_S1 x17", nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), gd, 8 * 17, pair)
-        run("pair: gaussian blur width 25 sigma 2.0 x1", nj.StageGaussianBlur(ctx, 1, nj.GaussSigma.s2d00, 25), gd, 8, pair)
-        run("pair: value erosion x1", nj.ErosionStage(ctx, 1), gd, 8, pair)
-        run("pair: value erosion x5", nj.ErosionStage(ctx, 5), gd, 8 * 5, pair)
-        seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
-        run("pair: flow map x5", nj.FlowMapStage(ctx, 5, 0.0, 0.005), gd, 24 + 44 * 4 + 20, pair)
-        gd.write.Dispose()
-        gd.write = None
+        run("pair: filter Gauss5_S1 x1", nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 1), pd, 8, pair)
+        run("pair: filter Gauss5_S1 x17", nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), pd, 8 * 17, pair)
+        run("pair: gaussian blur width 25 sigma 2.0 x1", nj.StageGaussianBlur(ctx, 1, nj.GaussSigma.s2d00, 25), pd, 8, pair)
+        run("pair: value erosion x1", nj.ErosionStage(ctx, 1), pd, 8, pair)
+        run("pair: value erosion x5", nj.ErosionStage(ctx, 5), pd, 8 * 5, pair)
+        seed.Schedule(nj.PipelineWorkItem(pd), nj.JobHandle())
+        run("pair: flow map x5", nj.FlowMapStage(ctx, 5, 0.0, 0.005), pd, 24 + 44 * 4 + 20, pair)
+        pd.data.Dispose()
+        pd.write.Dispose()
         seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
         run("constant MULTIPLY", nj.ConstantStage(ctx, nj.ConstantOperationType.MULTIPLY, 0.999), gd, 8)
         run("constant BINARIZE", nj.ConstantStage(ctx, nj.ConstantOperationType.BINARIZE, 0.5), gd, 8)
