@@ -143,16 +143,32 @@ __device__ __forceinline__ uint32_t mesh_index(uint32_t i, uint32_t R) {
     return corner == 0 ? a : (corner == 1 ? b : c);
 }
 
-__global__ __launch_bounds__(CT) void mesh_index_kernel(uint32_t *__restrict__ idx, uint32_t R, size_t n, size_t istride) {
+// Four consecutive indices (one 16-byte store) lie in at most two neighbouring quads: one division by the run-time R
+// per thread (reciprocal multiply + two corrections, exact for every 32-bit quad number) instead of one per index.
+//   quad q = (zq, xq):  e0..e5 = vi-R-2, vi-1, vi-R-1 | vi-R-1, vi-1, vi   with vi = (R+1)(zq+1) + xq+1
+__global__ __launch_bounds__(CT) void mesh_index_kernel(uint32_t *__restrict__ idx, uint32_t R, uint32_t Rinv, size_t n,
+                                                       size_t istride) {
     idx += blockIdx.y * istride;
     size_t i = ((size_t)blockIdx.x * CT + threadIdx.x) * 4;
     if (i >= n) return;
     if (i + 4 <= n && ((reinterpret_cast<uintptr_t>(idx) & 15) == 0)) {
+        const uint32_t i0 = (uint32_t)i, q = i0 / 6u, rem = i0 - q * 6u;  // rem = 0, 2 or 4
+        uint32_t zq = __umulhi(q, Rinv);  // floor(2^32 / R): at most two short of q / R
+        uint32_t xq = q - zq * R;
+        if (xq >= R) { zq += 1u; xq -= R; }
+        if (xq >= R) { zq += 1u; xq -= R; }
+        const uint32_t vi = (R + 1u) * (zq + 1u) + xq + 1u;
+        const bool wrap = xq + 1u >= R;                      // the next quad starts the next row of quads
+        const uint32_t vi2 = wrap ? vi + 2u : vi + 1u;       // (R+1)(zq+2) + 1 = vi - xq + R + 1 with xq = R - 1
+        const uint32_t e0 = vi - R - 2u, e1 = vi - 1u, e2 = vi - R - 1u, e5 = vi;
         uint4 v;
-        v.x = mesh_index((uint32_t)i, R);
-        v.y = mesh_index((uint32_t)i + 1, R);
-        v.z = mesh_index((uint32_t)i + 2, R);
-        v.w = mesh_index((uint32_t)i + 3, R);
+        if (rem == 0u) {
+            v = make_uint4(e0, e1, e2, e2);
+        } else if (rem == 2u) {
+            v = make_uint4(e2, e2, e1, e5);
+        } else {
+            v = make_uint4(e1, e5, vi2 - R - 2u, vi2 - 1u);
+        }
         nt_store(reinterpret_cast<uint4 *>(idx + i), v);
     } else {
         for (size_t k = i; k < n && k < i + 4; k++) idx[k] = mesh_index((uint32_t)k, R);
@@ -160,6 +176,12 @@ __global__ __launch_bounds__(CT) void mesh_index_kernel(uint32_t *__restrict__ i
 }
 
 }  // namespace
+
+// floor(2^32 / R), saturated (R = 1), for mesh_index_kernel's quad -> (row, column) split
+static uint32_t mesh_rinv(int res) {
+    uint64_t v = 0x100000000ULL / (uint64_t)res;
+    return v > 0xffffffffULL ? 0xffffffffu : (uint32_t)v;
+}
 
 int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *indices, int res, int in_res,
                        float tile_height, float tile_size, const float *heights, int count) {
@@ -193,7 +215,7 @@ int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *in
     NZ_HIP(hipGetLastError());
     size_t nthreads = (ni + 3) / 4;
     hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT), count), dim3(CT), 0, s, indices,
-                       (uint32_t)res, ni, ni);
+                       (uint32_t)res, mesh_rinv(res), ni, ni);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -214,7 +236,7 @@ int32_t nz_launch_mesh_planar(hipStream_t s, void *vertices, uint32_t *indices, 
     NZ_HIP(hipGetLastError());
     size_t nthreads = (ni + 3) / 4;
     hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT)), dim3(CT), 0, s, indices,
-                       (uint32_t)res, ni, (size_t)0);
+                       (uint32_t)res, mesh_rinv(res), ni, (size_t)0);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
