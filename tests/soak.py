@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak run of the random sweeps of tests/test_gpu_sweep.py with many more seeds (one-off hunt for rare
-mismatches between the HIP path and the oracle).  usage: soak.py [minutes]"""
+mismatches between the HIP path and the oracle; kept under tests/ because it drives the oracle, not collected by
+pytest).  usage: python3 tests/soak.py [minutes]"""
 import os
 import sys
 import time
@@ -9,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # test_gpu_sweep, conftest
 import noize_job_amd as nj  # noqa: E402
 import oracle as O  # noqa: E402
 import test_gpu_sweep as S  # noqa: E402
