@@ -79,6 +79,41 @@ def pmc_traffic(kernel_key):
     return best
 
 
+def two_tiles(nj, ctx, stages, gd, res, p, swap, steps=100):
+    """Informational, outside the timed steps: two INDEPENDENT tiles, each with its own context (HIP stream), pipelines
+    issued alternately.  The fp32-bound and the HBM-bound kernels of different tiles overlap; `value` above is the
+    single tile BASELINE.json names."""
+    ctx2 = nj.Context(ctx.device)
+    cells = res * res
+    stages2 = [nj.NoiseStage(ctx2, nj.FractalNoise.Simplex, p.hurst, p.startingAmplitude, p.octaves, p.stepdown,
+                             p.detuneRate, p.noiseSize),
+               nj.KernelFilterStage(ctx2, nj.KernelFilterType.Gauss5_S1, G_IT),
+               nj.FlowMapStage(ctx2, F_IT, p.normMin, p.normMax), nj.ErosionStage(ctx2, E_IT)]
+    gd2 = nj.GeneratorData("bench2", ctx2.alloc(cells), res, res, 0, write=ctx2.alloc(cells) if swap else None)
+    h0 = nj.JobHandle()
+
+    def both():
+        for a, b in zip(stages, stages2):
+            a.Schedule(nj.PipelineWorkItem(gd), h0)
+            b.Schedule(nj.PipelineWorkItem(gd2), h0)
+    for _ in range(20):
+        both()
+    ctx.synchronize(); ctx2.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        both()
+    ctx.synchronize(); ctx2.synchronize()
+    dt = (time.perf_counter() - t0) / (2 * steps)
+    for st in stages2:
+        st.OnDestroy()
+    gd2.data.Dispose()
+    if gd2.write is not None:
+        gd2.write.Dispose()
+    ctx2.close()
+    return {"streams": 2, "ms_per_tile": round(dt * 1e3, 4), "Mcells/s": round(cells / dt / 1e6, 1),
+            "note": "two independent 4096^2 tiles on two HIP streams, not the headline value"}
+
+
 def cpu_baseline(res):
     import oracle as O
     O.lib()
@@ -305,6 +340,8 @@ def main():
                                     "traffic": None if sharded else pmc_traffic("noise"),
                                     "note": "fBm octave accumulation; %d VALU slots per octave-cell counted in the ISA"
                                             % int(NOISE_OPS_PER_OCTAVE_CELL)}
+        if not sharded:
+            out["two_tiles_in_flight"] = two_tiles(nj, ctx, stages, gd, res, p, swap)
         if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(args.cpu_res)
     if sharded:

@@ -9,7 +9,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import noize_job_amd as nj  # noqa: E402
 
-R, STEPS = 4096, 20
+R, STEPS = 4096, 100  # long enough for the clocks to settle
 
 
 def make(ctx):
@@ -17,7 +17,7 @@ def make(ctx):
     stages = [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700),
               nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), nj.FlowMapStage(ctx, 5, 0.0, 0.005),
               nj.ErosionStage(ctx, 5)]
-    gd = nj.GeneratorData("p", data, R, 0, 0)
+    gd = nj.GeneratorData("p", data, R, 0, 0, write=ctx.alloc(R * R))  # READ / WRITE pair
     wi = nj.PipelineWorkItem(gd)
     for s in stages:
         s.Schedule(wi, nj.JobHandle())
