@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--flush", choices=("swap", "copy"), default="swap",
                     help="N=1: the tile is a READ / WRITE plane pair and TileHelpers.SWAP_RWTILE is a pointer swap "
                          "(nz_*_rw entries), or one plane with the in-place entries and their flush copies")
+    ap.add_argument("--stripes", type=int, default=1,
+                    help="N=1: run the tile as this many independent row stripes, each on its own HIP stream (ghost "
+                         "rows recomputed from the closed-form noise; the fp32-bound kernels of one stripe overlap "
+                         "the HBM-bound kernels of another); 1 = the stage pipeline on one stream")
     ap.add_argument("--cpu-res", type=int, default=4096)
     return ap.parse_args()
 
@@ -112,6 +116,31 @@ def two_tiles(nj, ctx, stages, gd, res, p, swap, steps=100):
     ctx2.close()
     return {"streams": 2, "ms_per_tile": round(dt * 1e3, 4), "Mcells/s": round(cells / dt / 1e6, 1),
             "note": "two independent 4096^2 tiles on two HIP streams, not the headline value"}
+
+
+def two_stripes(nj, sh, torch, device, data, res, p, steps=100):
+    """Informational, outside the timed steps: the SAME 4096^2 tile as two independent row stripes, each on its own
+    HIP stream (ghost rows recomputed from the closed-form noise, the last launch storing into the tile's plane):
+    what `--stripes 2` times as its headline."""
+    ctxs = [nj.Context(device) for _ in range(2)]
+    try:
+        tile = sh.StripedTile(ctxs, data.data_ptr(), res, res, p,
+                              lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda"))
+        torch.cuda.synchronize()
+        for _ in range(20):
+            tile.run()
+        tile.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tile.run()
+        tile.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        for c in ctxs:
+            c.close()
+    return {"streams": 2, "ms_per_tile": round(dt * 1e3, 4), "Mcells/s": round(res * res / dt / 1e6, 1),
+            "note": "one 4096^2 tile as two independent row stripes on two HIP streams (bench.py --stripes 2), "
+                    "not the headline value"}
 
 
 def cpu_baseline(res):
@@ -232,9 +261,24 @@ def main():
         if args.as_rank is not None:
             parallelism = "rehearsal of rank %d of %d on one GPU" % (prank, pworld)
 
+    striped = None
+    if not sharded and args.stripes > 1:
+        # the same tile, same kernels, as independent stripes on their own streams; no per-stage markers here
+        sctx = [nj.Context(local_rank) for _ in range(args.stripes)]
+        striped = sh.StripedTile(sctx, data.data_ptr(), res, res, p,
+                                 lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda"))
+        torch.cuda.synchronize()
+
+        def step(record):  # noqa: F811
+            striped.run()
+        parallelism = "single tile as %d row stripes on %d HIP streams" % (args.stripes, args.stripes)
+        flush_note = "stripe entries (explicit src / dst planes), last launch stores into the tile's plane"
+
     def fence():
         if sharded:
             dist.barrier()
+        if striped is not None:
+            striped.synchronize()
         torch.cuda.synchronize()
 
     # The chip's clocks need some tens of ms of continuous work to settle (see --steps above).  A caller that asks
@@ -340,13 +384,22 @@ def main():
                                     "traffic": None if sharded else pmc_traffic("noise"),
                                     "note": "fBm octave accumulation; %d VALU slots per octave-cell counted in the ISA"
                                             % int(NOISE_OPS_PER_OCTAVE_CELL)}
-        if not sharded:
-            out["two_tiles_in_flight"] = two_tiles(nj, ctx, stages, gd, res, p, swap)
+        if not sharded and striped is None:
+            # informational, outside the timed steps; never allowed to cost the JSON line
+            for key, fn in (("two_tiles_in_flight", lambda: two_tiles(nj, ctx, stages, gd, res, p, swap)),
+                            ("tile_as_two_stripes", lambda: two_stripes(nj, sh, torch, local_rank, data, res, p))):
+                try:
+                    out[key] = fn()
+                except Exception as e:  # noqa: BLE001
+                    out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(args.cpu_res)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
+    if striped is not None:
+        for c in sctx:
+            c.close()
     ctx.close()
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
