@@ -384,16 +384,27 @@ def main():
                                     "traffic": None if sharded else pmc_traffic("noise"),
                                     "note": "fBm octave accumulation; %d VALU slots per octave-cell counted in the ISA"
                                             % int(NOISE_OPS_PER_OCTAVE_CELL)}
+        if not args.no_cpu_baseline and not sharded:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_res)
         if not sharded and striped is None:
-            # informational, outside the timed steps; never allowed to cost the JSON line
+            # informational, outside the timed steps; never allowed to cost the JSON line: an exception is recorded, and
+            # should one of them ever block, a watchdog prints the line without them and ends the process
+            import threading
+
+            def bail():
+                out["extras"] = "skipped: an informational measurement did not return within 120 s"
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+                os._exit(0)
+            watchdog = threading.Timer(120.0, bail)
+            watchdog.daemon = True
+            watchdog.start()
             for key, fn in (("two_tiles_in_flight", lambda: two_tiles(nj, ctx, stages, gd, res, p, swap)),
                             ("tile_as_two_stripes", lambda: two_stripes(nj, sh, torch, local_rank, data, res, p))):
                 try:
                     out[key] = fn()
                 except Exception as e:  # noqa: BLE001
                     out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if not args.no_cpu_baseline and not sharded:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_res)
+            watchdog.cancel()
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
