@@ -270,7 +270,12 @@ def main():
         torch.cuda.synchronize()
 
         def step(record):  # noqa: F811
-            striped.run()
+            if record:  # stream markers of stripe 0 (its kernels share the chip with the other stripes')
+                hs = {}
+                striped.run(on_stage=lambda name: hs.__setitem__(name, sctx[0].record()))
+                marks.append([hs[n] for n in ("noise", "gauss", "flow", "erosion", "end")])
+            else:
+                striped.run()
         parallelism = "single tile as %d row stripes on %d HIP streams" % (args.stripes, args.stripes)
         flush_note = "stripe entries (explicit src / dst planes), last launch stores into the tile's plane"
 
@@ -319,17 +324,20 @@ def main():
             flow_cap = nj._native.lib.nz_flow_fused_max_iterations()
             flow_launches = len(sh.split_iterations(F_IT, flow_cap))
             # the tile API ends a one-launch flow stage with a copy back into the caller's plane; stripes ping-pong
-            pingpong = sharded or swap  # explicit src / dst: no copy back, no even-launch-count rule
+            pingpong = sharded or swap or striped is not None  # explicit src / dst: no copy back, no even-launch-count rule
+            mctx = sctx[0] if striped is not None else ctx    # the context whose stream carries the markers
             ero_cap = nj._native.lib.nz_erosion_max_fused_iterations()
             launches = {"noise": 1, "gauss": None,
                         "flow": flow_launches + (1 if flow_launches == 1 and not pingpong else 0),
                         "erosion": len(sh.split_iterations(E_IT, ero_cap)) if pingpong else 2}
             KERNEL_OF["erosion"] = "erosion_reg_kernel<%d>" % (sh.split_iterations(E_IT, ero_cap)[0] if pingpong else 3)
             rcells = cells // world  # rank 0's own cells: the stage figures are per GPU
+            if striped is not None:
+                rcells = striped.parts[0][1].nown * res  # stripe 0's own cells
             acc = {n: 0.0 for n in names}
             for hs in marks:
                 for i, n in enumerate(names):
-                    acc[n] += ctx.elapsed_ms(hs[i], hs[i + 1])
+                    acc[n] += mctx.elapsed_ms(hs[i], hs[i + 1])
             stages_out = {}
             for n in names:
                 ms = acc[n] / len(marks)

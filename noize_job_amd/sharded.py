@@ -249,10 +249,11 @@ class StripedTile:
                     alloc(FLOW_PLANES, plan.rows, cols))
             self.parts.append((ops, plan, bufs, PlaneWindow(plane_ptr, plan)))
 
-    def run(self):
-        """Enqueues one pass of the pipeline on every stripe's stream (no host synchronisation)."""
-        for ops, plan, bufs, final in self.parts:
-            run_pipeline(ops, NoComm(), plan, self.p, bufs, final=final)
+    def run(self, on_stage=None):
+        """Enqueues one pass of the pipeline on every stripe's stream (no host synchronisation).  `on_stage(name)` is
+        called at the stage boundaries of stripe 0 (see pipeline_steps)."""
+        for i, (ops, plan, bufs, final) in enumerate(self.parts):
+            run_pipeline(ops, NoComm(), plan, self.p, bufs, on_stage=on_stage if i == 0 else None, final=final)
 
     def synchronize(self):
         for ops, _, _, _ in self.parts:
