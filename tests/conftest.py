@@ -19,6 +19,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that blocks (a kernel that never finishes, a stream wait that never returns) must end the run with
+    a stack dump, not sit there until the box's limit: pytest-timeout, thread method (a blocked C call cannot be
+    interrupted by a signal).  The whole GPU suite takes about 15 s."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(300, method="thread"))
+
+
 def pytest_sessionstart(session):
     """The built artefacts are kept out of git: a fresh checkout builds them once (the same
     __graft_entry__.build() the driver calls; hipcc cross-compiles gfx950 without a GPU).  The product

@@ -20,6 +20,7 @@ deadline = time.time() + 60 * minutes
 ctx = nj.Context(0)
 f32 = np.float32
 seed, fails, runs = int(os.environ.get("SOAK_SEED", "10000")), 0, 0
+last_print = time.time()
 orig_rng = np.random.default_rng
 while time.time() < deadline:
     seed += 1
@@ -27,6 +28,7 @@ while time.time() < deadline:
     np.random.default_rng = lambda s=None, _k=seed: orig_rng(None if s is None else s * 7919 + _k)
     for name, fn, args in (("stencils", S.test_filters_erosion_flow_random_sizes, (nj, ctx, O, 1)),
                            ("pairs", S.test_rw_pair_random_stage_chains, (nj, ctx, O, 1)),
+                           ("striped", S.test_striped_tile_random_shapes, (nj, ctx, O, 1)),
                            ("mesh", S.test_mesh_random_shapes, (nj, ctx, O, 1)),
                            ("stripes", S.test_stripe_entry_points_random_geometry_and_pitch, (nj, ctx, O, 1)),
                            ("noise", S.test_noise_random_parameters, (nj, ctx, O, 1 + seed % 7)),
@@ -39,7 +41,8 @@ while time.time() < deadline:
             print("MISMATCH seed %d %s: %s" % (seed, name, str(e).splitlines()[0][:300]), flush=True)
         except nj.NoizeError as e:
             print("seed %d %s: rejected shape (%s)" % (seed, name, e), flush=True)
-    if seed % 20 == 0:
+    if seed % 20 == 0 or time.time() - last_print > 30:  # the box kills a run that stays silent for minutes
+        last_print = time.time()
         print("seed %d: %d runs, %d mismatches" % (seed, runs, fails), flush=True)
 np.random.default_rng = orig_rng
 print("done: %d runs, %d mismatches" % (runs, fails))
