@@ -12,6 +12,9 @@ __global__ __launch_bounds__(256) void k(float *out, float a, float b) {
     float r[8];
     for (int i = 0; i < 8; i++) r[i] = a + threadIdx.x * 1e-6f + i;
     float c = b;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f q[8], cc = {b, b}, aa = {a, a};
+    for (int i = 0; i < 8; i++) q[i] = (v2f){r[i], r[i] + 0.5f};
     asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555" ::: "vcc");
     asm volatile("s_mov_b32 s10, 0x33333333\n\ts_mov_b32 s11, 0x33333333" ::: "s10", "s11");
     for (int it = 0; it < ITER; it++) {
@@ -32,6 +35,8 @@ __global__ __launch_bounds__(256) void k(float *out, float a, float b) {
 #define MED3(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(c), "v"(a));
 #define CNDE64V(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(c));
 #define CND2(i) asm volatile("v_cndmask_b32 %0, %1, %0, vcc" : "+v"(r[i]) : "v"(c));
+#define PKMUL(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(q[i]) : "v"(cc));
+#define PKFMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(cc), "v"(aa));
 #define SQRT(i) asm volatile("v_sqrt_f32 %0, %0" : "+v"(r[i]));
         if (KIND == 0) { REP8(FMA) }
         if (KIND == 1) { REP8(MUL) }
@@ -45,6 +50,8 @@ __global__ __launch_bounds__(256) void k(float *out, float a, float b) {
         if (KIND == 9) { REP8(SQRT) }
         if (KIND == 10) { REP8(ADD) }
         if (KIND == 16) { REP8(CNDE64V) }
+        if (KIND == 20) { REP8(PKMUL) }
+        if (KIND == 21) { REP8(PKFMA) }
         if (KIND == 18) { REP8(FMA) CNDMASK(0) REP8(FMA) CNDMASK(1) }   // 16 fma + 2 e32 selects
         if (KIND == 19) { REP8(FMA) CNDE64V(0) REP8(FMA) CNDE64V(1) }  // 16 fma + 2 e64 selects
         if (KIND == 17) { REP8(CND2) }
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(256) void k(float *out, float a, float b) {
         if (KIND == 11) { REP8(CNDE64) }
     }
     float s = 0;
-    for (int i = 0; i < 8; i++) s += r[i];
+    for (int i = 0; i < 8; i++) s += r[i] + q[i].x + q[i].y;
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
@@ -78,7 +85,7 @@ double run(float *d, const char *name) {
 
 int main() {
     float *d; hipMalloc(&d, 256 * 8 * 256 * 4);
-    run<0>(d, "v_fma_f32"); run<0>(d, "v_fma_f32"); run<1>(d, "v_mul_f32"); run<10>(d, "v_add_f32"); run<11>(d, "v_cndmask_e64 sgpr"); run<6>(d, "v_max_f32"); run<12>(d, "v_floor_f32"); run<13>(d, "v_cvt_i32_f32"); run<14>(d, "v_cmp_gt_f32 -> sgpr"); run<15>(d, "v_med3_f32"); run<7>(d, "v_cndmask_b32 e32 vcc"); run<16>(d, "v_cndmask_e64 vcc"); run<17>(d, "v_cndmask e32 swapped"); run<18>(d, "(16 fma + 2 cnd e32)/8"); run<19>(d, "(16 fma + 2 cnd e64)/8"); run<8>(d, "v_mov_b32_dpp");
+    run<0>(d, "v_fma_f32"); run<0>(d, "v_fma_f32"); run<1>(d, "v_mul_f32"); run<20>(d, "v_pk_mul_f32 (2 results)"); run<21>(d, "v_pk_fma_f32 (2 results)"); run<10>(d, "v_add_f32"); run<11>(d, "v_cndmask_e64 sgpr"); run<6>(d, "v_max_f32"); run<12>(d, "v_floor_f32"); run<13>(d, "v_cvt_i32_f32"); run<14>(d, "v_cmp_gt_f32 -> sgpr"); run<15>(d, "v_med3_f32"); run<7>(d, "v_cndmask_b32 e32 vcc"); run<16>(d, "v_cndmask_e64 vcc"); run<17>(d, "v_cndmask e32 swapped"); run<18>(d, "(16 fma + 2 cnd e32)/8"); run<19>(d, "(16 fma + 2 cnd e64)/8"); run<8>(d, "v_mov_b32_dpp");
     run<2>(d, "v_rcp_f32"); run<9>(d, "v_sqrt_f32"); run<3>(d, "v_div_scale_f32"); run<4>(d, "v_div_fmas_f32"); run<5>(d, "v_div_fixup_f32");
     return 0;
 }
