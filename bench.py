@@ -10,31 +10,42 @@ erosion x5) over one device-resident grid; nothing crosses PCIe inside the timed
           recomputes the 49 ghost rows per side the stencils consume (--halo recompute, default; no
           data-path collective).  --halo exchange swaps ghost rows with the neighbour ranks over
           RCCL before every stencil launch instead (the form an uploaded height map would need).
-Rank 0 prints ONE JSON line.  `roofline` describes the stage that takes the most GPU time, `stages`
-every stage; both come from HIP events recorded on the kernels' stream inside the timed steps.
-`cpu_baseline` is the CPU oracle (reference-shaped restatement of the Burst jobs) timed on this
-box's host cores on one full 4096^2 pass.
+Rank 0 prints ONE JSON line:
+  * `stages`  : per stage, launch time from HIP events recorded on the kernels' stream inside the timed steps, and
+                -- from the counter summary profiles/*_counters.json that belongs to THESE kernel sources -- the
+                fraction of the fp32 VALU issue rate and of the HBM peak the kernel reaches; `bound` = the larger.
+  * `roofline`: the kernel with the largest share of the step under the bound that limits it (frac <= 1).
+  * `pipeline_hbm`: the 400 B/cell algorithmic-equivalent figure of SURVEY.md 8(d) (exceeds the HBM peak by design:
+                filter / flow iterations are fused on chip, so it is not a roofline).
+  * `cpu_baseline`: the CPU oracle (reference-shaped restatement of the Burst jobs) timed on this box's host cores,
+                and `verified`: the device plane of the last timed step compared with the oracle's plane, bit for bit.
+  * `grid_16384`: BASELINE config 5's grid split over the N ranks (N = 1: the whole grid on one GPU) -- the strong-
+                scaling quantity the >= 6x target is defined on -- with ghost rows recomputed and, at N > 1, exchanged.
 """
 import argparse
 import glob
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_PEAK_GOPS = 78643.2     # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, non-FMA fp32 ops
+# peaks: /opt/skills/guides/MI355X_MICROARCH.md (HBM3E 8 TB/s spec; 256 CU x 4 SIMD x 2.4 GHz, a wave64 fp32 VALU
+# instruction occupies its SIMD for 2 cycles = 32 lanes/clk)
+HBM_PEAK_GBS = 8000.0
+N_SIMD, CLK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 2.0
+VALU_PEAK_TOPS = N_SIMD * 32 * CLK_HZ / 1e12   # 78.64 T lane-ops/s (non-FMA fp32 ops)
 
 # algorithmic bytes per cell (SURVEY.md 8d): fused minimum, one read + one write per plane per application
 G_IT, F_IT, E_IT = 17, 5, 5
 BYTES = {"noise": 4.0, "gauss": 8.0 * G_IT, "flow": 24.0 + 44.0 * (F_IT - 1) + 20.0, "erosion": 8.0 * E_IT}
-KERNEL_OF = {"noise": "fractal_simplex_tab_kernel<2>", "gauss": "conv_reg_kernel<5, true>",
-             "flow": "flow_fused_kernel<true, true, 4>", "erosion": "erosion_reg_kernel<3>"}
-NOISE_OPS_PER_OCTAVE_CELL = 83.0  # VALU instructions of the table-driven simplex octave (ISA count: 166 per 2 cells)
-
+STAGES = ["noise", "gauss", "flow", "erosion"]
+KERNEL_PREFIX = {"noise": "fractal_simplex_tab_kernel", "gauss": "conv_reg_kernel<5", "flow": "flow_fused_kernel",
+                 "erosion": "erosion_reg_kernel"}
 
 CPU_PASSES = 11         # ~10 s of host work on the GPU box's 32 cores (0.9-1.0 s per 4096^2 pass)
 PREHEAT_MIN_STEPS = 50  # untimed passes before the timed region, warm-up included (clock settling)
@@ -51,7 +62,10 @@ def parse():
     ap.add_argument("--res", type=int, default=4096, help="tile resolution at N=1")
     ap.add_argument("--stripe-rows", type=int, default=2048, help="rows per rank at N>1")
     ap.add_argument("--cols", type=int, default=16384, help="grid columns at N>1")
+    ap.add_argument("--grid", type=int, default=16384,
+                    help="side of the strong-scaling grid reported as grid_16384 at every N (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational measurements after the timed steps")
     ap.add_argument("--sharded", action="store_true", help="run the row-stripe path even with one rank (rehearsal)")
     ap.add_argument("--halo", choices=("recompute", "exchange", "exchange_once"), default="recompute",
                     help="N>1: ghost rows recomputed from the closed-form noise (no data-path communication) or "
@@ -65,22 +79,60 @@ def parse():
                     help="N=1: run the tile as this many independent row stripes, each on its own HIP stream (ghost "
                          "rows recomputed from the closed-form noise; the fp32-bound kernels of one stripe overlap "
                          "the HBM-bound kernels of another); 1 = the stage pipeline on one stream")
-    ap.add_argument("--cpu-res", type=int, default=4096)
+    ap.add_argument("--cpu-res", type=int, default=0, help="tile side of the CPU baseline (0 = --res)")
     return ap.parse_args()
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch from the newest committed PMC summary (profiles/*pmc*.json), or None."""
+# ---- counter summaries ---------------------------------------------------------------------------------------------
+def kernel_sources_sha():
+    """sha256 over the kernel sources: a counter summary is only used for a run of the very same kernels."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "noize_job_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".hpp")) or name == "Makefile":
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def load_counters(res, flush):
+    """Newest profiles/*_counters.json (tools/fold_counters.py) taken with these kernel sources and this flush mode:
+    per kernel SQ_INSTS_VALU and HBM bytes (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes) per launch.  A summary of
+    another tile size is used scaled by the cell count and says so.  None if nothing matches."""
+    sha = kernel_sources_sha()
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json"))):
         try:
             with open(path) as f:
                 d = json.load(f)
-            if kernel_key in d.get("kernels", {}):
-                best = d["kernels"][kernel_key].get("hbm_bytes_per_launch")
         except (OSError, ValueError):
-            pass
-    return best
+            continue
+        c = d.get("config", {})
+        if c.get("kernel_sources_sha") == sha and c.get("flush") == flush and not c.get("sharded"):
+            best = (path, d)
+    if best is None:
+        return None
+    path, d = best
+    scale = float(res * res) / float(d["config"]["res"] ** 2)
+    return {"file": os.path.relpath(path, ROOT), "commit": d["config"].get("commit"), "kernels": d["kernels"],
+            "scale": scale, "res": d["config"]["res"]}
+
+
+def counters_for(cnt, stage):
+    if cnt is None:
+        return None
+    for name, e in cnt["kernels"].items():
+        if name.startswith(KERNEL_PREFIX[stage]):
+            return name, e
+    return None
+
+
+# ---- informational measurements --------------------------------------------------------------------------------------
+def make_stages(nj, ctx, p):
+    return [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, p.hurst, p.startingAmplitude, p.octaves, p.stepdown,
+                          p.detuneRate, p.noiseSize),
+            nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, G_IT),
+            nj.FlowMapStage(ctx, F_IT, p.normMin, p.normMax), nj.ErosionStage(ctx, E_IT)]
 
 
 def two_tiles(nj, ctx, stages, gd, res, p, swap, steps=100):
@@ -89,10 +141,7 @@ def two_tiles(nj, ctx, stages, gd, res, p, swap, steps=100):
     single tile BASELINE.json names."""
     ctx2 = nj.Context(ctx.device)
     cells = res * res
-    stages2 = [nj.NoiseStage(ctx2, nj.FractalNoise.Simplex, p.hurst, p.startingAmplitude, p.octaves, p.stepdown,
-                             p.detuneRate, p.noiseSize),
-               nj.KernelFilterStage(ctx2, nj.KernelFilterType.Gauss5_S1, G_IT),
-               nj.FlowMapStage(ctx2, F_IT, p.normMin, p.normMax), nj.ErosionStage(ctx2, E_IT)]
+    stages2 = make_stages(nj, ctx2, p)
     gd2 = nj.GeneratorData("bench2", ctx2.alloc(cells), res, res, 0, write=ctx2.alloc(cells) if swap else None)
     h0 = nj.JobHandle()
 
@@ -115,11 +164,11 @@ def two_tiles(nj, ctx, stages, gd, res, p, swap, steps=100):
         gd2.write.Dispose()
     ctx2.close()
     return {"streams": 2, "ms_per_tile": round(dt * 1e3, 4), "Mcells/s": round(cells / dt / 1e6, 1),
-            "note": "two independent 4096^2 tiles on two HIP streams, not the headline value"}
+            "note": "two independent %d^2 tiles on two HIP streams, not the headline value" % res}
 
 
 def two_stripes(nj, sh, torch, device, data, res, p, steps=100):
-    """Informational, outside the timed steps: the SAME 4096^2 tile as two independent row stripes, each on its own
+    """Informational, outside the timed steps: the SAME tile as two independent row stripes, each on its own
     HIP stream (ghost rows recomputed from the closed-form noise, the last launch storing into the tile's plane):
     what `--stripes 2` times as its headline."""
     ctxs = [nj.Context(device) for _ in range(2)]
@@ -139,26 +188,131 @@ def two_stripes(nj, sh, torch, device, data, res, p, steps=100):
         for c in ctxs:
             c.close()
     return {"streams": 2, "ms_per_tile": round(dt * 1e3, 4), "Mcells/s": round(res * res / dt / 1e6, 1),
-            "note": "one 4096^2 tile as two independent row stripes on two HIP streams (bench.py --stripes 2), "
-                    "not the headline value"}
+            "note": "one %d^2 tile as two independent row stripes on two HIP streams (bench.py --stripes 2), "
+                    "not the headline value" % res}
+
+
+def in_place_entries(nj, ctx, res, p, steps=60):
+    """Informational: the strictly drop-in form -- ONE plane, the in-place stage entries, results land in `data` as in
+    the reference (their flush copies stand for TileHelpers.SWAP_RWTILE) -- what `--flush copy` times as its headline."""
+    cells = res * res
+    stages = make_stages(nj, ctx, p)
+    gd = nj.GeneratorData("inplace", ctx.alloc(cells), res, 0, 0)
+    pipe = nj.BasePipeline(stages, "in-place")
+
+    def one():
+        pipe.Schedule(gd)
+        pipe.pipelineRunning = False
+    for _ in range(20):
+        one()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pipe.Destroy()
+    gd.data.Dispose()
+    return {"ms_per_step": round(dt * 1e3, 4), "Mcells/s": round(cells / dt / 1e6, 1),
+            "note": "one plane, in-place entries with their flush copies (bench.py --flush copy): results land in "
+                    "`data` exactly as in the reference"}
+
+
+class TimedComm:
+    """Wraps a halo-exchange object: stream markers around every exchange, so the time the compute stream spends
+    waiting for ghost rows is known per step."""
+
+    def __init__(self, comm, ctx):
+        self.comm, self.ctx, self.spans = comm, ctx, []
+
+    def exchange(self, planes, plan, up_rows, down_rows):
+        a = self.ctx.record()
+        self.comm.exchange(planes, plan, up_rows, down_rows)
+        self.spans.append((a, self.ctx.record()))
+
+    def total_ms(self):
+        t = sum(self.ctx.elapsed_ms(a, b) for a, b in self.spans)
+        self.spans = []
+        return t
+
+
+def strong_grid(nj, sh, torch, dist, ctx, grid, rank, world, steps=20, warm=5):
+    """BASELINE config 5's grid (grid^2) split into `world` row stripes, one per rank: the quantity the >= 6x target is
+    defined on, measured at EVERY N (N = 1: the whole grid on one GPU).  Ghost rows recomputed from the closed-form
+    noise (no communication) and, at N > 1, exchanged with the neighbour ranks over RCCL before every launch, with the
+    time the compute stream spends in the exchanges split out.  Barrier + synchronize on both sides, max over ranks."""
+    out = {}
+    ops = sh.HipStripeOps(ctx)
+    modes = ("recompute", "exchange", "exchange_once") if world > 1 else ("recompute",)
+    for mode in modes:
+        p = sh.PipelineParams(gaussIterations=G_IT, flowIterations=F_IT, erosionIterations=E_IT, haloMode=mode)
+        halo = sh.halo_rows_needed(ops, p)
+        plan = sh.StripePlan(rank, world, grid, grid, halo, neighbours_own_halo=mode != "recompute")
+        bufs = (torch.zeros(plan.rows, grid, dtype=torch.float32, device="cuda"),
+                torch.zeros(plan.rows, grid, dtype=torch.float32, device="cuda"),
+                torch.zeros(sh.FLOW_PLANES, plan.rows, grid, dtype=torch.float32, device="cuda"),
+                torch.zeros(sh.FLOW_PLANES, plan.rows, grid, dtype=torch.float32, device="cuda"))
+        comm = sh.NoComm() if mode == "recompute" else TimedComm(sh.TorchComm(dist), ctx)
+
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+        for _ in range(warm):
+            sh.run_pipeline(ops, comm, plan, p, bufs)
+        fence()
+        if isinstance(comm, TimedComm):
+            comm.total_ms()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sh.run_pipeline(ops, comm, plan, p, bufs)
+        fence()
+        dt = time.perf_counter() - t0
+        ex_ms = comm.total_ms() / steps if isinstance(comm, TimedComm) else 0.0
+        if world > 1:
+            t = torch.tensor([dt, ex_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, ex_ms = float(t[0].item()), float(t[1].item())
+        e = {"ms_per_step": round(dt / steps * 1e3, 4), "Mcells/s": round(grid * grid / (dt / steps) / 1e6, 1)}
+        if mode != "recompute":
+            e["exchange_ms_per_step"] = round(ex_ms, 4)
+        out[mode] = e
+        del bufs
+        torch.cuda.empty_cache()
+    out["grid"] = "%dx%d as %d row stripes of %d rows" % (grid, grid, world, grid // world)
+    out["steps"] = steps
+    out["note"] = ("strong scaling: the same %d^2 grid at every N; speed-up at N GPUs = this figure at N / this figure "
+                   "at N = 1" % grid)
+    return out
 
 
 def cpu_baseline(res):
     import oracle as O
     O.lib()
-    times = []
+    times, plane = [], None
     for _ in range(CPU_PASSES):
         t0 = time.perf_counter()
-        O.pipeline(res, res, O.SIMPLEX, 0.4, 1.0, 2.0, 0.0, 13, 0, 0, 1700, O.GAUSS5_S1, G_IT, F_IT, 0.0, 0.005, E_IT)
+        plane = O.pipeline(res, res, O.SIMPLEX, 0.4, 1.0, 2.0, 0.0, 13, 0, 0, 1700, O.GAUSS5_S1, G_IT, F_IT, 0.0, 0.005,
+                           E_IT)
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
+    flags = "?"
+    try:
+        with open(os.path.join(ROOT, "oracle", "Makefile")) as f:
+            mk = f.read()
+        flags = " ".join(mk.split("CFLAGS  ?=")[1].split("LDFLAGS")[0].replace("\\\n", " ").split())
+    except (OSError, IndexError):
+        pass
     return {"value": round(res * res / dt / 1e6, 2), "unit": "Mcells/s", "cores": O.get_threads(), "kind": "port",
-            "sample": "median of %d passes of the full metric pipeline on a %dx%d tile (%.2f s per pass), OpenMP "
-                      "row-parallel passes with the reference's serial flush copies" % (CPU_PASSES, res, res, dt)}
+            "sample": "median of %d passes of the full metric pipeline on a %dx%d tile (%.2f s per pass); oracle/"
+                      "noize_oracle.c built with gcc %s; OpenMP `parallel for` over rows per pass (schedule(dynamic,1) "
+                      "for the fBm rows, static for the stencil passes), the reference's serial flush copy after every "
+                      "read-write pass" % (CPU_PASSES, res, res, dt, flags)}, plane
 
 
 def main():
     args = parse()
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -196,6 +350,7 @@ def main():
 
     p = sh.PipelineParams(gaussIterations=G_IT, flowIterations=F_IT, erosionIterations=E_IT, haloMode=args.halo)
     marks = []  # per step: handles at stage boundaries
+    cold_ms = None
 
     if not sharded:
         res = args.res
@@ -204,11 +359,7 @@ def main():
         tile = ctx.wrap(data.data_ptr(), cells)
         swap = args.flush == "swap"
         data_w = torch.empty(cells, dtype=torch.float32, device="cuda") if swap else None
-        stages = [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, p.hurst, p.startingAmplitude, p.octaves, p.stepdown,
-                                p.detuneRate, p.noiseSize),
-                  nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, G_IT),
-                  nj.FlowMapStage(ctx, F_IT, p.normMin, p.normMax),
-                  nj.ErosionStage(ctx, E_IT)]
+        stages = make_stages(nj, ctx, p)
         pipe = nj.BasePipeline(stages, "metric")
         gd = nj.GeneratorData("bench", tile, res, 0, 0, write=ctx.wrap(data_w.data_ptr(), cells) if swap else None)
 
@@ -286,6 +437,17 @@ def main():
             striped.synchronize()
         torch.cuda.synchronize()
 
+    if not sharded:
+        # first-tile latency: what a tile server sees for a request that finds the chip idle (code objects loaded and
+        # buffers allocated by one untimed pass, then half a second of idleness for the clocks to fall back)
+        step(False)
+        fence()
+        time.sleep(0.5)
+        t0 = time.perf_counter()
+        step(False)
+        fence()
+        cold_ms = (time.perf_counter() - t0) * 1e3
+
     # The chip's clocks need some tens of ms of continuous work to settle (see --steps above).  A caller that asks
     # for a short run still gets the steady-state rate: the GPU is kept busy with untimed passes first, so that
     # warm-up + preheat cover at least PREHEAT_MIN_STEPS passes.  The K timed steps are exactly the K asked for.
@@ -306,6 +468,7 @@ def main():
         dt = float(t.item())
 
     out = None
+    out_lock = threading.Lock()
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = cells / (dt / args.steps) / 1e6
@@ -318,101 +481,170 @@ def main():
                           "algorithmic_bytes_per_cell": total_bytes, "flush": flush_note},
                "pipeline_hbm": {"achieved": round(total_bytes * cells / (dt / args.steps) / 1e9 / world, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
-                                "frac": round(total_bytes * cells / (dt / args.steps) / 1e9 / world / HBM_PEAK_GBS, 4)}}
-        if marks:
-            names = ["noise", "gauss", "flow", "erosion"]
-            flow_cap = nj._native.lib.nz_flow_fused_max_iterations()
-            flow_launches = len(sh.split_iterations(F_IT, flow_cap))
-            # the tile API ends a one-launch flow stage with a copy back into the caller's plane; stripes ping-pong
-            pingpong = sharded or swap or striped is not None  # explicit src / dst: no copy back, no even-launch-count rule
-            mctx = sctx[0] if striped is not None else ctx    # the context whose stream carries the markers
-            ero_cap = nj._native.lib.nz_erosion_max_fused_iterations()
-            launches = {"noise": 1, "gauss": None,
-                        "flow": flow_launches + (1 if flow_launches == 1 and not pingpong else 0),
-                        "erosion": len(sh.split_iterations(E_IT, ero_cap)) if pingpong else 2}
-            KERNEL_OF["erosion"] = "erosion_reg_kernel<%d>" % (sh.split_iterations(E_IT, ero_cap)[0] if pingpong else 3)
-            rcells = cells // world  # rank 0's own cells: the stage figures are per GPU
-            if striped is not None:
-                rcells = striped.parts[0][1].nown * res  # stripe 0's own cells
-            acc = {n: 0.0 for n in names}
-            for hs in marks:
-                for i, n in enumerate(names):
-                    acc[n] += mctx.elapsed_ms(hs[i], hs[i + 1])
-            stages_out = {}
-            for n in names:
-                ms = acc[n] / len(marks)
-                gbs = BYTES[n] * rcells / (ms * 1e-3) / 1e9
-                stages_out[n] = {"kernel": KERNEL_OF[n], "ms": round(ms, 4), "algorithmic_GB/s": round(gbs, 1),
-                                 "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
-            stages_out["noise"]["valu_Gops/s"] = round(13 * NOISE_OPS_PER_OCTAVE_CELL * rcells /
-                                                       (stages_out["noise"]["ms"] * 1e-3) / 1e9, 1)
-            stages_out["noise"]["frac_valu"] = round(stages_out["noise"]["valu_Gops/s"] / VALU_PEAK_GOPS, 4)
-            stages_out["gauss"]["launches"] = N_gauss = len(sh.split_iterations(G_IT, nj._native.lib.nz_kernel_filter_max_fused(2)))
-            if N_gauss & 1 and not pingpong:  # the tile API keeps the launch count even (result back in `src`)
-                stages_out["gauss"]["launches"] = N_gauss + 1
-            out["stages"] = stages_out
-            # The tile API's one-launch flow stage ends with a plane copy back into the caller's buffer: time
-            # that copy on its own (outside the timed steps) so the flow KERNEL's launch time is known
-            kernel_ms = {n: stages_out[n]["ms"] for n in names}
-            if not pingpong and flow_launches == 1:
-                scratch = ctx.alloc(rcells)
-                hc0 = ctx.record()
-                for _ in range(20):
-                    ctx.call("nz_flush_write_slice", scratch.ptr, tile.ptr, rcells)
-                hc1 = ctx.record()
-                hc1.Complete()
-                copy_ms = ctx.elapsed_ms(hc0, hc1) / 20
-                scratch.Dispose()
-                stages_out["flow"]["copy_back_ms"] = round(copy_ms, 4)
-                kernel_ms["flow"] = stages_out["flow"]["ms"] - copy_ms
-                launches["flow"] = 1
-            # `roofline`: the HBM-bound kernel with the largest share of the step.  The fBm kernel is reported
-            # beside it against the fp32 VALU rate that bounds it (4 B/cell written for ~1.2 k VALU slots/cell).
-            dom = max(("gauss", "flow", "erosion"), key=lambda n: kernel_ms[n])
-            n_launch = stages_out["gauss"]["launches"] if dom == "gauss" else launches[dom]
-            s = stages_out[dom]
-            launch_ms = kernel_ms[dom] / n_launch
-            alg_bytes = BYTES[dom] * rcells / n_launch
-            out["roofline"] = {"kernel": s["kernel"], "bound": "hbm",
-                               "achieved": round(alg_bytes / (launch_ms * 1e-3) / 1e9, 1),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(alg_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "traffic": None if sharded else pmc_traffic(dom),
-                               "launches_per_step": n_launch, "avg_launch_ms": round(launch_ms, 4),
-                               "algorithmic_bytes_per_launch": round(alg_bytes),
-                               "note": "HBM-bound kernel with the largest share of the step (kernel time / launches); "
-                                       "its iterations are fused on chip, so algorithmic bytes per launch exceed the "
-                                       "HBM bytes actually moved (traffic) and frac can exceed 1"}
-            if out["roofline"]["traffic"]:  # HBM bytes actually moved per launch (PMC) over the launch time
-                out["roofline"]["traffic_GB/s"] = round(out["roofline"]["traffic"] / (launch_ms * 1e-3) / 1e9, 1)
-            out["valu_roofline"] = {"kernel": stages_out["noise"]["kernel"], "bound": "fp32-valu",
-                                    "achieved": stages_out["noise"]["valu_Gops/s"], "peak": VALU_PEAK_GOPS,
-                                    "unit": "Gop/s", "frac": stages_out["noise"]["frac_valu"],
-                                    "avg_launch_ms": stages_out["noise"]["ms"],
-                                    "traffic": None if sharded else pmc_traffic("noise"),
-                                    "note": "fBm octave accumulation; %d VALU slots per octave-cell counted in the ISA"
-                                            % int(NOISE_OPS_PER_OCTAVE_CELL)}
-        if not args.no_cpu_baseline and not sharded:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_res)
-        if not sharded and striped is None:
-            # informational, outside the timed steps; never allowed to cost the JSON line: an exception is recorded, and
-            # should one of them ever block, a watchdog prints the line without them and ends the process
-            import threading
+                                "frac": round(total_bytes * cells / (dt / args.steps) / 1e9 / world / HBM_PEAK_GBS, 4),
+                                "note": "algorithmic-equivalent bytes (SURVEY.md 8d: 400 B/cell, one plane round trip per "
+                                        "filter / flow / erosion application) over the step time.  NOT a roofline: the "
+                                        "applications are fused on chip, the HBM traffic actually moved is `stages.*."
+                                        "hbm_bytes_per_launch`, so this figure may exceed the peak"}}
+        if cold_ms is not None:
+            out["cold_ms"] = round(cold_ms, 4)
+            out["config"]["cold_ms_note"] = "one step from an idle chip (0.5 s after the previous one), host-timed"
+    if rank == 0 and marks:
+        flow_cap = nj._native.lib.nz_flow_fused_max_iterations()
+        flow_launches = len(sh.split_iterations(F_IT, flow_cap))
+        # the tile API ends a one-launch flow stage with a copy back into the caller's plane; stripes ping-pong
+        pingpong = sharded or swap or striped is not None  # explicit src / dst: no copy back, no even-launch-count rule
+        mctx = sctx[0] if striped is not None else ctx    # the context whose stream carries the markers
+        ero_cap = nj._native.lib.nz_erosion_max_fused_iterations()
+        n_gauss = len(sh.split_iterations(G_IT, nj._native.lib.nz_kernel_filter_max_fused(2)))
+        if n_gauss & 1 and not pingpong:  # the tile API keeps the launch count even (result back in `src`)
+            n_gauss += 1
+        launches = {"noise": 1, "gauss": n_gauss, "flow": flow_launches,
+                    "erosion": len(sh.split_iterations(E_IT, ero_cap)) if pingpong else 2}
+        rcells = cells // world  # rank 0's own cells: the stage figures are per GPU
+        if striped is not None:
+            rcells = striped.parts[0][1].nown * res  # stripe 0's own cells
+        acc = {n: 0.0 for n in STAGES}
+        for hs in marks:
+            for i, n in enumerate(STAGES):
+                acc[n] += mctx.elapsed_ms(hs[i], hs[i + 1])
+        stage_ms = {n: acc[n] / len(marks) for n in STAGES}
+        kernel_ms = dict(stage_ms)
+        stages_out = {n: {"ms": round(stage_ms[n], 4), "launches": launches[n]} for n in STAGES}
+        # The in-place tile API's one-launch flow stage ends with a plane copy back into the caller's buffer (and the
+        # in-place erosion with none: two launches): time that copy on its own so the flow KERNEL's time is known
+        if not pingpong and flow_launches == 1:
+            scratch = ctx.alloc(rcells)
+            hc0 = ctx.record()
+            for _ in range(20):
+                ctx.call("nz_flush_write_slice", scratch.ptr, tile.ptr, rcells)
+            hc1 = ctx.record()
+            hc1.Complete()
+            copy_ms = ctx.elapsed_ms(hc0, hc1) / 20
+            scratch.Dispose()
+            stages_out["flow"]["copy_back_ms"] = round(copy_ms, 4)
+            kernel_ms["flow"] = stage_ms["flow"] - copy_ms
+        # Counter summary of these very kernels (same source hash, same flush mode), if one is committed: VALU
+        # instructions and HBM bytes per launch.  Launch times are this run's; the counters are not re-measured here
+        # (rocprofv3 --pmc cannot run inside the timed region) and `counters_source` says where they come from.
+        cnt = None if (sharded or striped is not None) else load_counters(res, args.flush)
+        valu_floor_ms = 0.0
+        for n in STAGES:
+            s = stages_out[n]
+            launch_ms = kernel_ms[n] / launches[n]
+            s["avg_launch_ms"] = round(launch_ms, 4)
+            gbs = BYTES[n] * rcells / (stage_ms[n] * 1e-3) / 1e9
+            s["algorithmic_equivalent_GB/s"] = round(gbs, 1)
+            hit = counters_for(cnt, n)
+            if hit is None:
+                s.update({"kernel": KERNEL_PREFIX[n], "valu_issue_frac": None, "hbm_traffic_frac": None, "bound": None})
+                continue
+            name, e = hit
+            insts = e["SQ_INSTS_VALU"] * cnt["scale"]
+            hbm = e["hbm_bytes_per_launch"] * cnt["scale"]
+            valu_frac = insts * VALU_CYCLES_PER_INST / (N_SIMD * CLK_HZ) / (launch_ms * 1e-3)
+            hbm_frac = hbm / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            valu_floor_ms += launches[n] * insts * VALU_CYCLES_PER_INST / (N_SIMD * CLK_HZ) * 1e3
+            s.update({"kernel": name, "valu_insts_per_launch": round(insts), "hbm_bytes_per_launch": round(hbm),
+                      "valu_issue_frac": round(valu_frac, 4), "hbm_traffic_frac": round(hbm_frac, 4),
+                      "bound": "valu-fp32" if valu_frac >= hbm_frac else "hbm"})
+        out["stages"] = stages_out
+        dom = max(STAGES, key=lambda n: kernel_ms[n])
+        s = stages_out[dom]
+        if s.get("bound") == "hbm":
+            ach = s["hbm_bytes_per_launch"] / (s["avg_launch_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"kernel": s["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                               "traffic": s["hbm_bytes_per_launch"]}
+        elif s.get("bound") == "valu-fp32":
+            ach = s["valu_insts_per_launch"] * 64 / (s["avg_launch_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": s["kernel"], "bound": "valu-fp32", "achieved": round(ach, 2),
+                               "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tlane-op/s",
+                               "frac": round(ach / VALU_PEAK_TOPS, 4), "traffic": s["hbm_bytes_per_launch"],
+                               "hbm_traffic_frac": s["hbm_traffic_frac"]}
+        else:  # no counter summary of these kernels: the only figure this run can form itself
+            ach = BYTES[dom] * rcells / launches[dom] / (s["avg_launch_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"kernel": s["kernel"], "bound": "unknown", "achieved": None, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": None, "traffic": None,
+                               "algorithmic_equivalent_GB/s": round(ach, 1)}
+        out["roofline"].update({
+            "stage": dom, "share_of_step": round(kernel_ms[dom] / sum(stage_ms.values()), 4),
+            "launches_per_step": launches[dom], "avg_launch_ms": s["avg_launch_ms"],
+            "note": "the kernel with the largest share of the step, under the larger of its two fractions: VALU issue "
+                    "(SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x launch time)) and HBM traffic (FETCH_SIZE x2 + "
+                    "WRITE_SIZE bytes / launch time / 8 TB/s); launch time from this run's HIP events, counters from "
+                    "`counters_source`"})
+        if cnt is not None:
+            out["counters_source"] = {"file": cnt["file"], "commit": cnt["commit"],
+                                      "kernel_sources_sha": kernel_sources_sha(),
+                                      "scaled_from_res": cnt["res"] if cnt["scale"] != 1.0 else None,
+                                      "collected": "rocprofv3 --kernel-trace --pmc, one pass per counter group "
+                                                   "(tools/collect_profiles.sh), folded by tools/fold_counters.py"}
+            out["step_valu"] = {"floor_ms": round(valu_floor_ms, 4), "frac": round(valu_floor_ms / ms_per_step, 4),
+                                "note": "sum over the step's launches of SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz)"
+                                        ": the time the step's VALU instructions need at full issue rate, over "
+                                        "ms_per_step"}
+        else:
+            out["counters_source"] = None
+    if rank == 0 and not args.no_cpu_baseline and not sharded:
+        cres = args.cpu_res or res
+        out["cpu_baseline"], plane = cpu_baseline(cres)
+        if cres == res:
+            # the device plane the last timed step left behind against the oracle's (outside the timed region)
+            got = np.empty(cells, np.float32)
+            src = gd.data if striped is None else tile
+            nj._native.check(nj._native.lib.nz_tile_download(ctx._h, src.ptr, got.ctypes.data, cells, 0, None), "download")
+            fence()
+            same = bool(np.array_equal(got.reshape(res, res), plane))
+            out["verified"] = same
+            if not same:
+                bad = ~(np.abs(got.reshape(res, res) - plane) <= 1e-5 * np.abs(plane) + 1e-6)
+                out["verified_detail"] = {"cells_outside_1e-5_rel": int(bad.sum()),
+                                          "max_abs_diff": float(np.abs(got.reshape(res, res) - plane).max())}
+        else:
+            out["verified"] = None
+    extras = not args.no_extras
+    if rank == 0 and extras and not sharded and striped is None:
+        # informational, outside the timed steps; never allowed to cost the JSON line: an exception is recorded, and
+        # should one of them ever block, a watchdog prints the line without them and ends the process
+        printed = []
 
-            def bail():
-                out["extras"] = "skipped: an informational measurement did not return within 120 s"
-                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        def bail():
+            with out_lock:
+                if printed:
+                    return
+                printed.append(1)
+                line = dict(out)
+                line["extras"] = "skipped: an informational measurement did not return within 240 s"
+                os.write(real_stdout, (json.dumps(line) + "\n").encode())
                 os._exit(0)
-            watchdog = threading.Timer(120.0, bail)
-            watchdog.daemon = True
-            watchdog.start()
-            for key, fn in (("two_tiles_in_flight", lambda: two_tiles(nj, ctx, stages, gd, res, p, swap)),
-                            ("tile_as_two_stripes", lambda: two_stripes(nj, sh, torch, local_rank, data, res, p))):
-                try:
-                    out[key] = fn()
-                except Exception as e:  # noqa: BLE001
-                    out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
-            watchdog.cancel()
+        watchdog = threading.Timer(240.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        for key, fn in (("in_place_entries", lambda: in_place_entries(nj, ctx, res, p) if swap else None),
+                        ("two_tiles_in_flight", lambda: two_tiles(nj, ctx, stages, gd, res, p, swap)),
+                        ("tile_as_two_stripes", lambda: two_stripes(nj, sh, torch, local_rank, data, res, p))):
+            try:
+                r = fn()
+            except Exception as e:  # noqa: BLE001
+                r = {"error": "%s: %s" % (type(e).__name__, e)}
+            with out_lock:
+                if r is not None:
+                    out[key] = r
+        watchdog.cancel()
+    # BASELINE config 5's grid at this N (every rank takes part)
+    if extras and args.grid > 0 and args.as_rank is None and striped is None and args.grid % world == 0:
+        if not sharded:  # N = 1 without a process group: the whole grid as one stripe
+            g = None
+            try:
+                g = strong_grid(nj, sh, torch, None, ctx, args.grid, 0, 1)
+            except Exception as e:  # noqa: BLE001  (e.g. not enough free memory next to other processes)
+                g = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["grid_%d" % args.grid] = g
+        else:
+            g = strong_grid(nj, sh, torch, dist, ctx, args.grid, rank, world)
+            if rank == 0:
+                out["grid_%d" % args.grid] = g
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
@@ -424,7 +656,8 @@ def main():
     os.dup2(real_stdout, 1)
     os.close(real_stdout)
     if out is not None:
-        print(json.dumps(out), flush=True)
+        with out_lock:
+            print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -114,11 +114,23 @@ int32_t nz_bytes_download(nz_ctx *ctx, const void *dev, void *host, size_t n_byt
 int32_t nz_flush_write_slice(nz_ctx *ctx, float *write_, const float *read_, size_t n_floats, nz_handle dep,
                              nz_handle *out);
 
-/* JobHandle: marker recorded on the stream after the last kernel of a call */
+/* JobHandle: marker recorded on the stream after the last kernel of a call.  A handle value names the context that
+ * issued it (context id in the bits above bit 40), so it may be passed as `dep` to ANY context of the process:
+ * a dependency on another context's handle makes this context's stream wait for that marker on the device
+ * (hipStreamWaitEvent) without blocking the host -- the reference's JobHandle dependencies between pipelines
+ * (Pipeline/Executable/ReducePipeline.cs:82-148) and the job-fence locks of
+ * Pipeline/PipelineState/PipelineStateLock.cs:12-39.  Handles of a destroyed context read as completed. */
 int32_t nz_handle_record(nz_ctx *ctx, nz_handle *out);
+/* `ctx` may be any live context: the handle names its owner */
 int32_t nz_handle_query(nz_ctx *ctx, nz_handle h, int32_t *is_completed); /* JobHandle.IsCompleted */
 int32_t nz_handle_wait(nz_ctx *ctx, nz_handle h);                          /* JobHandle.Complete() */
-/* GPU time between two handles in ms (hipEventElapsedTime); both must have completed */
+/* JobHandle.CombineDependencies(h0, h1, ...): a marker on ctx's stream that completes after all of them (handles of
+ * any context; count may be 0) */
+int32_t nz_handle_combine(nz_ctx *ctx, const nz_handle *handles, int32_t count, nz_handle *out);
+/* the id (>= 1) of a context, and of the context a handle was issued by (0 for default(JobHandle)) */
+int32_t nz_ctx_id(nz_ctx *ctx);
+int32_t nz_handle_context_id(nz_handle h);
+/* GPU time between two handles of `ctx` in ms (hipEventElapsedTime); both must have completed */
 int32_t nz_handle_elapsed_ms(nz_ctx *ctx, nz_handle start, nz_handle stop, float *ms);
 
 /* ---- noise: FractalJobDelegate, Noise/Fractal/Fractal.cs:76-88 ------------------------------ */
@@ -251,6 +263,8 @@ int32_t nz_kernel_filter_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_
 int32_t nz_gauss_blur_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t sigma,
                                   int32_t iterations, int32_t resolution, int32_t count, nz_handle dep,
                                   nz_handle *out);
+int32_t nz_smooth_blur_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t iterations,
+                                   int32_t resolution, int32_t count, nz_handle dep, nz_handle *out);
 int32_t nz_erosion_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t iterations, int32_t resolution,
                                int32_t count, nz_handle dep, nz_handle *out);
 int32_t nz_flowmap_stage_batch(nz_ctx *ctx, float *src, float *work, int32_t iterations, float normMin,

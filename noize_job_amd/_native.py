@@ -59,6 +59,9 @@ SIGNATURES = {
     "nz_handle_query": (_i, [ctx_p, handle_t, C.POINTER(_i)]),
     "nz_handle_wait": (_i, [ctx_p, handle_t]),
     "nz_handle_elapsed_ms": (_i, [ctx_p, handle_t, handle_t, C.POINTER(_f)]),
+    "nz_handle_combine": (_i, [ctx_p, handle_p, _i, handle_p]),
+    "nz_ctx_id": (_i, [ctx_p]),
+    "nz_handle_context_id": (_i, [handle_t]),
     "nz_fractal": (_i, [ctx_p, _i, dev_ptr, _i, _f, _f, _f, _f, _i, _i, _i, _i] + _tail),
     "nz_fractal_stripe": (_i, [ctx_p, _i, dev_ptr, stripe_p, _f, _f, _f, _f, _i, _i, _i, _i] + _tail),
     "nz_kernel_filter": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
@@ -97,6 +100,7 @@ SIGNATURES = {
     "nz_fractal_batch": (_i, [ctx_p, _i, dev_ptr, _i, _i, dev_ptr, _f, _f, _f, _f, _i, _i] + _tail),
     "nz_kernel_filter_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _i] + _tail),
     "nz_gauss_blur_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _i, _i] + _tail),
+    "nz_smooth_blur_stage_batch": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _i] + _tail),
     "nz_kernel_filter_stage_rw": (_i, [ctx_p, rw_tile_p, _i, _i] + _tail),
     "nz_gauss_blur_stage_rw": (_i, [ctx_p, rw_tile_p, _i, _i, _i] + _tail),
     "nz_smooth_blur_stage_rw": (_i, [ctx_p, rw_tile_p, _i, _i] + _tail),

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 #include "../../include/noize_hip.h"
@@ -36,9 +37,14 @@ struct nz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    // JobHandle ring: handle h lives in events[h % size] while h > last_handle - size
+    // JobHandle ring: the handle with sequence number q lives in events[q % size] while q > last_seq - size.
+    // A handle VALUE is (ctx id << NZ_HANDLE_SEQ_BITS) | q, so that a handle names its context: a dependency on
+    // another context's handle becomes a hipStreamWaitEvent (JobHandle dependencies across pipelines,
+    // Pipeline/Executable/ReducePipeline.cs:82-148).  `hmx` guards the ring against a foreign context's lookup.
     std::vector<hipEvent_t> events;
-    uint64_t last_handle = 0;
+    uint64_t last_seq = 0;
+    uint32_t id = 0;
+    std::mutex hmx;
     // psrnoise gradient tables (rot 0 and rot 0.62), built with the host libm
     float *d_rgrad = nullptr;
     // snoise lattice tables: int T1[292] (16*permute(i)) followed by float4 T2[580] (gradient of permute(j))
@@ -54,7 +60,9 @@ struct nz_ctx {
         if (rc_t_) return rc_t_;    \
     } while (0)
 
-int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep);           // set device, check `dep`
+constexpr int NZ_HANDLE_SEQ_BITS = 40;
+constexpr uint64_t NZ_HANDLE_SEQ_MASK = (1ull << NZ_HANDLE_SEQ_BITS) - 1;
+int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep);           // set device, order the stream after `dep`
 int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out);         // record the JobHandle marker
 int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out);
 

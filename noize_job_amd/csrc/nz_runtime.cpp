@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "nz_internal.hpp"
 
@@ -41,6 +42,8 @@ extern "C" int32_t nz_device_count(int32_t *count) {
 // ---------------------------------------------------------------------------------------------
 static constexpr size_t NZ_EVENT_RING = 4096;
 static int32_t ctx_sync_all(nz_ctx *ctx);
+static void registry_add(nz_ctx *ctx);
+static void registry_remove(nz_ctx *ctx);
 
 
 static float h_mod289(float x);
@@ -199,6 +202,7 @@ static int32_t ctx_create(int32_t device, hipStream_t stream, bool own, nz_ctx *
         delete ctx;
         return rc;
     }
+    registry_add(ctx);
     *out = ctx;
     return NZ_OK;
 }
@@ -213,6 +217,7 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     if (!ctx) return NZ_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    registry_remove(ctx);  // from here on its handles read as completed
     for (hipEvent_t ev : ctx->events)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->d_rgrad) (void)hipFree(ctx->d_rgrad);
@@ -236,33 +241,86 @@ static int32_t ctx_sync_all(nz_ctx *ctx) {
     return NZ_OK;
 }
 
+// ---- context registry: a handle value carries the id of the context that issued it ------------------------------
+static std::mutex g_reg_mx;
+static std::vector<nz_ctx *> g_reg;  // index = ctx id - 1; nullptr once destroyed
+
+static void registry_add(nz_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_reg_mx);
+    for (size_t i = 0; i < g_reg.size(); i++)
+        if (!g_reg[i]) {
+            g_reg[i] = ctx;
+            ctx->id = (uint32_t)i + 1;
+            return;
+        }
+    g_reg.push_back(ctx);
+    ctx->id = (uint32_t)g_reg.size();
+}
+
+static void registry_remove(nz_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_reg_mx);
+    if (ctx->id && ctx->id <= g_reg.size() && g_reg[ctx->id - 1] == ctx) g_reg[ctx->id - 1] = nullptr;
+}
+
+static inline uint32_t handle_ctx_id(nz_handle h) { return (uint32_t)(h >> NZ_HANDLE_SEQ_BITS); }
+static inline uint64_t handle_seq(nz_handle h) { return h & NZ_HANDLE_SEQ_MASK; }
+
+static bool seq_live(nz_ctx *c, uint64_t q) { return q != 0 && q <= c->last_seq && q + NZ_EVENT_RING > c->last_seq; }
+
+// Runs fn(owner, seq) with the registry locked (the owner cannot be destroyed meanwhile) and the owner's ring
+// locked.  owner == nullptr: the issuing context no longer exists -- nz_ctx_destroy synchronised its stream, so
+// everything it ever issued has completed.
+template <class F>
+static int32_t with_owner(nz_handle h, F fn) {
+    std::lock_guard<std::mutex> lk(g_reg_mx);
+    uint32_t id = handle_ctx_id(h);
+    NZ_REQUIRE(id >= 1 && id <= g_reg.size(), "handle %llu was never issued by a context of this process",
+               (unsigned long long)h);
+    nz_ctx *owner = g_reg[id - 1];
+    if (!owner) return fn((nz_ctx *)nullptr, handle_seq(h));
+    std::lock_guard<std::mutex> lk2(owner->hmx);
+    return fn(owner, handle_seq(h));
+}
+
+// The event that stands for `q` of `owner`: its own while it is in the ring, otherwise the owner's newest marker
+// (later in stream order, so waiting on it implies `q`).
+static hipEvent_t event_for(nz_ctx *owner, uint64_t q) {
+    if (seq_live(owner, q)) return owner->events[q % NZ_EVENT_RING];
+    return owner->last_seq ? owner->events[owner->last_seq % NZ_EVENT_RING] : nullptr;
+}
+
 int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep) {
     NZ_REQUIRE(ctx, "ctx is NULL");
     NZ_HIP(hipSetDevice(ctx->device));
-    // all work of a ctx is ordered on its stream, so a dependency on one of its own handles is
-    // already satisfied by that order; anything else is a caller error
-    NZ_REQUIRE(dep <= ctx->last_handle, "dependency handle %llu was not issued by this context",
-               (unsigned long long)dep);
-    return NZ_OK;
-}
-
-static int32_t handle_new_event(nz_ctx *ctx, hipEvent_t **ev, uint64_t *h) {
-    if (ctx->events.empty()) ctx->events.assign(NZ_EVENT_RING, nullptr);
-    *h = ctx->last_handle + 1;
-    *ev = &ctx->events[*h % NZ_EVENT_RING];
-    if (!**ev) NZ_HIP(hipEventCreate(*ev));
-    return NZ_OK;
+    if (dep == 0) return NZ_OK;  // default(JobHandle)
+    if (handle_ctx_id(dep) == ctx->id) {
+        // all work of a ctx is ordered on its stream: a dependency on one of its own handles is already satisfied
+        NZ_REQUIRE(handle_seq(dep) <= ctx->last_seq, "dependency handle %llu was never issued",
+                   (unsigned long long)dep);
+        return NZ_OK;
+    }
+    // a handle of ANOTHER context (another HIP stream): this stream waits for its marker on the device, the host
+    // does not block (JobHandle dependencies between pipelines, ReducePipeline.cs:82-148, PipelineStateLock.cs:12-39)
+    return with_owner(dep, [&](nz_ctx *owner, uint64_t q) -> int32_t {
+        if (!owner) return NZ_OK;
+        NZ_REQUIRE(q <= owner->last_seq, "dependency handle %llu was never issued", (unsigned long long)dep);
+        hipEvent_t ev = event_for(owner, q);
+        if (ev) NZ_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
+        return NZ_OK;
+    });
 }
 
 int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out) {
     if (!out) return NZ_OK;
-    hipEvent_t *ev;
-    uint64_t h;
-    int32_t rc = handle_new_event(ctx, &ev, &h);
-    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->hmx);
+    if (ctx->events.empty()) ctx->events.assign(NZ_EVENT_RING, nullptr);
+    uint64_t q = ctx->last_seq + 1;
+    NZ_REQUIRE(q < NZ_HANDLE_SEQ_MASK, "handle sequence exhausted");
+    hipEvent_t *ev = &ctx->events[q % NZ_EVENT_RING];
+    if (!*ev) NZ_HIP(hipEventCreate(ev));
     NZ_HIP(hipEventRecord(*ev, ctx->stream));
-    ctx->last_handle = h;
-    *out = h;
+    ctx->last_seq = q;
+    *out = ((uint64_t)ctx->id << NZ_HANDLE_SEQ_BITS) | q;
     return NZ_OK;
 }
 
@@ -291,50 +349,72 @@ extern "C" int32_t nz_handle_record(nz_ctx *ctx, nz_handle *out) {
     return nz_ctx_finish(ctx, out);
 }
 
-static bool handle_live(nz_ctx *ctx, nz_handle h) {
-    return h != 0 && h <= ctx->last_handle && h + NZ_EVENT_RING > ctx->last_handle;
+// JobHandle.CombineDependencies(h0, h1, ...): a marker on ctx's stream that completes after every one of them
+extern "C" int32_t nz_handle_combine(nz_ctx *ctx, const nz_handle *handles, int32_t count, nz_handle *out) {
+    NZ_REQUIRE(ctx && out && (handles || count == 0) && count >= 0, "ctx/out/handles invalid");
+    NZ_HIP(hipSetDevice(ctx->device));
+    for (int32_t i = 0; i < count; i++) NZ_TRY_(nz_ctx_begin(ctx, handles[i]));
+    return nz_ctx_finish(ctx, out);
 }
 
+extern "C" int32_t nz_handle_context_id(nz_handle h) { return (int32_t)handle_ctx_id(h); }
+extern "C" int32_t nz_ctx_id(nz_ctx *ctx) { return ctx ? (int32_t)ctx->id : 0; }
+
+// `ctx` may be any live context (kept for the signature's sake): the handle names its owner
 extern "C" int32_t nz_handle_query(nz_ctx *ctx, nz_handle h, int32_t *is_completed) {
     NZ_REQUIRE(ctx && is_completed, "ctx/is_completed is NULL");
-    NZ_REQUIRE(h <= ctx->last_handle, "unknown handle");
-    NZ_HIP(hipSetDevice(ctx->device));
     if (h == 0) {
         *is_completed = 1;  // default(JobHandle).IsCompleted == true
         return NZ_OK;
     }
-    hipError_t e = handle_live(ctx, h) ? hipEventQuery(ctx->events[h % NZ_EVENT_RING])
-                                      : hipStreamQuery(ctx->stream);
-    if (e == hipSuccess) {
-        *is_completed = 1;
-    } else if (e == hipErrorNotReady) {
-        *is_completed = 0;
-        (void)hipGetLastError();
-    } else {
-        nz_set_error("handle query: %s", hipGetErrorString(e));
-        return NZ_ERR_HIP;
-    }
-    return NZ_OK;
+    return with_owner(h, [&](nz_ctx *owner, uint64_t q) -> int32_t {
+        if (!owner) {
+            *is_completed = 1;
+            return NZ_OK;
+        }
+        NZ_REQUIRE(q <= owner->last_seq, "unknown handle");
+        NZ_HIP(hipSetDevice(owner->device));
+        hipError_t e = seq_live(owner, q) ? hipEventQuery(owner->events[q % NZ_EVENT_RING]) : hipStreamQuery(owner->stream);
+        if (e == hipSuccess) {
+            *is_completed = 1;
+        } else if (e == hipErrorNotReady) {
+            *is_completed = 0;
+            (void)hipGetLastError();
+        } else {
+            nz_set_error("handle query: %s", hipGetErrorString(e));
+            return NZ_ERR_HIP;
+        }
+        return NZ_OK;
+    });
 }
 
 extern "C" int32_t nz_handle_wait(nz_ctx *ctx, nz_handle h) {
     NZ_REQUIRE(ctx, "ctx is NULL");
-    NZ_REQUIRE(h <= ctx->last_handle, "unknown handle");
-    NZ_HIP(hipSetDevice(ctx->device));
     if (h == 0) return NZ_OK;
-    if (handle_live(ctx, h)) {
-        NZ_HIP(hipEventSynchronize(ctx->events[h % NZ_EVENT_RING]));
-    } else {
-        NZ_TRY_(ctx_sync_all(ctx));
-    }
+    hipEvent_t ev = nullptr;
+    int dev = 0;
+    int32_t rc = with_owner(h, [&](nz_ctx *owner, uint64_t q) -> int32_t {
+        if (!owner) return NZ_OK;
+        NZ_REQUIRE(q <= owner->last_seq, "unknown handle");
+        ev = event_for(owner, q);
+        dev = owner->device;
+        return NZ_OK;
+    });
+    if (rc || !ev) return rc;
+    // outside the locks: the host blocks here.  (An event of the ring is only destroyed by nz_ctx_destroy, which the
+    // caller must not run concurrently with a wait on that context's handles.)
+    NZ_HIP(hipSetDevice(dev));
+    NZ_HIP(hipEventSynchronize(ev));
     return NZ_OK;
 }
 
 extern "C" int32_t nz_handle_elapsed_ms(nz_ctx *ctx, nz_handle start, nz_handle stop, float *ms) {
     NZ_REQUIRE(ctx && ms, "ctx/ms is NULL");
-    NZ_REQUIRE(handle_live(ctx, start) && handle_live(ctx, stop), "handle expired or unknown");
+    NZ_REQUIRE(handle_ctx_id(start) == ctx->id && handle_ctx_id(stop) == ctx->id, "handles of another context");
+    NZ_REQUIRE(seq_live(ctx, handle_seq(start)) && seq_live(ctx, handle_seq(stop)), "handle expired or unknown");
     NZ_HIP(hipSetDevice(ctx->device));
-    NZ_HIP(hipEventElapsedTime(ms, ctx->events[start % NZ_EVENT_RING], ctx->events[stop % NZ_EVENT_RING]));
+    NZ_HIP(hipEventElapsedTime(ms, ctx->events[handle_seq(start) % NZ_EVENT_RING],
+                               ctx->events[handle_seq(stop) % NZ_EVENT_RING]));
     return NZ_OK;
 }
 

@@ -688,6 +688,16 @@ extern "C" int32_t nz_gauss_blur_stage_batch(nz_ctx *ctx, float *src, float *tmp
     return nz_ctx_finish(ctx, out);
 }
 
+extern "C" int32_t nz_smooth_blur_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t width, int32_t iterations,
+                                              int32_t resolution, int32_t count, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_batch(resolution, count));
+    nz_kernel_taps t;
+    NZ_TRY(smooth_taps(width, &t));
+    NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_batch(resolution, count), t, iterations));
+    return nz_ctx_finish(ctx, out);
+}
+
 extern "C" int32_t nz_erosion_stage_batch(nz_ctx *ctx, float *src, float *tmp, int32_t iterations, int32_t resolution,
                                           int32_t count, nz_handle dep, nz_handle *out) {
     NZ_BEGIN(ctx, dep);

@@ -5,18 +5,24 @@ Pipeline/PipelineState/PipelineSerialization.cs:
                                            (FileDirectory / FileObject :15-97, JsonUtility field order)
   <base>/save__<alias>/data/<name>.data    the buffer's raw little-endian bytes (BinaryIO.WriteBytes :130-146,
                                            PipelineSerdeManager.GetFQN :206-208)
-`type` is `typeof(T).Name` (:214), i.e. "Single" for the float planes of this path; `size` is the
-element count.  A plane written here can be loaded by the reference's PipelineStateManager and vice
-versa.  Device tiles go through nz_tile_download / nz_tile_upload.
+`type` is `typeof(T).Name` (:218,231) where T is the CONTAINER type the state manager was asked for
+(PipelineStateManager.cs:64,111: SaveBufferToDisk<V, T> / GetBuffer<V, T> with T = NativeArray<float>), i.e. the CLR
+name "NativeArray`1" for every plane of this path -- the element type is not recorded; `size` is the element count.
+A plane written here is found by the reference's PipelineStateManager.GetBuffer and vice versa.  (Directories written
+by this package's first version carried the element name, "Single"; they are still found on read.)  Device tiles go
+through nz_tile_download / nz_tile_upload.
 """
 import json
 import os
 
 import numpy as np
 
-_DOTNET_NAMES = {np.dtype(np.float32): "Single", np.dtype(np.int32): "Int32", np.dtype(np.uint32): "UInt32",
-                 np.dtype(np.float64): "Double", np.dtype(np.uint8): "Byte", np.dtype(np.int16): "Int16",
-                 np.dtype(np.uint16): "UInt16"}
+# typeof(T).Name of the serialised container types (ConstraintsLinear.SERIALIZED_TYPES, PipelineState.cs:53-57)
+NATIVE_ARRAY, NATIVE_LIST, NATIVE_REFERENCE = "NativeArray`1", "NativeList`1", "NativeReference`1"
+# element names this package's first version wrote into `type`; accepted when reading
+_LEGACY_ELEMENT_NAMES = {np.dtype(np.float32): "Single", np.dtype(np.int32): "Int32", np.dtype(np.uint32): "UInt32",
+                         np.dtype(np.float64): "Double", np.dtype(np.uint8): "Byte", np.dtype(np.int16): "Int16",
+                         np.dtype(np.uint16): "UInt16"}
 _INVALID = "/\0"  # System.IO.Path.GetInvalidFileNameChars() on Unix
 
 
@@ -74,16 +80,20 @@ class PipelineSerdeManager:  # :184-236
     def GetFQN(self, name):
         return os.path.join(self.basePath, "save__%s" % self.alias, "data", "%s.data" % clean_file_name(name))
 
-    def WriteData(self, data, name):
-        """data: numpy array or DeviceTile."""
+    def WriteData(self, data, name, container=NATIVE_ARRAY):
+        """WriteData<T> :214-219.  data: numpy array or DeviceTile; container = typeof(T).Name."""
         host = data.ToArray() if hasattr(data, "ToArray") else np.ascontiguousarray(data)
         path = self.GetFQN(name)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         host.reshape(-1).astype(host.dtype.newbyteorder("<"), copy=False).tofile(path)
-        self.directory.SetCount(name, _DOTNET_NAMES[host.dtype], host.size)
+        self.directory.SetCount(name, container, host.size)
 
-    def CachedSize(self, name, dtype=np.float32):
-        return self.directory.GetCount(name, _DOTNET_NAMES[np.dtype(dtype)])
+    def CachedSize(self, name, dtype=np.float32, container=NATIVE_ARRAY):
+        """CachedSize<T> :230-234; -1 when the index has no entry."""
+        r = self.directory.GetCount(name, container)
+        if r < 0 and np.dtype(dtype) in _LEGACY_ELEMENT_NAMES:
+            r = self.directory.GetCount(name, _LEGACY_ELEMENT_NAMES[np.dtype(dtype)])
+        return r
 
     def ReadData(self, name, target=None, dtype=np.float32):
         """Returns the stored array, or fills `target` (numpy array or DeviceTile); None when no file exists

@@ -120,6 +120,14 @@ class GeneratorData(StageIO):  # StageIOTypes/GeneratorData.cs:9-15
         self.write = write
 
 
+def _tiles_of(d):
+    """The planes an element-wise / per-tile job has to visit: the payload's one plane, or every tile of a
+    GeneratorDataBatch (those jobs take `resolution`, not a cell count, so a batch goes tile by tile)."""
+    if isinstance(d, GeneratorDataBatch):
+        return [d.tile(k) for k in range(d.count)]
+    return [d.data]
+
+
 def _call_rw(ctx, name, d, *args, dep=None):
     """Runs an nz_*_rw entry on the payload's READ / WRITE pair and adopts the pair as the call left it."""
     t = N.RWTile(d.data.ptr, d.write.ptr, d.resolution, getattr(d, "count", 1))
@@ -368,8 +376,12 @@ class StageSmoothBlur(PipelineStage):  # Filter/Kernel/Blur/StageSmoothBlur.cs:1
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
         width_ = BlurHelper.limitWidth(self.width)
-        if d.write is not None and not isinstance(d, GeneratorDataBatch):
+        if d.write is not None:  # a batch too: the _rw entries honour nz_rw_tile.count
             self.jobHandle = _call_rw(self.ctx, "nz_smooth_blur_stage_rw", d, width_, self.iterations, dep=dependency)
+            return
+        if isinstance(d, GeneratorDataBatch):
+            self.jobHandle = self.ctx.call("nz_smooth_blur_stage_batch", d.data.ptr, self.tmp.ptr, width_,
+                                           self.iterations, d.resolution, d.count, dep=dependency)
             return
         self.jobHandle = self.ctx.call("nz_smooth_blur_stage", d.data.ptr, self.tmp.ptr, width_, self.iterations,
                                        d.resolution, dep=dependency)
@@ -422,8 +434,9 @@ class ConstantStage(PipelineStage):  # Filter/ConstantStage.cs:13-56
     def Schedule(self, requirements, dependency):
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
-        self.jobHandle = self.ctx.call("nz_constant_job", int(self.operation), d.data.ptr, self.tmp.ptr, self.value,
-                                       d.resolution, dep=dependency)
+        for t in _tiles_of(d):
+            self.jobHandle = dependency = self.ctx.call("nz_constant_job", int(self.operation), t.ptr, self.tmp.ptr,
+                                                        self.value, d.resolution, dep=dependency)
 
     def OnDestroy(self):
         if self.tmp is not None and self.tmp.IsCreated:
@@ -482,8 +495,9 @@ class CurveStage(PipelineStage):  # Filter/Curve/CurveStage.cs:13-71
     def Schedule(self, requirements, dependency):
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
-        self.jobHandle = self.ctx.call("nz_curve_job", d.data.ptr, self.tmp.ptr, self.curve.ptr, self.samples,
-                                       d.resolution, dep=dependency)
+        for t in _tiles_of(d):
+            self.jobHandle = dependency = self.ctx.call("nz_curve_job", t.ptr, self.tmp.ptr, self.curve.ptr,
+                                                        self.samples, d.resolution, dep=dependency)
 
     def OnDestroy(self):
         for t in (self.curve, self.tmp):
@@ -515,8 +529,10 @@ class StageThermalErosion(PipelineStage):  # Filter/Kernel/Blur/StageThermalEros
     def Schedule(self, requirements, dependency):
         self.CheckRequirements(GeneratorData, requirements)
         d = requirements.data
-        self.jobHandle = self.ctx.call("nz_thermal_erosion", d.data.ptr, float(self.talus), self.increment,
-                                       self.meshHeightWidthRatio, self.iterations, d.resolution, dep=dependency)
+        for t in _tiles_of(d):
+            self.jobHandle = dependency = self.ctx.call("nz_thermal_erosion", t.ptr, float(self.talus), self.increment,
+                                                        self.meshHeightWidthRatio, self.iterations, d.resolution,
+                                                        dep=dependency)
 
 
 class FlowMapStage(PipelineStage):  # Geologic/Stage/FlowMapStage.cs:16-220
@@ -710,9 +726,16 @@ class ReducePipeline(BasePipeline):  # Pipeline/Executable/ReducePipeline.cs:31-
     two planes.  `ctx` allocates the right-hand plane (the reference's Persistent NativeArray)."""
 
     def __init__(self, ctx, stages, upstreamPipelineLeft, upstreamPipelineRight, alias="Unnamed Pipeline",
-                 contextManager=None):
+                 contextManager=None, deviceJoin=False):
         super().__init__(stages, alias, contextManager)
         self.ctx = ctx
+        # deviceJoin (new-framework): the upstream pipelines may run on other contexts (HIP streams).  Instead of
+        # waiting on the host for both to COMPLETE (the reference polls JobHandle.IsCompleted, :123-149), this
+        # pipeline's stages are scheduled as soon as both upstreams are SCHEDULED, with
+        # JobHandle.CombineDependencies(left, right) as their dependency: the join happens on the device
+        # (hipStreamWaitEvent), the host never blocks between the three pipelines.
+        self.deviceJoin = deviceJoin
+        self._scheduled = {}
         self.upstreamPipelineLeft = upstreamPipelineLeft
         self.upstreamPipelineRight = upstreamPipelineRight
         self.upstreamsRunning = False
@@ -747,9 +770,29 @@ class ReducePipeline(BasePipeline):  # Pipeline/Executable/ReducePipeline.cs:31-
              Upstream.RIGHT: GeneratorData(leftData.uuid, self.rightData, leftData.resolution, leftData.xpos,
                                            leftData.zpos)},
             wi.completeAction)
+        if self.deviceJoin:
+            self._scheduled = {}
+            self.upstreamPipelineLeft.Enqueue(self.currentWorkItem.stages[Upstream.LEFT],
+                                              scheduleAction=lambda res, h: self.OnScheduledUpstream(res, h, Upstream.LEFT))
+            self.upstreamPipelineRight.Enqueue(self.currentWorkItem.stages[Upstream.RIGHT],
+                                               scheduleAction=lambda res, h: self.OnScheduledUpstream(res, h, Upstream.RIGHT))
+            return
         self.upstreamPipelineLeft.Enqueue(self.currentWorkItem.stages[Upstream.LEFT], completeAction=self.OnCompleteLeft)
         self.upstreamPipelineRight.Enqueue(self.currentWorkItem.stages[Upstream.RIGHT],
                                            completeAction=self.OnCompleteRight)
+
+    def OnScheduledUpstream(self, res, handle, side):
+        """deviceJoin: an upstream has enqueued all its work; `handle` is its pipelineHandle."""
+        self._scheduled[side] = handle
+        self.currentWorkItem.status[side] = True
+        self.currentWorkItem.stages[side] = res
+        if self.currentWorkItem.ready:
+            self.upstreamsRunning = False
+            j = self.currentWorkItem
+            dep = JobHandle.CombineDependencies(self.stage_instances[0].ctx, self._scheduled[Upstream.LEFT],
+                                                self._scheduled[Upstream.RIGHT])
+            self.Schedule(ReduceData(res.uuid, j.stages[Upstream.LEFT].data, j.stages[Upstream.RIGHT].data,
+                                     res.resolution, res.xpos, res.zpos), completeAction=j.action, dependency=dep)
 
     def OnCompleteUpstream(self, res, side):  # :123-149
         self.currentWorkItem.status[side] = True

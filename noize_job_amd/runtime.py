@@ -13,8 +13,9 @@ from . import _native as N
 
 
 class JobHandle:
-    """Unity.Jobs.JobHandle analogue: a marker on the context's stream.  `JobHandle()` ==
-    default(JobHandle), which is already complete."""
+    """Unity.Jobs.JobHandle analogue: a marker on the issuing context's stream.  `JobHandle()` ==
+    default(JobHandle), which is already complete.  The id names its context (nz_handle_context_id), so a handle may
+    be handed as a dependency to a stage of ANY context: the consumer's stream waits for it on the device."""
     __slots__ = ("ctx", "id")
 
     def __init__(self, ctx=None, hid=0):
@@ -33,8 +34,18 @@ class JobHandle:
         if self.id and self.ctx is not None:
             N.check(N.lib.nz_handle_wait(self.ctx._h, self.id), "nz_handle_wait")
 
+    @staticmethod
+    def CombineDependencies(ctx, *handles):
+        """JobHandle.CombineDependencies: a marker on `ctx`'s stream that completes after all `handles` (of any
+        contexts)."""
+        ids = [h.id for h in handles if h is not None and h.id]
+        arr = (N.handle_t * max(1, len(ids)))(*ids)
+        out = N.handle_t(0)
+        N.check(N.lib.nz_handle_combine(ctx._h, arr, len(ids), C.byref(out)), "nz_handle_combine")
+        return JobHandle(ctx, out.value)
+
     def __repr__(self):
-        return "JobHandle(%d)" % self.id
+        return "JobHandle(ctx %d, #%d)" % (self.id >> 40, self.id & ((1 << 40) - 1))
 
 
 def _dep(dep):

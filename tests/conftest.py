@@ -36,7 +36,14 @@ def pytest_sessionstart(session):
     package itself never builds or falls back -- importing it without the library raises."""
     built = [os.path.join(ROOT, "noize_job_amd", "libnoize_hip.so"), os.path.join(ROOT, "oracle", "libnoize_oracle.so"),
              os.path.join(ROOT, "noize_job_amd", "host", "host_demo")]
-    if not all(os.path.exists(p) for p in built):
+    sources = []
+    for d, exts in (("noize_job_amd/csrc", (".hip", ".cpp", ".hpp")), ("noize_job_amd/host", (".cpp", ".hpp")),
+                    ("oracle", (".c", ".h")), ("include", (".h",))):
+        full = os.path.join(ROOT, d)
+        sources += [os.path.join(full, f) for f in os.listdir(full) if f.endswith(exts)]
+    stale = (not all(os.path.exists(p) for p in built) or
+             max(os.path.getmtime(p) for p in sources) > min(os.path.getmtime(p) for p in built))
+    if stale:  # never test a binary older than its sources (make rebuilds only what changed)
         import __graft_entry__
         __graft_entry__.build()
 

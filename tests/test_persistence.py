@@ -19,7 +19,9 @@ def test_layout_and_round_trip(tmp_path):
     assert (base / "data" / "tile_0_0.data").read_bytes() == plane.astype("<f4").tobytes()  # raw little-endian
     idx = json.loads((base / "files.json").read_text())
     assert list(idx) == ["alias", "version", "files"] and idx["alias"] == "terrain" and idx["version"] == "v1"
-    assert idx["files"] == [{"id": "tile_0_0", "type": "Single", "size": 1024}, {"id": "ids", "type": "Int32", "size": 7}]
+    # typeof(T).Name with T = NativeArray<float> / NativeArray<int> (PipelineStateManager.cs:64,111): the container's CLR name
+    assert idx["files"] == [{"id": "tile_0_0", "type": "NativeArray`1", "size": 1024},
+                            {"id": "ids", "type": "NativeArray`1", "size": 7}]
     m2 = PipelineSerdeManager(str(tmp_path), "terrain", "v1")  # a fresh manager finds the index
     assert m2.CachedSize("tile_0_0") == 1024 and m2.CachedSize("missing") == -1
     assert np.array_equal(m2.ReadData("tile_0_0").reshape(32, 32), plane)
@@ -27,6 +29,22 @@ def test_layout_and_round_trip(tmp_path):
     m2.WriteData(plane[:16], "tile_0_0")  # SetCount updates in place
     assert PipelineSerdeManager(str(tmp_path), "terrain", "v1").CachedSize("tile_0_0") == 512
     assert clean_file_name("a/b//c..") == "a_b_c" and clean_file_name("plain") == "plain"
+
+
+def test_reads_an_index_written_by_the_reference_and_by_version_1(tmp_path):
+    from noize_job_amd.persistence import PipelineSerdeManager
+    base = tmp_path / "save__terrain"
+    (base / "data").mkdir(parents=True)
+    plane = np.arange(16, dtype=np.float32)
+    plane.astype("<f4").tofile(base / "data" / "a.data")
+    plane.astype("<f4").tofile(base / "data" / "b.data")
+    # JsonUtility.ToJson(FileDirectory): what the reference's SaveBufferToDisk<float, NativeArray<float>> leaves behind,
+    # next to an entry in this package's first-version spelling
+    (base / "files.json").write_text('{"alias":"terrain","version":"v1","files":[{"id":"a","type":"NativeArray`1","size":16},'
+                                     '{"id":"b","type":"Single","size":16}]}')
+    m = PipelineSerdeManager(str(tmp_path), "terrain", "v1")
+    assert m.CachedSize("a") == 16 and m.CachedSize("b") == 16 and m.CachedSize("c") == -1
+    assert np.array_equal(m.ReadData("a"), plane)
 
 
 @pytest.mark.gpu
