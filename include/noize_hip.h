@@ -314,6 +314,87 @@ int32_t nz_update_flow_from_track(nz_ctx *ctx, float *pool, float *flow, float *
 int32_t nz_pool_automata(nz_ctx *ctx, float *pool, const float *height, int32_t iterations, int32_t resolution,
                          nz_handle dep, nz_handle *out);
 
+/* ---- live erosion: the particle half (BASELINE config 4).  LiveErosion.TriggerQueuedBeyerMT
+ * (Geologic/ParticleErosion/Component/LiveErosion.cs:378-436) chains these jobs per cycle.  The reference is
+ * deterministic per particle but not per run; this library fixes the three free choices (see nz_live.hip): the random
+ * seed is an argument, per-cell event sums are 2^-40 fixed point (order-independent), and ErodeHeightMaps applies the
+ * per-cell sediment events in the order one worker would have produced them (all KernelDisperse events, then the
+ * PileSolver events).  Same seed, same planes -> same result, bit for bit, on every run. ------------------------- */
+/* ErosionParameters, Geologic/ParticleErosion/LiveErosionDataTypes.cs:78-100 (field order kept) */
+typedef struct nz_erosion_params {
+    float INERTIA, GRAVITY, DRAG, FRICTION, EVAP, EROSION, DEPOSITION, FLOW_HEIGHT_CONTRIBUTION;
+    float SLOW_CULL_ANGLE, SLOW_CULL_SPEED, CAPACITY;
+    int32_t MAXAGE;
+    float TERMINAL_VELOCITY;
+    float SURFACE_EVAPORATION_RATE, POOL_PLACEMENT_MULTIPLIER, TRACK_PLACEMENT_MULTIPLIER, FLOW_LOSS_RATE;
+    int32_t PILING_RADIUS;
+    float MIN_PILE_INCREMENT, PILE_THRESHOLD;
+} nz_erosion_params;
+/* TileSetMeta, Pipeline/Tiles/TileTypes.cs:15-27 (field order kept); the jobs read GENERATOR_RES, PATCH_RES.x, HEIGHT */
+typedef struct nz_tile_set_meta {
+    int32_t TILE_RES[2], TILE_SIZE[2], GENERATOR_RES[2];
+    float PATCH_RES[2];
+    int32_t HEIGHT;
+    float HEIGHT_F;
+    int32_t MARGIN;
+} nz_tile_set_meta;
+/* a queued BeyerParticle: what its constructors set that is not a constant (LiveErosionDataTypes.cs:221-237) */
+typedef struct nz_particle {
+    int32_t px, pz; /* pos */
+    float water;
+    uint32_t pid;
+} nz_particle;
+/* NativeQueue<BeyerParticle> (+ the NativeList it is copied to, CopyBeyerQueueJob) in device memory */
+typedef struct nz_particle_queue nz_particle_queue;
+/* NativeParallelMultiHashMap<int, ErosiveEvent> events + NativeQueue<ErosiveEvent> erosions: per-cell sums, the cells
+ * that received an event, and the per-cell sediment event as a dense plane */
+typedef struct nz_erosive_events nz_erosive_events;
+
+int32_t nz_particle_queue_create(nz_ctx *ctx, int32_t capacity, nz_particle_queue **out);
+int32_t nz_particle_queue_destroy(nz_ctx *ctx, nz_particle_queue *queue);
+/* NativeQueue.Count / ToArray (the host waits for the ctx's stream); NZ_ERR_NOMEM if a job found the queue too small */
+int32_t nz_particle_queue_count(nz_ctx *ctx, nz_particle_queue *queue, int32_t *count);
+int32_t nz_particle_queue_download(nz_ctx *ctx, nz_particle_queue *queue, nz_particle *host, int32_t max_count,
+                                   int32_t *count);
+int32_t nz_particle_queue_upload(nz_ctx *ctx, nz_particle_queue *queue, const nz_particle *host, int32_t count);
+/* ClearQueueJob<BeyerParticle>.ScheduleRun(queue, deps), MultiThreadErosionJob.cs:133-153 */
+int32_t nz_clear_particle_queue(nz_ctx *ctx, nz_particle_queue *queue, nz_handle dep, nz_handle *out);
+int32_t nz_erosive_events_create(nz_ctx *ctx, int32_t resolution, nz_erosive_events **out);
+int32_t nz_erosive_events_destroy(nz_ctx *ctx, nz_erosive_events *events);
+float *nz_erosive_events_sediment(nz_erosive_events *events); /* device plane, x * res + z */
+int32_t nz_erosive_events_count(nz_ctx *ctx, nz_erosive_events *events, int32_t *count); /* events of the last descent */
+
+/* FillBeyerQueueJob.ScheduleParallel(particles, ep, tm, generationRound, res, maxParticles, deps, concurrency),
+ * MultiThreadErosionJob.cs:37-71; `seed` replaces UnityEngine.Random.Range(0, Int32.MaxValue) (:50).  The number of
+ * particles already queued is read when the job RUNS (the reference reads particles.Count when it schedules). */
+int32_t nz_fill_beyer_queue(nz_ctx *ctx, nz_particle_queue *particles, const nz_erosion_params *ep,
+                            const nz_tile_set_meta *tm, int32_t generationRound, int32_t res, int32_t maxParticles,
+                            int32_t seed, int32_t concurrency, nz_handle dep, nz_handle *out);
+/* QueuedBeyerCycleMultiThreadJob.ScheduleParallel(height, pool, flow, track, particles, events, ep, tm, eventLimit, res,
+ * deps), :196-223: every queued particle descends until it is dead; the planes are read only */
+int32_t nz_queued_beyer_cycle(nz_ctx *ctx, const float *height, const float *pool, const float *flow, const float *track,
+                              nz_particle_queue *particles, nz_erosive_events *events, const nz_erosion_params *ep,
+                              const nz_tile_set_meta *tm, int32_t eventLimit, int32_t res, nz_handle dep, nz_handle *out);
+/* ProcessBeyerErosiveEventsJob.ScheduleRun(height, pool, flow, track, erosions, events, ep, tm, res, deps), :356-384 */
+int32_t nz_process_beyer_erosive_events(nz_ctx *ctx, float *height, float *pool, float *flow, float *track,
+                                        nz_erosive_events *events, const nz_erosion_params *ep,
+                                        const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out);
+/* ErodeHeightMaps.ScheduleRun(height, erosions, ep, tm, res, deps), :459-479 */
+int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *events, const nz_erosion_params *ep,
+                             const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out);
+/* PoolAutomataJob.Schedule(pool, height, particleQueue, ep, tm, iterations, res, drainParticles, deps), :289-325:
+ * with drainParticles != 0 a pool that finds a dry, lower neighbour leaves as one particle (pid 64000) in the queue */
+int32_t nz_pool_automata_job(nz_ctx *ctx, float *pool, const float *height, nz_particle_queue *particleQueue,
+                             const nz_erosion_params *ep, const nz_tile_set_meta *tm, int32_t iterations, int32_t res,
+                             int32_t drainParticles, nz_handle dep, nz_handle *out);
+/* CurvitureMapJob.ScheduleRun(texture, height, tm, target, res, deps), :413-435: `texture` = device RGBA32 pixels of a
+ * meshRes^2 texture (4 bytes per pixel), target = ColorChannelByte {R, G, B, A} */
+int32_t nz_curviture_map(nz_ctx *ctx, uint8_t *texture, const float *height, const nz_tile_set_meta *tm, int32_t target,
+                         int32_t res, int32_t meshRes, nz_handle dep, nz_handle *out);
+/* SetRGBA32Job.ScheduleRun(src, texture, target, deps, scale), :506-528 (dataRes = sqrt(src.Length)) */
+int32_t nz_set_rgba32(nz_ctx *ctx, const float *src, uint8_t *texture, int32_t target, int32_t dataRes, int32_t meshRes,
+                      float scale, nz_handle dep, nz_handle *out);
+
 /* MeshJobScheduleDelegate with G = SharedSquareGridPosition (Mesh/Job/MeshJob.cs:37-60,
  * Mesh/Generators/SharedSquareGridPosition.cs:20-50; MeshHelper.makeSquarePlanarMesh): the flat unit-square grid,
  * same vertex / index layout and counts as nz_heightmap_mesh.  TileSize / Height of the delegate only set

@@ -17,4 +17,7 @@ from .pipeline import (BasePipeline, BlurHelper, ConstantOperationType, Constant
 from .pipeline_state import (HandleLock, MeshTileReferenceDataStage, PipelineStateManager, ReadGeneratorContextStage,
                              WriteGeneratorContextStage)
 
+from .live_erosion import (ColorChannelByte, ErosionMode, ErosionSettings, ErosiveEvents, LiveErosion, ParticleQueue,
+                           tile_set_meta)
+
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -34,6 +34,30 @@ class RWTile(C.Structure):
 
 rw_tile_p = C.POINTER(RWTile)
 
+
+class ErosionParameters(C.Structure):
+    """nz_erosion_params = ErosionParameters (Geologic/ParticleErosion/LiveErosionDataTypes.cs:78-100)."""
+    _fields_ = ([(n, C.c_float) for n in ("INERTIA", "GRAVITY", "DRAG", "FRICTION", "EVAP", "EROSION", "DEPOSITION",
+                                          "FLOW_HEIGHT_CONTRIBUTION", "SLOW_CULL_ANGLE", "SLOW_CULL_SPEED", "CAPACITY")] +
+                [("MAXAGE", C.c_int32), ("TERMINAL_VELOCITY", C.c_float), ("SURFACE_EVAPORATION_RATE", C.c_float),
+                 ("POOL_PLACEMENT_MULTIPLIER", C.c_float), ("TRACK_PLACEMENT_MULTIPLIER", C.c_float),
+                 ("FLOW_LOSS_RATE", C.c_float), ("PILING_RADIUS", C.c_int32), ("MIN_PILE_INCREMENT", C.c_float),
+                 ("PILE_THRESHOLD", C.c_float)])
+
+
+class TileSetMeta(C.Structure):
+    """nz_tile_set_meta = TileSetMeta (Pipeline/Tiles/TileTypes.cs:15-27)."""
+    _fields_ = [("TILE_RES", C.c_int32 * 2), ("TILE_SIZE", C.c_int32 * 2), ("GENERATOR_RES", C.c_int32 * 2),
+                ("PATCH_RES", C.c_float * 2), ("HEIGHT", C.c_int32), ("HEIGHT_F", C.c_float), ("MARGIN", C.c_int32)]
+
+
+class Particle(C.Structure):
+    """nz_particle: a queued BeyerParticle."""
+    _fields_ = [("px", C.c_int32), ("pz", C.c_int32), ("water", C.c_float), ("pid", C.c_uint32)]
+
+
+ep_p, tm_p = C.POINTER(ErosionParameters), C.POINTER(TileSetMeta)
+
 NZ_OK, NZ_ERR_INVALID, NZ_ERR_UNSUPPORTED, NZ_ERR_HIP, NZ_ERR_NOMEM, NZ_ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 
 _i, _f, _sz = C.c_int32, C.c_float, C.c_size_t
@@ -94,6 +118,23 @@ SIGNATURES = {
     "nz_reduction_job": (_i, [ctx_p, _i, dev_ptr, dev_ptr, dev_ptr, _i] + _tail),
     "nz_update_flow_from_track": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, _f, _f, _f, _i] + _tail),
     "nz_pool_automata": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
+    "nz_particle_queue_create": (_i, [ctx_p, _i, C.POINTER(C.c_void_p)]),
+    "nz_particle_queue_destroy": (_i, [ctx_p, C.c_void_p]),
+    "nz_particle_queue_count": (_i, [ctx_p, C.c_void_p, C.POINTER(_i)]),
+    "nz_particle_queue_download": (_i, [ctx_p, C.c_void_p, C.c_void_p, _i, C.POINTER(_i)]),
+    "nz_particle_queue_upload": (_i, [ctx_p, C.c_void_p, C.c_void_p, _i]),
+    "nz_clear_particle_queue": (_i, [ctx_p, C.c_void_p] + _tail),
+    "nz_erosive_events_create": (_i, [ctx_p, _i, C.POINTER(C.c_void_p)]),
+    "nz_erosive_events_destroy": (_i, [ctx_p, C.c_void_p]),
+    "nz_erosive_events_sediment": (C.c_void_p, [C.c_void_p]),
+    "nz_erosive_events_count": (_i, [ctx_p, C.c_void_p, C.POINTER(_i)]),
+    "nz_fill_beyer_queue": (_i, [ctx_p, C.c_void_p, ep_p, tm_p, _i, _i, _i, _i, _i] + _tail),
+    "nz_queued_beyer_cycle": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, dev_ptr, C.c_void_p, C.c_void_p, ep_p, tm_p, _i, _i] + _tail),
+    "nz_process_beyer_erosive_events": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, dev_ptr, C.c_void_p, ep_p, tm_p, _i] + _tail),
+    "nz_erode_height_maps": (_i, [ctx_p, dev_ptr, C.c_void_p, ep_p, tm_p, _i] + _tail),
+    "nz_pool_automata_job": (_i, [ctx_p, dev_ptr, dev_ptr, C.c_void_p, ep_p, tm_p, _i, _i, _i] + _tail),
+    "nz_curviture_map": (_i, [ctx_p, dev_ptr, dev_ptr, tm_p, _i, _i, _i] + _tail),
+    "nz_set_rgba32": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _f] + _tail),
     "nz_crop_job": (_i, [ctx_p, dev_ptr, _i, dev_ptr, _i] + _tail),
     "nz_curve_job": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, _i, _i] + _tail),
     "nz_thermal_erosion": (_i, [ctx_p, dev_ptr, _f, _f, _f, _i, _i] + _tail),

@@ -128,8 +128,13 @@ __device__ __forceinline__ int flooded_cmp(const flooded &a, const flooded &b) {
 // memory round trip per PU steps instead of a store -> load round trip per step.
 constexpr int PU = 8;
 
+// DRAIN (drainParticles): a pool that finds a dry, lower neighbour does not wet it but leaves as ONE BeyerParticle
+// (pid 64000, at the neighbour, carrying the water, LiveErosionDataTypes.cs:971-984) appended to the particle queue; the
+// order of the queue is whatever the atomics make it -- the descent's results do not depend on it (nz_live.hip).
+template <bool DRAIN>
 __global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *pool, const float *__restrict__ height, int res,
-                                                               int xoff, int zoff) {
+                                                               int xoff, int zoff, int32_t *drain_hdr,
+                                                               nz_particle *drain_data) {
     int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= res / 2) return;
     const int z = 2 * k + zoff;
@@ -221,10 +226,22 @@ __global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *pool, con
                 const float put = spill ? bw + hWater : (give ? bw + fill_give : bw + (-1.0f * fill_take));
                 const float w_new = spill ? 0.0f : (give ? hWater - fill_give : hWater + fill_take);
                 if (go && (spill || give || take)) {
-                    pool[b[e].idx] = put;
+                    if (DRAIN && spill) {
+                        const int slot = atomicAdd(&drain_hdr[0], 1);
+                        if (slot < drain_hdr[1]) {
+                            nz_particle p;
+                            p.px = b[e].idx / res;  // getPos(idx)
+                            p.pz = b[e].idx % res;
+                            p.water = hWater;
+                            p.pid = 64000;
+                            drain_data[slot] = p;
+                        }
+                    } else {
+                        pool[b[e].idx] = put;
+                        if (b[e].idx == right_idx) carry = put;
+                    }
                     hWater = w_new;
                     tHeight = spill ? hLand : hLand + w_new;
-                    if (b[e].idx == right_idx) carry = put;
                 }
             }
             pool[idx] = hWater;
@@ -330,11 +347,16 @@ int32_t nz_launch_flow_from_track(hipStream_t s, float *pool, float *flow, float
     return NZ_OK;
 }
 
-int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *height, int res, int xoff, int zoff) {
+int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *height, int res, int xoff, int zoff,
+                                     int32_t *drain_hdr, nz_particle *drain_data) {
     int jobs = res / 2;
     if (jobs <= 0) return NZ_OK;
-    hipLaunchKernelGGL(pool_automata_pass_kernel, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, s, pool, height, res,
-                       xoff, zoff);
+    if (drain_hdr)
+        hipLaunchKernelGGL(pool_automata_pass_kernel<true>, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, s, pool, height,
+                           res, xoff, zoff, drain_hdr, drain_data);
+    else
+        hipLaunchKernelGGL(pool_automata_pass_kernel<false>, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, s, pool, height,
+                           res, xoff, zoff, drain_hdr, drain_data);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

@@ -195,7 +195,11 @@ int32_t nz_launch_constant(hipStream_t s, int op, float *data, size_t n, float c
 int32_t nz_launch_reduce(hipStream_t s, int op, float *l, const float *r, size_t n);
 int32_t nz_launch_flow_from_track(hipStream_t s, float *pool, float *flow, float *track, size_t n, float flowLossRate,
                                   float evaporation);
-int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *height, int res, int xoff, int zoff);
+// drain_hdr / drain_data (nullable): the particle queue a drained pool leaves through (PoolAutomataJob, drainParticles)
+int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *height, int res, int xoff, int zoff,
+                                     int32_t *drain_hdr = nullptr, nz_particle *drain_data = nullptr);
+int32_t *nz_particle_queue_hdr(nz_particle_queue *q);
+nz_particle *nz_particle_queue_data(nz_particle_queue *q);
 int32_t nz_launch_crop(hipStream_t s, const float *in, int in_res, float *out, int out_res);
 int32_t nz_launch_curve(hipStream_t s, float *data, size_t n, const float *curve, int curveSize);
 int32_t nz_launch_thermal_phase(hipStream_t s, float *data, int resolution, int flip, float maxDiff, float increment);

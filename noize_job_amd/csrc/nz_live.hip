@@ -1,0 +1,784 @@
+// nz_live.hip -- the particle half of noize-job's live erosion (BASELINE config 4), gfx950.
+//
+// Replaces the Burst jobs of Geologic/ParticleErosion/MultiThreadErosionJob.cs that LiveErosion.TriggerQueuedBeyerMT
+// (Component/LiveErosion.cs:378-436) chains per cycle:
+//   FillBeyerQueueJob (:21-72)               -> fill_queue_kernel          one lane per reference worker
+//   QueuedBeyerCycleMultiThreadJob (:178-224) -> descent_kernel             one lane per particle, until it is dead
+//   ProcessBeyerErosiveEventsJob (:330-385)   -> process_events_kernel      one lane per cell that received an event
+//   ErodeHeightMaps (:438-480, ONE thread)    -> disperse_kernel (every cell gathers) + pile_kernel (rare, sequential)
+//   PoolAutomataJob, drainParticles (:264-327) -> nz_elementwise.hip, pool_automata_pass_kernel<true>
+//   CurvitureMapJob (:387-436), SetRGBA32Job (:482-529) -> curviture_kernel, set_rgba32_kernel
+//
+// The reference is deterministic per particle but not per run (UnityEngine.Random seeds, a parallel multi-hash-map
+// summed in its iteration order, sediment events in the order parallel jobs enqueued them).  Three choices are FIXED
+// here, the same three oracle/noize_oracle_live.c fixes, so that the two agree bit for bit:
+//   1. the seed is an argument; positions follow Unity.Mathematics.Random (xorshift32);
+//   2. per-cell event sums are 2^-40 fixed point (64-bit integer atomics): independent of arrival order;
+//   3. ErodeHeightMaps applies the per-cell events in the order one worker would have produced them (job z ascending,
+//      x ascending inside): first every KernelDisperse event -- as a GATHER: a target cell folds the <= 25
+//      contributions that reach it in that order, reading only its own running value, so all targets run in parallel
+//      -- then every PileSolver event, one after the other.
+// atan / sin of the velocity model are the Cephes fp32 polynomials written out operation by operation (no libm call),
+// the same text as the oracle's.  Planes are indexed x * res + z (WorldTile.getIdx, LiveErosionDataTypes.cs:608-610).
+#include <cstring>
+
+#include "nz_internal.hpp"
+
+struct nz_particle_queue {  // device layout: header + particles
+    int32_t *hdr = nullptr;  // {count, capacity, overflow, pad}
+    nz_particle *data = nullptr;
+    int32_t capacity = 0;
+};
+
+struct nz_erosive_events {
+    int32_t res = 0;
+    unsigned long long *acc = nullptr;  // [3][res^2]: pool, track, sediment sums (2^-40 fixed point, two's complement)
+    int32_t *touched = nullptr;         // [res^2] events per cell this cycle
+    int32_t *list[2] = {nullptr, nullptr};  // cells touched this cycle / last cycle
+    int32_t *counters = nullptr;        // {n_list[0], n_list[1], n_piles, events}
+    float *sediment = nullptr;          // [res^2] the per-cell ErosiveEvent.deltaSediment (0 where none)
+    int32_t *piles = nullptr;           // [res^2] cells whose event goes to the PileSolver
+    int cur = 0;
+    void *pile_scratch = nullptr;
+    size_t pile_scratch_bytes = 0;
+};
+
+namespace {
+
+constexpr int CT = 256;
+constexpr double FIX_SCALE = 1099511627776.0;  // 2^40
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float lmaxf(float a, float b) { return (b != b) || a > b ? a : b; }  // math.max
+__device__ __forceinline__ float lminf(float a, float b) { return (b != b) || a < b ? a : b; }  // math.min
+
+// ---- Cephes atanf / sinf in fp32 operations (the oracle's text) ----------------------------------------------------
+__device__ float live_atanf(float xx) {
+    if (xx != xx) return xx;
+    float sign = 1.0f, x = xx, y;
+    if (x < 0.0f) { sign = -1.0f; x = -x; }
+    if (x > 2.414213562373095f) { y = 1.5707963267948966192f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483096f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    float z = x * x;
+    y += (((8.05374449538e-2f * z - 1.38776856032E-1f) * z + 1.99777106478E-1f) * z - 3.33329491539E-1f) * z * x + x;
+    return sign * y;
+}
+
+__device__ float live_sinf(float xx) {
+    if (xx != xx) return xx;
+    float sign = 1.0f, x = xx, y;
+    if (x < 0.0f) { sign = -1.0f; x = -x; }
+    if (x > 8192.0f) return 0.0f;
+    int j = (int)(1.27323954473516f * x);
+    y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    if (j > 3) { sign = -sign; j -= 4; }
+    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = x * x;
+    if (j == 1 || j == 2) {
+        y = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z;
+        y -= 0.5f * z;
+        y += 1.0f;
+    } else {
+        y = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * x;
+        y += x;
+    }
+    return sign * y;
+}
+
+// ---- FillBeyerQueueJob + FlowMaster.CreateRandomParticles ----------------------------------------------------------
+__device__ __forceinline__ uint32_t rnd_next_state(uint32_t &s) {  // Unity.Mathematics.Random.NextState
+    uint32_t t = s;
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return t;
+}
+
+__global__ void fill_queue_kernel(int32_t *hdr, nz_particle *data, int generationRound, int res, int maxParticles,
+                                  int seed, int concurrency) {
+    __shared__ int s_current, s_count;
+    if (threadIdx.x == 0) {
+        int current = hdr[0];
+        int required = maxParticles - current;
+        if (required < 1) required = 1;
+        int COUNT = required / concurrency;
+        if (COUNT < 1) COUNT = 1;
+        if (current + concurrency * COUNT > hdr[1]) {  // the reference's queue grows; this one reports
+            hdr[2] = 1;
+            COUNT = 0;
+        }
+        s_current = current;
+        s_count = COUNT;
+    }
+    __syncthreads();
+    const int i = threadIdx.x, COUNT = s_count;
+    if (i < concurrency) {
+        uint32_t st = (uint32_t)(seed + i);
+        (void)rnd_next_state(st);  // Random(uint seed): state = seed; NextState()
+        uint16_t pid = (uint16_t)(generationRound * maxParticles);
+        for (int k = 0; k < COUNT; k++) {
+            pid = (uint16_t)(pid + (uint16_t)((i * COUNT) + k));
+            nz_particle p;
+            p.px = (int)(((uint64_t)rnd_next_state(st) * (uint64_t)(uint32_t)res) >> 32);
+            p.pz = (int)(((uint64_t)rnd_next_state(st) * (uint64_t)(uint32_t)res) >> 32);
+            p.water = 1.0f;
+            p.pid = pid;
+            data[s_current + i * COUNT + k] = p;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) hdr[0] = s_current + concurrency * COUNT;
+}
+
+// ---- Heading (LiveErosionDataTypes.cs:1297-1444) ---------------------------------------------------------------------
+enum { H_N = 1, H_S = 2, H_E = 4, H_W = 8, H_NONE = 0 };
+__device__ __forceinline__ int heading_from(float dx, float dz) {
+    int b = 0;
+    if (dx > 0.0f) b |= H_E; else if (dx < 0.0f) b |= H_W;
+    if (dz > 0.0f) b |= H_N; else if (dz < 0.0f) b |= H_S;
+    return b;
+}
+// nb[] / WTORDER index of a heading (N, E, S, W, NE, SE, SW, NW), -1 for NONE
+__device__ __forceinline__ int heading_wt_idx(int h) {
+    switch (h) {
+        case 1: return 0;   // N
+        case 4: return 1;   // E
+        case 2: return 2;   // S
+        case 8: return 3;   // W
+        case 5: return 4;   // NE
+        case 6: return 5;   // SE
+        case 10: return 6;  // SW
+        case 9: return 7;   // NW
+    }
+    return -1;
+}
+// position in ADJACENT (N, NE, E, SE, S, SW, W, NW) and back
+__device__ __forceinline__ int heading_adj_idx(int h) {
+    switch (h) {
+        case 1: return 0;
+        case 5: return 1;
+        case 4: return 2;
+        case 6: return 3;
+        case 2: return 4;
+        case 10: return 5;
+        case 8: return 6;
+        case 9: return 7;
+    }
+    return 8;
+}
+__device__ __forceinline__ int adj_heading(int i) {
+    const int A[8] = {1, 5, 4, 6, 2, 10, 8, 9};
+    return A[i & 7];
+}
+
+__device__ __forceinline__ long long to_fix(float v) {
+    if (!(fabsf(v) < 4194304.0f)) return 0;  // NaN, inf and anything beyond 2^22 is dropped
+    return __double2ll_rn((double)v * FIX_SCALE);
+}
+__device__ __forceinline__ float from_fix(unsigned long long a) { return (float)((double)(long long)a * (1.0 / FIX_SCALE)); }
+
+struct live_planes {
+    const float *height, *pool, *flow;
+    unsigned long long *acc;
+    int32_t *touched, *list, *counters;
+    int list_slot;
+    size_t n;
+};
+
+__device__ __forceinline__ void emit(const live_planes &P, int idx, float dTrack, float dPool, float dSed) {
+    long long a = to_fix(dPool), b = to_fix(dTrack), c = to_fix(dSed);
+    if (atomicAdd(&P.touched[idx], 1) == 0) P.list[atomicAdd(&P.counters[P.list_slot], 1)] = idx;
+    if (a) atomicAdd(&P.acc[idx], (unsigned long long)a);
+    if (b) atomicAdd(&P.acc[P.n + idx], (unsigned long long)b);
+    if (c) atomicAdd(&P.acc[2 * P.n + idx], (unsigned long long)c);
+}
+
+// BeyerParticle.DescendSimultaneous (LiveErosionDataTypes.cs:273-432), repeated until the particle is dead
+// (FlowMaster.BeyerSimultaneousDescentSingle, LiveErosionComponents.cs:79-91).  The planes are read only.
+__global__ __launch_bounds__(64) void descent_kernel(live_planes P, const int32_t *hdr, const nz_particle *particles,
+                                                    nz_erosion_params ep, int res, float HEIGHT, float patchRes) {
+    const int pi = blockIdx.x * 64 + threadIdx.x;
+    const int n = min(hdr[0], hdr[1]);
+    if (pi >= n) return;
+    const int NBDX[8] = {0, 1, 0, -1, 1, 1, -1, -1}, NBDZ[8] = {1, 0, -1, 0, 1, -1, -1, 1};
+    const nz_particle src = particles[pi];
+    float posx = (float)src.px, posz = (float)src.pz, dirx = 0.0f, dirz = 0.0f;
+    float vel = .01f, water = src.water, sediment = 0.0f;
+    int age = 0, events = 0;
+    // every path of the loop either returns or ages the particle, and age >= MAXAGE returns: the bound below only
+    // matters for MAXAGE beyond it (a particle that old is cut off, on the oracle's side too by construction of the tests)
+    for (;;) {
+        events++;
+        const int ix = (int)rintf(posx), iz = (int)rintf(posz);
+        const int idx = ix * res + iz;
+        float eTrack = 0.0f, ePool = 0.0f, eSed = 0.0f;
+        int heading = heading_from(dirx, dirz);
+        if (water < .01f) {
+            eSed = sediment / HEIGHT;
+            emit(P, idx, eTrack, ePool, eSed);
+            break;
+        }
+        if (age >= ep.MAXAGE) {
+            ePool = water / HEIGHT;
+            eSed = sediment / HEIGHT;
+            emit(P, idx, eTrack, ePool, eSed);
+            break;
+        }
+        const int sidx = clampi((int)posx, 0, res - 1) * res + clampi((int)posz, 0, res - 1);
+        const float currentHeight = HEIGHT * (P.height[sidx] + P.pool[sidx]);
+        int nb[8];
+        int hmin = 0x7fffffff, kmin = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int ni = clampi(ix + NBDX[k], 0, res - 1) * res + clampi(iz + NBDZ[k], 0, res - 1);
+            const float all = HEIGHT * (P.height[ni] + P.pool[ni]) + ep.FLOW_HEIGHT_CONTRIBUTION * (P.flow[ni]);
+            nb[k] = (int)(100.0f * all);
+            if (nb[k] < hmin) { hmin = nb[k]; kmin = k; }  // nbSort[0] and its first index (IndexOf)
+        }
+        const float drainHeight = (float)hmin / 100.0f;
+        int drainDx = NBDX[kmin], drainDz = NBDZ[kmin];
+        if (heading == H_NONE) heading = heading_from((float)drainDx, (float)drainDz);
+        const float fl = lmaxf(P.flow[idx], 0.0f);
+        const float effectiveDrag = ep.DRAG * (1.0f - fl);
+        const float effectiveFriction = ep.FRICTION * (1.0f - fl);
+        const int ai = heading_adj_idx(heading);
+        const int hl = adj_heading(ai + 7), hr = adj_heading(ai + 1);
+        const int wl = heading_wt_idx(hl), wc = heading_wt_idx(heading), wr = heading_wt_idx(hr);
+        if (ai >= 8 || wl < 0 || wc < 0 || wr < 0) break;  // unreachable: the drain direction is never (0, 0)
+        float hx = 0.0f, hy = 0.0f, hz = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {  // nb[] stays in registers: select, do not index
+            const float v = (float)nb[k] / 100.0f;
+            hx = (k == wl) ? v : hx;
+            hy = (k == wc) ? v : hy;
+            hz = (k == wr) ? v : hz;
+        }
+        float headingHeight;
+        int flowH;
+        if (hx < hy && hx < hz) { headingHeight = hx; flowH = hl; }
+        else if (hz < hx && hz < hy) { headingHeight = hz; flowH = hr; }
+        else { headingHeight = hy; flowH = heading; }
+        const int flowDx = ((flowH >> 2) & 1) ? 1 : (((flowH >> 3) & 1) ? -1 : 0);
+        const int flowDz = ((flowH >> 0) & 1) ? 1 : (((flowH >> 1) & 1) ? -1 : 0);
+        float hDiff = headingHeight - currentHeight;
+        float velocityLoss = 0.0f;
+        vel = vel - (vel * effectiveDrag);
+        bool uphillOk = false;
+        if (!(hDiff < 0.0f)) {  // UphillVelocityLoss :253-260
+            const float theta = live_atanf(hDiff / patchRes);
+            const float st = live_sinf(theta);
+            const float acceleration = (ep.GRAVITY * st) + effectiveFriction;
+            velocityLoss = sqrtf(2.0f * fabsf(acceleration) * (hDiff / st));
+            uphillOk = velocityLoss <= vel;
+        }
+        if (hDiff < 0.0f || uphillOk) {
+            drainDx = flowDx;
+            drainDz = flowDz;
+        } else {
+            velocityLoss = 0.0f;
+            hDiff = drainHeight - currentHeight;
+            if (hDiff > 0.0f) {
+                ePool = water / HEIGHT;
+                eSed = sediment / HEIGHT;
+                emit(P, idx, eTrack, ePool, eSed);
+                break;
+            }
+        }
+        dirx = (float)drainDx;
+        dirz = (float)drainDz;
+        const float pnx = posx + dirx, pnz = posz + dirz;
+        if ((int)pnx < 0 || (int)pnz < 0 || (int)pnx >= res || (int)pnz >= res) {
+            emit(P, idx, eTrack, ePool, eSed);
+            break;
+        }
+        const float vDiff = fabsf(hDiff);
+        float thetaD = 0.0f, deltaV = 0.0f;
+        if (vDiff > 0.0f) {
+            const float theta = live_atanf(vDiff / patchRes);
+            thetaD = theta * 180.0f / 3.14159f;
+            if (hDiff > 0.0f) {
+                deltaV = -1.0f * velocityLoss;
+            } else {  // DownhillVelocityGain :262-270
+                const float st = live_sinf(theta);
+                const float acceleration = (ep.GRAVITY * st) - effectiveFriction;
+                deltaV = sqrtf(2.0f * fabsf(acceleration) * (vDiff / st));
+            }
+        }
+        vel = lmaxf((vel + deltaV), 0.0f);
+        const float over = vel - ep.TERMINAL_VELOCITY;
+        vel = vel - lmaxf(lminf(over, lmaxf(effectiveDrag * 0.25f * over * over, 0.0f)), 0.0f);
+        if (thetaD < 3.0f && vel < 1.0f) {
+            ePool += water / HEIGHT;
+            eSed += sediment / HEIGHT;
+            emit(P, idx, eTrack, ePool, eSed);
+            break;
+        }
+        const float currentCapacity = vel * water * ep.CAPACITY;
+        float depositionAmount;
+        if (sediment < currentCapacity) depositionAmount = -1.0f * ep.EROSION * (currentCapacity - sediment);
+        else depositionAmount = ep.DEPOSITION * (sediment - currentCapacity);
+        if (fabsf(depositionAmount) > 0.0f) {
+            eSed += depositionAmount / HEIGHT;
+            sediment -= depositionAmount;
+        }
+        eTrack = water;
+        water = water * (1 - ep.EVAP);
+        posx = pnx;
+        posz = pnz;
+        age++;
+        emit(P, idx, eTrack, ePool, eSed);
+    }
+    atomicAdd(&P.counters[3], events);
+}
+
+// ProcessBeyerErosiveEventsJob + CombineBeyerEvents / HandleBeyerEvent (MultiThreadErosionJob.cs:330-385,
+// LiveErosionComponents.cs:93-110), over the cells that received an event; first the sediment plane forgets the
+// previous cycle's events.
+__global__ __launch_bounds__(CT) void forget_kernel(float *sediment, const int32_t *list, const int32_t *counters, int slot) {
+    const int n = counters[slot];
+    for (int i = blockIdx.x * CT + threadIdx.x; i < n; i += gridDim.x * CT) sediment[list[i]] = 0.0f;
+}
+
+__global__ __launch_bounds__(CT) void process_events_kernel(float *pool, float *track, float *sediment, int32_t *piles,
+                                                           unsigned long long *acc, int32_t *touched, const int32_t *list,
+                                                           int32_t *counters, int slot, size_t ncell, float poolMul,
+                                                           float trackMul, float pileThreshold) {
+    const int n = counters[slot];
+    for (int i = blockIdx.x * CT + threadIdx.x; i < n; i += gridDim.x * CT) {
+        const int idx = list[i];
+        const float poolV = from_fix(acc[idx]), trackV = from_fix(acc[ncell + idx]), sedimentV = from_fix(acc[2 * ncell + idx]);
+        if (fabsf(poolV) > 0.0f) {  // Place :181-185
+            float last = pool[idx];
+            last += poolV * poolMul;
+            pool[idx] = last;
+        }
+        if (fabsf(trackV) > 0.0f) {
+            float last = track[idx];
+            last += trackV * trackMul;
+            track[idx] = last;
+        }
+        sediment[idx] = sedimentV;
+        // WriteSedimentMap :118-128: negative or small events are dispersed, the others piled (NaN: piled, a no-op)
+        if (sedimentV != 0.0f && !(sedimentV < 0.0f || sedimentV <= pileThreshold)) piles[atomicAdd(&counters[2], 1)] = idx;
+        acc[idx] = 0;
+        acc[ncell + idx] = 0;
+        acc[2 * ncell + idx] = 0;
+        touched[idx] = 0;
+    }
+}
+
+// FlowMaster.KernelDisperse (LiveErosionComponents.cs:130-157) for every dispersed event at once, as a gather.
+__constant__ float KERNEL5[5] = {0.12007838424321349f, 0.23388075658535032f, 0.29208171834287244f, 0.23388075658535032f,
+                                 0.12007838424321349f};
+
+__global__ __launch_bounds__(CT) void disperse_kernel(const float *__restrict__ height, float *__restrict__ out,
+                                                     const float *__restrict__ sediment, int res, float pileThreshold) {
+    // z is the fast index of the planes: consecutive lanes take consecutive z of one x
+    const int tz = blockIdx.x * CT + threadIdx.x, tx = blockIdx.y;
+    if (tz >= res) return;
+    float v = height[(size_t)tx * res + tz];
+    const int x0 = max(tx - 2, 0), x1 = min(tx + 2, res - 1), z0 = max(tz - 2, 0), z1 = min(tz + 2, res - 1);
+    const bool border = tx < 2 || tz < 2 || tx >= res - 2 || tz >= res - 2;
+    for (int sz = z0; sz <= z1; sz++)
+        for (int sx = x0; sx <= x1; sx++) {
+            const float val = sediment[(size_t)sx * res + sz];
+            if (val == 0.0f || !(val < 0.0f || val <= pileThreshold)) continue;
+            if (!border) {  // exactly one kernel tap of this source lands here
+                const float newDiff = ((val * (KERNEL5[tx - sx + 2] * KERNEL5[tz - sz + 2])) / 1.0f);
+                const float nextV = v + newDiff;
+                if (!(nextV > 1.0f) && !(nextV < 0.0f)) v = v + newDiff;
+            } else {
+                for (int kx = 0; kx < 5; kx++)
+                    for (int kz = 0; kz < 5; kz++) {
+                        if (clampi(sx - 2 + kx, 0, res - 1) != tx || clampi(sz - 2 + kz, 0, res - 1) != tz) continue;
+                        const float newDiff = ((val * (KERNEL5[kx] * KERNEL5[kz])) / 1.0f);
+                        const float nextV = v + newDiff;
+                        if (nextV > 1.0f) continue;
+                        if (nextV < 0.0f) continue;
+                        v = v + newDiff;
+                    }
+            }
+        }
+    out[(size_t)tx * res + tz] = v;
+}
+
+// PileSolver (LiveErosionDataTypes.cs:1053-1225): the piled events in canonical order, sequentially (they read and write
+// overlapping height cells).  One workgroup: a rank sort of the pile list by (z, x), then lane 0 walks it.
+struct mvert {
+    int idx;
+    float val;
+    short ox, oz;
+    unsigned char modified, valid;
+};
+
+__global__ __launch_bounds__(CT) void pile_kernel(float *height, const float *sediment, const int32_t *piles,
+                                                 int32_t *sorted, int32_t *counters, mvert *verts, int nverts, int res,
+                                                 int maxDistance, float increment) {
+    const int n = counters[2];
+    for (int i = threadIdx.x; i < n; i += CT) {
+        const int idx = piles[i];
+        const long long key = (long long)(idx % res) * res + idx / res;  // job z, then x
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            const int o = piles[j];
+            rank += ((long long)(o % res) * res + o / res) < key;
+        }
+        sorted[rank] = idx;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int e = 0; e < n; e++) {
+        const int cell = sorted[e];
+        const int px = cell / res, pz = cell % res;
+        const float amount = sediment[cell];
+        for (int i = 0; i < nverts; i++) {  // SetPile
+            const int x = px + verts[i].ox, z = pz + verts[i].oz;
+            if (x < 0 || z < 0 || x >= res || z >= res) { verts[i].valid = 0; continue; }
+            verts[i].valid = 1;
+            verts[i].modified = 0;
+            verts[i].idx = x * res + z;
+            verts[i].val = height[verts[i].idx];
+        }
+        float remaining = amount;
+        for (int guard = 0; remaining > 0.0f && increment > 0.0f && guard < 4096; guard++) {  // HandlePile / DepositSediment
+            const float amt = remaining;
+            float deposited = 0.0f, rem = amt;
+            bool done = false;
+            for (int round = 1; round <= maxDistance && !done; round++) {
+                const float level = verts[0].val + (increment * (float)round);
+                int c = -1;
+                for (int dist = 0; dist < round && !done; dist++)
+                    for (int dir = 0; dir < 4 && !done; dir++)
+                        for (int i = 0; i <= dist + 1; i++) {
+                            c++;
+                            mvert &t = verts[c];
+                            if (!t.valid) continue;
+                            if (!(t.val < level)) continue;
+                            const float inc = lminf(increment, rem);
+                            t.modified = 1;
+                            t.val += inc;
+                            deposited += inc;
+                            rem = amt - deposited;
+                            if (rem <= 0.0f) { done = true; break; }
+                        }
+            }
+            remaining = done ? 0.0f : rem;
+        }
+        for (int i = 0; i < nverts; i++)  // CommitChanges
+            if (verts[i].valid && verts[i].modified) height[verts[i].idx] = verts[i].val;
+    }
+    counters[2] = 0;
+}
+
+// WorldTile.Curviture (LiveErosionDataTypes.cs:726-866) + CurvitureMapJob (MultiThreadErosionJob.cs:387-436)
+__global__ __launch_bounds__(CT) void curviture_kernel(unsigned char *texture, int channel, const float *__restrict__ height,
+                                                      int res, int meshRes, int offset, float HEIGHT, float w) {
+    const int x = blockIdx.x * CT + threadIdx.x, z = blockIdx.y;
+    if (x >= meshRes) return;
+    const int cx = z + offset, cz = x + offset;  // pos = (srcZ, x + offset)
+    auto HH = [&](int dx, int dz) {
+        return height[(size_t)clampi(cx + dx, 0, res - 1) * res + clampi(cz + dz, 0, res - 1)] * HEIGHT;
+    };
+    const float w2 = w * w;
+    const float z1x = HH(-1, 1), z1y = HH(0, 1), z1z = HH(1, 1), z1w = HH(-1, 0);
+    const float z5 = height[(size_t)cx * res + cz] * HEIGHT;
+    const float z6x = HH(1, 0), z6y = HH(-1, -1), z6z = HH(0, -1), z6w = HH(1, -1);
+    const float zx = (z1z + z6x + z6w - z1x - z1w - z6y) / (6.0f * w);
+    const float zy = (z1x + z1y + z1z - z6y - z6z - z6w) / (6.0f * w);
+    const float zxx = (z1x + z1z + z1w + z6x + z6y + z6w - 2.0f * (z1y + z5 + z6z)) / (3.0f * w2);
+    const float zyy = (z1x + z1y + z1z + z6y + z6z + z6w - 2.0f + (z1w + z5 + z6x)) / (3.0f * w2);  // `- 2.0f +` as written
+    const float zxy = (z1z + z6y - z1x - z6w) / (4.0f * w2);
+    const float dzx = -zx, dzy = -zy, dxx = -zxx, dyy = -zyy, dxy = -zxy;
+    const float zx2 = dzx * dzx, zy2 = dzy * dzy, p = zx2 + zy2;
+    const float nn = zy2 * dxx - 2.0f * dxy * dzx * dzy + zx2 * dyy;
+    const float d = p * powf(p + 1.0f, 0.5f);
+    float v = fabsf(d) < 1e-18f ? 0.0f : nn / d;
+    v = fabsf(v);
+    const float sign_ = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+    const float log_ = logf(1.0f + powf(10.0f, .05f) * fabsf(v));
+    const float r = fabsf(sign_ * log_) / 2.0f;
+    texture[((size_t)z * meshRes + x) * 4 + channel] = (unsigned char)(lmaxf(0.0f, lminf(1.0f, r)) * 255.0f);
+}
+
+__global__ __launch_bounds__(CT) void set_rgba32_kernel(unsigned char *texture, int channel, const float *__restrict__ src,
+                                                       int dataRes, int meshRes, int offset, float scale) {
+    const int x = blockIdx.x * CT + threadIdx.x, z = blockIdx.y;
+    if (x >= meshRes) return;
+    const float c = lmaxf(0.0f, lminf(1.0f, src[(size_t)(z + offset) * dataRes + x + offset] * scale));
+    texture[((size_t)z * meshRes + x) * 4 + channel] = (unsigned char)(c * 255.0f);
+}
+
+}  // namespace
+
+#define NZ_BEGIN(ctx, dep)                   \
+    do {                                     \
+        int32_t rc_ = nz_ctx_begin(ctx, dep); \
+        if (rc_) return rc_;                 \
+    } while (0)
+
+static int32_t check_live(const nz_erosion_params *ep, const nz_tile_set_meta *tm, int32_t res) {
+    NZ_REQUIRE(ep && tm, "ep / tm is NULL");
+    NZ_REQUIRE(res >= 2 && res <= 32768, "resolution %d out of range [2,32768]", res);
+    NZ_REQUIRE(tm->GENERATOR_RES[0] == res && tm->GENERATOR_RES[1] == res, "tm.GENERATOR_RES (%d, %d) is not the plane's resolution %d",
+               tm->GENERATOR_RES[0], tm->GENERATOR_RES[1], res);
+    NZ_REQUIRE(tm->HEIGHT != 0, "tm.HEIGHT is 0");
+    return NZ_OK;
+}
+
+// ---- containers --------------------------------------------------------------------------------------------------------
+extern "C" int32_t nz_particle_queue_create(nz_ctx *ctx, int32_t capacity, nz_particle_queue **out) {
+    NZ_REQUIRE(ctx && out && capacity >= 1, "ctx/out is NULL or capacity < 1");
+    NZ_HIP(hipSetDevice(ctx->device));
+    nz_particle_queue *q = new nz_particle_queue();
+    q->capacity = capacity;
+    if (hipMalloc((void **)&q->hdr, 16) != hipSuccess || hipMalloc((void **)&q->data, (size_t)capacity * sizeof(nz_particle)) != hipSuccess) {
+        if (q->hdr) (void)hipFree(q->hdr);
+        delete q;
+        nz_set_error("hipMalloc of a %d-particle queue failed", capacity);
+        return NZ_ERR_NOMEM;
+    }
+    int32_t hdr[4] = {0, capacity, 0, 0};
+    NZ_HIP(hipMemcpy(q->hdr, hdr, sizeof hdr, hipMemcpyHostToDevice));
+    *out = q;
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_particle_queue_destroy(nz_ctx *ctx, nz_particle_queue *q) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    if (!q) return NZ_OK;
+    NZ_HIP(hipSetDevice(ctx->device));
+    NZ_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(q->hdr);
+    (void)hipFree(q->data);
+    delete q;
+    return NZ_OK;
+}
+
+// NativeQueue.Count (host synchronises with the ctx's stream); NZ_ERR_NOMEM if a job found the queue too small
+extern "C" int32_t nz_particle_queue_count(nz_ctx *ctx, nz_particle_queue *q, int32_t *count) {
+    NZ_REQUIRE(ctx && q && count, "ctx/queue/count is NULL");
+    NZ_HIP(hipSetDevice(ctx->device));
+    int32_t hdr[4];
+    NZ_HIP(hipMemcpyAsync(hdr, q->hdr, sizeof hdr, hipMemcpyDeviceToHost, ctx->stream));
+    NZ_HIP(hipStreamSynchronize(ctx->stream));
+    *count = hdr[0] < hdr[1] ? hdr[0] : hdr[1];
+    if (hdr[2] || hdr[0] > hdr[1]) {
+        nz_set_error("particle queue overflow: capacity %d, %d wanted", hdr[1], hdr[0]);
+        return NZ_ERR_NOMEM;
+    }
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_particle_queue_download(nz_ctx *ctx, nz_particle_queue *q, nz_particle *host, int32_t max_count,
+                                              int32_t *count) {
+    int32_t n = 0;
+    int32_t rc = nz_particle_queue_count(ctx, q, &n);
+    if (rc) return rc;
+    if (n > max_count) n = max_count;
+    if (n > 0) NZ_HIP(hipMemcpy(host, q->data, (size_t)n * sizeof(nz_particle), hipMemcpyDeviceToHost));
+    if (count) *count = n;
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_particle_queue_upload(nz_ctx *ctx, nz_particle_queue *q, const nz_particle *host, int32_t count) {
+    NZ_REQUIRE(ctx && q && (host || count == 0) && count >= 0 && count <= q->capacity, "bad queue upload");
+    NZ_HIP(hipSetDevice(ctx->device));
+    NZ_HIP(hipStreamSynchronize(ctx->stream));
+    if (count) NZ_HIP(hipMemcpy(q->data, host, (size_t)count * sizeof(nz_particle), hipMemcpyHostToDevice));
+    int32_t hdr[4] = {count, q->capacity, 0, 0};
+    NZ_HIP(hipMemcpy(q->hdr, hdr, sizeof hdr, hipMemcpyHostToDevice));
+    return NZ_OK;
+}
+
+// ClearQueueJob<BeyerParticle>.ScheduleRun(queue, deps), MultiThreadErosionJob.cs:133-153
+extern "C" int32_t nz_clear_particle_queue(nz_ctx *ctx, nz_particle_queue *q, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(q, "queue is NULL");
+    NZ_HIP(hipMemsetAsync(q->hdr, 0, 4, ctx->stream));
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_erosive_events_create(nz_ctx *ctx, int32_t resolution, nz_erosive_events **out) {
+    NZ_REQUIRE(ctx && out && resolution >= 2 && resolution <= 32768, "ctx/out is NULL or resolution out of range");
+    NZ_HIP(hipSetDevice(ctx->device));
+    nz_erosive_events *ev = new nz_erosive_events();
+    ev->res = resolution;
+    const size_t n = (size_t)resolution * resolution;
+    bool ok = hipMalloc((void **)&ev->acc, 3 * n * 8) == hipSuccess && hipMalloc((void **)&ev->touched, n * 4) == hipSuccess &&
+              hipMalloc((void **)&ev->list[0], n * 4) == hipSuccess && hipMalloc((void **)&ev->list[1], n * 4) == hipSuccess &&
+              hipMalloc((void **)&ev->counters, 16) == hipSuccess && hipMalloc((void **)&ev->sediment, n * 4) == hipSuccess &&
+              hipMalloc((void **)&ev->piles, 2 * n * 4) == hipSuccess;
+    if (ok) ok = hipMemset(ev->acc, 0, 3 * n * 8) == hipSuccess && hipMemset(ev->touched, 0, n * 4) == hipSuccess &&
+                 hipMemset(ev->counters, 0, 16) == hipSuccess && hipMemset(ev->sediment, 0, n * 4) == hipSuccess;
+    if (!ok) {
+        void *ps[] = {ev->acc, ev->touched, ev->list[0], ev->list[1], ev->counters, ev->sediment, ev->piles};
+        for (void *p : ps)
+            if (p) (void)hipFree(p);
+        delete ev;
+        (void)hipGetLastError();
+        nz_set_error("hipMalloc of the event planes (%d^2 cells x 40 bytes) failed", resolution);
+        return NZ_ERR_NOMEM;
+    }
+    *out = ev;
+    return NZ_OK;
+}
+
+extern "C" int32_t nz_erosive_events_destroy(nz_ctx *ctx, nz_erosive_events *ev) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    if (!ev) return NZ_OK;
+    NZ_HIP(hipSetDevice(ctx->device));
+    NZ_HIP(hipStreamSynchronize(ctx->stream));
+    void *ps[] = {ev->acc, ev->touched, ev->list[0], ev->list[1], ev->counters, ev->sediment, ev->piles, ev->pile_scratch};
+    for (void *p : ps)
+        if (p) (void)hipFree(p);
+    delete ev;
+    return NZ_OK;
+}
+
+extern "C" float *nz_erosive_events_sediment(nz_erosive_events *ev) { return ev ? ev->sediment : nullptr; }
+
+// events of the last nz_queued_beyer_cycle (host synchronises)
+extern "C" int32_t nz_erosive_events_count(nz_ctx *ctx, nz_erosive_events *ev, int32_t *events) {
+    NZ_REQUIRE(ctx && ev && events, "ctx/events is NULL");
+    NZ_HIP(hipSetDevice(ctx->device));
+    int32_t c[4];
+    NZ_HIP(hipMemcpyAsync(c, ev->counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    NZ_HIP(hipStreamSynchronize(ctx->stream));
+    *events = c[3];
+    return NZ_OK;
+}
+
+// ---- jobs --------------------------------------------------------------------------------------------------------------
+extern "C" int32_t nz_fill_beyer_queue(nz_ctx *ctx, nz_particle_queue *particles, const nz_erosion_params *ep,
+                                       const nz_tile_set_meta *tm, int32_t generationRound, int32_t res,
+                                       int32_t maxParticles, int32_t seed, int32_t concurrency, nz_handle dep,
+                                       nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(particles, "particles is NULL");
+    if (int32_t rc = check_live(ep, tm, res)) return rc;
+    NZ_REQUIRE(concurrency >= 1 && concurrency <= 1024 && maxParticles >= 0, "concurrency %d out of range [1,1024] or maxParticles < 0",
+               concurrency);
+    hipLaunchKernelGGL(fill_queue_kernel, dim3(1), dim3((unsigned)((concurrency + 63) / 64 * 64)), 0, ctx->stream, particles->hdr,
+                       particles->data, generationRound, res, maxParticles, seed, concurrency);
+    NZ_HIP(hipGetLastError());
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_queued_beyer_cycle(nz_ctx *ctx, const float *height, const float *pool, const float *flow,
+                                         const float *track, nz_particle_queue *particles, nz_erosive_events *events,
+                                         const nz_erosion_params *ep, const nz_tile_set_meta *tm, int32_t eventLimit,
+                                         int32_t res, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    (void)track;       // the job's WorldTile carries it; the descent never reads it
+    (void)eventLimit;  // unused by the reference job as well (:205)
+    NZ_REQUIRE(height && pool && flow && particles && events, "a plane / the queue / the events is NULL");
+    if (int32_t rc = check_live(ep, tm, res)) return rc;
+    NZ_REQUIRE(events->res == res, "events were created for resolution %d", events->res);
+    live_planes P{height, pool, flow, events->acc, events->touched, events->list[events->cur], events->counters, events->cur,
+                  (size_t)res * res};
+    NZ_HIP(hipMemsetAsync(events->counters + 3, 0, 4, ctx->stream));
+    const unsigned blocks = (unsigned)((particles->capacity + 63) / 64);  // the count lives on the device: lanes beyond it leave
+    hipLaunchKernelGGL(descent_kernel, dim3(blocks), dim3(64), 0, ctx->stream, P, particles->hdr, particles->data, *ep, res,
+                       (float)tm->HEIGHT, tm->PATCH_RES[0]);
+    NZ_HIP(hipGetLastError());
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_process_beyer_erosive_events(nz_ctx *ctx, float *height, float *pool, float *flow, float *track,
+                                                   nz_erosive_events *events, const nz_erosion_params *ep,
+                                                   const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    (void)height;
+    (void)flow;
+    NZ_REQUIRE(pool && track && events, "pool / track / events is NULL");
+    if (int32_t rc = check_live(ep, tm, res)) return rc;
+    NZ_REQUIRE(events->res == res, "events were created for resolution %d", events->res);
+    const int cur = events->cur, prev = cur ^ 1;
+    hipLaunchKernelGGL(forget_kernel, dim3(512), dim3(CT), 0, ctx->stream, events->sediment, events->list[prev], events->counters, prev);
+    NZ_HIP(hipMemsetAsync(events->counters + prev, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(process_events_kernel, dim3(512), dim3(CT), 0, ctx->stream, pool, track, events->sediment, events->piles,
+                       events->acc, events->touched, events->list[cur], events->counters, cur, (size_t)res * res,
+                       ep->POOL_PLACEMENT_MULTIPLIER, ep->TRACK_PLACEMENT_MULTIPLIER, ep->PILE_THRESHOLD / (float)tm->HEIGHT);
+    NZ_HIP(hipGetLastError());
+    events->cur = prev;  // the next cycle's events go to the other list; this one is forgotten then
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *events, const nz_erosion_params *ep,
+                                        const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(height && events, "height / events is NULL");
+    if (int32_t rc = check_live(ep, tm, res)) return rc;
+    NZ_REQUIRE(events->res == res, "events were created for resolution %d", events->res);
+    NZ_REQUIRE(ep->PILING_RADIUS >= 0 && ep->PILING_RADIUS <= 120, "PILING_RADIUS %d out of range [0,120]", ep->PILING_RADIUS);
+    const size_t n = (size_t)res * res;
+    float *tmp = nullptr;
+    NZ_TRY_(nz_ctx_scratch(ctx, n, &tmp));
+    const float thr = ep->PILE_THRESHOLD / (float)tm->HEIGHT;
+    hipLaunchKernelGGL(disperse_kernel, dim3((unsigned)((res + CT - 1) / CT), (unsigned)res), dim3(CT), 0, ctx->stream, height,
+                       tmp, events->sediment, res, thr);
+    NZ_HIP(hipGetLastError());
+    NZ_HIP(hipMemcpyAsync(height, tmp, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    // PileSolver.Init :1058-1098: vertex offsets (host), GetOffset = dist * dirA + i * (dirB - dirA)
+    const int D = ep->PILING_RADIUS;
+    if (D >= 1) {
+        std::vector<mvert> verts;
+        const int DAX[4] = {0, 1, 0, -1}, DAZ[4] = {1, 0, -1, 0}, DBX[4] = {1, 0, -1, 0}, DBZ[4] = {0, -1, 0, 1};
+        for (int dist = 0; dist < D; dist++)
+            for (int dir = 0; dir < 4; dir++)
+                for (int i = 0; i <= dist + 1; i++) {
+                    mvert v{};
+                    v.ox = (short)(dist * DAX[dir] + i * (DBX[dir] - DAX[dir]));
+                    v.oz = (short)(dist * DAZ[dir] + i * (DBZ[dir] - DAZ[dir]));
+                    verts.push_back(v);
+                }
+        const size_t bytes = verts.size() * sizeof(mvert);
+        if (bytes > events->pile_scratch_bytes) {
+            if (events->pile_scratch) {
+                NZ_HIP(hipStreamSynchronize(ctx->stream));
+                (void)hipFree(events->pile_scratch);
+                events->pile_scratch = nullptr;
+            }
+            NZ_HIP(hipMalloc(&events->pile_scratch, bytes));
+            events->pile_scratch_bytes = bytes;
+        }
+        NZ_HIP(hipMemcpyAsync(events->pile_scratch, verts.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        NZ_HIP(hipStreamSynchronize(ctx->stream));  // `verts` is pageable host memory
+        hipLaunchKernelGGL(pile_kernel, dim3(1), dim3(CT), 0, ctx->stream, height, events->sediment, events->piles,
+                           events->piles + n, events->counters, (mvert *)events->pile_scratch, (int)verts.size(), res, D,
+                           ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT);
+        NZ_HIP(hipGetLastError());
+    } else {
+        NZ_HIP(hipMemsetAsync(events->counters + 2, 0, 4, ctx->stream));
+    }
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_curviture_map(nz_ctx *ctx, uint8_t *texture, const float *height, const nz_tile_set_meta *tm,
+                                    int32_t target, int32_t res, int32_t meshRes, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(texture && height && tm, "texture / height / tm is NULL");
+    NZ_REQUIRE(res >= 2 && meshRes >= 1 && meshRes <= res && target >= 0 && target < 4, "bad resolution / channel");
+    hipLaunchKernelGGL(curviture_kernel, dim3((unsigned)((meshRes + CT - 1) / CT), (unsigned)meshRes), dim3(CT), 0, ctx->stream,
+                       texture, target, height, res, meshRes, (res - meshRes) / 2, (float)tm->HEIGHT, tm->PATCH_RES[0]);
+    NZ_HIP(hipGetLastError());
+    return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_set_rgba32(nz_ctx *ctx, const float *src, uint8_t *texture, int32_t target, int32_t dataRes,
+                                 int32_t meshRes, float scale, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(texture && src, "texture / src is NULL");
+    NZ_REQUIRE(dataRes >= 1 && meshRes >= 1 && meshRes <= dataRes && target >= 0 && target < 4, "bad resolution / channel");
+    hipLaunchKernelGGL(set_rgba32_kernel, dim3((unsigned)((meshRes + CT - 1) / CT), (unsigned)meshRes), dim3(CT), 0, ctx->stream,
+                       texture, target, src, dataRes, meshRes, (dataRes - meshRes) / 2, scale);
+    NZ_HIP(hipGetLastError());
+    return nz_ctx_finish(ctx, out);
+}
+
+// the queue's device pieces, for PoolAutomataJob's drain (nz_stages.cpp)
+int32_t *nz_particle_queue_hdr(nz_particle_queue *q) { return q ? q->hdr : nullptr; }
+nz_particle *nz_particle_queue_data(nz_particle_queue *q) { return q ? q->data : nullptr; }

@@ -964,6 +964,26 @@ extern "C" int32_t nz_pool_automata(nz_ctx *ctx, float *pool, const float *heigh
     return nz_ctx_finish(ctx, out);
 }
 
+// PoolAutomataJob.Schedule with its whole argument list (:289-325); drainParticles feeds the particle queue
+extern "C" int32_t nz_pool_automata_job(nz_ctx *ctx, float *pool, const float *height, nz_particle_queue *particleQueue,
+                                        const nz_erosion_params *ep, const nz_tile_set_meta *tm, int32_t iterations,
+                                        int32_t res, int32_t drainParticles, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    (void)ep;
+    (void)tm;
+    NZ_TRY(check_res(res));
+    NZ_REQUIRE(pool && height && pool != height, "pool/height must be two distinct planes");
+    NZ_REQUIRE(res >= 2 && iterations >= 0, "resolution < 2 or iterations < 0");
+    NZ_REQUIRE(!drainParticles || particleQueue, "drainParticles needs a particle queue");
+    int32_t *hdr = drainParticles ? nz_particle_queue_hdr(particleQueue) : nullptr;
+    nz_particle *data = drainParticles ? nz_particle_queue_data(particleQueue) : nullptr;
+    for (int i = 0; i < iterations; i++)
+        for (int xoff = 0; xoff < 2; xoff++)
+            for (int zoff = 0; zoff < 2; zoff++)
+                NZ_TRY(nz_launch_pool_automata_pass(ctx->stream, pool, height, res, xoff, zoff, hdr, data));
+    return nz_ctx_finish(ctx, out);
+}
+
 // CropJobDelegate, Filter/Sample/CropJob.cs:62-68
 extern "C" int32_t nz_crop_job(nz_ctx *ctx, const float *input, int32_t inputResolution, float *output,
                                int32_t outputResolution, nz_handle dep, nz_handle *out) {

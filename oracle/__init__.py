@@ -26,7 +26,7 @@ MESH_SQUARE, MESH_OVERSHOOT = 0, 1
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, n) for n in ("noize_oracle.c", "noize_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, n) for n in ("noize_oracle.c", "noize_oracle_live.c", "noize_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libnoize_oracle.so"],
@@ -84,6 +84,20 @@ def lib():
         L.nzo_pool_automata.argtypes = [f32p, f32p, i, i]
         L.nzo_thermal_erosion.argtypes = [f32p, i, f, f, f, i]
         L.nzo_pipeline.argtypes = [f32p, f32p, i, i, i, f, f, f, f, i, i, i, i, i, i, i, f, f, i]
+        # live erosion, particle half (noize_oracle_live.c)
+        ip, llp, vp = C.POINTER(i), C.POINTER(C.c_longlong), C.c_void_p
+        for n in ("nzo_live_atanf", "nzo_live_sinf"):
+            getattr(L, n).argtypes = [f]
+            getattr(L, n).restype = f
+        L.nzo_live_from_fix.argtypes = [C.c_longlong]
+        L.nzo_live_from_fix.restype = f
+        L.nzo_fill_beyer_queue.argtypes = [vp, ip, i, i, i, i, i, i]
+        L.nzo_beyer_descent.argtypes = [f32p, f32p, f32p, i, vp, i, vp, i, f, llp, llp, llp, ip]
+        L.nzo_process_beyer_events.argtypes = [f32p, f32p, f32p, i, vp, llp, llp, llp, ip]
+        L.nzo_erode_height_maps.argtypes = [f32p, f32p, i, vp, i]
+        L.nzo_pool_automata_drain.argtypes = [f32p, f32p, i, i, vp, ip, i]
+        L.nzo_curviture_map.argtypes = [vp, i, f32p, i, i, i, f]
+        L.nzo_set_rgba32.argtypes = [vp, i, f32p, i, i, f]
         # the GPU box grants a CPU share, not the whole host: size the OpenMP team to the affinity mask
         try:
             ncpu = len(os.sched_getaffinity(0))
@@ -373,3 +387,123 @@ def thermal_erosion(a, talus=45.0, increment=0.5, ratio=0.75, iterations=1):
     assert a.shape[0] == a.shape[1]
     lib().nzo_thermal_erosion(_p(a), a.shape[0], talus, increment, ratio, iterations)
     return a
+
+
+# ---- live erosion, particle half (BASELINE config 4; oracle/noize_oracle_live.c) ---------------------------------
+PARTICLE_DTYPE = np.dtype([("px", np.int32), ("pz", np.int32), ("water", np.float32), ("pid", np.uint32)])
+EROSION_PARAMS_DTYPE = np.dtype([(n, np.float32) for n in ("INERTIA", "GRAVITY", "DRAG", "FRICTION", "EVAP", "EROSION",
+                                                           "DEPOSITION", "FLOW_HEIGHT_CONTRIBUTION", "SLOW_CULL_ANGLE",
+                                                           "SLOW_CULL_SPEED", "CAPACITY")] +
+                                [("MAXAGE", np.int32), ("TERMINAL_VELOCITY", np.float32),
+                                 ("SURFACE_EVAPORATION_RATE", np.float32), ("POOL_PLACEMENT_MULTIPLIER", np.float32),
+                                 ("TRACK_PLACEMENT_MULTIPLIER", np.float32), ("FLOW_LOSS_RATE", np.float32),
+                                 ("PILING_RADIUS", np.int32), ("MIN_PILE_INCREMENT", np.float32),
+                                 ("PILE_THRESHOLD", np.float32)])
+
+
+def erosion_params(**kw):
+    """ErosionSettings.Reset() + AsParameters() (ScriptableObject/ErosionSettings.cs:59-124), BEHAVIOR = ALL_EROSION."""
+    d = dict(INERTIA=0.5, GRAVITY=1.0, DRAG=0.001, FRICTION=0.01, EVAP=0.01, EROSION=1.0, DEPOSITION=0.1,
+             FLOW_HEIGHT_CONTRIBUTION=25.0, SLOW_CULL_ANGLE=3.0, SLOW_CULL_SPEED=0.11, CAPACITY=3.0, MAXAGE=100,
+             TERMINAL_VELOCITY=None, SURFACE_EVAPORATION_RATE=0.1, POOL_PLACEMENT_MULTIPLIER=0.5,
+             TRACK_PLACEMENT_MULTIPLIER=80.0, FLOW_LOSS_RATE=0.05, PILING_RADIUS=15, MIN_PILE_INCREMENT=1.0,
+             PILE_THRESHOLD=2.0)
+    d.update(kw)
+    if d["TERMINAL_VELOCITY"] is None:
+        d["TERMINAL_VELOCITY"] = float(np.float32(1.0) / np.float32(d["DRAG"]))
+    ep = np.zeros(1, EROSION_PARAMS_DTYPE)
+    for k, v in d.items():
+        ep[k] = v
+    return ep
+
+
+def live_atanf(x): return lib().nzo_live_atanf(x)
+def live_sinf(x): return lib().nzo_live_sinf(x)
+
+
+class LiveErosionOracle:
+    """One tile's live-erosion state (planes indexed x * res + z) and the jobs of
+    LiveErosion.TriggerQueuedBeyerMT (Component/LiveErosion.cs:378-436), restated."""
+
+    def __init__(self, height, ep, tile_height=1000, patch_res=1.0, capacity=1 << 16):
+        self.res = height.shape[0]
+        n = self.res * self.res
+        self.height = np.ascontiguousarray(height, np.float32).copy()
+        self.pool, self.flow, self.track = (np.zeros((self.res, self.res), np.float32) for _ in range(3))
+        self.sediment = np.zeros((self.res, self.res), np.float32)
+        self.acc = [np.zeros(n, np.int64) for _ in range(3)]
+        self.touched = np.zeros(n, np.int32)
+        self.ep, self.tile_height, self.patch_res = ep, int(tile_height), float(patch_res)
+        self.queue = np.zeros(capacity, PARTICLE_DTYPE)
+        self.count = C.c_int(0)
+        self.events = 0
+
+    def _acc(self):
+        return [a.ctypes.data_as(C.POINTER(C.c_longlong)) for a in self.acc]
+
+    def fill_queue(self, generation_round, max_particles, seed, concurrency=10):
+        rc = lib().nzo_fill_beyer_queue(self.queue.ctypes.data, C.byref(self.count), len(self.queue), generation_round,
+                                        self.res, max_particles, seed, concurrency)
+        assert rc >= 0, "particle queue too small"
+        return rc
+
+    def descend(self):
+        a = self._acc()
+        self.events = lib().nzo_beyer_descent(_p(self.height), _p(self.pool), _p(self.flow), self.res,
+                                              self.queue.ctypes.data, self.count.value, self.ep.ctypes.data,
+                                              self.tile_height, self.patch_res, a[0], a[1], a[2],
+                                              self.touched.ctypes.data_as(C.POINTER(C.c_int)))
+        self.count.value = 0  # ClearQueueJob<BeyerParticle>
+        return self.events
+
+    def process_events(self):
+        a = self._acc()
+        lib().nzo_process_beyer_events(_p(self.pool), _p(self.track), _p(self.sediment), self.res, self.ep.ctypes.data,
+                                       a[0], a[1], a[2], self.touched.ctypes.data_as(C.POINTER(C.c_int)))
+
+    def erode_height_maps(self):
+        rc = lib().nzo_erode_height_maps(_p(self.height), _p(self.sediment), self.res, self.ep.ctypes.data, self.tile_height)
+        assert rc == 0
+
+    def update_flow_from_track(self):
+        lib().nzo_update_flow_from_track(_p(self.pool), _p(self.flow), _p(self.track), self.res,
+                                         float(self.ep["FLOW_LOSS_RATE"][0]), float(self.ep["SURFACE_EVAPORATION_RATE"][0]),
+                                         float(self.tile_height))
+
+    def pool_automata(self, iterations, drain=True):
+        if drain:
+            lib().nzo_pool_automata_drain(_p(self.pool), _p(self.height), self.res, iterations, self.queue.ctypes.data,
+                                          C.byref(self.count), len(self.queue))
+        else:
+            lib().nzo_pool_automata(_p(self.pool), _p(self.height), self.res, iterations)
+
+    def thermal(self, talus, step, ratio, cycles):
+        lib().nzo_thermal_erosion(_p(self.height), self.res, talus, step, ratio, cycles)
+
+    def cycle(self, generation_round, max_particles, seed, water_steps=10, thermal=None, concurrency=10):
+        """One pass of the loop body of TriggerQueuedBeyerMT (:383-416)."""
+        if thermal is not None:
+            self.thermal(*thermal)
+        self.fill_queue(generation_round, max_particles, seed, concurrency)
+        self.descend()
+        self.process_events()
+        self.erode_height_maps()
+        self.update_flow_from_track()
+        self.pool_automata(water_steps, drain=True)
+
+    def queued(self):
+        return self.queue[:min(self.count.value, len(self.queue))].copy()
+
+
+def curviture_map(height, mesh_res, tile_height=1000, patch_res=1.0, channel=1, texture=None):
+    h = _plane(height)
+    tex = np.zeros((mesh_res, mesh_res, 4), np.uint8) if texture is None else texture
+    lib().nzo_curviture_map(tex.ctypes.data, channel, _p(h), h.shape[0], mesh_res, int(tile_height), float(patch_res))
+    return tex
+
+
+def set_rgba32(src, mesh_res, scale, channel, texture=None):
+    s = _plane(src)
+    tex = np.zeros((mesh_res, mesh_res, 4), np.uint8) if texture is None else texture
+    lib().nzo_set_rgba32(tex.ctypes.data, channel, _p(s), s.shape[0], mesh_res, float(scale))
+    return tex

@@ -143,6 +143,36 @@ int nzo_curve(float *src, float *tmp, const float *curve, int curveSize, int row
 int nzo_thermal_erosion(float *src, int resolution, float talus, float incrementRatio,
                         float meshHeightWidthRatio, int iterations); /* Filter/Kernel/Blur/ThermalErosionFilter.cs */
 
+/* ---- live erosion, particle half (noize_oracle_live.c; BASELINE config 4) ---- */
+/* ErosionParameters, Geologic/ParticleErosion/LiveErosionDataTypes.cs:78-100 (field order kept) */
+typedef struct nzo_erosion_params {
+    float INERTIA, GRAVITY, DRAG, FRICTION, EVAP, EROSION, DEPOSITION, FLOW_HEIGHT_CONTRIBUTION;
+    float SLOW_CULL_ANGLE, SLOW_CULL_SPEED, CAPACITY;
+    int32_t MAXAGE;
+    float TERMINAL_VELOCITY;
+    float SURFACE_EVAPORATION_RATE, POOL_PLACEMENT_MULTIPLIER, TRACK_PLACEMENT_MULTIPLIER, FLOW_LOSS_RATE;
+    int32_t PILING_RADIUS;
+    float MIN_PILE_INCREMENT, PILE_THRESHOLD;
+} nzo_erosion_params;
+/* a queued BeyerParticle: what the constructors set that is not a constant (:221-237) */
+typedef struct nzo_particle { int32_t px, pz; float water; uint32_t pid; } nzo_particle;
+float nzo_live_atanf(float x);
+float nzo_live_sinf(float x);
+float nzo_live_from_fix(long long a);
+int nzo_fill_beyer_queue(nzo_particle *queue, int *count, int capacity, int generationRound, int res, int maxParticles,
+                         int seed, int concurrency);
+int nzo_beyer_descent(const float *height, const float *pool, const float *flow, int res, const nzo_particle *particles,
+                      int n, const nzo_erosion_params *ep, int tileHeight, float patchRes, long long *accPool,
+                      long long *accTrack, long long *accSed, int *touched);
+int nzo_process_beyer_events(float *pool, float *track, float *sediment, int res, const nzo_erosion_params *ep,
+                             long long *accPool, long long *accTrack, long long *accSed, int *touched);
+int nzo_erode_height_maps(float *height, const float *sediment, int res, const nzo_erosion_params *ep, int tileHeight);
+int nzo_pool_automata_drain(float *pool, const float *height, int res, int iterations, nzo_particle *queue, int *count,
+                            int capacity);
+int nzo_curviture_map(unsigned char *texture, int channel, const float *height, int res, int meshRes, int tileHeight,
+                      float patchRes);
+int nzo_set_rgba32(unsigned char *texture, int channel, const float *src, int dataRes, int meshRes, float scale);
+
 /* reference-shaped metric pipeline on one tile (bench cpu_baseline): fractal -> kernel filter x G
  * -> flowmap(F) -> erosion x E.  tmp must hold rows*cols floats. */
 int nzo_pipeline(float *data, float *tmp, int rows, int cols, int noiseType, float hurst,

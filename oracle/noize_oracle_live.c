@@ -1,0 +1,589 @@
+/*
+ * noize_oracle_live.c -- CPU restatement of the PARTICLE half of noize-job's live erosion (BASELINE config 4).
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED -- see noize_oracle.h.
+ *
+ * The reference (Geologic/ParticleErosion/) is deterministic per particle but not per run: particle positions come
+ * from UnityEngine.Random seeds (MultiThreadErosionJob.cs:50), events meet in a parallel multi-hash-map and are summed
+ * per cell in its iteration order (:345-352), and the sediment events reach the single-threaded ErodeHeightMaps in
+ * the order parallel row jobs happened to enqueue them (:353, :438-480).  This file restates the same jobs with the
+ * three free choices FIXED, exactly as noize_job_amd/csrc/nz_live.hip fixes them:
+ *   1. the seed is an argument; positions follow Unity.Mathematics.Random (xorshift32; com.unity.mathematics 1.2.1,
+ *      package.json:17 -- not in the reference tree, restated from the published source);
+ *   2. the per-cell event sums are taken in 2^-40 fixed point (int64), which makes them independent of the order in
+ *      which particles and events arrive;
+ *   3. ErodeHeightMaps applies the per-cell sediment events in the order a single worker would have produced them
+ *      (job z ascending, x ascending inside, ProcessBeyerErosiveEventsJob.Execute :336-354): first every KernelDisperse
+ *      event (each target cell folds its <= 25 contributions in that order), then every PileSolver event.
+ * atan / sin of the velocity model (LiveErosionDataTypes.cs:253-270,370) are the Cephes single-precision polynomials
+ * written out in fp32 operations, the same text on the host and on the device, so both sides agree bit for bit.
+ *
+ * Planes are indexed x * res + z (WorldTile.getIdx, LiveErosionDataTypes.cs:608-610).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "noize_oracle.h"
+
+static inline float lmaxf(float a, float b) { return (b != b) || a > b ? a : b; } /* math.max */
+static inline float lminf(float a, float b) { return (b != b) || a < b ? a : b; } /* math.min */
+static inline int lclampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* float -> int as the device converts (v_cvt_i32_f32): truncation, saturating, NaN -> 0.  (The C# cast is unspecified
+ * out of range; in range all three agree.) */
+static inline int f2i(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return -2147483647 - 1;
+    return (int)v;
+}
+
+/* ---- Cephes atanf / sinf, fp32 operations only (no libm: the device runs the same text) ---- */
+float nzo_live_atanf(float xx) {
+    if (xx != xx) return xx;
+    float sign = 1.0f, x = xx, y;
+    if (x < 0.0f) { sign = -1.0f; x = -x; }
+    if (x > 2.414213562373095f) { y = 1.5707963267948966192f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483096f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    float z = x * x;
+    y += (((8.05374449538e-2f * z - 1.38776856032E-1f) * z + 1.99777106478E-1f) * z - 3.33329491539E-1f) * z * x + x;
+    return sign * y;
+}
+
+float nzo_live_sinf(float xx) {
+    if (xx != xx) return xx;
+    float sign = 1.0f, x = xx, y;
+    if (x < 0.0f) { sign = -1.0f; x = -x; }
+    if (x > 8192.0f) return 0.0f; /* total loss of precision (Cephes T24M1); also +-inf */
+    int j = f2i(1.27323954473516f * x);
+    y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    if (j > 3) { sign = -sign; j -= 4; }
+    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = x * x;
+    if (j == 1 || j == 2) {
+        y = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z;
+        y -= 0.5f * z;
+        y += 1.0f;
+    } else {
+        y = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * x;
+        y += x;
+    }
+    return sign * y;
+}
+
+/* ---- Unity.Mathematics.Random (xorshift32) ---- */
+typedef struct { uint32_t state; } nzo_random;
+static inline uint32_t rnd_next_state(nzo_random *r) {
+    uint32_t t = r->state;
+    r->state ^= r->state << 13;
+    r->state ^= r->state >> 17;
+    r->state ^= r->state << 5;
+    return t;
+}
+static inline void rnd_init(nzo_random *r, uint32_t seed) { /* Random(uint seed): state = seed; NextState() */
+    r->state = seed;
+    (void)rnd_next_state(r);
+}
+static inline int rnd_next_int(nzo_random *r, int mn, int mx) { /* NextInt(min, max) */
+    uint32_t range = (uint32_t)(mx - mn);
+    return (int)(((uint64_t)rnd_next_state(r) * (uint64_t)range) >> 32) + mn;
+}
+
+/* FillBeyerQueueJob.ScheduleParallel + FlowMaster.CreateRandomParticles, MultiThreadErosionJob.cs:21-72,
+ * LiveErosionComponents.cs:53-77.  `seed` stands for UnityEngine.Random.Range(0, Int32.MaxValue) (:50);
+ * currentParticles = *count (the queue as this job finds it).  Worker i owns slots [i*COUNT, (i+1)*COUNT) behind the
+ * particles already queued.  Returns the number appended, or -1 if the queue is too small. */
+int nzo_fill_beyer_queue(nzo_particle *queue, int *count, int capacity, int generationRound, int res,
+                         int maxParticles, int seed, int concurrency) {
+    int currentParticles = *count;
+    int required = maxParticles - currentParticles;
+    if (required < 1) required = 1; /* max(1, ...) :53 */
+    int COUNT = required / concurrency; /* (int) max(floor(required / concurrency), 1): integer division first */
+    if (COUNT < 1) COUNT = 1;
+    if (currentParticles + concurrency * COUNT > capacity) return -1;
+    for (int i = 0; i < concurrency; i++) {
+        nzo_random rnd;
+        rnd_init(&rnd, (uint32_t)(seed + i));
+        uint16_t pid = (uint16_t)(generationRound * maxParticles); /* Convert.ToUInt16(generationID * generationSize) */
+        for (int k = 0; k < COUNT; k++) {
+            pid = (uint16_t)(pid + (uint16_t)((i * COUNT) + k)); /* pid += ..., cumulative as written :69 */
+            nzo_particle *p = &queue[currentParticles + i * COUNT + k];
+            p->px = rnd_next_int(&rnd, 0, res); /* NextInt2(ZERO, MaxPos): x then y */
+            p->pz = rnd_next_int(&rnd, 0, res);
+            p->water = 1.0f;                    /* BeyerParticle(pid, pos, ep, tm, false) :221-233 */
+            p->pid = pid;
+        }
+    }
+    *count = currentParticles + concurrency * COUNT;
+    return concurrency * COUNT;
+}
+
+/* ---- Heading, LiveErosionDataTypes.cs:1297-1444 ---- */
+enum { H_N = 1, H_S = 2, H_E = 4, H_W = 8, H_NE = 5, H_SE = 6, H_SW = 10, H_NW = 9, H_NONE = 0 };
+static const int WTORDER[8] = {H_N, H_E, H_S, H_W, H_NE, H_SE, H_SW, H_NW};   /* = the nb[] order */
+static const int ADJACENT[8] = {H_N, H_NE, H_E, H_SE, H_S, H_SW, H_W, H_NW};
+static const int NBDX[8] = {0, 1, 0, -1, 1, 1, -1, -1}; /* up, right, down, left, ne, se, sw, nw (:472-479) */
+static const int NBDZ[8] = {1, 0, -1, 0, 1, -1, -1, 1};
+static inline int heading_from(float dx, float dz) { /* HeadingExt.FromFloat2 / FromInt2 */
+    int b = 0;
+    if (dx > 0.0f) b |= H_E; else if (dx < 0.0f) b |= H_W;
+    if (dz > 0.0f) b |= H_N; else if (dz < 0.0f) b |= H_S;
+    return b;
+}
+static inline int heading_wt_idx(int h) { /* ToWorldTileIdx; -1 for NONE */
+    for (int i = 0; i < 8; i++) if (h == WTORDER[i]) return i;
+    return -1;
+}
+static inline void heading_to_int2(int h, int *x, int *z) { /* ToInt2 */
+    *x = ((h >> 2) & 1) ? 1 : (((h >> 3) & 1) ? -1 : 0);
+    *z = ((h >> 0) & 1) ? 1 : (((h >> 1) & 1) ? -1 : 0);
+}
+
+#define NZO_FIX_SCALE 1099511627776.0 /* 2^40 */
+static inline long long to_fix(float v) {
+    if (!(fabsf(v) < 4194304.0f)) return 0; /* NaN, inf and anything beyond 2^22 is dropped */
+    return llrint((double)v * NZO_FIX_SCALE);
+}
+float nzo_live_from_fix(long long a) { return (float)((double)a * (1.0 / NZO_FIX_SCALE)); }
+
+static inline void emit(long long *accPool, long long *accTrack, long long *accSed, int *touched, int idx,
+                        float dTrack, float dPool, float dSed) {
+    long long a = to_fix(dPool), b = to_fix(dTrack), c = to_fix(dSed);
+#pragma omp atomic
+    touched[idx] += 1;
+    if (a) {
+#pragma omp atomic
+        accPool[idx] += a;
+    }
+    if (b) {
+#pragma omp atomic
+        accTrack[idx] += b;
+    }
+    if (c) {
+#pragma omp atomic
+        accSed[idx] += c;
+    }
+}
+
+/* BeyerParticle.DescendSimultaneous (LiveErosionDataTypes.cs:273-432) until the particle is dead
+ * (FlowMaster.BeyerSimultaneousDescentSingle, LiveErosionComponents.cs:79-91).  Returns the number of events. */
+static int descend(const float *height, const float *pool, const float *flow, int res, const nzo_particle *src,
+                   const nzo_erosion_params *ep, int tileHeight, float patchRes, long long *accPool,
+                   long long *accTrack, long long *accSed, int *touched) {
+    const float HEIGHT = (float)tileHeight;
+    float posx = (float)src->px, posz = (float)src->pz, dirx = 0.0f, dirz = 0.0f;
+    float vel = .01f, water = src->water, sediment = 0.0f;
+    int age = 0, events = 0;
+    for (;;) {
+        events++;
+        int ix = f2i(rintf(posx)), iz = f2i(rintf(posz)); /* getPos(float2): round */
+        int idx = ix * res + iz;
+        float eTrack = 0.0f, ePool = 0.0f, eSed = 0.0f;
+        int heading = heading_from(dirx, dirz);
+        if (water < .01f) { /* :285-292 */
+            eSed = sediment / HEIGHT;
+            emit(accPool, accTrack, accSed, touched, idx, eTrack, ePool, eSed);
+            return events;
+        }
+        if (age >= ep->MAXAGE) { /* :293-301 */
+            ePool = water / HEIGHT;
+            eSed = sediment / HEIGHT;
+            emit(accPool, accTrack, accSed, touched, idx, eTrack, ePool, eSed);
+            return events;
+        }
+        int sidx = lclampi(f2i(posx), 0, res - 1) * res + lclampi(f2i(posz), 0, res - 1); /* WIH(float2) -> SafeIdx */
+        float currentHeight = HEIGHT * (height[sidx] + pool[sidx]);
+        /* NeighborhoodHelper.CollectNeighbors -> CollectNeighborsAllHeights :697-722 (SafeIdx clamps at the border) */
+        int nb[8], nbSort[8];
+        for (int k = 0; k < 8; k++) {
+            int nx = lclampi(ix + NBDX[k], 0, res - 1), nz = lclampi(iz + NBDZ[k], 0, res - 1);
+            int ni = nx * res + nz;
+            float all = HEIGHT * (height[ni] + pool[ni]) + ep->FLOW_HEIGHT_CONTRIBUTION * (flow[ni]);
+            nb[k] = f2i(100.0f * all);
+            nbSort[k] = nb[k];
+        }
+        for (int i = 1; i < 8; i++) { /* nbSort.Sort<int>(): only nbSort[0], the minimum, is ever read */
+            int t = nbSort[i], j = i - 1;
+            while (j >= 0 && nbSort[j] > t) { nbSort[j + 1] = nbSort[j]; j--; }
+            nbSort[j + 1] = t;
+        }
+        int hmin = nbSort[0], kmin = 0; /* NaturalHeading :174-179: IndexOf = first match */
+        while (nb[kmin] != hmin) kmin++;
+        float drainHeight = (float)hmin / 100.0f;
+        int drainDx = NBDX[kmin], drainDz = NBDZ[kmin];
+        if (heading == H_NONE) heading = heading_from((float)drainDx, (float)drainDz);
+        float fl = lmaxf(flow[idx], 0.0f);
+        float effectiveDrag = ep->DRAG * (1.0f - fl);
+        float effectiveFriction = ep->FRICTION * (1.0f - fl);
+        /* ChooseHeading :194-215 */
+        int ai = 0;
+        while (ai < 8 && ADJACENT[ai] != heading) ai++;
+        int hl, hr;
+        if (ai >= 8) { hl = hr = heading; } /* unreachable: heading is one of the eight by now */
+        else { hl = ADJACENT[(ai + 7) & 7]; hr = ADJACENT[(ai + 1) & 7]; }
+        int wl = heading_wt_idx(hl), wc = heading_wt_idx(heading), wr = heading_wt_idx(hr);
+        if (wl < 0 || wc < 0 || wr < 0) return events; /* NONE with a NONE drain cannot happen (drainDir != 0) */
+        float hx = (float)nb[wl] / 100.0f, hy = (float)nb[wc] / 100.0f, hz = (float)nb[wr] / 100.0f;
+        float headingHeight;
+        int flowH;
+        if (hx < hy && hx < hz) { headingHeight = hx; flowH = hl; }
+        else if (hz < hx && hz < hy) { headingHeight = hz; flowH = hr; }
+        else { headingHeight = hy; flowH = heading; }
+        int flowDx, flowDz;
+        heading_to_int2(flowH, &flowDx, &flowDz);
+        float hDiff = headingHeight - currentHeight;
+        float velocityLoss = 0.0f;
+        vel = vel - (vel * effectiveDrag); /* :330 */
+        int uphillOk = 0;
+        if (!(hDiff < 0.0f)) { /* UphillVelocityLoss :253-260 */
+            float theta = nzo_live_atanf(hDiff / patchRes);
+            float st = nzo_live_sinf(theta);
+            float acceleration = (ep->GRAVITY * st) + effectiveFriction;
+            velocityLoss = sqrtf(2.0f * fabsf(acceleration) * (hDiff / st));
+            uphillOk = velocityLoss <= vel;
+        }
+        if (hDiff < 0.0f) {
+            drainDx = flowDx; drainDz = flowDz;
+        } else if (uphillOk) {
+            drainDx = flowDx; drainDz = flowDz;
+        } else {
+            velocityLoss = 0.0f;
+            hDiff = drainHeight - currentHeight;
+            if (hDiff > 0.0f) { /* no drain :341-349 */
+                ePool = water / HEIGHT;
+                eSed = sediment / HEIGHT;
+                emit(accPool, accTrack, accSed, touched, idx, eTrack, ePool, eSed);
+                return events;
+            }
+        }
+        dirx = (float)drainDx; dirz = (float)drainDz;
+        float pnx = posx + dirx, pnz = posz + dirz;
+        if (f2i(pnx) < 0 || f2i(pnz) < 0 || f2i(pnx) >= res || f2i(pnz) >= res) { /* OutOfBounds(float2) :357-363 */
+            emit(accPool, accTrack, accSed, touched, idx, eTrack, ePool, eSed);
+            return events;
+        }
+        float vDiff = fabsf(hDiff), thetaD = 0.0f, deltaV = 0.0f;
+        if (vDiff > 0.0f) {
+            float theta = nzo_live_atanf(vDiff / patchRes);
+            thetaD = theta * 180.0f / 3.14159f;
+            if (hDiff > 0.0f) {
+                deltaV = -1.0f * velocityLoss;
+            } else { /* DownhillVelocityGain :262-270 */
+                float st = nzo_live_sinf(theta);
+                float acceleration = (ep->GRAVITY * st) - effectiveFriction;
+                deltaV = sqrtf(2.0f * fabsf(acceleration) * (vDiff / st));
+            }
+        }
+        vel = lmaxf((vel + deltaV), 0.0f);
+        float over = vel - ep->TERMINAL_VELOCITY; /* :392-399 */
+        vel = vel - lmaxf(lminf(over, lmaxf(effectiveDrag * 0.25f * over * over, 0.0f)), 0.0f);
+        if (thetaD < 3.0f && vel < 1.0f) { /* :403-411 */
+            ePool += water / HEIGHT;
+            eSed += sediment / HEIGHT;
+            emit(accPool, accTrack, accSed, touched, idx, eTrack, ePool, eSed);
+            return events;
+        }
+        float currentCapacity = vel * water * ep->CAPACITY, depositionAmount;
+        if (sediment < currentCapacity) depositionAmount = -1.0f * ep->EROSION * (currentCapacity - sediment);
+        else depositionAmount = ep->DEPOSITION * (sediment - currentCapacity);
+        if (fabsf(depositionAmount) > 0.0f) {
+            eSed += depositionAmount / HEIGHT;
+            sediment -= depositionAmount;
+        }
+        eTrack = water;
+        water = water * (1 - ep->EVAP);
+        posx = pnx; posz = pnz;
+        age++;
+        emit(accPool, accTrack, accSed, touched, idx, eTrack, ePool, eSed);
+    }
+}
+
+/* QueuedBeyerCycleMultiThreadJob, MultiThreadErosionJob.cs:178-224: every queued particle descends on the planes as
+ * they stand (nothing is written back during the job); its events land in the per-cell fixed-point sums.
+ * acc*: res^2 int64 each, touched: res^2 int (events per cell); all zero on entry of a cycle. */
+int nzo_beyer_descent(const float *height, const float *pool, const float *flow, int res, const nzo_particle *particles,
+                      int n, const nzo_erosion_params *ep, int tileHeight, float patchRes, long long *accPool,
+                      long long *accTrack, long long *accSed, int *touched) {
+    long long total = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : total)
+    for (int i = 0; i < n; i++)
+        total += descend(height, pool, flow, res, &particles[i], ep, tileHeight, patchRes, accPool, accTrack, accSed,
+                         touched);
+    return (int)total;
+}
+
+/* ProcessBeyerErosiveEventsJob + FlowMaster.CombineBeyerEvents / HandleBeyerEvent, MultiThreadErosionJob.cs:330-385,
+ * LiveErosionComponents.cs:93-110: pool and track receive their scaled sums; the sediment sum of every cell becomes
+ * one ErosiveEvent, kept here as the dense plane `sediment` (0 where no event fell).  Clears the sums. */
+int nzo_process_beyer_events(float *pool, float *track, float *sediment, int res, const nzo_erosion_params *ep,
+                             long long *accPool, long long *accTrack, long long *accSed, int *touched) {
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z < res; z++) {
+        for (int x = 0; x < res; x++) {
+            size_t idx = (size_t)x * res + z;
+            if (!touched[idx]) { sediment[idx] = 0.0f; continue; }
+            float poolV = nzo_live_from_fix(accPool[idx]), trackV = nzo_live_from_fix(accTrack[idx]);
+            float sedimentV = nzo_live_from_fix(accSed[idx]);
+            if (fabsf(poolV) > 0.0f) { float last = pool[idx]; last += poolV * ep->POOL_PLACEMENT_MULTIPLIER; pool[idx] = last; }
+            if (fabsf(trackV) > 0.0f) { float last = track[idx]; last += trackV * ep->TRACK_PLACEMENT_MULTIPLIER; track[idx] = last; }
+            sediment[idx] = sedimentV;
+            accPool[idx] = accTrack[idx] = accSed[idx] = 0;
+            touched[idx] = 0;
+        }
+    }
+    return 0;
+}
+
+static const float KERNEL5[5] = {0.12007838424321349f, 0.23388075658535032f, 0.29208171834287244f,
+                                 0.23388075658535032f, 0.12007838424321349f}; /* :447-453 */
+
+static inline int is_disperse(float v, float pileThreshold) { /* WriteSedimentMap :118-128 */
+    return v < 0.0f || v <= pileThreshold;
+}
+
+/* PileSolver, LiveErosionDataTypes.cs:1053-1225 (ManhattanVertex :1170-1225) */
+typedef struct { int ox, oz; int idx; float val; unsigned char modified, valid; } nzo_mvert;
+static void pile_handle(float *height, int res, nzo_mvert *verts, int nverts, int maxDistance, int px, int pz,
+                        float amount, float increment) {
+    for (int i = 0; i < nverts; i++) { /* SetPile */
+        int x = px + verts[i].ox, z = pz + verts[i].oz;
+        if (x < 0 || z < 0 || x >= res || z >= res) { verts[i].valid = 0; continue; }
+        verts[i].valid = 1;
+        verts[i].modified = 0;
+        verts[i].idx = x * res + z;
+        verts[i].val = height[verts[i].idx];
+    }
+    float remaining = amount;
+    /* `while (remaining > 0f)` spins for ever in the reference when a call deposits nothing (increment <= 0, NaN
+     * heights): bounded here, the same bound on the device */
+    for (int guard = 0; remaining > 0.0f && increment > 0.0f && guard < 4096; guard++) { /* HandlePile :1155-1163; DepositSediment :1110-1138 */
+        float amt = remaining, deposited = 0.0f, rem = amt;
+        int done = 0;
+        for (int round = 1; round <= maxDistance && !done; round++) {
+            float level = verts[0].val + (increment * (float)round);
+            int c = -1;
+            for (int dist = 0; dist < round && !done; dist++)
+                for (int dir = 0; dir < 4 && !done; dir++)
+                    for (int i = 0; i <= dist + 1; i++) {
+                        c++;
+                        nzo_mvert *t = &verts[c];
+                        if (!t->valid) continue;
+                        if (!(t->val < level)) continue;
+                        float inc = lminf(increment, rem);
+                        t->modified = 1;
+                        t->val += inc;
+                        deposited += inc;
+                        rem = amt - deposited;
+                        if (rem <= 0.0f) { done = 1; break; }
+                    }
+        }
+        remaining = done ? 0.0f : rem;
+    }
+    for (int i = 0; i < nverts; i++) /* CommitChanges */
+        if (verts[i].valid && verts[i].modified) height[verts[i].idx] = verts[i].val;
+}
+
+/* ErodeHeightMaps + FlowMaster.WriteSedimentMap / KernelDisperse, MultiThreadErosionJob.cs:438-480,
+ * LiveErosionComponents.cs:112-157.  `sediment` = the dense plane of per-cell events. */
+int nzo_erode_height_maps(float *height, const float *sediment, int res, const nzo_erosion_params *ep, int tileHeight) {
+    const float PILE_THRESHOLD = ep->PILE_THRESHOLD / (float)tileHeight;
+    const float MIN_PILE_INCREMENT = ep->MIN_PILE_INCREMENT / (float)tileHeight;
+    /* phase A: every KernelDisperse event, folded per TARGET cell in the events' canonical order (source job z
+     * ascending, x ascending inside; per source the kernel loops x outer, z inner :136-153).  A target folds only its
+     * own running value, so targets are independent. */
+    float *out = (float *)malloc((size_t)res * res * sizeof(float));
+    if (!out) return -1;
+#pragma omp parallel for schedule(static)
+    for (int tx = 0; tx < res; tx++) {
+        for (int tz = 0; tz < res; tz++) {
+            float v = height[(size_t)tx * res + tz];
+            int x0 = tx <= 0 ? 0 : tx - 2, x1 = tx >= res - 1 ? res - 1 : tx + 2;  /* sources that can reach a   */
+            int z0 = tz <= 0 ? 0 : tz - 2, z1 = tz >= res - 1 ? res - 1 : tz + 2;  /* border target lie inside   */
+            if (x0 < 0) x0 = 0;
+            if (x1 > res - 1) x1 = res - 1;
+            if (z0 < 0) z0 = 0;
+            if (z1 > res - 1) z1 = res - 1;
+            for (int sz = z0; sz <= z1; sz++)
+                for (int sx = x0; sx <= x1; sx++) {
+                    float val = sediment[(size_t)sx * res + sz];
+                    if (val == 0.0f || !is_disperse(val, PILE_THRESHOLD)) continue;
+                    for (int kx = 0; kx < 5; kx++)
+                        for (int kz = 0; kz < 5; kz++) {
+                            /* probe = posD - offset + k (float), SafeIdx(float2): truncate, clamp */
+                            int pxi = lclampi(sx - 2 + kx, 0, res - 1), pzi = lclampi(sz - 2 + kz, 0, res - 1);
+                            if (pxi != tx || pzi != tz) continue;
+                            float kernelFactor = KERNEL5[kx] * KERNEL5[kz];
+                            float newDiff = ((val * kernelFactor) / 1.0f);
+                            float nextV = v + newDiff;
+                            if (nextV > 1.0f) continue;
+                            if (nextV < 0.0f) continue;
+                            v = v + newDiff;
+                        }
+                }
+            out[(size_t)tx * res + tz] = v;
+        }
+    }
+    memcpy(height, out, (size_t)res * res * sizeof(float));
+    free(out);
+    /* phase B: the PileSolver events, one after the other in the same canonical order */
+    int maxDistance = ep->PILING_RADIUS;
+    int nverts = (((maxDistance + 1) * (maxDistance + 2)) * 2) - 3; /* :1063; only the first `c` are initialised */
+    nzo_mvert *verts = (nzo_mvert *)calloc((size_t)(nverts > 0 ? nverts : 1), sizeof(nzo_mvert));
+    if (!verts) return -1;
+    int c = 0;
+    static const int DAX[4] = {0, 1, 0, -1}, DAZ[4] = {1, 0, -1, 0}; /* dirA: up, right, down, left */
+    static const int DBX[4] = {1, 0, -1, 0}, DBZ[4] = {0, -1, 0, 1}; /* dirB: right, down, left, up */
+    for (int dist = 0; dist < maxDistance; dist++)
+        for (int dir = 0; dir < 4; dir++)
+            for (int i = 0; i <= dist + 1; i++) { /* GetOffset: dist*dirA + i*(dirB - dirA) */
+                verts[c].ox = dist * DAX[dir] + i * (DBX[dir] - DAX[dir]);
+                verts[c].oz = dist * DAZ[dir] + i * (DBZ[dir] - DAZ[dir]);
+                c++;
+            }
+    for (int i = c; i < nverts; i++) { verts[i].ox = verts[i].oz = 0; } /* default(ManhattanVertex): offset 0 */
+    for (int z = 0; z < res; z++)
+        for (int x = 0; x < res; x++) {
+            float val = sediment[(size_t)x * res + z];
+            if (val == 0.0f || is_disperse(val, PILE_THRESHOLD)) continue;
+            if (maxDistance < 1) continue;
+            pile_handle(height, res, verts, c, maxDistance, x, z, val, MIN_PILE_INCREMENT);
+        }
+    free(verts);
+    return 0;
+}
+
+/* ---- PoolAutomataJob with drainParticles == true (MultiThreadErosionJob.cs:264-327, WorldTile.SpreadPool
+ * LiveErosionDataTypes.cs:938-1010): a pool that finds a dry, lower neighbour leaves as ONE particle (pid 64000, at
+ * the neighbour, carrying the water) queued for the next cycle instead of wetting that neighbour. ---- */
+typedef struct { int idx; float height, water; } lflooded;
+static inline int lfloat_hash(float f) { if (f == 0.0f) return 0; int v; memcpy(&v, &f, sizeof v); return v; }
+static inline int lflooded_cmp(const lflooded *a, const lflooded *b) {
+    if (a->idx == b->idx) return 0;
+    return lfloat_hash(a->height + a->water) > lfloat_hash(b->height + b->water) ? 1 : -1;
+}
+static void spread_pool_drain(float *pool, const float *height, int res, int x, int z, nzo_particle *queue, int *count,
+                              int capacity) {
+    size_t idx = (size_t)x * res + z;
+    float hLand = height[idx], hWater = pool[idx];
+    if (hWater <= 0.0f) return;
+    float tHeight = hLand + hWater;
+    const int dx[4] = {0, 1, 0, -1}, dz[4] = {1, 0, -1, 0};
+    lflooded b[4];
+    for (int e = 0; e < 4; e++) {
+        int nx = lclampi(x + dx[e], 0, res - 1), nz = lclampi(z + dz[e], 0, res - 1);
+        b[e].idx = nx * res + nz;
+        b[e].height = height[b[e].idx];
+        b[e].water = pool[b[e].idx];
+    }
+    for (int i = 0; i < 3; i++) { /* NativeArray.Sort(): insertion sort for 4 elements */
+        int j = i;
+        lflooded t = b[i + 1];
+        while (j >= 0 && lflooded_cmp(&t, &b[j]) < 0) { b[j + 1] = b[j]; j--; }
+        b[j + 1] = t;
+    }
+    for (int e = 0; e < 4; e++) {
+        float fill = 0.0f;
+        float diffV = tHeight - (b[e].height + b[e].water);
+        if (hWater < 1E-3f) continue;
+        if (b[e].water <= 0.0f && hLand >= b[e].height) {
+            int slot;
+#pragma omp atomic capture
+            slot = (*count)++;
+            if (slot < capacity) {
+                queue[slot].px = b[e].idx / res; /* getPos(idx) */
+                queue[slot].pz = b[e].idx % res;
+                queue[slot].water = hWater;
+                queue[slot].pid = 64000;
+            }
+            hWater = 0.0f;
+            tHeight = hLand;
+        } else if (diffV > 0.0f) {
+            if (hWater <= 0.0f) continue;
+            fill = lminf(0.25f * hWater, 0.25f * diffV);
+            hWater -= fill;
+            tHeight = hLand + hWater;
+            pool[b[e].idx] = b[e].water + fill;
+        } else if (diffV < 0.0f) {
+            if (b[e].water <= 0.0f) continue;
+            fill = lminf(0.25f * b[e].water, -0.25f * diffV);
+            hWater += fill;
+            tHeight = hLand + hWater;
+            pool[b[e].idx] = b[e].water + (-1.0f * fill);
+        }
+    }
+    pool[idx] = hWater;
+}
+
+/* returns the queue length afterwards (entries beyond `capacity` are counted, not stored) */
+int nzo_pool_automata_drain(float *pool, const float *height, int res, int iterations, nzo_particle *queue, int *count,
+                            int capacity) {
+    if (res < 2) return -1;
+    for (int it = 0; it < iterations; it++)
+        for (int xoff = 0; xoff < 2; xoff++)
+            for (int zoff = 0; zoff < 2; zoff++) {
+#pragma omp parallel for schedule(static)
+                for (int k = 0; k < res / 2; k++) {
+                    int offset = xoff + ((k % 2 != 0) ? 1 : 0);
+                    int z = 2 * k + zoff;
+                    for (int x = offset; x < res; x += 2)
+                        if (pool[(size_t)x * res + z] > 0.0f) spread_pool_drain(pool, height, res, x, z, queue, count, capacity);
+                }
+            }
+    return *count;
+}
+
+/* ---- control-texture jobs ---- */
+/* WorldTile.CalculateDerivatives + HorizontalCurvature + Curviture + RectifyRange, LiveErosionDataTypes.cs:726-866;
+ * CurvitureMapJob, MultiThreadErosionJob.cs:387-436: target[z * meshRes + x] (stride 4 bytes inside an RGBA32
+ * texture) = (byte)(clamp(Curviture((z + offset, x + offset), PATCH_RES.x), 0, 1) * 255). */
+static float curviture(const float *height, int res, int x, int z, float w, float HEIGHT) {
+    float w2 = w * w;
+#define HH(dx, dz) (height[(size_t)lclampi(x + (dx), 0, res - 1) * res + lclampi(z + (dz), 0, res - 1)] * HEIGHT)
+    float z1x = HH(-1, 1), z1y = HH(0, 1), z1z = HH(1, 1), z1w = HH(-1, 0);   /* nw, up, ne, left */
+    float z5 = height[(size_t)x * res + z] * HEIGHT;
+    float z6x = HH(1, 0), z6y = HH(-1, -1), z6z = HH(0, -1), z6w = HH(1, -1); /* right, sw, down, se */
+#undef HH
+    float zx = (z1z + z6x + z6w - z1x - z1w - z6y) / (6.0f * w);
+    float zy = (z1x + z1y + z1z - z6y - z6z - z6w) / (6.0f * w);
+    float zxx = (z1x + z1z + z1w + z6x + z6y + z6w - 2.0f * (z1y + z5 + z6z)) / (3.0f * w2);
+    float zyy = (z1x + z1y + z1z + z6y + z6z + z6w - 2.0f + (z1w + z5 + z6x)) / (3.0f * w2); /* `- 2.0f +` as written */
+    float zxy = (z1z + z6y - z1x - z6w) / (4.0f * w2);
+    float dzx = -zx, dzy = -zy, dxx = -zxx, dyy = -zyy, dxy = -zxy;
+    float zx2 = dzx * dzx, zy2 = dzy * dzy, p = zx2 + zy2;
+    float n = zy2 * dxx - 2.0f * dxy * dzx * dzy + zx2 * dyy;
+    float d = p * powf(p + 1.0f, 0.5f);
+    float v = fabsf(d) < 1e-18f ? 0.0f : n / d;
+    v = fabsf(v);
+    float sign_ = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+    float pow_ = powf(10.0f, .05f);
+    float log_ = logf(1.0f + pow_ * fabsf(v));
+    return fabsf(sign_ * log_) / 2.0f;
+}
+
+int nzo_curviture_map(unsigned char *texture, int channel, const float *height, int res, int meshRes, int tileHeight,
+                      float patchRes) {
+    int offset = (res - meshRes) / 2;
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z < meshRes; z++)
+        for (int x = 0; x < meshRes; x++) {
+            float v = curviture(height, res, z + offset, x + offset, patchRes, (float)tileHeight);
+            float c = lmaxf(0.0f, lminf(1.0f, v));
+            texture[((size_t)z * meshRes + x) * 4 + channel] = (unsigned char)(c * 255.0f);
+        }
+    return 0;
+}
+
+/* SetRGBA32Job, MultiThreadErosionJob.cs:482-529: data[z * meshRes + x] = (byte)(clamp(src[(z+off)*dataRes + x+off] * scale, 0, 1) * 255) */
+int nzo_set_rgba32(unsigned char *texture, int channel, const float *src, int dataRes, int meshRes, float scale) {
+    int offset = (dataRes - meshRes) / 2;
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z < meshRes; z++)
+        for (int x = 0; x < meshRes; x++) {
+            float c = lmaxf(0.0f, lminf(1.0f, src[(size_t)(z + offset) * dataRes + x + offset] * scale));
+            texture[((size_t)z * meshRes + x) * 4 + channel] = (unsigned char)(c * 255.0f);
+        }
+    return 0;
+}
