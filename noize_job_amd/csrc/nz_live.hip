@@ -5,7 +5,7 @@
 //   FillBeyerQueueJob (:21-72)               -> fill_queue_kernel          one lane per reference worker
 //   QueuedBeyerCycleMultiThreadJob (:178-224) -> descent_kernel             one lane per particle, until it is dead
 //   ProcessBeyerErosiveEventsJob (:330-385)   -> process_events_kernel      one lane per cell that received an event
-//   ErodeHeightMaps (:438-480, ONE thread)    -> disperse_kernel (every cell gathers) + pile_kernel (rare, sequential)
+//   ErodeHeightMaps (:438-480, ONE thread)    -> disperse_kernel (every cell gathers) + pile_kernel (one wave per block)
 //   PoolAutomataJob, drainParticles (:264-327) -> nz_elementwise.hip, pool_automata_pass_kernel<true>
 //   CurvitureMapJob (:387-436), SetRGBA32Job (:482-529) -> curviture_kernel, set_rgba32_kernel
 //
@@ -17,7 +17,8 @@
 //   3. ErodeHeightMaps applies the per-cell events in the order one worker would have produced them (job z ascending,
 //      x ascending inside): first every KernelDisperse event -- as a GATHER: a target cell folds the <= 25
 //      contributions that reach it in that order, reading only its own running value, so all targets run in parallel
-//      -- then every PileSolver event, one after the other.
+//      -- then every PileSolver event: blocks of side 2 * (PILING_RADIUS + 1), 4-coloured, colour after colour, the
+//      canonical order inside a block (piles of one colour's blocks cannot see each other; see pile_kernel).
 // atan / sin of the velocity model are the Cephes fp32 polynomials written out operation by operation (no libm call),
 // the same text as the oracle's.  Planes are indexed x * res + z (WorldTile.getIdx, LiveErosionDataTypes.cs:608-610).
 #include <cstring>
@@ -37,9 +38,8 @@ struct nz_erosive_events {
     int32_t *list[2] = {nullptr, nullptr};  // cells touched this cycle / last cycle
     int32_t *counters = nullptr;        // {n_list[0], n_list[1], n_piles, events}
     float *sediment = nullptr;          // [res^2] the per-cell ErosiveEvent.deltaSediment (0 where none)
-    int32_t *piles = nullptr;           // [res^2] cells whose event goes to the PileSolver
     int cur = 0;
-    void *pile_scratch = nullptr;
+    void *pile_scratch = nullptr;       // the ManhattanVertex offsets of the current PILING_RADIUS
     size_t pile_scratch_bytes = 0;
 };
 
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(CT) void forget_kernel(float *sediment, const int32
     for (int i = blockIdx.x * CT + threadIdx.x; i < n; i += gridDim.x * CT) sediment[list[i]] = 0.0f;
 }
 
-__global__ __launch_bounds__(CT) void process_events_kernel(float *pool, float *track, float *sediment, int32_t *piles,
+__global__ __launch_bounds__(CT) void process_events_kernel(float *pool, float *track, float *sediment,
                                                            unsigned long long *acc, int32_t *touched, const int32_t *list,
                                                            int32_t *counters, int slot, size_t ncell, float poolMul,
                                                            float trackMul, float pileThreshold) {
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(CT) void process_events_kernel(float *pool, float *
         }
         sediment[idx] = sedimentV;
         // WriteSedimentMap :118-128: negative or small events are dispersed, the others piled (NaN: piled, a no-op)
-        if (sedimentV != 0.0f && !(sedimentV < 0.0f || sedimentV <= pileThreshold)) piles[atomicAdd(&counters[2], 1)] = idx;
+        if (sedimentV != 0.0f && !(sedimentV < 0.0f || sedimentV <= pileThreshold)) atomicAdd(&counters[2], 1);  // statistics
         acc[idx] = 0;
         acc[ncell + idx] = 0;
         acc[2 * ncell + idx] = 0;
@@ -405,72 +405,80 @@ __global__ __launch_bounds__(CT) void disperse_kernel(const float *__restrict__ 
     out[(size_t)tx * res + tz] = v;
 }
 
-// PileSolver (LiveErosionDataTypes.cs:1053-1225): the piled events in canonical order, sequentially (they read and write
-// overlapping height cells).  One workgroup: a rank sort of the pile list by (z, x), then lane 0 walks it.
-struct mvert {
-    int idx;
-    float val;
-    short ox, oz;
-    unsigned char modified, valid;
-};
-
-__global__ __launch_bounds__(CT) void pile_kernel(float *height, const float *sediment, const int32_t *piles,
-                                                 int32_t *sorted, int32_t *counters, mvert *verts, int nverts, int res,
-                                                 int maxDistance, float increment) {
-    const int n = counters[2];
-    for (int i = threadIdx.x; i < n; i += CT) {
-        const int idx = piles[i];
-        const long long key = (long long)(idx % res) * res + idx / res;  // job z, then x
-        int rank = 0;
-        for (int j = 0; j < n; j++) {
-            const int o = piles[j];
-            rank += ((long long)(o % res) * res + o / res) < key;
-        }
-        sorted[rank] = idx;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    for (int e = 0; e < n; e++) {
-        const int cell = sorted[e];
-        const int px = cell / res, pz = cell % res;
-        const float amount = sediment[cell];
-        for (int i = 0; i < nverts; i++) {  // SetPile
-            const int x = px + verts[i].ox, z = pz + verts[i].oz;
-            if (x < 0 || z < 0 || x >= res || z >= res) { verts[i].valid = 0; continue; }
-            verts[i].valid = 1;
-            verts[i].modified = 0;
-            verts[i].idx = x * res + z;
-            verts[i].val = height[verts[i].idx];
-        }
-        float remaining = amount;
-        for (int guard = 0; remaining > 0.0f && increment > 0.0f && guard < 4096; guard++) {  // HandlePile / DepositSediment
-            const float amt = remaining;
-            float deposited = 0.0f, rem = amt;
-            bool done = false;
-            for (int round = 1; round <= maxDistance && !done; round++) {
-                const float level = verts[0].val + (increment * (float)round);
-                int c = -1;
-                for (int dist = 0; dist < round && !done; dist++)
-                    for (int dir = 0; dir < 4 && !done; dir++)
-                        for (int i = 0; i <= dist + 1; i++) {
-                            c++;
-                            mvert &t = verts[c];
-                            if (!t.valid) continue;
-                            if (!(t.val < level)) continue;
-                            const float inc = lminf(increment, rem);
-                            t.modified = 1;
-                            t.val += inc;
-                            deposited += inc;
-                            rem = amt - deposited;
-                            if (rem <= 0.0f) { done = true; break; }
+// PileSolver (LiveErosionDataTypes.cs:1053-1225).  A pile reads and raises heights within Chebyshev distance
+// PILING_RADIUS + 1 of its cell, so piles in different blocks of side B = 2 * (PILING_RADIUS + 1) with one block between
+// them cannot see each other.  The grid is cut into such blocks, 4-coloured by (bx & 1, bz & 1); one launch per colour,
+// one wave per block; inside a block the events keep the canonical order (z ascending, x ascending inside).  (The
+// reference runs all of them on one thread in whatever order its parallel queue writers produced.)
+// Per pile the wave loads the vertex values side by side (SetPile), lane 0 walks DepositSediment -- sequential by
+// nature: a running remainder -- over LDS, and commits the modified vertices in vertex order (the ManhattanVertex list
+// names the centre four times and many ring cells twice, each copy with a value of its own: the LAST copy wins).
+__global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__restrict__ sediment,
+                                                 const short2 *__restrict__ ofs, int nverts, int res, int maxDistance,
+                                                 int B, int nb, int cx, int cz, float pileThreshold, float increment) {
+    extern __shared__ unsigned char s_raw[];
+    float *s_val = reinterpret_cast<float *>(s_raw);
+    int *s_idx = reinterpret_cast<int *>(s_raw + (size_t)nverts * 4);
+    unsigned char *s_flag = s_raw + (size_t)nverts * 8;  // bit 0 valid, bit 1 modified
+    const int per_row = (nb - cx + 1) / 2;
+    const int bx = cx + 2 * (int)(blockIdx.x % per_row), bz = cz + 2 * (int)(blockIdx.x / per_row);
+    const int lane = threadIdx.x;
+    const int x0 = bx * B, z0 = bz * B, x1 = min(x0 + B, res), z1 = min(z0 + B, res);
+    for (int z = z0; z < z1; z++) {
+        for (int xb = x0; xb < x1; xb += 64) {
+            const int x = xb + lane;
+            const float val = x < x1 ? sediment[(size_t)x * res + z] : 0.0f;
+            const bool is_pile = val != 0.0f && !(val < 0.0f || val <= pileThreshold);
+            unsigned long long todo = __ballot(is_pile);
+            while (todo) {  // wave-uniform
+                const int src_lane = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int px = xb + src_lane, pz = z;
+                const float amount = __shfl(val, src_lane);
+                for (int i = lane; i < nverts; i += 64) {  // SetPile
+                    const int vx = px + ofs[i].x, vz = pz + ofs[i].y;
+                    const bool ok = vx >= 0 && vz >= 0 && vx < res && vz < res;
+                    s_flag[i] = ok ? 1 : 0;
+                    s_idx[i] = ok ? vx * res + vz : 0;
+                    s_val[i] = ok ? height[(size_t)vx * res + vz] : 0.0f;
+                }
+                __syncthreads();  // one wave per workgroup: orders the LDS traffic
+                if (lane == 0) {
+                    float remaining = amount;
+                    int cmax = -1;
+                    for (int guard = 0; remaining > 0.0f && increment > 0.0f && guard < 4096; guard++) {
+                        const float amt = remaining;
+                        float deposited = 0.0f, rem = amt;
+                        bool done = false;
+                        for (int round = 1; round <= maxDistance && !done; round++) {
+                            const float level = s_val[0] + (increment * (float)round);
+                            int c = -1;
+                            for (int dist = 0; dist < round && !done; dist++)
+                                for (int dir = 0; dir < 4 && !done; dir++)
+                                    for (int i = 0; i <= dist + 1; i++) {
+                                        c++;
+                                        if (!(s_flag[c] & 1)) continue;
+                                        const float v = s_val[c];
+                                        if (!(v < level)) continue;
+                                        const float inc = lminf(increment, rem);
+                                        s_flag[c] |= 2;
+                                        s_val[c] = v + inc;
+                                        cmax = max(cmax, c);
+                                        deposited += inc;
+                                        rem = amt - deposited;
+                                        if (rem <= 0.0f) { done = true; break; }
+                                    }
                         }
+                        remaining = done ? 0.0f : rem;
+                    }
+                    for (int c = 0; c <= cmax; c++)  // CommitChanges, in vertex order
+                        if ((s_flag[c] & 3) == 3) height[s_idx[c]] = s_val[c];
+                    __threadfence_block();
+                }
+                __syncthreads();  // the next pile of this block reads the committed heights
             }
-            remaining = done ? 0.0f : rem;
         }
-        for (int i = 0; i < nverts; i++)  // CommitChanges
-            if (verts[i].valid && verts[i].modified) height[verts[i].idx] = verts[i].val;
     }
-    counters[2] = 0;
 }
 
 // WorldTile.Curviture (LiveErosionDataTypes.cs:726-866) + CurvitureMapJob (MultiThreadErosionJob.cs:387-436)
@@ -609,12 +617,11 @@ extern "C" int32_t nz_erosive_events_create(nz_ctx *ctx, int32_t resolution, nz_
     const size_t n = (size_t)resolution * resolution;
     bool ok = hipMalloc((void **)&ev->acc, 3 * n * 8) == hipSuccess && hipMalloc((void **)&ev->touched, n * 4) == hipSuccess &&
               hipMalloc((void **)&ev->list[0], n * 4) == hipSuccess && hipMalloc((void **)&ev->list[1], n * 4) == hipSuccess &&
-              hipMalloc((void **)&ev->counters, 16) == hipSuccess && hipMalloc((void **)&ev->sediment, n * 4) == hipSuccess &&
-              hipMalloc((void **)&ev->piles, 2 * n * 4) == hipSuccess;
+              hipMalloc((void **)&ev->counters, 16) == hipSuccess && hipMalloc((void **)&ev->sediment, n * 4) == hipSuccess;
     if (ok) ok = hipMemset(ev->acc, 0, 3 * n * 8) == hipSuccess && hipMemset(ev->touched, 0, n * 4) == hipSuccess &&
                  hipMemset(ev->counters, 0, 16) == hipSuccess && hipMemset(ev->sediment, 0, n * 4) == hipSuccess;
     if (!ok) {
-        void *ps[] = {ev->acc, ev->touched, ev->list[0], ev->list[1], ev->counters, ev->sediment, ev->piles};
+        void *ps[] = {ev->acc, ev->touched, ev->list[0], ev->list[1], ev->counters, ev->sediment};
         for (void *p : ps)
             if (p) (void)hipFree(p);
         delete ev;
@@ -631,7 +638,7 @@ extern "C" int32_t nz_erosive_events_destroy(nz_ctx *ctx, nz_erosive_events *ev)
     if (!ev) return NZ_OK;
     NZ_HIP(hipSetDevice(ctx->device));
     NZ_HIP(hipStreamSynchronize(ctx->stream));
-    void *ps[] = {ev->acc, ev->touched, ev->list[0], ev->list[1], ev->counters, ev->sediment, ev->piles, ev->pile_scratch};
+    void *ps[] = {ev->acc, ev->touched, ev->list[0], ev->list[1], ev->counters, ev->sediment, ev->pile_scratch};
     for (void *p : ps)
         if (p) (void)hipFree(p);
     delete ev;
@@ -679,7 +686,7 @@ extern "C" int32_t nz_queued_beyer_cycle(nz_ctx *ctx, const float *height, const
     NZ_REQUIRE(events->res == res, "events were created for resolution %d", events->res);
     live_planes P{height, pool, flow, events->acc, events->touched, events->list[events->cur], events->counters, events->cur,
                   (size_t)res * res};
-    NZ_HIP(hipMemsetAsync(events->counters + 3, 0, 4, ctx->stream));
+    NZ_HIP(hipMemsetAsync(events->counters + 2, 0, 8, ctx->stream));  // piles and events of this cycle
     const unsigned blocks = (unsigned)((particles->capacity + 63) / 64);  // the count lives on the device: lanes beyond it leave
     hipLaunchKernelGGL(descent_kernel, dim3(blocks), dim3(64), 0, ctx->stream, P, particles->hdr, particles->data, *ep, res,
                        (float)tm->HEIGHT, tm->PATCH_RES[0]);
@@ -699,7 +706,7 @@ extern "C" int32_t nz_process_beyer_erosive_events(nz_ctx *ctx, float *height, f
     const int cur = events->cur, prev = cur ^ 1;
     hipLaunchKernelGGL(forget_kernel, dim3(512), dim3(CT), 0, ctx->stream, events->sediment, events->list[prev], events->counters, prev);
     NZ_HIP(hipMemsetAsync(events->counters + prev, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(process_events_kernel, dim3(512), dim3(CT), 0, ctx->stream, pool, track, events->sediment, events->piles,
+    hipLaunchKernelGGL(process_events_kernel, dim3(512), dim3(CT), 0, ctx->stream, pool, track, events->sediment,
                        events->acc, events->touched, events->list[cur], events->counters, cur, (size_t)res * res,
                        ep->POOL_PLACEMENT_MULTIPLIER, ep->TRACK_PLACEMENT_MULTIPLIER, ep->PILE_THRESHOLD / (float)tm->HEIGHT);
     NZ_HIP(hipGetLastError());
@@ -713,7 +720,7 @@ extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_e
     NZ_REQUIRE(height && events, "height / events is NULL");
     if (int32_t rc = check_live(ep, tm, res)) return rc;
     NZ_REQUIRE(events->res == res, "events were created for resolution %d", events->res);
-    NZ_REQUIRE(ep->PILING_RADIUS >= 0 && ep->PILING_RADIUS <= 120, "PILING_RADIUS %d out of range [0,120]", ep->PILING_RADIUS);
+    NZ_REQUIRE(ep->PILING_RADIUS >= 0 && ep->PILING_RADIUS <= 50, "PILING_RADIUS %d out of range [0,50]", ep->PILING_RADIUS);
     const size_t n = (size_t)res * res;
     float *tmp = nullptr;
     NZ_TRY_(nz_ctx_scratch(ctx, n, &tmp));
@@ -725,34 +732,33 @@ extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_e
     // PileSolver.Init :1058-1098: vertex offsets (host), GetOffset = dist * dirA + i * (dirB - dirA)
     const int D = ep->PILING_RADIUS;
     if (D >= 1) {
-        std::vector<mvert> verts;
+        std::vector<short2> ofs;
         const int DAX[4] = {0, 1, 0, -1}, DAZ[4] = {1, 0, -1, 0}, DBX[4] = {1, 0, -1, 0}, DBZ[4] = {0, -1, 0, 1};
         for (int dist = 0; dist < D; dist++)
             for (int dir = 0; dir < 4; dir++)
-                for (int i = 0; i <= dist + 1; i++) {
-                    mvert v{};
-                    v.ox = (short)(dist * DAX[dir] + i * (DBX[dir] - DAX[dir]));
-                    v.oz = (short)(dist * DAZ[dir] + i * (DBZ[dir] - DAZ[dir]));
-                    verts.push_back(v);
-                }
-        const size_t bytes = verts.size() * sizeof(mvert);
-        if (bytes > events->pile_scratch_bytes) {
-            if (events->pile_scratch) {
-                NZ_HIP(hipStreamSynchronize(ctx->stream));
-                (void)hipFree(events->pile_scratch);
-                events->pile_scratch = nullptr;
-            }
+                for (int i = 0; i <= dist + 1; i++)
+                    ofs.push_back(make_short2((short)(dist * DAX[dir] + i * (DBX[dir] - DAX[dir])),
+                                              (short)(dist * DAZ[dir] + i * (DBZ[dir] - DAZ[dir]))));
+        const size_t bytes = ofs.size() * sizeof(short2);
+        if (bytes != events->pile_scratch_bytes) {  // the table of another radius: rebuild (rare)
+            NZ_HIP(hipStreamSynchronize(ctx->stream));
+            if (events->pile_scratch) (void)hipFree(events->pile_scratch);
+            events->pile_scratch = nullptr;
             NZ_HIP(hipMalloc(&events->pile_scratch, bytes));
+            NZ_HIP(hipMemcpy(events->pile_scratch, ofs.data(), bytes, hipMemcpyHostToDevice));
             events->pile_scratch_bytes = bytes;
         }
-        NZ_HIP(hipMemcpyAsync(events->pile_scratch, verts.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-        NZ_HIP(hipStreamSynchronize(ctx->stream));  // `verts` is pageable host memory
-        hipLaunchKernelGGL(pile_kernel, dim3(1), dim3(CT), 0, ctx->stream, height, events->sediment, events->piles,
-                           events->piles + n, events->counters, (mvert *)events->pile_scratch, (int)verts.size(), res, D,
-                           ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT);
-        NZ_HIP(hipGetLastError());
-    } else {
-        NZ_HIP(hipMemsetAsync(events->counters + 2, 0, 4, ctx->stream));
+        const int nverts = (int)ofs.size(), B = 2 * (D + 1), nb = (res + B - 1) / B;
+        const size_t lds = (size_t)nverts * 9;
+        for (int colour = 0; colour < 4; colour++) {
+            const int cx = colour & 1, cz = colour >> 1;
+            const int bxn = (nb - cx + 1) / 2, bzn = (nb - cz + 1) / 2;
+            if (bxn <= 0 || bzn <= 0) continue;
+            hipLaunchKernelGGL(pile_kernel, dim3((unsigned)(bxn * bzn)), dim3(64), lds, ctx->stream, height, events->sediment,
+                               (const short2 *)events->pile_scratch, nverts, res, D, B, nb, cx, cz, thr,
+                               ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT);
+            NZ_HIP(hipGetLastError());
+        }
     }
     return nz_ctx_finish(ctx, out);
 }

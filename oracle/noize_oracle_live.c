@@ -428,31 +428,58 @@ int nzo_erode_height_maps(float *height, const float *sediment, int res, const n
     }
     memcpy(height, out, (size_t)res * res * sizeof(float));
     free(out);
-    /* phase B: the PileSolver events, one after the other in the same canonical order */
+    /* phase B: the PileSolver events.  A pile reads and raises heights within Chebyshev distance PILING_RADIUS + 1 of
+     * its cell, so piles whose cells lie in different blocks of side 2 * (PILING_RADIUS + 1) with one block between
+     * them cannot see each other: the grid is cut into such blocks, the blocks are 4-coloured by (bx & 1, bz & 1), the
+     * colours run one after the other ((0,0), (1,0), (0,1), (1,1)), all blocks of a colour independently, and inside a
+     * block the events keep the canonical order (z ascending, x ascending inside). */
     int maxDistance = ep->PILING_RADIUS;
-    int nverts = (((maxDistance + 1) * (maxDistance + 2)) * 2) - 3; /* :1063; only the first `c` are initialised */
-    nzo_mvert *verts = (nzo_mvert *)calloc((size_t)(nverts > 0 ? nverts : 1), sizeof(nzo_mvert));
-    if (!verts) return -1;
-    int c = 0;
-    static const int DAX[4] = {0, 1, 0, -1}, DAZ[4] = {1, 0, -1, 0}; /* dirA: up, right, down, left */
-    static const int DBX[4] = {1, 0, -1, 0}, DBZ[4] = {0, -1, 0, 1}; /* dirB: right, down, left, up */
-    for (int dist = 0; dist < maxDistance; dist++)
-        for (int dir = 0; dir < 4; dir++)
-            for (int i = 0; i <= dist + 1; i++) { /* GetOffset: dist*dirA + i*(dirB - dirA) */
-                verts[c].ox = dist * DAX[dir] + i * (DBX[dir] - DAX[dir]);
-                verts[c].oz = dist * DAZ[dir] + i * (DBZ[dir] - DAZ[dir]);
-                c++;
+    if (maxDistance < 1) return 0;
+    int nverts = 0;
+    for (int dist = 0; dist < maxDistance; dist++) nverts += 4 * (dist + 2);
+    short *ofs = (short *)malloc((size_t)nverts * 2 * sizeof(short));
+    if (!ofs) return -1;
+    {
+        int c = 0;
+        static const int DAX[4] = {0, 1, 0, -1}, DAZ[4] = {1, 0, -1, 0}; /* dirA: up, right, down, left */
+        static const int DBX[4] = {1, 0, -1, 0}, DBZ[4] = {0, -1, 0, 1}; /* dirB: right, down, left, up */
+        for (int dist = 0; dist < maxDistance; dist++)
+            for (int dir = 0; dir < 4; dir++)
+                for (int i = 0; i <= dist + 1; i++) { /* GetOffset: dist*dirA + i*(dirB - dirA) */
+                    ofs[2 * c] = (short)(dist * DAX[dir] + i * (DBX[dir] - DAX[dir]));
+                    ofs[2 * c + 1] = (short)(dist * DAZ[dir] + i * (DBZ[dir] - DAZ[dir]));
+                    c++;
+                }
+    }
+    const int B = 2 * (maxDistance + 1), nb = (res + B - 1) / B;
+    int failed = 0;
+    for (int colour = 0; colour < 4; colour++) {
+        const int cx = colour & 1, cz = colour >> 1;
+#pragma omp parallel
+        {
+            nzo_mvert *verts = (nzo_mvert *)calloc((size_t)nverts, sizeof(nzo_mvert));
+            if (!verts) {
+#pragma omp atomic write
+                failed = 1;
+            } else {
+                for (int i = 0; i < nverts; i++) { verts[i].ox = ofs[2 * i]; verts[i].oz = ofs[2 * i + 1]; }
+#pragma omp for schedule(dynamic, 4) collapse(2)
+                for (int bz = cz; bz < nb; bz += 2)
+                    for (int bx = cx; bx < nb; bx += 2) {
+                        int x1 = (bx + 1) * B < res ? (bx + 1) * B : res, z1 = (bz + 1) * B < res ? (bz + 1) * B : res;
+                        for (int z = bz * B; z < z1; z++)
+                            for (int x = bx * B; x < x1; x++) {
+                                float val = sediment[(size_t)x * res + z];
+                                if (val == 0.0f || is_disperse(val, PILE_THRESHOLD)) continue;
+                                pile_handle(height, res, verts, nverts, maxDistance, x, z, val, MIN_PILE_INCREMENT);
+                            }
+                    }
+                free(verts);
             }
-    for (int i = c; i < nverts; i++) { verts[i].ox = verts[i].oz = 0; } /* default(ManhattanVertex): offset 0 */
-    for (int z = 0; z < res; z++)
-        for (int x = 0; x < res; x++) {
-            float val = sediment[(size_t)x * res + z];
-            if (val == 0.0f || is_disperse(val, PILE_THRESHOLD)) continue;
-            if (maxDistance < 1) continue;
-            pile_handle(height, res, verts, c, maxDistance, x, z, val, MIN_PILE_INCREMENT);
         }
-    free(verts);
-    return 0;
+    }
+    free(ofs);
+    return failed ? -1 : 0;
 }
 
 /* ---- PoolAutomataJob with drainParticles == true (MultiThreadErosionJob.cs:264-327, WorldTile.SpreadPool

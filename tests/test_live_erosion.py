@@ -228,7 +228,7 @@ def test_config4_reduced_live_erosion_equals_oracle(nj, ctx, oracle):
     # heights stay in [0, 1], erosion moved material but did not create it beyond what left the tile
     pool, flow, height = L.pool, L.flow, L.height
     assert pool.min() >= 0 and L.track.max() == 0 and 0 <= flow.min() and flow.max() < 1 and 0 <= height.min() and height.max() <= 1
-    assert not np.array_equal(height, h) and float(np.abs(height - h).max()) < 0.05
+    assert not np.array_equal(height, h) and float(np.abs(height - h).max()) < 0.2
     mres = tm.TILE_RES[0]
     tex = G.textureControl.ToArray().reshape(mres, mres, 4)
     wat = G.waterControl.ToArray().reshape(mres, mres, 4)
@@ -238,3 +238,37 @@ def test_config4_reduced_live_erosion_equals_oracle(nj, ctx, oracle):
     cur = oracle.curviture_map(L.height, mres, th, float(tm.PATCH_RES[0]), 1)[..., 1]
     assert np.abs(tex[..., 1].astype(int) - cur.astype(int)).max() <= 1   # powf / logf of the device: one byte step at most
     G.OnDestroy()
+
+
+@pytest.mark.gpu
+def test_config4_full_size_is_deterministic_and_keeps_its_invariants(nj, ctx, oracle):
+    # BASELINE config 4 at its full size, 8192^2 cellular fBm 13 octaves + live erosion: too large to hand to the oracle
+    # cycle by cycle in the suite's time, so the size-independent properties -- two runs from the same seeds agree bit
+    # for bit (every atomic in the path is an integer add or an order-free append), a different seed does not, pools
+    # and flow stay in range, the particle track is consumed, heights stay in [0, 1]
+    res, particles = 8192, 10000
+    es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, CYCLES=2, WATER_STEPS=2)
+    tm = nj.tile_set_meta(res, height=1000, tile_size=8000, tile_res=res - 16, margin=8)
+    base = nj.GeneratorData("c4", ctx.alloc(res * res), res, 0, 0)
+    st = nj.NoiseStage(ctx, nj.FractalNoise.Cellular, 0.4, 1.0, 13, 2.0, 0.0, 1700)
+    st.ReceiveHandledInput(nj.PipelineWorkItem(base), nj.JobHandle())
+    st.jobHandle.Complete()
+    runs = []
+    for seeds in ([5, 6], [5, 6], [5, 7]):
+        h = ctx.alloc(res * res)
+        ctx.call("nz_flush_write_slice", h.ptr, base.data.ptr, res * res).Complete()
+        G = nj.LiveErosion(ctx, h, tm, es)
+        G.TriggerQueuedBeyerMT(seeds).Complete()
+        runs.append((h.ToArray(), G.poolMap.ToArray(), G.streamMap.ToArray(), G.particleTrack.ToArray(), G.events.Count,
+                     np.sort(G.particleQueue.ToArray(), order=["px", "pz", "water"])))
+        G.OnDestroy()
+        h.Dispose()
+    a, b, c = runs
+    for i in range(4):
+        assert np.array_equal(a[i], b[i])
+    assert a[4] == b[4] and np.array_equal(a[5], b[5])
+    assert not np.array_equal(a[0], c[0])
+    height, pool, flow, track = a[:4]
+    assert pool.min() >= 0 and track.max() == 0 and flow.min() >= 0 and flow.max() < 1 and 0 <= height.min() and height.max() <= 1
+    assert a[4] > particles   # events of the last cycle: every particle leaves at least its death event
+    base.data.Dispose()

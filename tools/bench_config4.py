@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 on one MI355X: 8192^2 cellular fBm (13 octaves) base + live particle erosion
+(LiveErosion.TriggerQueuedBeyerMT: thermal -> spawn -> descent -> event reduce -> sediment -> flow from track ->
+pool automaton), per-job GPU time from HIP events on the context's stream, whole cycles per second.
+usage: bench_config4.py [--res 8192] [--particles 10000] [--cycles 20] [--water-steps 10] [--json out.json]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import noize_job_amd as nj  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--res", type=int, default=8192)
+    ap.add_argument("--particles", type=int, default=10000)
+    ap.add_argument("--cycles", type=int, default=20)
+    ap.add_argument("--water-steps", type=int, default=10)
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    res = a.res
+    out = {"config": "%dx%d cellular-13oct base + live particle erosion, %d particles per cycle, WATER_STEPS %d" %
+                     (res, res, a.particles, a.water_steps)}
+    with nj.Context(0) as ctx:
+        h = ctx.alloc(res * res)
+        gd = nj.GeneratorData("c4", h, res, 0, 0)
+        st = nj.NoiseStage(ctx, nj.FractalNoise.Cellular, 0.4, 1.0, 13, 2.0, 0.0, 1700)
+        for _ in range(2):
+            st.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        a0 = ctx.record()
+        st.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
+        a1 = ctx.record()
+        a1.Complete()
+        out["noise_base_ms"] = round(ctx.elapsed_ms(a0, a1), 4)
+        es = nj.ErosionSettings(PARTICLES_PER_CYCLE=a.particles, CYCLES=1, WATER_STEPS=a.water_steps)
+        tm = nj.tile_set_meta(res, height=1000, tile_size=res, tile_res=res - 16, margin=8)
+        G = nj.LiveErosion(ctx, h, tm, es)
+        ep = es.AsParameters()
+        epp, tmp_ = C.byref(ep), C.byref(tm)
+        jobs = [
+            ("thermal", lambda: ctx.call("nz_thermal_erosion", h.ptr, float(es.TALUS), float(es.THERMAL_STEP),
+                                         float(tm.TILE_SIZE[0] // tm.HEIGHT), es.THERMAL_CYCLES, res)),
+            ("spawn", lambda: ctx.call("nz_fill_beyer_queue", G.particleQueue._h, epp, tmp_, 0, res, a.particles, 7, 10)),
+            ("descent", lambda: ctx.call("nz_queued_beyer_cycle", h.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
+                                         G.particleQueue._h, G.events._h, epp, tmp_, 1500, res)),
+            ("event_reduce", lambda: ctx.call("nz_process_beyer_erosive_events", h.ptr, G.poolMap.ptr, G.streamMap.ptr,
+                                              G.particleTrack.ptr, G.events._h, epp, tmp_, res)),
+            ("clear_queue", lambda: G.particleQueue.Clear()),
+            ("erode_height_maps", lambda: ctx.call("nz_erode_height_maps", h.ptr, G.events._h, epp, tmp_, res)),
+            ("flow_from_track", lambda: ctx.call("nz_update_flow_from_track", G.poolMap.ptr, G.streamMap.ptr,
+                                                 G.particleTrack.ptr, ep.FLOW_LOSS_RATE, ep.SURFACE_EVAPORATION_RATE,
+                                                 float(tm.HEIGHT), res)),
+            ("pool_automata", lambda: ctx.call("nz_pool_automata_job", G.poolMap.ptr, h.ptr, G.particleQueue._h, epp, tmp_,
+                                               a.water_steps, res, 1)),
+        ]
+        acc = {n: 0.0 for n, _ in jobs}
+        events = 0
+        for cyc in range(a.cycles + 2):
+            marks = [ctx.record()]
+            for _, fn in jobs:
+                fn()
+                marks.append(ctx.record())
+            marks[-1].Complete()
+            if cyc >= 2:
+                for i, (n, _) in enumerate(jobs):
+                    acc[n] += ctx.elapsed_ms(marks[i], marks[i + 1])
+                events += G.events.Count
+        out["per_job_ms"] = {n: round(v / a.cycles, 4) for n, v in acc.items()}
+        out["cycle_ms"] = round(sum(acc.values()) / a.cycles, 4)
+        out["events_per_cycle"] = events // a.cycles
+        # whole Updates through the host driver, wall clock
+        es.CYCLES = 3
+        G.TriggerQueuedBeyerMT([1, 2, 3]).Complete()
+        t0 = time.perf_counter()
+        n_up = max(1, a.cycles // 3)
+        for u in range(n_up):
+            G.TriggerQueuedBeyerMT([10 * u + 1, 10 * u + 2, 10 * u + 3])
+        G.jobHandle.Complete()
+        dt = time.perf_counter() - t0
+        out["driver_cycles_per_s"] = round(3 * n_up / dt, 2)
+        out["driver_particle_steps_per_s"] = round(out["events_per_cycle"] * 3 * n_up / dt)
+        G.OnDestroy()
+    print(json.dumps(out, indent=1))
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
