@@ -93,9 +93,38 @@ __device__ unsigned long long *nz_probe_buf = nullptr;  // [workgroup][16]
 #endif
 constexpr int conv_waves(int ks, int nt) { return ks == 5 ? NZ_CONV5_WAVES : nt >= 512 ? 4 : 6; }
 
-template <int KS, bool UNIT, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(KS, NT)))) void conv_reg_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
-                                                     nz_kernel_taps taps, int T, int aligned) {
+// 16-byte accesses that other XCDs can see / that see other XCDs' stores while the kernel runs: `sc1` buffer loads and
+// stores (they bypass the CU's L1; the stores write through and leave the XCD's L2), 4-byte ones as agent-scope relaxed
+// atomics (global_load/store_dword sc1).  Used by the chained kernel below, where a tile of launch l + 1 reads what
+// workgroups of launch l on other XCDs stored microseconds earlier (MI355X_MICROARCH.md, inter-workgroup visibility).
+typedef unsigned nz_v4u __attribute__((ext_vector_type(4)));
+constexpr int NZ_AUX_SC1 = 16;
+__device__ __forceinline__ float4 load16_sc1(const float *base, size_t float_off) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, -1, 0x00020000);
+    nz_v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, NZ_AUX_SC1);
+    // (__builtin_bit_cast on the vector's ELEMENTS is miscompiled by ROCm 7.2's clang: the load is narrowed to one
+    // dword and x is broadcast; __uint_as_float is not)
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+}
+__device__ __forceinline__ void store16_sc1(float *base, size_t float_off, float4 v) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000);
+    nz_v4u t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)(float_off * 4), 0, NZ_AUX_SC1);
+}
+// 4-byte forms for edge tiles: buffer accesses again (agent-scope atomic loads would each be waited for on their own)
+__device__ __forceinline__ float load4_sc1(const float *base, size_t float_off) {
+    return __hip_atomic_load(base + float_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store4_sc1(float *base, size_t float_off, float v) {
+    __hip_atomic_store(base + float_off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One workgroup's tile: T applications on the (NT/4) x 128 register tile whose interior starts at (ox0, oz0).
+// SC1: every global access is an sc1 access (see above); the plane must then be smaller than 4 GiB (32-bit offsets).
+template <int KS, bool UNIT, int NT, bool SC1>
+__device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *__restrict__ dst, const nz_geom &g,
+                                          const nz_kernel_taps &taps, int T, int aligned, int ox0, int oz0,
+                                          float4 *s_edge_raw) {
     constexpr int O = (KS - 1) / 2;
     constexpr int WN = 4 + 2 * O;   // X window
     constexpr int ZN = RB + 2 * O;  // Z window
@@ -104,15 +133,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
     // (one barrier per application) for the 3-tap kernel; the others keep one buffer and pay a second barrier
     // instead of giving up a resident workgroup (5 taps: 3 x 32 KB; 7/9 taps: 2 x 48/64 KB).
     constexpr int NBUF = O >= 2 ? 1 : 2;
-    __shared__ float4 s_edge[NBUF][TH / RB][2][O][TW / 4];
+    float4 (*s_edge)[TH / RB][2][O][TW / 4] = reinterpret_cast<float4 (*)[TH / RB][2][O][TW / 4]>(s_edge_raw);
 
     const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
     const int H = T * O, HX = (H + 3) & ~3;
     const int OW = TW - 2 * HX, OH = TH - 2 * H;
-    src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
-    dst += blockIdx.y * g.bstride;
-    int ox0, oz0;
-    tile_origin(g, OW, OH, ox0, oz0);
     const int lx0 = ox0 - HX, lz0 = oz0 - H;
     const int gx0 = lx0 + cg * 4, gzb = lz0 + rb * RB;
     const bool inside = lx0 >= 0 && lx0 + TW <= g.cols && lz0 >= g.zc0 && lz0 + TH - 1 <= g.zc1;
@@ -125,7 +150,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
     if (fast) {  // a real branch (the asm keeps the two forms from being merged into 4-byte accesses with selected addresses)
 #pragma unroll
         for (int r = 0; r < RB; r++) {
-            float4 t = *reinterpret_cast<const float4 *>(src + (size_t)(gzb + r) * g.pitch + gx0);
+            float4 t = SC1 ? load16_sc1(src, (size_t)(gzb + r) * g.pitch + gx0)
+                           : *reinterpret_cast<const float4 *>(src + (size_t)(gzb + r) * g.pitch + gx0);
             v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
         }
         asm volatile("; 16-byte loads issued" ::: "memory");  // after the loads: they cannot be sunk into a common tail
@@ -135,7 +161,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
         for (int r = 0; r < RB; r++) {
             size_t row = (size_t)clampi(gzb + r, g.zc0, g.zc1) * g.pitch;
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[r][e] = src[row + clampi(gx0 + e, 0, g.cols - 1)];
+            for (int e = 0; e < 4; e++) {
+                const size_t off = row + clampi(gx0 + e, 0, g.cols - 1);
+                v[r][e] = SC1 ? load4_sc1(src, off) : src[off];
+            }
         }
     }
     // window indices of the last grid column / first and last grid rows, for the clamps of edge tiles
@@ -240,7 +269,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
         for (int r = 0; r < RB; r++) {
             int lr = rb * RB + r, gz = gzb + r;
             bool in = lr >= H && lr < H + OH && cg * 4 >= HX && cg * 4 < HX + OW && gz < g.or1;
-            if (in) *reinterpret_cast<float4 *>(dst + (size_t)gz * g.pitch + gx0) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+            if (in) {
+                if (SC1) store16_sc1(dst, (size_t)gz * g.pitch + gx0, make_float4(v[r][0], v[r][1], v[r][2], v[r][3]));
+                else *reinterpret_cast<float4 *>(dst + (size_t)gz * g.pitch + gx0) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+            }
         }
     } else {
         asm volatile("; guarded stores of an edge tile" ::: "memory");
@@ -251,12 +283,122 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
             if (in) {
 #pragma unroll
                 for (int e = 0; e < 4; e++)
-                    if (gx0 + e < g.cols) dst[(size_t)gz * g.pitch + gx0 + e] = v[r][e];
+                    if (gx0 + e < g.cols) {
+                        if (SC1) store4_sc1(dst, (size_t)gz * g.pitch + gx0 + e, v[r][e]);
+                        else dst[(size_t)gz * g.pitch + gx0 + e] = v[r][e];
+                    }
             }
         }
     }
     NZ_PROBE_T(12);
 }
+
+template <int KS, bool UNIT, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(KS, NT)))) void conv_reg_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
+                                                     nz_kernel_taps taps, int T, int aligned) {
+    constexpr int O = (KS - 1) / 2;
+    constexpr int TH = NT / 32 * RB;
+    constexpr int NBUF = O >= 2 ? 1 : 2;
+    __shared__ float4 s_edge[NBUF][TH / RB][2][O][TW / 4];
+    const int H = T * O, HX = (H + 3) & ~3;
+    src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
+    dst += blockIdx.y * g.bstride;
+    int ox0, oz0;
+    tile_origin(g, TW - 2 * HX, TH - 2 * H, ox0, oz0);
+    conv_tile<KS, UNIT, NT, false>(src, dst, g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0]);
+}
+
+// ---- the launches of a stage as ONE grid with tile-level dependencies -------------------------------------------------
+// KernelFilterStage's `iterations` applications are L fused launches that ping-pong between two planes.  Run as L
+// kernels, every launch is two rounds of workgroups that load together (idle SIMDs), compute together (idle memory)
+// and store together, and the chip drains at every launch boundary.  Here the tiles of ALL L launches form one grid:
+// a workgroup takes the next work item of its class (class = blockIdx.x & 7, the workgroups an XCD receives; items
+// are dealt so that a class works through a contiguous eighth of every launch's tiles, in launch order), waits until
+// the <= 9 tiles of the previous launch that its input window touches have been stored, and runs the same tile code
+// with sc1 accesses.  Loads of launch l + 1 overlap arithmetic of launch l, and nothing drains in between.
+//   * work items are claimed with an atomic ticket per class, so a workgroup only ever waits for items that were
+//     claimed before its own: the wait cannot deadlock whatever order the hardware starts workgroups in;
+//   * hand-off: producer = sc1 stores, every wave s_waitcnt vmcnt(0), workgroup barrier, ONE lane stores the tile's
+//     flag (agent scope); consumer = up to nine lanes poll one flag each (sc1 loads), workgroup barrier, sc1 loads;
+//   * the poll is bounded: a workgroup that gives up raises ctl[NZ_CHAIN_ERR] and carries on, so the grid always
+//     drains and the host reports the failure at its next synchronisation instead of hanging;
+//   * flags carry the launch's epoch, and the last workgroup out zeroes the tickets: nothing is cleared between stages.
+// (A persistent form -- resident workgroups that claim item after item and let a tile's stores drain behind the next
+// tile's loads -- was built and measured: 0.555 ms for Gauss5 x17 against 0.197 ms, the loop-carried state costs the
+// 80-register budget 39 spills.  One item per workgroup it stays.)
+constexpr int NZ_CHAIN_MAXL = 8;
+constexpr int NZ_CHAIN_DONE = 8, NZ_CHAIN_ERR = 9;  // ctl[0..7] = tickets per class
+struct nz_chain {
+    int L, total;
+    int T[NZ_CHAIN_MAXL], first[NZ_CHAIN_MAXL + 1], tiles_x[NZ_CHAIN_MAXL];
+    unsigned epoch;
+    int *flags;       // one per work item, indexed first[l] + tile
+    unsigned *ctl;
+    float *plane[2];  // launch l reads plane[l & 1] and writes plane[(l + 1) & 1]
+};
+
+__host__ __device__ __forceinline__ int chain_class_count(int n, int c) { return n > c ? (n - c + 7) >> 3 : 0; }  // #{vb < n : vb % 8 == c}
+
+template <int KS, bool UNIT, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(KS, NT)))) void conv_chain_kernel(nz_geom g, nz_kernel_taps taps,
+                                                                                                                  nz_chain ch, int aligned) {
+    constexpr int O = (KS - 1) / 2;
+    constexpr int TH = NT / 32 * RB;
+    constexpr int NBUF = O >= 2 ? 1 : 2;
+    __shared__ float4 s_edge[NBUF][TH / RB][2][O][TW / 4];
+    __shared__ int s_item[2];
+    if (threadIdx.x == 0) {
+        const int cls = blockIdx.x & 7;
+        const int k = (int)atomicAdd(&ch.ctl[cls], 1u);
+        const int vb = 8 * k + cls;  // < total: the grid holds exactly as many workgroups of this class
+        int l = 0;
+        while (l + 1 < ch.L && vb >= ch.first[l + 1]) l++;
+        // the class's share of launch l is a contiguous run of tiles: classes before it, then its own earlier items
+        int start = 0;
+        for (int c = 0; c < cls; c++) start += chain_class_count(ch.first[l + 1], c) - chain_class_count(ch.first[l], c);
+        s_item[0] = l;
+        s_item[1] = start + chain_class_count(vb, cls) - chain_class_count(ch.first[l], cls);
+    }
+    __syncthreads();
+    const int l = s_item[0], tile = s_item[1];
+    const int T = ch.T[l], H = T * O, HX = (H + 3) & ~3;
+    const int OW = TW - 2 * HX, OH = TH - 2 * H;
+    const int by = tile / ch.tiles_x[l], bx = tile - by * ch.tiles_x[l];
+    const int ox0 = bx * OW, oz0 = g.or0 + by * OH;
+    if (l > 0) {
+        const int Tp = ch.T[l - 1], Hp = Tp * O, HXp = (Hp + 3) & ~3;
+        const int OWp = TW - 2 * HXp, OHp = TH - 2 * Hp;
+        const int ix0 = max(ox0 - HX, 0), ix1 = min(ox0 - HX + TW - 1, g.cols - 1);
+        const int iz0 = max(oz0 - H, g.or0), iz1 = min(oz0 - H + TH - 1, g.or1 - 1);
+        const int px0 = ix0 / OWp, px1 = ix1 / OWp, py0 = (iz0 - g.or0) / OHp, py1 = (iz1 - g.or0) / OHp;
+        const int nx = px1 - px0 + 1, nd = nx * (py1 - py0 + 1);
+        if ((int)threadIdx.x < nd) {
+            const int dep = (py0 + (int)threadIdx.x / nx) * ch.tiles_x[l - 1] + px0 + (int)threadIdx.x % nx;
+            const int *f = ch.flags + ch.first[l - 1] + dep;
+            int spins = 0;
+            while ((unsigned)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ch.epoch) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1 << 21)) {  // seconds: the producer is never coming
+                    __hip_atomic_store(&ch.ctl[NZ_CHAIN_ERR], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    conv_tile<KS, UNIT, NT, true>(ch.plane[l & 1], ch.plane[(l + 1) & 1], g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&ch.flags[ch.first[l] + tile], (int)ch.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)atomicAdd(&ch.ctl[NZ_CHAIN_DONE], 1u) == ch.total - 1) {  // the last one out resets the tickets for the next stage
+#pragma unroll
+            for (int c = 0; c <= NZ_CHAIN_DONE; c++) __hip_atomic_store(&ch.ctl[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+
 
 // E applications of the {-1,0} min window fused as one window min over [x-E,x] x [z-E,z], register
 // resident like conv_reg_kernel: the X pass reaches E <= 8 cells into the one or two lanes on the left
@@ -564,7 +706,73 @@ int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom 
     return NZ_OK;
 }
 
+template <int KS>
+int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
+                     int L, int *flags, unsigned *ctl, unsigned epoch) {
+    constexpr int O = (KS - 1) / 2;
+    constexpr int NT = KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT, RTH = NT / 32 * RB;
+    nz_chain ch{};
+    ch.L = L;
+    ch.first[0] = 0;
+    for (int l = 0; l < L; l++) {
+        int H = Ts[l] * O, HX = (H + 3) & ~3;
+        int OW = TW - 2 * HX, OH = RTH - 2 * H;
+        ch.T[l] = Ts[l];
+        ch.tiles_x[l] = (g.cols + OW - 1) / OW;
+        ch.first[l + 1] = ch.first[l] + ch.tiles_x[l] * ((g.or1 - g.or0 + OH - 1) / OH);
+    }
+    ch.total = ch.first[L];
+    ch.epoch = epoch;
+    ch.flags = flags;
+    ch.ctl = ctl;
+    ch.plane[0] = plane0;
+    ch.plane[1] = plane1;
+    int aligned = ((reinterpret_cast<uintptr_t>(plane0) | reinterpret_cast<uintptr_t>(plane1) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
+    if (k.factor == 1.0f)
+        hipLaunchKernelGGL((conv_chain_kernel<KS, true, NT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned);
+    else
+        hipLaunchKernelGGL((conv_chain_kernel<KS, false, NT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
 }  // namespace
+
+// work items (= flags) the chained form of L launches needs on this geometry
+int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L) {
+    const int O = (ksize - 1) / 2, RTH = (ksize >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT) / 32 * RB;
+    int n = 0;
+    for (int l = 0; l < L; l++) {
+        int H = Ts[l] * O, HX = (H + 3) & ~3;
+        int OW = TW - 2 * HX, OH = RTH - 2 * H;
+        n += ((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
+    }
+    return n;
+}
+
+// L <= 8 fused launches as ONE grid with tile-level dependencies (conv_chain_kernel): launch l reads plane (l & 1) and
+// writes the other one, so the result is in plane0 when L is even.  One grid of the geometry (g.count == 1), planes
+// below 4 GiB.  flags: nz_conv_chain_items() ints, never cleared; ctl: 16 words, zero before the first use.
+int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
+                             const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch) {
+    if (L < 1 || L > NZ_CHAIN_MAXL || g.count != 1 || (size_t)g.rows * g.pitch * 4 >= ((size_t)1 << 32)) {
+        nz_set_error("conv_chain: %d launches / %d grids / plane of %zu bytes unsupported", L, g.count, (size_t)g.rows * g.pitch * 4);
+        return NZ_ERR_INVALID;
+    }
+    for (int l = 0; l < L; l++)
+        if (Ts[l] < 1 || Ts[l] > nz_conv_max_fused(k.ksize)) {
+            nz_set_error("conv_chain: T=%d unsupported for kernelSize %d", Ts[l], k.ksize);
+            return NZ_ERR_INVALID;
+        }
+    if (g.or1 <= g.or0) return NZ_OK;
+    switch (k.ksize) {
+        case 3: return launch_chain<3>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch);
+        case 5: return launch_chain<5>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch);
+        case 7: return launch_chain<7>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch);
+        case 9: return launch_chain<9>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch);
+    }
+    return NZ_ERR_INVALID;
+}
 
 // largest T with a useful interior left (OH >= 32, OW >= 96); 0 = this size has no fused kernel
 int nz_conv_max_fused(int ksize) {

@@ -52,6 +52,12 @@ struct nz_ctx {
     // stage scratch owned by the ctx (grown on demand)
     float *scratch = nullptr;
     size_t scratch_floats = 0;
+    // chained launches (nz_launch_conv_chain): tile flags (grown on demand, never cleared: they carry an epoch) and
+    // the control block {8 tickets, done, error, ...}
+    int *chain_flags = nullptr;
+    size_t chain_flags_n = 0;
+    unsigned *chain_ctl = nullptr;
+    unsigned chain_epoch = 0;
 };
 
 #define NZ_TRY_(expr)             \
@@ -155,6 +161,11 @@ int nz_conv_max_fused(int ksize);
 // T fused applications of (X pass, Z pass) src -> dst on rows [or0, or1)
 int32_t nz_launch_conv_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g,
                              const nz_kernel_taps &k, int T);
+// L launches as one grid with tile-level dependencies; see nz_filter.hip
+int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L);
+int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
+                             const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch);
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch);
 // one whole application of a wide odd kernel (11..25 taps), src -> dst
 bool nz_conv_has_wide(int ksize);
 int32_t nz_launch_conv_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k);

@@ -44,6 +44,7 @@ static constexpr size_t NZ_EVENT_RING = 4096;
 static int32_t ctx_sync_all(nz_ctx *ctx);
 static void registry_add(nz_ctx *ctx);
 static void registry_remove(nz_ctx *ctx);
+static int32_t ctx_chain_check(nz_ctx *ctx);
 
 
 static float h_mod289(float x);
@@ -223,6 +224,8 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     if (ctx->d_rgrad) (void)hipFree(ctx->d_rgrad);
     if (ctx->d_simplex) (void)hipFree(ctx->d_simplex);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->chain_flags) (void)hipFree(ctx->chain_flags);
+    if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return NZ_OK;
@@ -231,7 +234,8 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
 extern "C" int32_t nz_ctx_synchronize(nz_ctx *ctx) {
     NZ_REQUIRE(ctx, "ctx is NULL");
     NZ_HIP(hipSetDevice(ctx->device));
-    return ctx_sync_all(ctx);
+    NZ_TRY_(ctx_sync_all(ctx));
+    return ctx_chain_check(ctx);
 }
 
 extern "C" void *nz_ctx_stream(nz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -240,6 +244,7 @@ static int32_t ctx_sync_all(nz_ctx *ctx) {
     NZ_HIP(hipStreamSynchronize(ctx->stream));
     return NZ_OK;
 }
+static int32_t ctx_chain_check(nz_ctx *ctx);
 
 // ---- context registry: a handle value carries the id of the context that issued it ------------------------------
 static std::mutex g_reg_mx;
@@ -343,6 +348,45 @@ int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out) {
     return NZ_OK;
 }
 
+// The flags / control block of the chained launches.  Flags are compared with an epoch that grows by one per launch, so
+// stale contents never match; a (re)allocated array is zeroed and the epoch restarts above zero.
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch) {
+    if (!ctx->chain_ctl) {
+        NZ_HIP(hipMalloc((void **)&ctx->chain_ctl, 64));
+        NZ_HIP(hipMemsetAsync(ctx->chain_ctl, 0, 64, ctx->stream));
+    }
+    if (items > ctx->chain_flags_n) {
+        if (ctx->chain_flags) {
+            NZ_TRY_(ctx_sync_all(ctx));
+            NZ_HIP(hipFree(ctx->chain_flags));
+            ctx->chain_flags = nullptr;
+            ctx->chain_flags_n = 0;
+        }
+        size_t n = items + items / 2 + 1024;
+        NZ_HIP(hipMalloc((void **)&ctx->chain_flags, n * sizeof(int)));
+        NZ_HIP(hipMemsetAsync(ctx->chain_flags, 0, n * sizeof(int), ctx->stream));
+        ctx->chain_flags_n = n;
+    }
+    if (++ctx->chain_epoch == 0) ctx->chain_epoch = 1;  // 0 is what a fresh flag holds
+    *flags = ctx->chain_flags;
+    *ctl = ctx->chain_ctl;
+    *epoch = ctx->chain_epoch;
+    return NZ_OK;
+}
+
+// a chained launch that gave up waiting for a producer tile has raised ctl[9]: reported wherever the host waits
+static int32_t ctx_chain_check(nz_ctx *ctx) {
+    if (!ctx->chain_ctl) return NZ_OK;
+    int err = 0;
+    NZ_HIP(hipMemcpy(&err, ctx->chain_ctl + 9, sizeof err, hipMemcpyDeviceToHost));
+    if (err) {
+        (void)hipMemset(ctx->chain_ctl, 0, 64);
+        nz_set_error("a chained kernel-filter launch timed out waiting for a producer tile: its results are invalid");
+        return NZ_ERR_HIP;
+    }
+    return NZ_OK;
+}
+
 extern "C" int32_t nz_handle_record(nz_ctx *ctx, nz_handle *out) {
     NZ_REQUIRE(ctx && out, "ctx/out is NULL");
     NZ_HIP(hipSetDevice(ctx->device));
@@ -405,7 +449,7 @@ extern "C" int32_t nz_handle_wait(nz_ctx *ctx, nz_handle h) {
     // caller must not run concurrently with a wait on that context's handles.)
     NZ_HIP(hipSetDevice(dev));
     NZ_HIP(hipEventSynchronize(ev));
-    return NZ_OK;
+    return handle_ctx_id(h) == ctx->id ? ctx_chain_check(ctx) : NZ_OK;
 }
 
 extern "C" int32_t nz_handle_elapsed_ms(nz_ctx *ctx, nz_handle start, nz_handle stop, float *ms) {

@@ -235,6 +235,20 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     int L = (iterations + cap - 1) / cap;
     if (!swapped && (L & 1) && L + 1 <= iterations) L += 1;  // an even count leaves the result in src
     int base = iterations / L, rem = iterations % L;
+    // the launches as ONE grid with tile-level dependencies (nz_filter.hip, conv_chain_kernel); NZ_CONV_CHAIN=0: one
+    // kernel per launch
+    static const bool chain_on = !(getenv("NZ_CONV_CHAIN") && atoi(getenv("NZ_CONV_CHAIN")) == 0);
+    if (chain_on && L >= 2 && L <= 8 && g.count == 1 && (size_t)g.rows * g.pitch * 4 < ((size_t)1 << 32) &&
+        (swapped || !(L & 1))) {
+        int Ts[8];
+        for (int i = 0; i < L; i++) Ts[i] = base + (i < rem ? 1 : 0);
+        int *flags = nullptr;
+        unsigned *ctl = nullptr, epoch = 0;
+        NZ_TRY_(nz_ctx_chain_state(ctx, (size_t)nz_conv_chain_items(t.ksize, g, Ts, L), &flags, &ctl, &epoch));
+        NZ_TRY_(nz_launch_conv_chain(ctx->stream, src, tmp, g, t, Ts, L, flags, ctl, epoch));
+        if (swapped) *swapped = (L & 1) != 0;
+        return NZ_OK;
+    }
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
         int T = base + (i < rem ? 1 : 0);
