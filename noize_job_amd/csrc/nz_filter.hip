@@ -113,10 +113,12 @@ __device__ __forceinline__ void store16_sc1(float *base, size_t float_off, float
 }
 // 4-byte forms for edge tiles: buffer accesses again (agent-scope atomic loads would each be waited for on their own)
 __device__ __forceinline__ float load4_sc1(const float *base, size_t float_off) {
-    return __hip_atomic_load(base + float_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, -1, 0x00020000);
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(float_off * 4), 0, NZ_AUX_SC1));
 }
 __device__ __forceinline__ void store4_sc1(float *base, size_t float_off, float v) {
-    __hip_atomic_store(base + float_off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(float_off * 4), 0, NZ_AUX_SC1);
 }
 
 // One workgroup's tile: T applications on the (NT/4) x 128 register tile whose interior starts at (ox0, oz0).
