@@ -1,0 +1,161 @@
+// Pipeline.cs -- the reference's operator API, Unity-free: StageIO payloads, PipelineWorkItem, PipelineStage and
+// BasePipeline with the same members and call order as
+//   Pipeline/Stage/StageIO.cs:8-11, Pipeline/Stage/StageIOTypes/*.cs, Pipeline/Stage/PipelineDefinition.cs:18-25,
+//   Pipeline/Stage/PipelineStage.cs:10-62, Pipeline/Executable/Pipeline.cs:19-287,
+// so stage graphs written against the reference (NoiseStage -> KernelFilterStage -> FlowMapStage -> MeshTileStage)
+// keep their shape; NativeSlice<float> is a DeviceTile, JobHandle a GpuJobHandle.  Source only (no .NET toolchain in
+// the build image).
+using System;
+using System.Collections.Concurrent;
+using System.Collections.Generic;
+
+namespace xshazwar.noize.hip {
+
+    public class StageIO {                       // StageIO.cs:8-11
+        public string uuid;
+        public DeviceTile data;
+    }
+
+    public class GeneratorData : StageIO {       // StageIOTypes/GeneratorData.cs:9-15
+        public int resolution, xpos, zpos;
+        // new: the WRITE slice of the tile's RWTileData pair (Pipeline/Tiles/TileData.cs:49-93).  When set, the stencil
+        // stages run their nz_*_rw forms and TileHelpers.SWAP_RWTILE is a swap of `data` and `write`.
+        public DeviceTile write;
+    }
+
+    public class MeshStageData : StageIO {       // StageIOTypes/MeshStageData.cs:9-21
+        public int resolution, inputResolution, marginPix, xpos, zpos;
+        public float tileSize, tileHeight;
+        public DeviceTile vertices, indices;     // stand in for UnityEngine.Mesh: 48-byte Stream0 records, uint indices
+    }
+
+    public class ReduceData : StageIO {          // StageIOTypes/ReduceData.cs:9-17
+        public DeviceTile rightData;
+        public int resolution, xpos, zpos;
+    }
+
+    public class PipelineWorkItem {              // PipelineDefinition.cs:18-25
+        public StageIO data;
+        public Action<StageIO> completeAction;
+        public Action<StageIO, GpuJobHandle> scheduledAction;
+        public GpuJobHandle dependency;
+    }
+
+    public abstract class PipelineStage {        // PipelineStage.cs:10-62
+        protected readonly GpuContext ctx;
+        public GpuJobHandle jobHandle;
+        public Action<PipelineWorkItem, GpuJobHandle> OnStageScheduledAction;
+        protected int dataLength = 0;
+        protected PipelineStage(GpuContext ctx) { this.ctx = ctx; }
+
+        public virtual void ResizeNativeContainers(int size) {}
+        public virtual bool IsSchedulable(PipelineWorkItem job) => true;
+
+        protected void CheckRequirements<T>(PipelineWorkItem requirements) where T : StageIO {   // :29-39
+            if (requirements.data is T d) {
+                if (d.data.Length != dataLength) { dataLength = d.data.Length; ResizeNativeContainers(d.data.Length); }
+            } else {
+                throw new Exception($"Unhandled stageio {requirements.data.GetType()}");
+            }
+        }
+
+        public abstract void Schedule(PipelineWorkItem requirements, GpuJobHandle dependency);
+        public virtual void TransformData(PipelineWorkItem data) {}
+
+        public void ReceiveHandledInput(PipelineWorkItem requirements, GpuJobHandle dependency) {  // :41-48
+            Schedule(requirements, dependency);
+            TransformData(requirements);
+            OnStageScheduledAction?.Invoke(requirements, jobHandle);
+        }
+
+        public virtual void OnStageComplete() {}
+        public virtual void OnDestroy() {}
+        protected GpuJobHandle Done(ulong h) => ctx.Wrap(h);
+
+        // adopt the READ / WRITE pair as an nz_*_rw entry left it
+        protected static void Adopt(GeneratorData d, NzRwTile t) {
+            if (t.read != d.data.Ptr) { DeviceTile s = d.data; d.data = d.write; d.write = s; }
+        }
+    }
+
+    public class BasePipeline {                  // Pipeline.cs:19-287
+        public string alias = "Unnamed Pipeline";
+        protected readonly List<PipelineStage> stage_instances;
+        protected readonly ConcurrentQueue<PipelineWorkItem> queue = new ConcurrentQueue<PipelineWorkItem>();
+        protected readonly List<PipelineWorkItem> dependencyHell = new List<PipelineWorkItem>();
+        protected PipelineWorkItem activeItem;
+        public GpuJobHandle pipelineHandle;
+        public bool pipelineRunning, pipelineBeingScheduled;
+
+        public BasePipeline(IEnumerable<PipelineStage> stages, string alias = "Unnamed Pipeline") {
+            this.alias = alias;
+            stage_instances = new List<PipelineStage>(stages);
+            Setup();
+        }
+
+        void Setup() {                           // :130-152
+            PipelineStage previous = null;
+            foreach (PipelineStage stage in stage_instances) {
+                if (previous != null) previous.OnStageScheduledAction += stage.ReceiveHandledInput;
+                previous = stage;
+            }
+            if (previous != null) previous.OnStageScheduledAction += OnPipelineFullyScheduled;
+        }
+
+        public void Enqueue(StageIO input, Action<StageIO, GpuJobHandle> scheduleAction = null, Action<StageIO> completeAction = null,
+                            GpuJobHandle dependency = default) {                                  // :76-90
+            queue.Enqueue(new PipelineWorkItem { data = input, completeAction = completeAction, scheduledAction = scheduleAction,
+                                                 dependency = dependency });
+        }
+
+        public void Schedule(PipelineWorkItem item) {                                               // :104-120
+            activeItem = item;
+            if (stage_instances.Count == 0) throw new Exception("No stages in pipeline");
+            pipelineBeingScheduled = true;
+            stage_instances[0].ReceiveHandledInput(activeItem, activeItem.dependency);
+        }
+
+        void OnPipelineFullyScheduled(PipelineWorkItem res, GpuJobHandle handle) {                  // :122-128
+            pipelineHandle = handle;
+            pipelineRunning = true;
+            pipelineBeingScheduled = false;
+            activeItem.scheduledAction?.Invoke(res.data, handle);
+        }
+
+        bool WorkIsSchedulable(PipelineWorkItem item) {                                             // :256-265
+            bool ready = true;
+            foreach (PipelineStage stage in stage_instances) ready = stage.IsSchedulable(item) && ready;
+            return ready;
+        }
+
+        PipelineWorkItem GetNextJob() {                                                             // :183-214
+            for (int i = 0; i < dependencyHell.Count; i++)
+                if (WorkIsSchedulable(dependencyHell[i])) { PipelineWorkItem j = dependencyHell[i]; dependencyHell.RemoveAt(i); return j; }
+            while (queue.TryDequeue(out PipelineWorkItem wi)) {
+                if (WorkIsSchedulable(wi)) return wi;
+                dependencyHell.Add(wi);
+            }
+            return null;
+        }
+
+        public void Update() {                                                                      // :154-158,224-230
+            if (!pipelineRunning && !pipelineBeingScheduled) {
+                PipelineWorkItem job = GetNextJob();
+                if (job != null) Schedule(job);
+            }
+        }
+
+        public bool LateUpdate() {                                                                  // :160-181
+            if (pipelineRunning && pipelineHandle.IsCompleted) {
+                pipelineHandle.Complete();
+                foreach (PipelineStage stage in stage_instances) stage.OnStageComplete();
+                activeItem.completeAction?.Invoke(activeItem.data);
+                pipelineRunning = false;
+                return true;
+            }
+            return false;
+        }
+
+        public void Destroy() { foreach (PipelineStage stage in stage_instances) stage.OnDestroy(); }  // :244-254
+    }
+}

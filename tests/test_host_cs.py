@@ -1,0 +1,131 @@
+"""host-cs/ -- the C# host (source only: no .NET toolchain in the image) -- is checked against the C ABI by parsing:
+Native.cs is what tools/gen_native_cs.py generates from include/noize_hip.h; every prototype matches its [DllImport] in
+name, arity, order and type; every Native.nz_* call in the hand-written files names a declared entry with the right
+argument count; the sequential structs carry their C counterparts' fields in order."""
+import importlib.util
+import os
+import re
+
+from conftest import ROOT
+
+spec = importlib.util.spec_from_file_location("gen_native_cs", os.path.join(ROOT, "tools", "gen_native_cs.py"))
+gen = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(gen)
+CS = os.path.join(ROOT, "host-cs")
+
+
+def _cs_sources():
+    out = {}
+    for d, _, files in os.walk(CS):
+        for f in files:
+            if f.endswith(".cs"):
+                out[os.path.relpath(os.path.join(d, f), CS)] = open(os.path.join(d, f)).read()
+    return out
+
+
+def test_native_cs_is_generated_from_the_header():
+    assert open(os.path.join(CS, "Native.cs")).read() == gen.generate(), "run tools/gen_native_cs.py"
+
+
+def test_every_prototype_has_its_dllimport_with_the_same_shape():
+    header = gen.parse_header()
+    cs = gen.parse_cs()
+    assert len(header) >= 85 and {n for n, _, _ in header} == set(cs)
+    for name, ret, params in header:
+        cs_ret, cs_params = cs[name]
+        assert cs_ret == gen.cs_return(ret), name
+        assert len(cs_params) == len(params), name
+        for (ctype, pname), got in zip(params, cs_params):
+            assert got == gen.cs_type(ctype, pname, name), (name, pname)
+        # the reference's delegates end in (JobHandle dependency) and return a JobHandle: (dep, out) close the list
+        if params and params[-1] == ("nz_handle*", "out") and len(params) >= 2 and params[-2][0] == "nz_handle":
+            assert cs_params[-2:] == ["ulong", "out ulong"], name
+    # scalar order of three delegates, spelled out against the C# reference signatures
+    f = dict((n, [p for _, p in ps]) for n, _, ps in header)
+    assert f["nz_fractal"] == ["ctx", "noiseType", "src", "resolution", "hurst", "startingAmplitude", "stepdown", "detuneRate",
+                               "octaves", "xpos", "zpos", "noiseSize", "dep", "out"]            # Fractal.cs:76-88
+    assert f["nz_heightmap_mesh"] == ["ctx", "meshType", "vertices", "indices", "resolution", "inputResolution", "marginPix",
+                                      "tileHeight", "tileSize", "heights", "dep", "out"]       # HeightMapMeshJob.cs:55-65
+    assert f["nz_flowmap_update_water"] == ["ctx", "waterMap", "waterMap__buff", "flowMapN", "flowMapS", "flowMapE", "flowMapW",
+                                            "resolution", "dep", "out"]                        # FlowMapJob.cs:154-165
+
+
+def _split_args(s):
+    args, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        args.append(cur.strip())
+    return args
+
+
+def test_hand_written_files_call_declared_entries_with_the_right_arity():
+    cs = gen.parse_cs()
+    calls = 0
+    for path, text in _cs_sources().items():
+        if path == "Native.cs":
+            continue
+        for m in re.finditer(r"Native\.(nz_\w+)\s*\(", text):
+            name = m.group(1)
+            assert name in cs, "%s calls undeclared %s" % (path, name)
+            i, depth = m.end(), 1
+            while depth:
+                depth += {"(": 1, ")": -1}.get(text[i], 0)
+                i += 1
+            args = _split_args(text[m.end():i - 1])
+            assert len(args) == len(cs[name][1]), "%s: %s takes %d arguments, called with %d" % (path, name, len(cs[name][1]), len(args))
+            for a, t in zip(args, cs[name][1]):   # out / ref at the call site where the declaration has them
+                if t.startswith("out "):
+                    assert a.startswith("out "), (path, name, a)
+                if t.startswith("ref "):
+                    assert a.startswith("ref "), (path, name, a)
+            calls += 1
+    assert calls >= 25
+    stages = _cs_sources()["Stages/Stages.cs"]
+    for cls in ("NoiseStage", "KernelFilterStage", "StageGaussianBlur", "StageSmoothBlur", "ErosionStage", "FlowMapStage",
+                "MeshTileStage", "ConstantStage", "ReduceStage", "CurveStage"):
+        assert re.search(r"class %s\s*:" % cls, stages), cls
+
+
+def test_sequential_structs_match_the_c_structs():
+    header = gen.strip_comments(open(gen.HEADER).read())
+    runtime = open(os.path.join(CS, "Runtime.cs")).read()
+
+    def c_fields(name):
+        body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (name, name), header, re.S).group(1)
+        out = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            ctype, rest = decl.split(" ", 1)
+            for n in rest.split(","):
+                n = n.strip()
+                ct = ctype + "*" if n.startswith("*") else ctype   # a pointer member
+                n = n.lstrip("*")
+                m = re.match(r"(\w+)\[(\d+)\]", n)
+                out += [(ct, "%s_%s" % (m.group(1), "xy"[k])) for k in range(int(m.group(2)))] if m else [(ct, n)]
+        return out
+
+    def cs_fields(name):
+        body = re.search(r"public struct %s\s*\{(.*?)\}" % name, runtime, re.S).group(1)
+        out = []
+        for decl in re.findall(r"public\s+(\w+)\s+([^;]+);", body):
+            out += [(decl[0], n.strip()) for n in decl[1].split(",")]
+        return out
+
+    kind = {"int32_t": "int", "float": "float", "uint32_t": "uint"}
+    for cname, csname in (("nz_stripe", "NzStripe"), ("nz_rw_tile", "NzRwTile"), ("nz_erosion_params", "NzErosionParams"),
+                          ("nz_tile_set_meta", "NzTileSetMeta")):
+        cf, sf = c_fields(cname), cs_fields(csname)
+        assert [n for _, n in cf] == [n for _, n in sf], cname
+        for (ct, n), (st, _) in zip(cf, sf):
+            assert st == ("IntPtr" if ct not in kind else kind[ct]), (cname, n)
