@@ -65,6 +65,14 @@ class StripePlan:
         v.g0, v.nown = self.grow0 + v.own0, v.own1 - v.own0
         return v
 
+    def rows_window(self, a, b):
+        """The same buffer producing only buffer rows [a, b) of the owned ones (a launch split into an interior part,
+        which reads no ghost row, and the border parts that wait for the halo exchange)."""
+        v = copy.copy(self)
+        v.own0, v.own1 = max(a, self.own0), min(b, self.own1)
+        v.g0, v.nown = self.grow0 + v.own0, max(0, v.own1 - v.own0)
+        return v
+
     @property
     def up(self):
         return self.rank - 1 if self.rank > 0 else None
@@ -157,10 +165,29 @@ def pipeline_steps(ops, plan, p, bufs, result, on_stage=None, final=None):
     need_down = sum(r[3] for r in radii) if recompute else 0
     if p.haloMode == "exchange_once":
         ops.fractal(cur, plan, p)                 # stands for any source plane, e.g. an uploaded height map
-        yield [cur], need_up, need_down           # its ghost rows for the whole pipeline, once
+        answer = yield [cur], need_up, need_down  # its ghost rows for the whole pipeline, once
+        if answer == "async":
+            yield ("finish",)                     # everything that follows reads them
     else:
         ops.fractal(cur, plan.widened(need_up, need_down), p)
     flow_launches = [i for i, r in enumerate(radii) if r[0] == "flow"]
+    def split_launch(launch, win, up, down, answer):
+        """Runs `launch(window)` once -- or, when the exchange that was just requested is asynchronous (the runner
+        answered "async"), first on the interior rows, which read no ghost row, while the halos are in flight, then
+        (after the runner has finished the exchange) on the border rows."""
+        lo, hi = win.own0 + up, win.own1 - down
+        if answer != "async" or hi <= lo:
+            if answer == "async":
+                yield ("finish",)
+            launch(win)
+            return
+        launch(win.rows_window(lo, hi))
+        yield ("finish",)
+        if up > 0:
+            launch(win.rows_window(win.own0, lo))
+        if down > 0:
+            launch(win.rows_window(hi, win.own1))
+
     for i, (stage, n, up, down) in enumerate(radii):
         if final is not None and i == len(radii) - 1:
             nxt = final  # the last launch writes its owned rows into the caller's plane
@@ -170,37 +197,59 @@ def pipeline_steps(ops, plan, p, bufs, result, on_stage=None, final=None):
         if recompute:
             need_up, need_down = need_up - up, need_down - down
         win = plan.widened(need_up, need_down)
+        answer = None
         if stage == "gauss":
             if not recompute:
-                yield [cur], up, down
-            ops.kernel_filter(cur, nxt, win, p.filter, n)
+                answer = yield [cur], up, down
+            yield from split_launch(lambda w: ops.kernel_filter(cur, nxt, w, p.filter, n), win, up, down, answer)
             cur, nxt = nxt, cur
         elif stage == "flow":
             first, last = i == flow_launches[0], i == flow_launches[-1]
             if not recompute:
                 if first:  # height: exchanged once, read by every launch
                     widest = max(radii[j][2] for j in flow_launches)
-                    yield [cur], widest, widest
+                    answer = yield [cur], widest, widest
                 else:
-                    yield [s_cur[k] for k in range(FLOW_PLANES)], up, down
-            ops.flow_fused(cur, s_cur, s_nxt, nxt, win, n, first, last, p.normMin, p.normMax)
+                    answer = yield [s_cur[k] for k in range(FLOW_PLANES)], up, down
+            yield from split_launch(lambda w: ops.flow_fused(cur, s_cur, s_nxt, nxt, w, n, first, last, p.normMin, p.normMax),
+                                    win, up, down, answer)
             s_cur, s_nxt = s_nxt, s_cur
             if last:
                 cur, nxt = nxt, cur
         else:
             if not recompute:
-                yield [cur], up, down
-            ops.erosion(cur, nxt, win, n)
+                answer = yield [cur], up, down
+            yield from split_launch(lambda w: ops.erosion(cur, nxt, w, n), win, up, down, answer)
             cur, nxt = nxt, cur
     mark("end")
     result.append(cur)
 
 
 def run_pipeline(ops, comm, plan, p, bufs, on_stage=None, final=None):
-    """One pass of the sharded metric pipeline on this rank; returns the plane holding the result."""
+    """One pass of the sharded metric pipeline on this rank; returns the plane holding the result.
+    A comm with begin() / finish() exchanges asynchronously: the launch that needs the ghost rows runs its interior
+    rows while they travel (RCCL P2P on the process group's own stream) and its border rows after finish()."""
     result = []
-    for planes, up_rows, down_rows in pipeline_steps(ops, plan, p, bufs, result, on_stage, final):
-        comm.exchange(planes, plan, up_rows, down_rows)
+    gen = pipeline_steps(ops, plan, p, bufs, result, on_stage, final)
+    overlap = getattr(comm, "overlap", False)
+    pending = None
+    try:
+        req = next(gen)
+        while True:
+            if req == ("finish",):
+                comm.finish(pending)
+                pending = None
+                req = next(gen)
+                continue
+            planes, up_rows, down_rows = req
+            if overlap:
+                pending = comm.begin(planes, plan, up_rows, down_rows)
+                req = gen.send("async")
+            else:
+                comm.exchange(planes, plan, up_rows, down_rows)
+                req = next(gen)
+    except StopIteration:
+        pass
     return result[0]
 
 
@@ -309,10 +358,13 @@ class TorchComm:
     """Neighbour halo exchange with torch.distributed P2P (backend `nccl` = RCCL over xGMI on the GPU
     box, `gloo` in the CPU tests).  Each exchange is one grouped batch: at most two neighbours."""
 
-    def __init__(self, dist):
+    def __init__(self, dist, overlap=True):
         self.dist = dist
+        self.overlap = overlap  # False: every exchange completes before the launch that follows is enqueued
 
-    def exchange(self, planes, plan, up_rows, down_rows):
+    def begin(self, planes, plan, up_rows, down_rows):
+        """Posts the batch; returns the requests.  On `nccl` the transfers run on the process group's stream behind
+        everything already enqueued on the current stream, and finish() makes the current stream wait for them."""
         d = self.dist
         ops = []
         for t in planes:
@@ -326,9 +378,14 @@ class TorchComm:
                     ops.append(d.P2POp(d.isend, t[plan.own0:plan.own0 + down_rows], plan.up))
                 if plan.down is not None:
                     ops.append(d.P2POp(d.irecv, t[plan.own1:plan.own1 + down_rows], plan.down))
-        if ops:
-            for req in d.batch_isend_irecv(ops):
-                req.wait()
+        return d.batch_isend_irecv(ops) if ops else []
+
+    def exchange(self, planes, plan, up_rows, down_rows):
+        self.finish(self.begin(planes, plan, up_rows, down_rows))
+
+    def finish(self, reqs):
+        for req in reqs:
+            req.wait()
 
 
 class NoComm:

@@ -37,7 +37,7 @@ def _worker(rank, world, port, grows, cols, pkw, out_path):
     nan = float("nan")
     bufs = (torch.full((plan.rows, cols), nan, device="cuda"), torch.full((plan.rows, cols), nan, device="cuda"),
             torch.full((5, plan.rows, cols), nan, device="cuda"), torch.full((5, plan.rows, cols), nan, device="cuda"))
-    comm = sh.NoComm() if p.haloMode == "recompute" else sh.TorchComm(dist)
+    comm = sh.NoComm() if p.haloMode == "recompute" else sh.TorchComm(dist)  # asynchronous: interior rows overlap the P2P batch
     res = sh.run_pipeline(ops, comm, plan, p, bufs)
     torch.cuda.synchronize()
     mine = res[plan.own0:plan.own1].contiguous()
@@ -63,5 +63,73 @@ def test_nccl_sharded_equals_monolithic(oracle, tmp_path, mode):
                haloMode=mode)
     out = str(tmp_path / "sharded.npy")
     mp.spawn(_worker, args=(world, _free_port(), grows, cols, pkw, out), nprocs=world, join=True)
+    want = oracle.pipeline(grows, cols, octaves=8, noise_size=300, xpos=100, zpos=900)
+    assert np.array_equal(np.load(out), want)
+
+
+def _single_rank_worker(rank, port, grows, cols, pkw, out_path):
+    """ONE process, ONE GPU, backend nccl: the process group, the stream it shares with the C ABI's context and
+    batch_isend_irecv on row slices of device planes are all real; the peer of every transfer is the rank itself (RCCL
+    runs a send and the matching receive of one group on the same device).  The grid is cut into `nstripes` stripes
+    that live in this process and are driven in lockstep; their ghost rows travel through RCCL."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import noize_job_amd as nj
+    from noize_job_amd import sharded as sh
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx = nj.Context(0, stream=stream.cuda_stream)
+    ops = sh.HipStripeOps(ctx)
+    p = sh.PipelineParams(**pkw)
+    nstripes = 3
+    halo = sh.halo_rows_needed(ops, p)
+    plans = [sh.StripePlan(r, nstripes, grows, cols, halo) for r in range(nstripes)]
+    nan = float("nan")
+    bufs = [(torch.full((pl.rows, cols), nan, device="cuda"), torch.full((pl.rows, cols), nan, device="cuda"),
+             torch.full((5, pl.rows, cols), nan, device="cuda"), torch.full((5, pl.rows, cols), nan, device="cuda"))
+            for pl in plans]
+    moved = [0]
+
+    def copy_rows(dst, d0, src, s0, n):  # ghost rows <- the neighbour stripe's owned rows, through RCCL
+        reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, src[s0:s0 + n], 0), dist.P2POp(dist.irecv, dst[d0:d0 + n], 0)])
+        for r in reqs:
+            r.wait()   # the current stream (the context's) waits; the host does not
+        moved[0] += n * cols * 4
+
+    res = sh.run_pipeline_lockstep([ops] * nstripes, plans, p, bufs, copy_rows)
+    torch.cuda.synchronize()
+    full = torch.cat([r[pl.own0:pl.own1] for r, pl in zip(res, plans)], 0)
+    t = torch.tensor([float(moved[0])], device="cuda")
+    dist.all_reduce(t)   # a collective on the same group for good measure
+    np.save(out_path, full.cpu().numpy())
+    assert t.item() == moved[0] and moved[0] > 0
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+@pytest.mark.timeout(400, method="thread")
+def test_nccl_single_rank_halo_exchange_through_rccl(oracle, tmp_path):
+    # what a one-GPU box can exercise of the RCCL path: init_process_group("nccl"), the context on torch's stream,
+    # batch_isend_irecv on row slices of device tensors between stripe kernels -- in a child process with a hard limit,
+    # so that a transfer that never completes fails the test instead of hanging the run
+    import multiprocessing as mp
+    grows, cols = 384, 256
+    pkw = dict(octaves=8, noiseSize=300, gaussIterations=17, flowIterations=5, erosionIterations=5, xpos=100, zpos=900,
+               haloMode="exchange")
+    out = str(tmp_path / "single.npy")
+    proc = mp.get_context("spawn").Process(target=_single_rank_worker, args=(0, _free_port(), grows, cols, pkw, out))
+    proc.start()
+    proc.join(300)
+    if proc.is_alive():
+        proc.kill()
+        proc.join()
+        pytest.fail("the single-rank nccl worker did not finish within 300 s")
+    assert proc.exitcode == 0
     want = oracle.pipeline(grows, cols, octaves=8, noise_size=300, xpos=100, zpos=900)
     assert np.array_equal(np.load(out), want)

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, grows, cols, pkw, out_path):
+def _worker(rank, world, port, grows, cols, pkw, out_path, overlap=True):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -34,7 +34,9 @@ def _worker(rank, world, port, grows, cols, pkw, out_path):
                          neighbours_own_halo=p.haloMode != "recompute")
     bufs = (torch.full((plan.rows, cols), float("nan")), torch.full((plan.rows, cols), float("nan")),
             torch.full((5, plan.rows, cols), float("nan")), torch.full((5, plan.rows, cols), float("nan")))
-    comm = sh.NoComm() if p.haloMode == "recompute" else sh.TorchComm(dist)  # "recompute" never communicates
+    # "recompute" never communicates; overlap: the launch that needs the ghost rows is split into its interior rows
+    # (enqueued while the halos travel) and its border rows (after finish())
+    comm = sh.NoComm() if p.haloMode == "recompute" else sh.TorchComm(dist, overlap=overlap)
     res = sh.run_pipeline(ops, comm, plan, p, bufs)
     mine = res[plan.own0:plan.own1].contiguous()
     parts = [None] * world
@@ -47,18 +49,67 @@ def _worker(rank, world, port, grows, cols, pkw, out_path):
 
 
 @pytest.mark.parametrize("world,grows,cols,mode", [(2, 64, 48, "exchange"), (3, 70, 33, "exchange"),
+                                                    (2, 64, 48, "exchange_blocking"), (3, 70, 33, "exchange_blocking"),
                                                     (2, 64, 48, "recompute"), (3, 70, 33, "recompute"),
                                                     (2, 64, 48, "exchange_once")])
 def test_sharded_schedule_equals_monolithic(oracle, tmp_path, world, grows, cols, mode):
+    overlap = mode != "exchange_blocking"
     pkw = dict(octaves=6, noiseSize=40, gaussIterations=7, flowIterations=3, erosionIterations=4, xpos=11, zpos=5,
-               haloMode=mode)
+               haloMode="exchange" if mode == "exchange_blocking" else mode)
     out = str(tmp_path / "sharded.npy")
-    mp.spawn(_worker, args=(world, _free_port(), grows, cols, pkw, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), grows, cols, pkw, out, overlap), nprocs=world, join=True)
     got = np.load(out)
     want = oracle.pipeline(grows, cols, octaves=6, noise_size=40, gauss_iterations=7, flow_iterations=3,
                            erosion_iterations=4, xpos=11, zpos=5)
     assert got.shape == want.shape
     assert np.array_equal(got, want)
+
+
+def test_overlapped_exchange_splits_a_launch_into_interior_and_border_rows():
+    # with an asynchronous comm the launch that needs ghost rows runs rows [own0 + up, own1 - down) first -- they read
+    # no ghost row -- and the border rows after finish(); a window thinner than its halos runs whole, after finish()
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from noize_job_amd import sharded as sh
+    from oracle_stripe_ops import OracleStripeOps
+    log = []
+
+    class Rec(OracleStripeOps):
+        def fractal(self, buf, pl, p):
+            log.append(("noise", pl.own0, pl.own1))
+
+        def kernel_filter(self, src, dst, pl, f, T):
+            log.append(("gauss", pl.own0, pl.own1))
+
+        def flow_fused(self, h, si, so, dst, pl, *a):
+            log.append(("flow", pl.own0, pl.own1))
+
+        def erosion(self, src, dst, pl, E):
+            log.append(("erosion", pl.own0, pl.own1))
+
+    class Comm:
+        overlap = True
+
+        def begin(self, planes, plan, up, down):
+            log.append(("begin", up, down))
+            return "req"
+
+        def finish(self, reqs):
+            assert reqs == "req"
+            log.append(("finish",))
+
+    p = sh.PipelineParams(gaussIterations=3, flowIterations=0, erosionIterations=2, haloMode="exchange")
+    ops = Rec()
+    plan = sh.StripePlan(1, 3, 90, 8, sh.halo_rows_needed(ops, p))
+    sh.run_pipeline(ops, Comm(), plan, p, (0, 1, [0] * 5, [1] * 5))
+    o0, o1 = plan.own0, plan.own1
+    assert log == [("noise", o0, o1),
+                   ("begin", 6, 6), ("gauss", o0 + 6, o1 - 6), ("finish",), ("gauss", o0, o0 + 6), ("gauss", o1 - 6, o1),
+                   ("begin", 2, 0), ("erosion", o0 + 2, o1), ("finish",), ("erosion", o0, o0 + 2)]
+    log.clear()
+    thin = sh.StripePlan(1, 9, 90, 8, sh.halo_rows_needed(ops, p))     # 10 owned rows < 6 + 6
+    sh.run_pipeline(ops, Comm(), thin, p, (0, 1, [0] * 5, [1] * 5))
+    assert log[1:4] == [("begin", 6, 6), ("finish",), ("gauss", thin.own0, thin.own1)]
 
 
 def test_stripe_plan_partitions_rows():
