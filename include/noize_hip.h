@@ -287,6 +287,13 @@ int32_t nz_heightmap_mesh(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_
                           float tileHeight, float tileSize, const float *heights, nz_handle dep,
                           nz_handle *out);
 
+/* HeightMapMeshJob<G, PositionStream16> (Mesh/Streams/PositionStream.cs:11-74, TriangleUInt16 Triangle.cs:7-17): the
+ * same 48-byte vertex records, indices truncated to 16 bits as `(ushort)` does -- "only valid for square mesh up to
+ * resolution 256*256" (:12).  `indices`: 6 * resolution^2 uint16. */
+int32_t nz_heightmap_mesh16(nz_ctx *ctx, int32_t meshType, void *vertices, uint16_t *indices, int32_t resolution,
+                            int32_t inputResolution, int32_t marginPix, float tileHeight, float tileSize,
+                            const float *heights, nz_handle dep, nz_handle *out);
+
 /* ---- element-wise stages either side of the path ------------------------------ */
 /* ConstantJobScheduleDelegate, Filter/ConstantJob.cs:47-53; operation = ConstantStage.ConstantOperationType
  * {MULTIPLY = 0, BINARIZE = 1} (Filter/ConstantStage.cs:15-18) */

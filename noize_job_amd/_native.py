@@ -153,6 +153,7 @@ SIGNATURES = {
     "nz_mesh_vertex_count": (_sz, [_i]),
     "nz_mesh_index_count": (_sz, [_i]),
     "nz_heightmap_mesh": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _i, _i, _i, _f, _f, dev_ptr] + _tail),
+    "nz_heightmap_mesh16": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _i, _i, _i, _f, _f, dev_ptr] + _tail),
     "nz_square_grid_mesh": (_i, [ctx_p, dev_ptr, dev_ptr, _i] + _tail),
     "nz_heightmap_mesh_batch": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _i, _i, _i, _f, _f, dev_ptr, _i] + _tail),
 }

@@ -199,7 +199,7 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
 
 int32_t nz_launch_mesh_planar(hipStream_t s, void *vertices, uint32_t *indices, int res);
 int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *indices, int res, int in_res,
-                       float tile_height, float tile_size, const float *heights, int count = 1);
+                       float tile_height, float tile_size, const float *heights, int count = 1, int index16 = 0);
 
 // element-wise stages (nz_elementwise.hip)
 int32_t nz_launch_constant(hipStream_t s, int op, float *data, size_t n, float c);

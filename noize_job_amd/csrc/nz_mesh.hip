@@ -175,6 +175,14 @@ __global__ __launch_bounds__(CT) void mesh_index_kernel(uint32_t *__restrict__ i
     }
 }
 
+// PositionStream16 / TriangleUInt16 (Mesh/Streams/PositionStream.cs:11-74, Triangle.cs:7-17): the same indices
+// truncated to 16 bits -- `(ushort) t.x`, valid only while (R + 1)^2 <= 65536 as the reference notes; four per thread
+__global__ __launch_bounds__(CT) void mesh_index16_kernel(uint16_t *__restrict__ idx, uint32_t R, size_t n, size_t istride) {
+    idx += blockIdx.y * istride;
+    size_t i = ((size_t)blockIdx.x * CT + threadIdx.x) * 4;
+    for (size_t k = i; k < n && k < i + 4; k++) idx[k] = (uint16_t)mesh_index((uint32_t)k, R);
+}
+
 }  // namespace
 
 // floor(2^32 / R), saturated (R = 1), for mesh_index_kernel's quad -> (row, column) split
@@ -184,7 +192,7 @@ static uint32_t mesh_rinv(int res) {
 }
 
 int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *indices, int res, int in_res,
-                       float tile_height, float tile_size, const float *heights, int count) {
+                       float tile_height, float tile_size, const float *heights, int count, int index16) {
     mesh_params g;
     g.res = res;
     g.in_res = in_res;
@@ -214,8 +222,12 @@ int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *in
                        reinterpret_cast<float4 *>(vertices), heights, g);
     NZ_HIP(hipGetLastError());
     size_t nthreads = (ni + 3) / 4;
-    hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT), count), dim3(CT), 0, s, indices,
-                       (uint32_t)res, mesh_rinv(res), ni, ni);
+    if (index16)
+        hipLaunchKernelGGL(mesh_index16_kernel, dim3((unsigned)((nthreads + CT - 1) / CT), count), dim3(CT), 0, s,
+                           reinterpret_cast<uint16_t *>(indices), (uint32_t)res, ni, ni);
+    else
+        hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT), count), dim3(CT), 0, s, indices,
+                           (uint32_t)res, mesh_rinv(res), ni, ni);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

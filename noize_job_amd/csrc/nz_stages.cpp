@@ -862,7 +862,8 @@ extern "C" size_t nz_mesh_index_count(int32_t resolution) {  // IndexCount, Over
 
 static int32_t heightmap_mesh_impl(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_t *indices,
                                    int32_t resolution, int32_t inputResolution, int32_t marginPix, float tileHeight,
-                                   float tileSize, const float *heights, int32_t count, nz_handle dep, nz_handle *out) {
+                                   float tileSize, const float *heights, int32_t count, nz_handle dep, nz_handle *out,
+                                   int index16 = 0) {
     NZ_BEGIN(ctx, dep);
     (void)marginPix;  // MarginScale is commented out of the vertex path (Overshoot :64)
     NZ_REQUIRE(vertices && indices && heights, "buffer is NULL");
@@ -882,8 +883,18 @@ static int32_t heightmap_mesh_impl(nz_ctx *ctx, int32_t meshType, void *vertices
         return NZ_ERR_INVALID;
     }
     NZ_TRY(nz_launch_mesh(ctx->stream, meshType, vertices, indices, resolution, inputResolution, tileHeight, tileSize,
-                          heights, count));
+                          heights, count, index16));
     return nz_ctx_finish(ctx, out);
+}
+
+// HeightMapMeshJob<G, PositionStream16>: the same vertex stream, TriangleUInt16 indices (the reference's own caveat:
+// only valid while the vertex count fits 16 bits, Mesh/Streams/PositionStream.cs:12)
+extern "C" int32_t nz_heightmap_mesh16(nz_ctx *ctx, int32_t meshType, void *vertices, uint16_t *indices,
+                                       int32_t resolution, int32_t inputResolution, int32_t marginPix,
+                                       float tileHeight, float tileSize, const float *heights, nz_handle dep,
+                                       nz_handle *out) {
+    return heightmap_mesh_impl(ctx, meshType, vertices, reinterpret_cast<uint32_t *>(indices), resolution, inputResolution,
+                               marginPix, tileHeight, tileSize, heights, 1, dep, out, 1);
 }
 
 extern "C" int32_t nz_heightmap_mesh(nz_ctx *ctx, int32_t meshType, void *vertices, uint32_t *indices,

@@ -697,3 +697,23 @@ def test_rw_pair_batch_and_errors(nj, ctx, oracle):
     with pytest.raises(nj.NoizeError):
         ctx.call("nz_flowmap_stage_rw", C.byref(t), None, 5, 0.0, 0.005)
     assert (t.read, t.write) == (b.data.ptr, b.write.ptr)  # a refused call leaves the pair alone
+
+
+def test_mesh_16_bit_index_stream(nj, ctx, oracle):
+    # PositionStream16 / TriangleUInt16 (Mesh/Streams/PositionStream.cs:11-74, Triangle.cs:7-17): same vertices, indices
+    # cast to ushort; 255^2 quads is the largest mesh whose (R + 1)^2 vertices fit, 300 shows the documented wrap-around
+    rng = np.random.default_rng(16)
+    for res in (64, 255, 300):
+        in_res = res + 8
+        h = rng.random((in_res, in_res), dtype=f32)
+        heights = ctx.from_host(h)
+        nv, ni = (res + 1) ** 2, 6 * res * res
+        vtx, idx = ctx.alloc(nv * 12), ctx.alloc((ni + 1) // 2, dtype=np.uint32)
+        ctx.call("nz_heightmap_mesh16", int(nj.MeshType.OvershootSquareGridHeightMap), vtx.ptr, idx.ptr, res, in_res, 4, 50.0,
+                 100.0, heights.ptr).Complete()
+        wv, wi = oracle.mesh_heightmap(oracle.MESH_OVERSHOOT, h, res, 4, 50.0, 100.0)
+        got = idx.ToArray().view(np.uint16)[:ni]
+        assert np.array_equal(got, wi.astype(np.uint16)) and np.array_equal(vtx.ToArray().reshape(-1, 12), wv)
+        assert (got.astype(np.uint32) == wi).all() == (nv <= 65536)
+        for t in (heights, vtx, idx):
+            t.Dispose()
