@@ -44,8 +44,9 @@ VALU_PEAK_TOPS = N_SIMD * 32 * CLK_HZ / 1e12   # 78.64 T lane-ops/s (non-FMA fp3
 G_IT, F_IT, E_IT = 17, 5, 5
 BYTES = {"noise": 4.0, "gauss": 8.0 * G_IT, "flow": 24.0 + 44.0 * (F_IT - 1) + 20.0, "erosion": 8.0 * E_IT}
 STAGES = ["noise", "gauss", "flow", "erosion"]
-KERNEL_PREFIX = {"noise": "fractal_simplex_tab_kernel", "gauss": "conv_reg_kernel<5", "flow": "flow_fused_kernel",
-                 "erosion": "erosion_reg_kernel"}
+# kernel of each stage as rocprofv3 names it (prefixes; the first that the counter summary holds)
+KERNEL_PREFIX = {"noise": ("fractal_simplex_tab_kernel",), "gauss": ("conv_chain_kernel<5", "conv_reg_kernel<5"),
+                 "flow": ("flow_fused_kernel",), "erosion": ("erosion_reg_kernel",)}
 
 CPU_PASSES = 11         # ~10 s of host work on the GPU box's 32 cores (0.9-1.0 s per 4096^2 pass)
 PREHEAT_MIN_STEPS = 50  # untimed passes before the timed region, warm-up included (clock settling)
@@ -121,9 +122,10 @@ def load_counters(res, flush):
 def counters_for(cnt, stage):
     if cnt is None:
         return None
-    for name, e in cnt["kernels"].items():
-        if name.startswith(KERNEL_PREFIX[stage]):
-            return name, e
+    for prefix in KERNEL_PREFIX[stage]:
+        for name, e in cnt["kernels"].items():
+            if name.startswith(prefix):
+                return name, e
     return None
 
 
@@ -511,6 +513,15 @@ def main():
         n_gauss = len(sh.split_iterations(G_IT, nj._native.lib.nz_kernel_filter_max_fused(2)))
         if n_gauss & 1 and not pingpong:  # the tile API keeps the launch count even (result back in `src`)
             n_gauss += 1
+        # the tile entries run these fused launches as ONE grid with tile-level dependencies (conv_chain_kernel) unless
+        # NZ_CONV_CHAIN=0; the stripe entries launch them one by one
+        gauss_chained = (not sharded and striped is None and os.environ.get("NZ_CONV_CHAIN", "1") != "0" and 2 <= n_gauss <= 8)
+        if gauss_chained:
+            stage_note = {"gauss": "%d fused launches (%s applications) as one chained grid" %
+                                   (n_gauss, "+".join(str(t) for t in sh.split_iterations(G_IT, nj._native.lib.nz_kernel_filter_max_fused(2))))}
+            n_gauss = 1
+        else:
+            stage_note = {}
         launches = {"noise": 1, "gauss": n_gauss, "flow": flow_launches,
                     "erosion": len(sh.split_iterations(E_IT, ero_cap)) if pingpong else 2}
         rcells = cells // world  # rank 0's own cells: the stage figures are per GPU
@@ -523,6 +534,8 @@ def main():
         stage_ms = {n: acc[n] / len(marks) for n in STAGES}
         kernel_ms = dict(stage_ms)
         stages_out = {n: {"ms": round(stage_ms[n], 4), "launches": launches[n]} for n in STAGES}
+        for n, note in stage_note.items():
+            stages_out[n]["note"] = note
         # The in-place tile API's one-launch flow stage ends with a plane copy back into the caller's buffer (and the
         # in-place erosion with none: two launches): time that copy on its own so the flow KERNEL's time is known
         if not pingpong and flow_launches == 1:
@@ -549,7 +562,7 @@ def main():
             s["algorithmic_equivalent_GB/s"] = round(gbs, 1)
             hit = counters_for(cnt, n)
             if hit is None:
-                s.update({"kernel": KERNEL_PREFIX[n], "valu_issue_frac": None, "hbm_traffic_frac": None, "bound": None})
+                s.update({"kernel": KERNEL_PREFIX[n][0], "valu_issue_frac": None, "hbm_traffic_frac": None, "bound": None})
                 continue
             name, e = hit
             insts = e["SQ_INSTS_VALU"] * cnt["scale"]
