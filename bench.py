@@ -515,7 +515,7 @@ def main():
             n_gauss += 1
         # the tile entries run these fused launches as ONE grid with tile-level dependencies (conv_chain_kernel) unless
         # NZ_CONV_CHAIN=0; the stripe entries launch them one by one
-        gauss_chained = (not sharded and striped is None and os.environ.get("NZ_CONV_CHAIN", "1") != "0" and 2 <= n_gauss <= 8)
+        gauss_chained = (not sharded and striped is None and os.environ.get("NZ_CONV_CHAIN", "1") != "0" and 3 <= n_gauss <= 8)
         if gauss_chained:
             stage_note = {"gauss": "%d fused launches (%s applications) as one chained grid" %
                                    (n_gauss, "+".join(str(t) for t in sh.split_iterations(G_IT, nj._native.lib.nz_kernel_filter_max_fused(2))))}

@@ -235,10 +235,14 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     int L = (iterations + cap - 1) / cap;
     if (!swapped && (L & 1) && L + 1 <= iterations) L += 1;  // an even count leaves the result in src
     int base = iterations / L, rem = iterations % L;
-    // the launches as ONE grid with tile-level dependencies (nz_filter.hip, conv_chain_kernel); NZ_CONV_CHAIN=0: one
-    // kernel per launch
-    static const bool chain_on = !(getenv("NZ_CONV_CHAIN") && atoi(getenv("NZ_CONV_CHAIN")) == 0);
-    if (chain_on && L >= 2 && L <= 8 && g.count == 1 && (size_t)g.rows * g.pitch * 4 < ((size_t)1 << 32) &&
+    // three or more launches of a 5..9-tap kernel run as ONE grid with tile-level dependencies (nz_filter.hip,
+    // conv_chain_kernel): Gauss5 x17 0.212 -> 0.198 ms at 4096^2.  Two launches gain nothing (Gauss9 x6 -3 %, Gauss5 x6
+    // +2.5 %, two single applications +15 %: a tile's poll and its sc1 accesses cost what the missing launch boundary
+    // saves), and the 64-row tiles of the 3-tap kernels lose (x6: 0.131 vs 0.066 ms).  NZ_CONV_CHAIN=0: never;
+    // NZ_CONV_CHAIN=2: whenever there are two launches or more (the test suite runs the parity tests under it).
+    static const int chain_mode = getenv("NZ_CONV_CHAIN") ? atoi(getenv("NZ_CONV_CHAIN")) : 1;
+    const bool chain_on = chain_mode == 2 ? L >= 2 : (chain_mode == 1 && L >= 3 && t.ksize >= 5);
+    if (chain_on && L <= 8 && g.count == 1 && (size_t)g.rows * g.pitch * 4 < ((size_t)1 << 32) &&
         (swapped || !(L & 1))) {
         int Ts[8];
         for (int i = 0; i < L; i++) Ts[i] = base + (i < rem ? 1 : 0);
