@@ -116,21 +116,249 @@ __device__ __forceinline__ int flooded_cmp(const flooded &a, const flooded &b) {
     return float_hash(a.height + a.water) > float_hash(b.height + b.water) ? 1 : -1;
 }
 
-// One colour pass of PoolAutomataJob (MultiThreadErosionJob.cs:264-327, drainParticles == false): thread k walks row
-// z = 2k + zoff over x = xoff (+1 for odd k), step 2, calling WorldTile.SpreadPool (LiveErosionDataTypes.cs:938-1010)
-// wherever water stands.  The walk along a row is sequential in the reference too; rows of one pass share no cell.
-// z is the fast index of the planes, so the lanes of a wave touch neighbouring addresses at every step.
+// One step of the walk: WorldTile.SpreadPool (LiveErosionDataTypes.cs:938-1010) at (x, z) with water standing.  `nh` /
+// `nw` = height / water of the up, right, down, left neighbours; `carry` enters as the right-hand neighbour's water and
+// leaves as its value after the step (the left-hand neighbour of the walk's next step).
 //
-// What one step leaves for a later step of the same walk is a single cell: the right-hand neighbour (x+1, z) of
-// step x is the left-hand neighbour of step x+2; every other cell a step reads (itself, (x, z+-1), (x+1, z)) is
-// written by no earlier step of the walk and by no other walk of the pass.  So the loads of PU consecutive steps are
-// issued together, ahead of the arithmetic, and the one carried cell travels in a register: the walk pays one
-// memory round trip per PU steps instead of a store -> load round trip per step.
-constexpr int PU = 8;
-
 // DRAIN (drainParticles): a pool that finds a dry, lower neighbour does not wet it but leaves as ONE BeyerParticle
 // (pid 64000, at the neighbour, carrying the water, LiveErosionDataTypes.cs:971-984) appended to the particle queue; the
 // order of the queue is whatever the atomics make it -- the descent's results do not depend on it (nz_live.hip).
+// A step acts only where at least 1E-3 of water stands when the walk reaches it (SpreadPool returns at once on a dry
+// cell, :940, and every transfer is guarded by hWater >= 1E-3, which no skipped transfer can raise); its own cell is
+// written by no other step of the pass, so that is decided by the plane as the pass finds it.
+__device__ __forceinline__ bool pool_step_acts(float w) { return w > 0.0f && !(w < 1E-3f); }
+
+// The acting-step bits of the four colour passes (class c = 2 xoff + zoff): bit b of word [(c * words + w) * walks + k]
+// = step 32 w + b of walk k, the cell (xoff + (k & 1) + 2 (32 w + b), 2 k + zoff).
+struct pool_masks {
+    unsigned *m;
+    int words, walks;
+};
+__device__ __forceinline__ void pool_mark_acting(const pool_masks &pm, int cx, int cz) {
+    const int k = cz >> 1, t = cx - (k & 1);
+    if (k >= pm.walks || t < 0) return;  // the last row of an odd plane, column 0 of an odd walk: no pass has a step there
+    const int c = 2 * (t & 1) + (cz & 1), st = t >> 1;
+    // no value comes back: the walk does not wait for it
+    (void)__hip_atomic_fetch_or(pm.m + ((size_t)c * pm.words + (st >> 5)) * pm.walks + k, 1u << (st & 31), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool DRAIN, bool MARK>
+__device__ __forceinline__ void spread_pool_step(float *pool, int res, int x, int z, int zu, int zd, float hWater,
+                                                 const float hLand, const float nh[4], const float nw[4], float &carry,
+                                                 int32_t *drain_hdr, nz_particle *drain_data, const pool_masks &pm) {
+    const int xr = min(x + 1, res - 1), xl = max(x - 1, 0);
+    const int idx = x * res + z, right_idx = xr * res + z;
+    float tHeight = hLand + hWater;
+    flooded b[4];
+    b[0].idx = x * res + zu;  b[1].idx = right_idx;  b[2].idx = x * res + zd;  b[3].idx = xl * res + z;
+    int key[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        b[e].height = nh[e];
+        b[e].water = nw[e];
+        key[e] = float_hash(nh[e] + nw[e]);
+    }
+    // NativeArray.Sort() of com.unity.collections 1.4.0 on 4 elements: insertion sort, element i+1 moves
+    // left while it compares < 0 (flooded_cmp above: same cell -> 0, else key > key ? 1 : -1).  The same
+    // comparisons in the same order, applied with selects so that the lanes of a wave do not diverge (the
+    // walk is bound by the length of its instruction stream)
+#define NZ_LT(ti, tk, j) ((ti) != b[j].idx && !((tk) > key[j]))
+#define NZ_SEL(dst, c, src_t) do { b[dst].idx = (c) ? (src_t##i) : b[dst].idx; b[dst].height = (c) ? (src_t##h) : b[dst].height; \
+                                   b[dst].water = (c) ? (src_t##w) : b[dst].water; key[dst] = (c) ? (src_t##k) : key[dst]; } while (0)
+#define NZ_MOV(dst, c, src) do { b[dst].idx = (c) ? b[src].idx : b[dst].idx; b[dst].height = (c) ? b[src].height : b[dst].height; \
+                                 b[dst].water = (c) ? b[src].water : b[dst].water; key[dst] = (c) ? key[src] : key[dst]; } while (0)
+    {
+        int ti = b[1].idx, tk = key[1];
+        float th = b[1].height, tw = b[1].water;
+        bool c0 = NZ_LT(ti, tk, 0);
+        NZ_MOV(1, c0, 0);
+        NZ_SEL(0, c0, t);
+        ti = b[2].idx; tk = key[2]; th = b[2].height; tw = b[2].water;
+        bool c1 = NZ_LT(ti, tk, 1);
+        c0 = c1 && NZ_LT(ti, tk, 0);
+        NZ_MOV(2, c1, 1);
+        NZ_MOV(1, c0, 0);
+        NZ_SEL(1, c1 && !c0, t);
+        NZ_SEL(0, c0, t);
+        ti = b[3].idx; tk = key[3]; th = b[3].height; tw = b[3].water;
+        bool c2 = NZ_LT(ti, tk, 2);
+        c1 = c2 && NZ_LT(ti, tk, 1);
+        c0 = c1 && NZ_LT(ti, tk, 0);
+        NZ_MOV(3, c2, 2);
+        NZ_MOV(2, c1, 1);
+        NZ_MOV(1, c0, 0);
+        NZ_SEL(2, c2 && !c1, t);
+        NZ_SEL(1, c1 && !c0, t);
+        NZ_SEL(0, c0, t);
+    }
+#undef NZ_LT
+#undef NZ_SEL
+#undef NZ_MOV
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float bw = b[e].water, bh = b[e].height;
+        const float diffV = tHeight - (bh + bw);
+        const bool go = !(hWater < 1E-3f);
+        const bool spill = bw <= 0.0f && hLand >= bh;                       // the dry neighbour takes it all
+        const bool give = !spill && diffV > 0.0f && !(hWater <= 0.0f);
+        const bool take = !spill && !(diffV > 0.0f) && diffV < 0.0f && !(bw <= 0.0f);
+        const float fill_give = fminf(0.25f * hWater, 0.25f * diffV);
+        const float fill_take = fminf(0.25f * bw, -0.25f * diffV);
+        const float put = spill ? bw + hWater : (give ? bw + fill_give : bw + (-1.0f * fill_take));
+        const float w_new = spill ? 0.0f : (give ? hWater - fill_give : hWater + fill_take);
+        if (go && (spill || give || take)) {
+            if (DRAIN && spill) {
+                const int slot = atomicAdd(&drain_hdr[0], 1);
+                if (slot < drain_hdr[1]) {
+                    nz_particle p;
+                    p.px = b[e].idx / res;  // getPos(idx)
+                    p.pz = b[e].idx % res;
+                    p.water = hWater;
+                    p.pid = 64000;
+                    drain_data[slot] = p;
+                }
+            } else {
+                pool[b[e].idx] = put;
+                if (b[e].idx == right_idx) carry = put;
+                // the neighbour's own pass must find it; one that was acting before has its bit already
+                if (MARK && pool_step_acts(put) && !pool_step_acts(bw)) {
+                    const int nx = b[e].idx == right_idx ? xr : (b[e].idx == xl * res + z ? xl : x);
+                    pool_mark_acting(pm, nx, b[e].idx - nx * res);
+                }
+            }
+            hWater = w_new;
+            tHeight = spill ? hLand : hLand + w_new;
+        }
+    }
+    pool[idx] = hWater;
+    if (idx == right_idx) carry = hWater;  // last column: the right-hand neighbour is the cell itself
+}
+
+// One colour pass of PoolAutomataJob (MultiThreadErosionJob.cs:264-327): walk k follows row z = 2k + zoff over
+// x = xoff (+1 for odd k), step 2, calling SpreadPool wherever water stands.  The walk along a row is sequential in the
+// reference; rows of one pass share no cell.  z is the fast index of the planes, so lanes = walks touch neighbouring
+// addresses at every step.
+//
+// What one step leaves for a later step of the same walk is a single cell: the right-hand neighbour (x+1, z) of
+// step x is the left-hand neighbour of step x+2; every other cell a step reads (itself, (x, z+-1), (x+1, z)) is
+// written by no earlier step of the walk and by no other walk of the pass.  A step that does not act writes nothing,
+// so the chain only links CONSECUTIVE ACTING steps: a walk falls apart into independent runs of acting steps, and the
+// runs of all rows proceed in parallel, each in its row's order -- the same values as the one-lane-per-row walk, bit
+// for bit, with res^2 / 4 threads instead of res / 2.
+//
+//   pool_masks_kernel   once per job: the acting-step bits of all four passes from one read of the plane
+//   pool_runs_kernel    thread (walk k, mask word w): for every run that STARTS among its 32 steps, walks the run to
+//                       its end (into the following words if need be); the loads of the next step are issued before
+//                       the arithmetic of the current one, the carried cell travels in a register.  Water a step
+//                       hands to a neighbour sets that neighbour's bit (its pass comes later; a pass only reads its own
+//                       class's bits, and no step changes those: the own cell of an acting step already has its bit).
+//   pool_masks_clean_kernel  between two iterations: drops the bits of steps that have stopped acting (only the words
+//                       that have bits look at the plane)
+// A pass cannot clear bits itself (its own class's bits are what the other threads cut their runs by, and the other
+// classes' bits are being set by it), and does not have to: a step that has stopped acting stays in its run and does
+// nothing there -- any SUPERSET of the acting steps cuts the walks into runs that give the row walk's values.
+__global__ __launch_bounds__(64) void pool_masks_kernel(const float *__restrict__ pool, pool_masks pm, int res) {
+    const int z = blockIdx.x * 64 + threadIdx.x, w = blockIdx.y;
+    const int k = z >> 1;
+    if (k >= pm.walks) return;
+    const int odd = k & 1;
+    unsigned m0 = 0, m1 = 0;  // xoff = 0: x = 64 w + odd + 2 b; xoff = 1: x = 64 w + 1 + odd + 2 b
+#pragma unroll 8
+    for (int b = 0; b < 32; b++) {
+        const int xa = 64 * w + odd + 2 * b, xb = xa + 1;
+        if (xa < res && pool_step_acts(pool[(size_t)xa * res + z])) m0 |= 1u << b;
+        if (xb < res && pool_step_acts(pool[(size_t)xb * res + z])) m1 |= 1u << b;
+    }
+    const int zoff = z & 1;
+    pm.m[((size_t)(0 + zoff) * pm.words + w) * pm.walks + k] = m0;
+    pm.m[((size_t)(2 + zoff) * pm.words + w) * pm.walks + k] = m1;
+}
+
+__global__ __launch_bounds__(64) void pool_masks_clean_kernel(const float *__restrict__ pool, pool_masks pm, int res) {
+    const int k = blockIdx.x * 64 + threadIdx.x, w = blockIdx.y, c = blockIdx.z;
+    if (k >= pm.walks) return;
+    unsigned *word = pm.m + ((size_t)c * pm.words + w) * pm.walks + k;
+    const unsigned m = *word;
+    if (m == 0) return;
+    const int z = 2 * k + (c & 1), x0 = (c >> 1) + (k & 1) + 64 * w;
+    unsigned keep = m;
+    for (unsigned rest = m; rest; rest &= rest - 1) {
+        const int b = __builtin_ctz(rest);
+        if (!pool_step_acts(pool[(size_t)(x0 + 2 * b) * res + z])) keep &= ~(1u << b);
+    }
+    if (keep != m) *word = keep;
+}
+
+template <bool DRAIN>
+__global__ __launch_bounds__(64) void pool_runs_kernel(float *pool, const float *__restrict__ height, pool_masks pm,
+                                                      int res, int xoff, int zoff, int32_t *drain_hdr,
+                                                      nz_particle *drain_data) {
+    const int walks = pm.walks, words = pm.words;
+    const unsigned *mask = pm.m + (size_t)(2 * xoff + zoff) * words * walks;  // read-only for the whole pass
+    const int k = blockIdx.x * 64 + threadIdx.x, w = blockIdx.y;
+    if (k >= walks) return;
+    const unsigned m0 = mask[(size_t)w * walks + k];
+    if (m0 == 0) return;
+    const unsigned before = w > 0 ? mask[(size_t)(w - 1) * walks + k] >> 31 : 0u;
+    unsigned starts = m0 & ~((m0 << 1) | before);
+    const int z = 2 * k + zoff;
+    const int zu = min(z + 1, res - 1), zd = max(z - 1, 0);  // SafeIdx clamps (:585-589)
+    const int xbase = xoff + (k & 1);
+    while (starts) {
+        const int first = __builtin_ctz(starts);
+        starts &= starts - 1;
+        int ww = w, bit = first;
+        unsigned m = m0;
+        int x = xbase + 2 * (32 * w + first);
+        float sw, sh, nh[4], nw[4];
+        {
+            const int xr = min(x + 1, res - 1), xl = max(x - 1, 0);
+            const size_t c = (size_t)x * res;
+            sw = pool[c + z];                       sh = height[c + z];
+            nh[0] = height[c + zu];                 nw[0] = pool[c + zu];                  // up
+            nh[1] = height[(size_t)xr * res + z];   nw[1] = pool[(size_t)xr * res + z];    // right
+            nh[2] = height[c + zd];                 nw[2] = pool[c + zd];                  // down
+            nh[3] = height[(size_t)xl * res + z];   nw[3] = pool[(size_t)xl * res + z];    // left
+        }
+        for (;;) {
+            // does the run go on?  (a step past the end of the row has no bit)
+            bool more;
+            if (bit < 31) {
+                more = (m >> (bit + 1)) & 1u;
+            } else {
+                m = ww + 1 < words ? mask[(size_t)(ww + 1) * walks + k] : 0u;
+                more = m & 1u;
+            }
+            float sw2 = 0.0f, sh2 = 0.0f, nh2[4] = {0.0f, 0.0f, 0.0f, 0.0f}, nw2[3] = {0.0f, 0.0f, 0.0f};
+            if (more) {  // the next step's cells, none of them written by this step -- except its left-hand one
+                const int x2 = x + 2;
+                const int xr = min(x2 + 1, res - 1);
+                const size_t c = (size_t)x2 * res;
+                sw2 = pool[c + z];                       sh2 = height[c + z];
+                nh2[0] = height[c + zu];                 nw2[0] = pool[c + zu];
+                nh2[1] = height[(size_t)xr * res + z];   nw2[1] = pool[(size_t)xr * res + z];
+                nh2[2] = height[c + zd];                 nw2[2] = pool[c + zd];
+                nh2[3] = height[(size_t)(x2 - 1) * res + z];
+            }
+            float carry = nw[1];
+            if (pool_step_acts(sw))  // a stale bit: the step stays in its run and does nothing
+                spread_pool_step<DRAIN, true>(pool, res, x, z, zu, zd, sw, sh, nh, nw, carry, drain_hdr, drain_data, pm);
+            if (!more) break;
+            x += 2;
+            if (bit < 31) bit++; else { bit = 0; ww++; }
+            sw = sw2; sh = sh2;
+            nh[0] = nh2[0]; nh[1] = nh2[1]; nh[2] = nh2[2]; nh[3] = nh2[3];
+            nw[0] = nw2[0]; nw[1] = nw2[1]; nw[2] = nw2[2]; nw[3] = carry;
+        }
+    }
+}
+
+// The one-lane-per-row form of the same pass (NZ_POOL_RUNS=0): the loads of PU consecutive steps are issued together,
+// ahead of the arithmetic, and the one carried cell travels in a register, so the walk pays one memory round trip per
+// PU steps.  Faster than the run form only where standing water covers most of the plane.
+constexpr int PU = 8;
+
 template <bool DRAIN>
 __global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *pool, const float *__restrict__ height, int res,
                                                                int xoff, int zoff, int32_t *drain_hdr,
@@ -159,93 +387,12 @@ __global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *pool, con
         for (int u = 0; u < PU; u++) {
             const int x = x0 + 2 * u;
             if (x >= res) break;
-            const int xr = min(x + 1, res - 1), xl = max(x - 1, 0);
-            const int idx = x * res + z, right_idx = xr * res + z;
             if (have_carry) nw[u][3] = carry;
-            float hWater = sw[u];
             carry = nw[u][1];
             have_carry = true;
-            if (!(hWater > 0.0f)) continue;
-            const float hLand = sh[u];
-            float tHeight = hLand + hWater;
-            flooded b[4];
-            b[0].idx = x * res + zu;  b[1].idx = right_idx;  b[2].idx = x * res + zd;  b[3].idx = xl * res + z;
-            int key[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                b[e].height = nh[u][e];
-                b[e].water = nw[u][e];
-                key[e] = float_hash(nh[u][e] + nw[u][e]);
-            }
-            // NativeArray.Sort() of com.unity.collections 1.4.0 on 4 elements: insertion sort, element i+1 moves
-            // left while it compares < 0 (flooded_cmp above: same cell -> 0, else key > key ? 1 : -1).  The same
-            // comparisons in the same order, applied with selects so that the lanes of a wave do not diverge (the
-            // walk is bound by the length of its instruction stream)
-#define NZ_LT(ti, tk, j) ((ti) != b[j].idx && !((tk) > key[j]))
-#define NZ_SEL(dst, c, src_t) do { b[dst].idx = (c) ? (src_t##i) : b[dst].idx; b[dst].height = (c) ? (src_t##h) : b[dst].height; \
-                                   b[dst].water = (c) ? (src_t##w) : b[dst].water; key[dst] = (c) ? (src_t##k) : key[dst]; } while (0)
-#define NZ_MOV(dst, c, src) do { b[dst].idx = (c) ? b[src].idx : b[dst].idx; b[dst].height = (c) ? b[src].height : b[dst].height; \
-                                 b[dst].water = (c) ? b[src].water : b[dst].water; key[dst] = (c) ? key[src] : key[dst]; } while (0)
-            {
-                int ti = b[1].idx, tk = key[1];
-                float th = b[1].height, tw = b[1].water;
-                bool c0 = NZ_LT(ti, tk, 0);
-                NZ_MOV(1, c0, 0);
-                NZ_SEL(0, c0, t);
-                ti = b[2].idx; tk = key[2]; th = b[2].height; tw = b[2].water;
-                bool c1 = NZ_LT(ti, tk, 1);
-                c0 = c1 && NZ_LT(ti, tk, 0);
-                NZ_MOV(2, c1, 1);
-                NZ_MOV(1, c0, 0);
-                NZ_SEL(1, c1 && !c0, t);
-                NZ_SEL(0, c0, t);
-                ti = b[3].idx; tk = key[3]; th = b[3].height; tw = b[3].water;
-                bool c2 = NZ_LT(ti, tk, 2);
-                c1 = c2 && NZ_LT(ti, tk, 1);
-                c0 = c1 && NZ_LT(ti, tk, 0);
-                NZ_MOV(3, c2, 2);
-                NZ_MOV(2, c1, 1);
-                NZ_MOV(1, c0, 0);
-                NZ_SEL(2, c2 && !c1, t);
-                NZ_SEL(1, c1 && !c0, t);
-                NZ_SEL(0, c0, t);
-            }
-#undef NZ_LT
-#undef NZ_SEL
-#undef NZ_MOV
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float bw = b[e].water, bh = b[e].height;
-                const float diffV = tHeight - (bh + bw);
-                const bool go = !(hWater < 1E-3f);
-                const bool spill = bw <= 0.0f && hLand >= bh;                       // the dry neighbour takes it all
-                const bool give = !spill && diffV > 0.0f && !(hWater <= 0.0f);
-                const bool take = !spill && !(diffV > 0.0f) && diffV < 0.0f && !(bw <= 0.0f);
-                const float fill_give = fminf(0.25f * hWater, 0.25f * diffV);
-                const float fill_take = fminf(0.25f * bw, -0.25f * diffV);
-                const float put = spill ? bw + hWater : (give ? bw + fill_give : bw + (-1.0f * fill_take));
-                const float w_new = spill ? 0.0f : (give ? hWater - fill_give : hWater + fill_take);
-                if (go && (spill || give || take)) {
-                    if (DRAIN && spill) {
-                        const int slot = atomicAdd(&drain_hdr[0], 1);
-                        if (slot < drain_hdr[1]) {
-                            nz_particle p;
-                            p.px = b[e].idx / res;  // getPos(idx)
-                            p.pz = b[e].idx % res;
-                            p.water = hWater;
-                            p.pid = 64000;
-                            drain_data[slot] = p;
-                        }
-                    } else {
-                        pool[b[e].idx] = put;
-                        if (b[e].idx == right_idx) carry = put;
-                    }
-                    hWater = w_new;
-                    tHeight = spill ? hLand : hLand + w_new;
-                }
-            }
-            pool[idx] = hWater;
-            if (idx == right_idx) carry = hWater;  // last column: the right-hand neighbour is the cell itself
+            if (!(sw[u] > 0.0f)) continue;
+            spread_pool_step<DRAIN, false>(pool, res, x, z, zu, zd, sw[u], sh[u], nh[u], nw[u], carry, drain_hdr, drain_data,
+                                           pool_masks{nullptr, 0, 0});
         }
     }
 }
@@ -347,16 +494,49 @@ int32_t nz_launch_flow_from_track(hipStream_t s, float *pool, float *flow, float
     return NZ_OK;
 }
 
+size_t nz_pool_automata_mask_words(int res) { return 4 * (size_t)(((res + 1) / 2 + 31) / 32) * (size_t)(res / 2); }
+
+// The acting-step bits of a job's four passes, from the plane as the job finds it
+int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res, unsigned *mask) {
+    if (res / 2 <= 0) return NZ_OK;
+    pool_masks pm{mask, ((res + 1) / 2 + 31) / 32, res / 2};
+    hipLaunchKernelGGL(pool_masks_kernel, dim3((unsigned)((res + 63) / 64), (unsigned)pm.words), dim3(64), 0, s, pool, pm, res);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_pool_automata_clean(hipStream_t s, const float *pool, int res, unsigned *mask) {
+    if (res / 2 <= 0) return NZ_OK;
+    pool_masks pm{mask, ((res + 1) / 2 + 31) / 32, res / 2};
+    hipLaunchKernelGGL(pool_masks_clean_kernel, dim3((unsigned)((pm.walks + 63) / 64), (unsigned)pm.words, 4), dim3(64), 0, s,
+                       pool, pm, res);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+// `mask` = the bits nz_launch_pool_automata_masks prepared (nz_pool_automata_mask_words(res) words, kept up to date by
+// the passes themselves): the pass runs as parallel runs; NULL: one lane per row
 int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *height, int res, int xoff, int zoff,
-                                     int32_t *drain_hdr, nz_particle *drain_data) {
+                                     int32_t *drain_hdr, nz_particle *drain_data, unsigned *mask) {
     int jobs = res / 2;
     if (jobs <= 0) return NZ_OK;
-    if (drain_hdr)
-        hipLaunchKernelGGL(pool_automata_pass_kernel<true>, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, s, pool, height,
-                           res, xoff, zoff, drain_hdr, drain_data);
-    else
-        hipLaunchKernelGGL(pool_automata_pass_kernel<false>, dim3((unsigned)((jobs + 63) / 64)), dim3(64), 0, s, pool, height,
-                           res, xoff, zoff, drain_hdr, drain_data);
+    dim3 grid((unsigned)((jobs + 63) / 64));
+    if (mask) {
+        pool_masks pm{mask, ((res + 1) / 2 + 31) / 32, jobs};
+        grid.y = (unsigned)pm.words;
+        if (drain_hdr)
+            hipLaunchKernelGGL(pool_runs_kernel<true>, grid, dim3(64), 0, s, pool, height, pm, res, xoff, zoff, drain_hdr,
+                               drain_data);
+        else
+            hipLaunchKernelGGL(pool_runs_kernel<false>, grid, dim3(64), 0, s, pool, height, pm, res, xoff, zoff, drain_hdr,
+                               drain_data);
+    } else if (drain_hdr) {
+        hipLaunchKernelGGL(pool_automata_pass_kernel<true>, grid, dim3(64), 0, s, pool, height, res, xoff, zoff, drain_hdr,
+                           drain_data);
+    } else {
+        hipLaunchKernelGGL(pool_automata_pass_kernel<false>, grid, dim3(64), 0, s, pool, height, res, xoff, zoff, drain_hdr,
+                           drain_data);
+    }
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

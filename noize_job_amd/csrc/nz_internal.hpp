@@ -207,8 +207,12 @@ int32_t nz_launch_reduce(hipStream_t s, int op, float *l, const float *r, size_t
 int32_t nz_launch_flow_from_track(hipStream_t s, float *pool, float *flow, float *track, size_t n, float flowLossRate,
                                   float evaporation);
 // drain_hdr / drain_data (nullable): the particle queue a drained pool leaves through (PoolAutomataJob, drainParticles)
+size_t nz_pool_automata_mask_words(int res);
+int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res, unsigned *mask);
+int32_t nz_launch_pool_automata_clean(hipStream_t s, const float *pool, int res, unsigned *mask);
 int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *height, int res, int xoff, int zoff,
-                                     int32_t *drain_hdr = nullptr, nz_particle *drain_data = nullptr);
+                                     int32_t *drain_hdr = nullptr, nz_particle *drain_data = nullptr,
+                                     unsigned *mask = nullptr);
 int32_t *nz_particle_queue_hdr(nz_particle_queue *q);
 nz_particle *nz_particle_queue_data(nz_particle_queue *q);
 int32_t nz_launch_crop(hipStream_t s, const float *in, int in_res, float *out, int out_res);

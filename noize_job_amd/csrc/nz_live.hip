@@ -41,6 +41,8 @@ struct nz_erosive_events {
     int cur = 0;
     void *pile_scratch = nullptr;       // the ManhattanVertex offsets of the current PILING_RADIUS
     size_t pile_scratch_bytes = 0;
+    int32_t *pile_blocks = nullptr;     // [nb][nb]: which PileSolver blocks hold a pile this cycle
+    size_t pile_blocks_n = 0;
 };
 
 namespace {
@@ -374,35 +376,86 @@ __global__ __launch_bounds__(CT) void process_events_kernel(float *pool, float *
 __constant__ float KERNEL5[5] = {0.12007838424321349f, 0.23388075658535032f, 0.29208171834287244f, 0.23388075658535032f,
                                  0.12007838424321349f};
 
-__global__ __launch_bounds__(CT) void disperse_kernel(const float *__restrict__ height, float *__restrict__ out,
-                                                     const float *__restrict__ sediment, int res, float pileThreshold) {
-    // z is the fast index of the planes: consecutive lanes take consecutive z of one x
-    const int tz = blockIdx.x * CT + threadIdx.x, tx = blockIdx.y;
-    if (tz >= res) return;
+// Events are sparse (a cycle's particles touch a few cells in a thousand), so the gather runs over the cycle's event
+// list, IN PLACE (a target reads the sediment plane and its own height only):
+//   disperse_list_kernel   thread = (listed cell s, tap): the target T = s + tap, if the tap stays two cells inside the
+//                          grid, belongs to the FIRST dispersing source of T's window in the canonical order -- that
+//                          thread folds the whole window, the others leave; tap 0 of a pile event flags its block
+//   disperse_frame_kernel  the two-cell frame of the grid, where clamped taps of one source pile onto one target: every
+//                          frame cell gathers in full
+__device__ __forceinline__ bool disperses(float val, float pileThreshold) {
+    return val != 0.0f && (val < 0.0f || val <= pileThreshold);  // WriteSedimentMap :118-128
+}
+
+__global__ __launch_bounds__(CT) void disperse_list_kernel(float *__restrict__ height, const float *__restrict__ sediment,
+                                                          const int32_t *__restrict__ list,
+                                                          const int32_t *__restrict__ counters, int slot, int res,
+                                                          float pileThreshold, int32_t *pile_blocks, int B, int nb) {
+    const long long n = (long long)counters[slot] * 25;
+    for (long long j = (long long)blockIdx.x * CT + threadIdx.x; j < n; j += (long long)gridDim.x * CT) {
+        const int s = list[j / 25], tap = (int)(j % 25);
+        const int sx = s / res, sz = s - sx * res;
+        const float own = sediment[s];
+        if (tap == 0 && pile_blocks && own != 0.0f && !disperses(own, pileThreshold)) pile_blocks[(sx / B) * nb + sz / B] = 1;
+        if (!disperses(own, pileThreshold)) continue;
+        const int tx = sx + tap / 5 - 2, tz = sz + tap % 5 - 2;
+        if (tx < 2 || tz < 2 || tx >= res - 2 || tz >= res - 2) continue;  // the frame kernel's
+        float v = height[(size_t)tx * res + tz];
+        bool first = true, mine = true;
+        for (int wz = tz - 2; wz <= tz + 2 && mine; wz++)
+            for (int wx = tx - 2; wx <= tx + 2; wx++) {
+                const float val = sediment[(size_t)wx * res + wz];
+                if (!disperses(val, pileThreshold)) continue;
+                if (first) {
+                    first = false;
+                    if (wx != sx || wz != sz) { mine = false; break; }
+                }
+                const float newDiff = ((val * (KERNEL5[tx - wx + 2] * KERNEL5[tz - wz + 2])) / 1.0f);  // its one tap here
+                const float nextV = v + newDiff;
+                if (!(nextV > 1.0f) && !(nextV < 0.0f)) v = v + newDiff;
+            }
+        if (mine) height[(size_t)tx * res + tz] = v;
+    }
+}
+
+__global__ __launch_bounds__(CT) void disperse_frame_kernel(float *__restrict__ height, const float *__restrict__ sediment,
+                                                           int res, float pileThreshold) {
+    // frame cell f: rows x = 0, 1, res-2, res-1 in full (z the fast index), then columns z = 0, 1, res-2, res-1 between them
+    const int rows = min(res, 4);
+    const long long nrow = (long long)rows * res, ncol = (long long)max(res - 4, 0) * 4;
+    const long long f = (long long)blockIdx.x * CT + threadIdx.x;
+    if (f >= nrow + ncol) return;
+    int tx, tz;
+    if (f < nrow) {
+        const int r = (int)(f / res);
+        tx = res <= 4 ? r : (r < 2 ? r : res - 4 + r);
+        tz = (int)(f % res);
+    } else {
+        const long long g = f - nrow;
+        const int c = (int)(g & 3);
+        tx = 2 + (int)(g >> 2);
+        tz = c < 2 ? c : res - 4 + c;
+        if (tz < 0 || tz >= res || (c >= 2 && tz < 2)) return;  // res < 4: the rows were everything
+    }
     float v = height[(size_t)tx * res + tz];
     const int x0 = max(tx - 2, 0), x1 = min(tx + 2, res - 1), z0 = max(tz - 2, 0), z1 = min(tz + 2, res - 1);
-    const bool border = tx < 2 || tz < 2 || tx >= res - 2 || tz >= res - 2;
+    bool any = false;
     for (int sz = z0; sz <= z1; sz++)
         for (int sx = x0; sx <= x1; sx++) {
             const float val = sediment[(size_t)sx * res + sz];
-            if (val == 0.0f || !(val < 0.0f || val <= pileThreshold)) continue;
-            if (!border) {  // exactly one kernel tap of this source lands here
-                const float newDiff = ((val * (KERNEL5[tx - sx + 2] * KERNEL5[tz - sz + 2])) / 1.0f);
-                const float nextV = v + newDiff;
-                if (!(nextV > 1.0f) && !(nextV < 0.0f)) v = v + newDiff;
-            } else {
-                for (int kx = 0; kx < 5; kx++)
-                    for (int kz = 0; kz < 5; kz++) {
-                        if (clampi(sx - 2 + kx, 0, res - 1) != tx || clampi(sz - 2 + kz, 0, res - 1) != tz) continue;
-                        const float newDiff = ((val * (KERNEL5[kx] * KERNEL5[kz])) / 1.0f);
-                        const float nextV = v + newDiff;
-                        if (nextV > 1.0f) continue;
-                        if (nextV < 0.0f) continue;
-                        v = v + newDiff;
-                    }
-            }
+            if (!disperses(val, pileThreshold)) continue;
+            any = true;
+            for (int kx = 0; kx < 5; kx++)
+                for (int kz = 0; kz < 5; kz++) {
+                    if (clampi(sx - 2 + kx, 0, res - 1) != tx || clampi(sz - 2 + kz, 0, res - 1) != tz) continue;
+                    const float newDiff = ((val * (KERNEL5[kx] * KERNEL5[kz])) / 1.0f);
+                    const float nextV = v + newDiff;
+                    if (nextV > 1.0f) continue;
+                    if (nextV < 0.0f) continue;
+                    v = v + newDiff;
+                }
         }
-    out[(size_t)tx * res + tz] = v;
+    if (any) height[(size_t)tx * res + tz] = v;
 }
 
 // PileSolver (LiveErosionDataTypes.cs:1053-1225).  A pile reads and raises heights within Chebyshev distance
@@ -414,6 +467,7 @@ __global__ __launch_bounds__(CT) void disperse_kernel(const float *__restrict__ 
 // nature: a running remainder -- over LDS, and commits the modified vertices in vertex order (the ManhattanVertex list
 // names the centre four times and many ring cells twice, each copy with a value of its own: the LAST copy wins).
 __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__restrict__ sediment,
+                                                 const int32_t *__restrict__ pile_blocks,
                                                  const short2 *__restrict__ ofs, int nverts, int res, int maxDistance,
                                                  int B, int nb, int cx, int cz, float pileThreshold, float increment) {
     extern __shared__ unsigned char s_raw[];
@@ -424,6 +478,7 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
     const int bx = cx + 2 * (int)(blockIdx.x % per_row), bz = cz + 2 * (int)(blockIdx.x / per_row);
     const int lane = threadIdx.x;
     const int x0 = bx * B, z0 = bz * B, x1 = min(x0 + B, res), z1 = min(z0 + B, res);
+    if (!pile_blocks[bx * nb + bz]) return;  // no pile event in this block (disperse_list_kernel flags them)
     for (int z = z0; z < z1; z++) {
         for (int xb = x0; xb < x1; xb += 64) {
             const int x = xb + lane;
@@ -638,7 +693,7 @@ extern "C" int32_t nz_erosive_events_destroy(nz_ctx *ctx, nz_erosive_events *ev)
     if (!ev) return NZ_OK;
     NZ_HIP(hipSetDevice(ctx->device));
     NZ_HIP(hipStreamSynchronize(ctx->stream));
-    void *ps[] = {ev->acc, ev->touched, ev->list[0], ev->list[1], ev->counters, ev->sediment, ev->pile_scratch};
+    void *ps[] = {ev->acc, ev->touched, ev->list[0], ev->list[1], ev->counters, ev->sediment, ev->pile_scratch, ev->pile_blocks};
     for (void *p : ps)
         if (p) (void)hipFree(p);
     delete ev;
@@ -721,16 +776,31 @@ extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_e
     if (int32_t rc = check_live(ep, tm, res)) return rc;
     NZ_REQUIRE(events->res == res, "events were created for resolution %d", events->res);
     NZ_REQUIRE(ep->PILING_RADIUS >= 0 && ep->PILING_RADIUS <= 50, "PILING_RADIUS %d out of range [0,50]", ep->PILING_RADIUS);
-    const size_t n = (size_t)res * res;
-    float *tmp = nullptr;
-    NZ_TRY_(nz_ctx_scratch(ctx, n, &tmp));
     const float thr = ep->PILE_THRESHOLD / (float)tm->HEIGHT;
-    hipLaunchKernelGGL(disperse_kernel, dim3((unsigned)((res + CT - 1) / CT), (unsigned)res), dim3(CT), 0, ctx->stream, height,
-                       tmp, events->sediment, res, thr);
-    NZ_HIP(hipGetLastError());
-    NZ_HIP(hipMemcpyAsync(height, tmp, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-    // PileSolver.Init :1058-1098: vertex offsets (host), GetOffset = dist * dirA + i * (dirB - dirA)
+    // the events ProcessBeyerErosiveEvents has just written are the cells of the list it filled (it flipped `cur` after)
+    const int slot = events->cur ^ 1;
     const int D = ep->PILING_RADIUS;
+    const int B = 2 * (D + 1), nb = (res + B - 1) / B;
+    if (D >= 1) {
+        if ((size_t)nb * nb != events->pile_blocks_n) {  // another radius: rare
+            NZ_HIP(hipStreamSynchronize(ctx->stream));
+            if (events->pile_blocks) (void)hipFree(events->pile_blocks);
+            events->pile_blocks = nullptr;
+            events->pile_blocks_n = 0;
+            NZ_HIP(hipMalloc((void **)&events->pile_blocks, (size_t)nb * nb * 4));
+            events->pile_blocks_n = (size_t)nb * nb;
+        }
+        NZ_HIP(hipMemsetAsync(events->pile_blocks, 0, (size_t)nb * nb * 4, ctx->stream));
+    }
+    hipLaunchKernelGGL(disperse_list_kernel, dim3(2048), dim3(CT), 0, ctx->stream, height, events->sediment, events->list[slot],
+                       events->counters, slot, res, thr, D >= 1 ? events->pile_blocks : nullptr, B, nb);
+    {
+        const long long frame = (long long)std::min(res, 4) * res + (long long)std::max(res - 4, 0) * 4;
+        hipLaunchKernelGGL(disperse_frame_kernel, dim3((unsigned)((frame + CT - 1) / CT)), dim3(CT), 0, ctx->stream, height,
+                           events->sediment, res, thr);
+    }
+    NZ_HIP(hipGetLastError());
+    // PileSolver.Init :1058-1098: vertex offsets (host), GetOffset = dist * dirA + i * (dirB - dirA)
     if (D >= 1) {
         std::vector<short2> ofs;
         const int DAX[4] = {0, 1, 0, -1}, DAZ[4] = {1, 0, -1, 0}, DBX[4] = {1, 0, -1, 0}, DBZ[4] = {0, -1, 0, 1};
@@ -748,14 +818,14 @@ extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_e
             NZ_HIP(hipMemcpy(events->pile_scratch, ofs.data(), bytes, hipMemcpyHostToDevice));
             events->pile_scratch_bytes = bytes;
         }
-        const int nverts = (int)ofs.size(), B = 2 * (D + 1), nb = (res + B - 1) / B;
+        const int nverts = (int)ofs.size();
         const size_t lds = (size_t)nverts * 9;
         for (int colour = 0; colour < 4; colour++) {
             const int cx = colour & 1, cz = colour >> 1;
             const int bxn = (nb - cx + 1) / 2, bzn = (nb - cz + 1) / 2;
             if (bxn <= 0 || bzn <= 0) continue;
             hipLaunchKernelGGL(pile_kernel, dim3((unsigned)(bxn * bzn)), dim3(64), lds, ctx->stream, height, events->sediment,
-                               (const short2 *)events->pile_scratch, nverts, res, D, B, nb, cx, cz, thr,
+                               events->pile_blocks, (const short2 *)events->pile_scratch, nverts, res, D, B, nb, cx, cz, thr,
                                ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT);
             NZ_HIP(hipGetLastError());
         }

@@ -978,6 +978,17 @@ extern "C" int32_t nz_update_flow_from_track(nz_ctx *ctx, float *pool, float *fl
     return nz_ctx_finish(ctx, out);
 }
 
+// Scratch for the acting-step bits of the job's passes, filled from the plane as the job finds it; NZ_POOL_RUNS=0 selects the one-lane-per-row walk (mask = NULL)
+static int32_t pool_mask(nz_ctx *ctx, const float *pool, int res, unsigned **mask) {
+    static const int runs = [] { const char *e = getenv("NZ_POOL_RUNS"); return e ? atoi(e) : 1; }();
+    *mask = nullptr;
+    if (!runs) return NZ_OK;
+    float *p = nullptr;
+    NZ_TRY(nz_ctx_scratch(ctx, nz_pool_automata_mask_words(res), &p));
+    *mask = reinterpret_cast<unsigned *>(p);
+    return nz_launch_pool_automata_masks(ctx->stream, pool, res, *mask);
+}
+
 // PoolAutomataJob.Schedule, MultiThreadErosionJob.cs:289-325, with drainParticles == false (the other setting feeds
 // the particle queue, which is outside the deterministic part)
 extern "C" int32_t nz_pool_automata(nz_ctx *ctx, float *pool, const float *height, int32_t iterations, int32_t resolution,
@@ -986,10 +997,15 @@ extern "C" int32_t nz_pool_automata(nz_ctx *ctx, float *pool, const float *heigh
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(pool && height && pool != height, "pool/height must be two distinct planes");
     NZ_REQUIRE(resolution >= 2 && iterations >= 0, "resolution < 2 or iterations < 0");
-    for (int i = 0; i < iterations; i++)
+    unsigned *mask = nullptr;
+    NZ_TRY(pool_mask(ctx, pool, resolution, &mask));
+    for (int i = 0; i < iterations; i++) {
+        if (i > 0 && mask) NZ_TRY(nz_launch_pool_automata_clean(ctx->stream, pool, resolution, mask));
         for (int xoff = 0; xoff < 2; xoff++)
             for (int zoff = 0; zoff < 2; zoff++)
-                NZ_TRY(nz_launch_pool_automata_pass(ctx->stream, pool, height, resolution, xoff, zoff));
+                NZ_TRY(nz_launch_pool_automata_pass(ctx->stream, pool, height, resolution, xoff, zoff, nullptr, nullptr,
+                                                    mask));
+    }
     return nz_ctx_finish(ctx, out);
 }
 
@@ -1006,10 +1022,14 @@ extern "C" int32_t nz_pool_automata_job(nz_ctx *ctx, float *pool, const float *h
     NZ_REQUIRE(!drainParticles || particleQueue, "drainParticles needs a particle queue");
     int32_t *hdr = drainParticles ? nz_particle_queue_hdr(particleQueue) : nullptr;
     nz_particle *data = drainParticles ? nz_particle_queue_data(particleQueue) : nullptr;
-    for (int i = 0; i < iterations; i++)
+    unsigned *mask = nullptr;
+    NZ_TRY(pool_mask(ctx, pool, res, &mask));
+    for (int i = 0; i < iterations; i++) {
+        if (i > 0 && mask) NZ_TRY(nz_launch_pool_automata_clean(ctx->stream, pool, res, mask));
         for (int xoff = 0; xoff < 2; xoff++)
             for (int zoff = 0; zoff < 2; zoff++)
-                NZ_TRY(nz_launch_pool_automata_pass(ctx->stream, pool, height, res, xoff, zoff, hdr, data));
+                NZ_TRY(nz_launch_pool_automata_pass(ctx->stream, pool, height, res, xoff, zoff, hdr, data, mask));
+    }
     return nz_ctx_finish(ctx, out);
 }
 

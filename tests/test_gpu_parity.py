@@ -606,6 +606,22 @@ def test_live_erosion_grid_jobs(nj, ctx, oracle, res):
         ctx.call("nz_pool_automata", d_pool.ptr, d_pool.ptr, 1, res)
 
 
+@pytest.mark.parametrize("res,cover", [(66, 1.0), (130, 0.6), (257, 1.0), (257, 0.03), (512, 0.9)])
+def test_pool_automata_runs_match_the_row_walk(nj, ctx, oracle, res, cover):
+    # the pass runs as parallel runs of acting steps (pool_runs_kernel): lakes that span mask words and whole rows,
+    # isolated puddles, water below the 1E-3 threshold between them, odd sizes -- all equal to the oracle's row walk
+    rng = np.random.default_rng(res + int(cover * 100))
+    height = (rng.random((res, res), dtype=f32) * f32(0.2)).astype(f32)
+    wet = rng.random((res, res)) < cover
+    pool = np.where(wet, f32(0.002) + rng.random((res, res), dtype=f32) * f32(0.3), 0).astype(f32)
+    pool[rng.random((res, res)) < 0.1] = f32(0.0005)      # standing water that does not act
+    pool[:, res // 2] = f32(0.25)                          # one full line of water either way
+    pool[res // 3, :] = f32(0.25)
+    d_pool, d_h = ctx.from_host(pool), ctx.from_host(height)
+    ctx.call("nz_pool_automata", d_pool.ptr, d_h.ptr, 2, res).Complete()
+    assert np.array_equal(d_pool.ToArray((res, res)), oracle.pool_automata(pool, height, 2))
+
+
 def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):
     # BasicDemo "ParallelFlowMap": Perlin fBm -> Invert (curve) -> FlowMapStage -> CurveBoostContrast
     res = 128

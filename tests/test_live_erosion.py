@@ -153,7 +153,8 @@ def test_spawn_matches_oracle(nj, ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("res,particles,tile_height,patch", [(256, 3000, 1000, 1.0), (384, 6000, 500, 2.5)])
+@pytest.mark.parametrize("res,particles,tile_height,patch", [(256, 3000, 1000, 1.0), (384, 6000, 500, 2.5),
+                                                             (40, 600, 1000, 1.0)])  # 40: a third of the cells in the frame
 def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, tile_height, patch):
     h = terrain(oracle, res)
     es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, PILE_THRESHOLD=0.4, PILING_RADIUS=7, MIN_PILE_INCREMENT=0.25)
@@ -187,8 +188,11 @@ def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, til
         L.erode_height_maps()
         piles = int(((L.sediment > f32(ep.PILE_THRESHOLD) / f32(tile_height))).sum())
         assert np.array_equal(G.heightMap.ToArray(shape), L.height), (cyc, piles)
-        if cyc == 0:
+        if cyc == 0 and res >= 256:
             assert piles > 0, "the parameters were chosen so that the PileSolver path runs"
+        if res < 256:  # events in the two-cell frame, where clamped taps of one source fold onto one target
+            frame = np.ones(shape, bool); frame[2:-2, 2:-2] = False
+            assert (L.sediment[frame] != 0).any()
         G.ctx.call("nz_update_flow_from_track", G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr, ep.FLOW_LOSS_RATE,
                    ep.SURFACE_EVAPORATION_RATE, float(tile_height), res)
         L.update_flow_from_track()

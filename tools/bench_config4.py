@@ -72,6 +72,22 @@ def main():
         out["per_job_ms"] = {n: round(v / a.cycles, 4) for n, v in acc.items()}
         out["cycle_ms"] = round(sum(acc.values()) / a.cycles, 4)
         out["events_per_cycle"] = events // a.cycles
+        # the automaton alone on a plane under water everywhere (every walk is one run as long as its row: the run form's
+        # worst case) and on a plane with a wet cell in fifty
+        import numpy as np
+        for name, plane in (("pool_automata_all_wet_ms", np.full((res, res), 0.01, np.float32)),
+                            ("pool_automata_2pct_wet_ms",
+                             np.where(np.random.default_rng(5).random((res, res)) < 0.02, 0.01, 0).astype(np.float32))):
+            ms = []
+            for _ in range(3):
+                wet = ctx.from_host(plane)
+                m0 = ctx.record()
+                ctx.call("nz_pool_automata", wet.ptr, h.ptr, a.water_steps, res)
+                m1 = ctx.record()
+                m1.Complete()
+                ms.append(ctx.elapsed_ms(m0, m1))
+            out[name] = round(min(ms), 4)
+        out["pool_runs"] = os.environ.get("NZ_POOL_RUNS", "1")
         # whole Updates through the host driver, wall clock
         es.CYCLES = 3
         G.TriggerQueuedBeyerMT([1, 2, 3]).Complete()
