@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void pool_masks_kernel(const float *__restrict_
     if (k >= pm.walks) return;
     const int odd = k & 1;
     unsigned m0 = 0, m1 = 0;  // xoff = 0: x = 64 w + odd + 2 b; xoff = 1: x = 64 w + 1 + odd + 2 b
-#pragma unroll 8
+#pragma unroll
     for (int b = 0; b < 32; b++) {
         const int xa = 64 * w + odd + 2 * b, xb = xa + 1;
         if (xa < res && pool_step_acts(pool[(size_t)xa * res + z])) m0 |= 1u << b;
@@ -275,19 +275,23 @@ __global__ __launch_bounds__(64) void pool_masks_kernel(const float *__restrict_
     pm.m[((size_t)(2 + zoff) * pm.words + w) * pm.walks + k] = m1;
 }
 
-__global__ __launch_bounds__(64) void pool_masks_clean_kernel(const float *__restrict__ pool, pool_masks pm, int res) {
-    const int k = blockIdx.x * 64 + threadIdx.x, w = blockIdx.y, c = blockIdx.z;
+constexpr int PCW = 8;  // mask words per thread of the clean kernel
+__global__ __launch_bounds__(256) void pool_masks_clean_kernel(const float *__restrict__ pool, pool_masks pm, int res) {
+    const int k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.z;
     if (k >= pm.walks) return;
-    unsigned *word = pm.m + ((size_t)c * pm.words + w) * pm.walks + k;
-    const unsigned m = *word;
-    if (m == 0) return;
-    const int z = 2 * k + (c & 1), x0 = (c >> 1) + (k & 1) + 64 * w;
-    unsigned keep = m;
-    for (unsigned rest = m; rest; rest &= rest - 1) {
-        const int b = __builtin_ctz(rest);
-        if (!pool_step_acts(pool[(size_t)(x0 + 2 * b) * res + z])) keep &= ~(1u << b);
+    const int z = 2 * k + (c & 1);
+    for (int w = blockIdx.y * PCW; w < min((int)blockIdx.y * PCW + PCW, pm.words); w++) {
+        unsigned *word = pm.m + ((size_t)c * pm.words + w) * pm.walks + k;
+        const unsigned m = *word;
+        if (m == 0) continue;
+        const int x0 = (c >> 1) + (k & 1) + 64 * w;
+        unsigned keep = m;
+        for (unsigned rest = m; rest; rest &= rest - 1) {
+            const int b = __builtin_ctz(rest);
+            if (!pool_step_acts(pool[(size_t)(x0 + 2 * b) * res + z])) keep &= ~(1u << b);
+        }
+        if (keep != m) *word = keep;
     }
-    if (keep != m) *word = keep;
 }
 
 template <bool DRAIN>
@@ -508,8 +512,8 @@ int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res,
 int32_t nz_launch_pool_automata_clean(hipStream_t s, const float *pool, int res, unsigned *mask) {
     if (res / 2 <= 0) return NZ_OK;
     pool_masks pm{mask, ((res + 1) / 2 + 31) / 32, res / 2};
-    hipLaunchKernelGGL(pool_masks_clean_kernel, dim3((unsigned)((pm.walks + 63) / 64), (unsigned)pm.words, 4), dim3(64), 0, s,
-                       pool, pm, res);
+    hipLaunchKernelGGL(pool_masks_clean_kernel, dim3((unsigned)((pm.walks + 255) / 256), (unsigned)((pm.words + PCW - 1) / PCW), 4),
+                       dim3(256), 0, s, pool, pm, res);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
