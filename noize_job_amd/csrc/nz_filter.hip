@@ -358,8 +358,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
         // the class's share of launch l is a contiguous run of tiles: classes before it, then its own earlier items
         int start = 0;
         for (int c = 0; c < cls; c++) start += chain_class_count(ch.first[l + 1], c) - chain_class_count(ch.first[l], c);
+        // Odd classes walk their run backwards.  A run's first row of tiles reads the last row of the run before it:
+        // if every class walked forwards, each would start launch l + 1 on the tiles whose producers its neighbour
+        // finishes launch l with -- a row of workgroups spinning at every launch boundary.  Walking towards each
+        // other, neighbouring classes finish a launch on the rows they share and start the next one at the far ends.
+        const int mine = chain_class_count(ch.first[l + 1], cls) - chain_class_count(ch.first[l], cls);
+        const int j = chain_class_count(vb, cls) - chain_class_count(ch.first[l], cls);
         s_item[0] = l;
-        s_item[1] = start + chain_class_count(vb, cls) - chain_class_count(ch.first[l], cls);
+        s_item[1] = start + ((cls & 1) ? mine - 1 - j : j);
     }
     __syncthreads();
     const int l = s_item[0], tile = s_item[1];
