@@ -1,0 +1,137 @@
+// LiveErosion.cs -- Component/LiveErosion.cs:200-436 without the MonoBehaviour: the driver of BASELINE config 4.
+// Owns heightMap / poolMap / streamMap / particleTrack (planes indexed x * res + z, LiveErosionDataTypes.cs:608-610),
+// the particle queue and the erosive events, and chains one Update's worth of jobs on the context's stream:
+//   per cycle: ThermalErosionFilter -> FillBeyerQueueJob -> QueuedBeyerCycleMultiThreadJob -> ProcessBeyerErosiveEventsJob
+//              -> ClearQueueJob -> ErodeHeightMaps -> UpdateFlowFromTrackJob -> PoolAutomataJob(drainParticles)
+//   then the RGBA32 control textures (SetRGBA32Job x5, CurvitureMapJob).
+// Where the reference draws its seeds from UnityEngine.Random (MultiThreadErosionJob.cs:50) the caller passes one seed
+// per cycle: the same seeds give the same planes, bit for bit, on every run.
+// Source only (no .NET toolchain in the build image); noize_job_amd/live_erosion.py is the same driver in Python and
+// is the one the GPU tests run.
+using System;
+
+namespace xshazwar.noize.hip {
+
+    public enum ErosionMode { ALL_EROSION, ONLY_FLOW_WATER, ONLY_THERMAL_EROSION, ONLY_PARTICLE_EROSION }   // LiveErosionDataTypes.cs:29-34
+    public enum ColorChannelByte { R, G, B, A }                                                             // :1235-1241
+
+    public class ErosionSettings {               // ScriptableObject/ErosionSettings.cs:5-124 (defaults = Reset())
+        public ErosionMode BEHAVIOR = ErosionMode.ALL_EROSION;
+        public int PARTICLES_PER_CYCLE = 1000, CYCLES = 1, WATER_STEPS = 10, THERMAL_CYCLES = 1;
+        public bool ENABLE_THERMAL = true;
+        public float TALUS = 45f, THERMAL_STEP = 0.5f;
+        public NzErosionParams parameters;       // AsParameters() :96-123
+    }
+
+    public sealed class ParticleQueue : IDisposable {
+        readonly GpuContext ctx;
+        public IntPtr Handle { get; private set; }
+        public ParticleQueue(GpuContext ctx, int capacity) {
+            this.ctx = ctx;
+            Native.Check(Native.nz_particle_queue_create(ctx.Handle, capacity, out IntPtr h), "nz_particle_queue_create");
+            Handle = h;
+        }
+        public int Count { get { Native.Check(Native.nz_particle_queue_count(ctx.Handle, Handle, out int n), "nz_particle_queue_count"); return n; } }
+        public GpuJobHandle Clear(GpuJobHandle dependency) {                                         // ClearQueueJob
+            Native.Check(Native.nz_clear_particle_queue(ctx.Handle, Handle, dependency.id, out ulong h), "nz_clear_particle_queue");
+            return ctx.Wrap(h);
+        }
+        public void Dispose() { if (Handle != IntPtr.Zero) { Native.nz_particle_queue_destroy(ctx.Handle, Handle); Handle = IntPtr.Zero; } }
+    }
+
+    public sealed class ErosiveEvents : IDisposable {
+        readonly GpuContext ctx;
+        public IntPtr Handle { get; private set; }
+        public ErosiveEvents(GpuContext ctx, int resolution) {
+            this.ctx = ctx;
+            Native.Check(Native.nz_erosive_events_create(ctx.Handle, resolution, out IntPtr h), "nz_erosive_events_create");
+            Handle = h;
+        }
+        public int Count { get { Native.Check(Native.nz_erosive_events_count(ctx.Handle, Handle, out int n), "nz_erosive_events_count"); return n; } }
+        public void Dispose() { if (Handle != IntPtr.Zero) { Native.nz_erosive_events_destroy(ctx.Handle, Handle); Handle = IntPtr.Zero; } }
+    }
+
+    public class LiveErosion {
+        readonly GpuContext ctx;
+        public NzTileSetMeta tileMeta;
+        public readonly int res;
+        public ErosionSettings erosionSettings;
+        public bool performErosion = true;
+        public DeviceTile heightMap, poolMap, streamMap, particleTrack;
+        public DeviceTile waterControl, textureControl;   // RGBA32, TILE_RES^2 x 4 bytes each (allocated as floats: one per texel)
+        public ParticleQueue particleQueue;
+        public ErosiveEvents events;
+        public int particleGenerationID = 0, EVENT_LIMIT = 1500, QUEUE_SIZE;
+        public GpuJobHandle jobHandle;
+
+        public LiveErosion(GpuContext ctx, DeviceTile heightMap, NzTileSetMeta tileMeta, ErosionSettings settings, bool performErosion = true) {
+            this.ctx = ctx; this.tileMeta = tileMeta; this.heightMap = heightMap; erosionSettings = settings; this.performErosion = performErosion;
+            res = tileMeta.GENERATOR_RES_x;
+            int n = res * res;
+            if (heightMap.Length != n) throw new Exception("heightMap is not GENERATOR_RES^2 cells");
+            float[] zeros = new float[n];
+            poolMap = ctx.Alloc(n); streamMap = ctx.Alloc(n); particleTrack = ctx.Alloc(n);
+            poolMap.CopyFrom(zeros); streamMap.CopyFrom(zeros); particleTrack.CopyFrom(zeros);
+            QUEUE_SIZE = performErosion ? settings.PARTICLES_PER_CYCLE : 1;                          // :215-219
+            particleQueue = new ParticleQueue(ctx, Math.Max(Math.Max(4 * QUEUE_SIZE, QUEUE_SIZE + n / 8), 1024));   // drained pools queue on top
+            events = new ErosiveEvents(ctx, res);
+        }
+
+        public void EnableControlTextures() {
+            int texels = tileMeta.TILE_RES_x * tileMeta.TILE_RES_x;
+            waterControl = ctx.Alloc(texels); textureControl = ctx.Alloc(texels);
+            float[] zeros = new float[texels];
+            waterControl.CopyFrom(zeros); textureControl.CopyFrom(zeros);
+        }
+
+        // TriggerQueuedBeyerMT :378-436.  seeds: one per cycle.
+        public GpuJobHandle TriggerQueuedBeyerMT(int[] seeds) {
+            ErosionSettings es = erosionSettings;
+            NzErosionParams ep = es.parameters;
+            NzTileSetMeta tm = tileMeta;
+            ulong h = 0;
+            IntPtr c = ctx.Handle;
+            if (performErosion) {
+                if (seeds.Length < es.CYCLES) throw new Exception("one seed per cycle");
+                for (int i = 0; i < es.CYCLES; i++) {
+                    // `TILE_SIZE.x / HEIGHT` divides two ints in the reference (:386)
+                    if (es.ENABLE_THERMAL && es.BEHAVIOR != ErosionMode.ONLY_FLOW_WATER)
+                        Native.Check(Native.nz_thermal_erosion(c, heightMap.Ptr, es.TALUS, es.THERMAL_STEP, (float) (tm.TILE_SIZE_x / tm.HEIGHT),
+                                                               es.THERMAL_CYCLES, res, h, out h), "nz_thermal_erosion");
+                    if (es.BEHAVIOR != ErosionMode.ONLY_FLOW_WATER)
+                        Native.Check(Native.nz_fill_beyer_queue(c, particleQueue.Handle, ref ep, ref tm, particleGenerationID % 4, res, QUEUE_SIZE, seeds[i],
+                                                                Math.Min(10, QUEUE_SIZE), h, out h), "nz_fill_beyer_queue");
+                    Native.Check(Native.nz_queued_beyer_cycle(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, particleQueue.Handle,
+                                                              events.Handle, ref ep, ref tm, EVENT_LIMIT, res, h, out h), "nz_queued_beyer_cycle");
+                    Native.Check(Native.nz_process_beyer_erosive_events(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, events.Handle,
+                                                                        ref ep, ref tm, res, h, out h), "nz_process_beyer_erosive_events");
+                    h = particleQueue.Clear(ctx.Wrap(h)).id;
+                    Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
+                    Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
+                                                                  ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out h), "nz_update_flow_from_track");
+                    Native.Check(Native.nz_pool_automata_job(c, poolMap.Ptr, heightMap.Ptr, particleQueue.Handle, ref ep, ref tm, es.WATER_STEPS, res,
+                                                             performErosion ? 1 : 0, h, out h), "nz_pool_automata_job");
+                }
+            }
+            if (waterControl != null) {                                                              // :418-430
+                int mres = tm.TILE_RES_x;
+                Native.Check(Native.nz_set_rgba32(c, poolMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.R, res, mres, 1000f, h, out h), "nz_set_rgba32");
+                Native.Check(Native.nz_set_rgba32(c, poolMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.G, res, mres, 1000f, h, out h), "nz_set_rgba32");
+                Native.Check(Native.nz_set_rgba32(c, streamMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.B, res, mres, 2f, h, out h), "nz_set_rgba32");
+                Native.Check(Native.nz_set_rgba32(c, streamMap.Ptr, textureControl.Ptr, (int) ColorChannelByte.G, res, mres, 3f, h, out h), "nz_set_rgba32");
+                Native.Check(Native.nz_curviture_map(c, textureControl.Ptr, heightMap.Ptr, ref tm, (int) ColorChannelByte.G, res, mres, h, out h), "nz_curviture_map");
+                Native.Check(Native.nz_set_rgba32(c, streamMap.Ptr, textureControl.Ptr, (int) ColorChannelByte.A, res, mres, 1f, h, out h), "nz_set_rgba32");
+            }
+            jobHandle = ctx.Wrap(h);
+            particleGenerationID += 1;                                                               // Update() :341
+            return jobHandle;
+        }
+
+        public void OnDestroy() {
+            jobHandle.Complete();
+            foreach (DeviceTile t in new[] { poolMap, streamMap, particleTrack, waterControl, textureControl }) t?.Dispose();
+            particleQueue.Dispose();
+            events.Dispose();
+        }
+    }
+}

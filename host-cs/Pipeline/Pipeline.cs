@@ -34,6 +34,11 @@ namespace xshazwar.noize.hip {
         public int resolution, xpos, zpos;
     }
 
+    public class DownsampleData : StageIO {      // StageIOTypes/DownsampleData.cs:9-17
+        public DeviceTile inputData;
+        public int resolution, inputResolution;
+    }
+
     public class PipelineWorkItem {              // PipelineDefinition.cs:18-25
         public StageIO data;
         public Action<StageIO> completeAction;
@@ -138,7 +143,7 @@ namespace xshazwar.noize.hip {
             return null;
         }
 
-        public void Update() {                                                                      // :154-158,224-230
+        public virtual void Update() {                                                                      // :154-158,224-230
             if (!pipelineRunning && !pipelineBeingScheduled) {
                 PipelineWorkItem job = GetNextJob();
                 if (job != null) Schedule(job);
@@ -156,6 +161,6 @@ namespace xshazwar.noize.hip {
             return false;
         }
 
-        public void Destroy() { foreach (PipelineStage stage in stage_instances) stage.OnDestroy(); }  // :244-254
+        public virtual void Destroy() { foreach (PipelineStage stage in stage_instances) stage.OnDestroy(); }  // :244-254
     }
 }

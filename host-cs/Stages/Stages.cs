@@ -8,6 +8,8 @@
 //   FlowMapStage          Geologic/Stage/FlowMapStage.cs:16-220
 //   MeshTileStage         Mesh/Stage/MeshTileStage.cs:28-61
 //   ConstantStage / ReduceStage / CurveStage   Filter/ConstantStage.cs, Filter/Reduce/ReduceStage.cs, Filter/Curve/CurveStage.cs
+//   CropStage             Filter/Sample/CropStage.cs:11-19
+//   StageThermalErosion   Filter/Kernel/Blur/StageThermalErosion.cs:12-29
 // Source only (no .NET toolchain in the build image).
 using System;
 
@@ -125,6 +127,28 @@ namespace xshazwar.noize.hip {
             } else {
                 Native.Check(Native.nz_erosion_stage(ctx.Handle, d.data.Ptr, tmp.Ptr, iterations, d.resolution, dependency.id, out h), "nz_erosion_stage");
             }
+            jobHandle = Done(h);
+        }
+    }
+
+    public class CropStage : PipelineStage {      // "CenterCropResolution": the job never sets its offset, so the crop is top-left (CropJob.cs:43-59)
+        public CropStage(GpuContext ctx) : base(ctx) {}
+        public override void Schedule(PipelineWorkItem requirements, GpuJobHandle dependency) {
+            if (!(requirements.data is DownsampleData d)) throw new Exception($"Unhandled stageio {requirements.data.GetType()}");
+            Native.Check(Native.nz_crop_job(ctx.Handle, d.inputData.Ptr, d.inputResolution, d.data.Ptr, d.resolution, dependency.id, out ulong h), "nz_crop_job");
+            jobHandle = Done(h);
+        }
+    }
+
+    public class StageThermalErosion : PipelineStage {
+        public int iterations = 1;
+        public float talus = 45f, increment = 0.5f, meshHeightWidthRatio = 0.75f;
+        public StageThermalErosion(GpuContext ctx) : base(ctx) {}
+        public override void Schedule(PipelineWorkItem requirements, GpuJobHandle dependency) {     // :20-28
+            CheckRequirements<GeneratorData>(requirements);
+            GeneratorData d = (GeneratorData) requirements.data;
+            Native.Check(Native.nz_thermal_erosion(ctx.Handle, d.data.Ptr, talus, increment, meshHeightWidthRatio, iterations, d.resolution,
+                                                   dependency.id, out ulong h), "nz_thermal_erosion");
             jobHandle = Done(h);
         }
     }

@@ -91,8 +91,15 @@ def test_hand_written_files_call_declared_entries_with_the_right_arity():
     assert calls >= 25
     stages = _cs_sources()["Stages/Stages.cs"]
     for cls in ("NoiseStage", "KernelFilterStage", "StageGaussianBlur", "StageSmoothBlur", "ErosionStage", "FlowMapStage",
-                "MeshTileStage", "ConstantStage", "ReduceStage", "CurveStage"):
+                "MeshTileStage", "ConstantStage", "ReduceStage", "CurveStage", "CropStage", "StageThermalErosion"):
         assert re.search(r"class %s\s*:" % cls, stages), cls
+    # the other halves of the operator API: the fan-in pipeline and the live-erosion driver with every job of its cycle
+    assert re.search(r"class ReducePipeline\s*:\s*BasePipeline", _cs_sources()["Pipeline/ReducePipeline.cs"])
+    live = _cs_sources()["LiveErosion/LiveErosion.cs"]
+    for job in ("nz_thermal_erosion", "nz_fill_beyer_queue", "nz_queued_beyer_cycle", "nz_process_beyer_erosive_events",
+                "nz_clear_particle_queue", "nz_erode_height_maps", "nz_update_flow_from_track", "nz_pool_automata_job",
+                "nz_set_rgba32", "nz_curviture_map"):
+        assert "Native.%s(" % job in live, job
 
 
 def test_sequential_structs_match_the_c_structs():
