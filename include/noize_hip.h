@@ -223,6 +223,18 @@ int32_t nz_flowmap_write_values(nz_ctx *ctx, float *src, const float *flowMapN, 
 /* MapNormalizeValuesDelegate, Filter/NormalizeJob.cs:94-100; args = HOST {min, max, range} */
 int32_t nz_map_normalize_values(nz_ctx *ctx, float *src, float *tmp, const float *args,
                                 int32_t resolution, nz_handle dep, nz_handle *out);
+/* GetMapRangeJob.Schedule, Filter/NormalizeJob.cs:17-55: res = DEVICE {min, max, max - min} of the plane, folded from
+ * lim_min / lim_max (the reference's defaults: +infinity / -infinity) with math.min / math.max: NaN cells are skipped,
+ * and where the extreme is zero its sign is that of the last zero cell, as the sequential fold leaves it */
+int32_t nz_get_map_range(nz_ctx *ctx, const float *map, size_t n_floats, float *res, float lim_min, float lim_max,
+                         nz_handle dep, nz_handle *out);
+/* MapNormalizeValuesDelegate with args = DEVICE {min, max, range} (what nz_get_map_range leaves; on a sharded grid,
+ * after the ranks have all-reduced min and max) */
+int32_t nz_map_normalize_values_dev(nz_ctx *ctx, float *src, float *tmp, const float *args, int32_t resolution,
+                                    nz_handle dep, nz_handle *out);
+/* ... on any contiguous run of cells (the owned rows of a stripe) */
+int32_t nz_normalize_cells_dev(nz_ctx *ctx, float *data, size_t n_floats, const float *args, nz_handle dep,
+                               nz_handle *out);
 /* FlowMapStage.Schedule, Geologic/Stage/FlowMapStage.cs:124-214: fill -> iterations x (flow, water)
  * -> velocity -> normalise, result in `src`.  `work` = stage-owned scratch of
  * nz_flowmap_stage_work_floats(resolution) floats (the stage's 11 planes; flux is defined as zero

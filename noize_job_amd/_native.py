@@ -109,6 +109,9 @@ SIGNATURES = {
     "nz_flowmap_update_water": (_i, [ctx_p] + [dev_ptr] * 6 + [_i] + _tail),
     "nz_flowmap_write_values": (_i, [ctx_p] + [dev_ptr] * 5 + [_i] + _tail),
     "nz_map_normalize_values": (_i, [ctx_p, dev_ptr, dev_ptr, f32p, _i] + _tail),
+    "nz_get_map_range": (_i, [ctx_p, dev_ptr, C.c_size_t, dev_ptr, C.c_float, C.c_float] + _tail),
+    "nz_map_normalize_values_dev": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, _i] + _tail),
+    "nz_normalize_cells_dev": (_i, [ctx_p, dev_ptr, C.c_size_t, dev_ptr] + _tail),
     "nz_flowmap_stage_work_floats": (_sz, [_i]),
     "nz_flowmap_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _f, _f, _i] + _tail),
     "nz_flow_fused_max_iterations": (_i, []),

@@ -401,6 +401,99 @@ __global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *pool, con
     }
 }
 
+// ---- GetMapRangeJob (Filter/NormalizeJob.cs:17-55): {min, max, max - min} of a plane, folded from the two limits the
+// caller passes.  The reference folds sequentially with math.min / math.max (NaN elements are skipped; on a tie the
+// LATER operand stays).  Values that compare equal have equal bits except the two zeros, so the fold is a plain
+// parallel min / max plus the position of the last +0 and the last -0: when the minimum (maximum) is zero, its sign is
+// that of the last zero the sequential fold would have met (the limit itself counts as position -1).
+struct map_range_part {
+    float mn, mx;
+    long long last_pz, last_nz;  // -2: none
+};
+__device__ __forceinline__ float umin(float x, float y) { return (y != y) || x < y ? x : y; }  // Unity.Mathematics math.min
+__device__ __forceinline__ float umax(float x, float y) { return (y != y) || x > y ? x : y; }
+__device__ __forceinline__ void map_range_take(map_range_part &p, float v, long long i) {
+    p.mn = umin(p.mn, v);
+    p.mx = umax(p.mx, v);
+    if (v == 0.0f) {
+        if (__builtin_signbit(v)) p.last_nz = i; else p.last_pz = i;  // i ascends within a thread
+    }
+}
+__device__ __forceinline__ void map_range_merge(map_range_part &a, const map_range_part &b) {
+    a.mn = umin(a.mn, b.mn);
+    a.mx = umax(a.mx, b.mx);
+    a.last_pz = a.last_pz > b.last_pz ? a.last_pz : b.last_pz;
+    a.last_nz = a.last_nz > b.last_nz ? a.last_nz : b.last_nz;
+}
+__device__ __forceinline__ map_range_part map_range_block(map_range_part p, map_range_part *s_part) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        map_range_part q;
+        q.mn = __shfl_down(p.mn, off);
+        q.mx = __shfl_down(p.mx, off);
+        q.last_pz = __shfl_down(p.last_pz, off);
+        q.last_nz = __shfl_down(p.last_nz, off);
+        map_range_merge(p, q);
+    }
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = p;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < CT / 64; w++) map_range_merge(p, s_part[w]);
+    return p;  // thread 0 holds the block's
+}
+
+__global__ __launch_bounds__(CT) void map_range_partial_kernel(const float *__restrict__ map, size_t n, int vec,
+                                                              map_range_part *__restrict__ parts) {
+    __shared__ map_range_part s_part[CT / 64];
+    map_range_part p{__builtin_inff(), -__builtin_inff(), -2, -2};
+    const size_t stride = (size_t)gridDim.x * CT;
+    if (vec) {
+        const size_t n4 = n / 4;
+        for (size_t i = (size_t)blockIdx.x * CT + threadIdx.x; i < n4; i += stride) {
+            const float4 t = reinterpret_cast<const float4 *>(map)[i];
+            map_range_take(p, t.x, (long long)(4 * i));
+            map_range_take(p, t.y, (long long)(4 * i + 1));
+            map_range_take(p, t.z, (long long)(4 * i + 2));
+            map_range_take(p, t.w, (long long)(4 * i + 3));
+        }
+        for (size_t i = n4 * 4 + (size_t)blockIdx.x * CT + threadIdx.x; i < n; i += stride) map_range_take(p, map[i], (long long)i);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * CT + threadIdx.x; i < n; i += stride) map_range_take(p, map[i], (long long)i);
+    }
+    p = map_range_block(p, s_part);
+    if (threadIdx.x == 0) parts[blockIdx.x] = p;
+}
+
+__global__ __launch_bounds__(CT) void map_range_final_kernel(const map_range_part *__restrict__ parts, int nparts,
+                                                            float lim_min, float lim_max, float *__restrict__ res) {
+    __shared__ map_range_part s_part[CT / 64];
+    map_range_part p{__builtin_inff(), -__builtin_inff(), -2, -2};
+    for (int i = threadIdx.x; i < nparts; i += CT) map_range_merge(p, parts[i]);
+    p = map_range_block(p, s_part);
+    if (threadIdx.x != 0) return;
+    float mn = lim_min, mx = lim_max;
+    if (!(p.mn == __builtin_inff() && p.mx == -__builtin_inff())) {  // some element was not NaN
+        mn = umin(lim_min, p.mn);
+        mx = umax(lim_max, p.mx);
+        const bool last_is_neg = p.last_nz > p.last_pz;  // both -2: no zero in the plane, the limit's own zero stays
+        if (mn == 0.0f && (p.last_pz >= 0 || p.last_nz >= 0)) mn = last_is_neg ? -0.0f : 0.0f;
+        if (mx == 0.0f && (p.last_pz >= 0 || p.last_nz >= 0)) mx = last_is_neg ? -0.0f : 0.0f;
+    }
+    res[0] = mn;
+    res[1] = mx;
+    res[2] = mx - mn;
+}
+
+// NormalizeMap with its args in device memory ({min, max, range}: what GetMapRangeJob leaves), NormalizeJob.cs:57-92
+__global__ __launch_bounds__(CT) void normalize_args_kernel(float *__restrict__ data, size_t n, const float *__restrict__ args) {
+    const size_t i = (size_t)blockIdx.x * CT + threadIdx.x;
+    if (i >= n) return;
+    const float nmin = args[0], nrange = args[2];
+    float v = data[i];
+    if (nrange < 1e-12f) v = 0.0f;
+    data[i] = (v - nmin) / nrange;
+}
+
 // CropJob (Filter/Sample/CropJob.cs:34-41): out(x,z) = in(clamp(x + Offset), clamp(z + Offset)); the reference never
 // sets Offset, so it is 0 (top-left crop).  One thread per output cell; rows of different pitch on either side.
 __global__ __launch_bounds__(CT) void crop_kernel(const float *__restrict__ in, int in_res, float *__restrict__ out,
@@ -541,6 +634,27 @@ int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *he
         hipLaunchKernelGGL(pool_automata_pass_kernel<false>, grid, dim3(64), 0, s, pool, height, res, xoff, zoff, drain_hdr,
                            drain_data);
     }
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+constexpr int MAP_RANGE_BLOCKS = 2048;
+size_t nz_map_range_scratch_floats() { return (size_t)MAP_RANGE_BLOCKS * sizeof(map_range_part) / sizeof(float); }
+
+int32_t nz_launch_map_range(hipStream_t s, const float *map, size_t n, float lim_min, float lim_max, float *res, void *scratch) {
+    map_range_part *parts = reinterpret_cast<map_range_part *>(scratch);
+    const int vec = (reinterpret_cast<uintptr_t>(map) & 15) == 0;
+    size_t want = (n / 4 + CT - 1) / CT;
+    const int blocks = (int)(want < 1 ? 1 : (want > (size_t)MAP_RANGE_BLOCKS ? (size_t)MAP_RANGE_BLOCKS : want));
+    hipLaunchKernelGGL(map_range_partial_kernel, dim3((unsigned)blocks), dim3(CT), 0, s, map, n, vec, parts);
+    hipLaunchKernelGGL(map_range_final_kernel, dim3(1), dim3(CT), 0, s, parts, blocks, lim_min, lim_max, res);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_normalize_args(hipStream_t s, float *data, size_t n, const float *args) {
+    if (n == 0) return NZ_OK;
+    hipLaunchKernelGGL(normalize_args_kernel, dim3((unsigned)((n + CT - 1) / CT)), dim3(CT), 0, s, data, n, args);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

@@ -207,6 +207,9 @@ int32_t nz_launch_reduce(hipStream_t s, int op, float *l, const float *r, size_t
 int32_t nz_launch_flow_from_track(hipStream_t s, float *pool, float *flow, float *track, size_t n, float flowLossRate,
                                   float evaporation);
 // drain_hdr / drain_data (nullable): the particle queue a drained pool leaves through (PoolAutomataJob, drainParticles)
+size_t nz_map_range_scratch_floats();
+int32_t nz_launch_map_range(hipStream_t s, const float *map, size_t n, float lim_min, float lim_max, float *res, void *scratch);
+int32_t nz_launch_normalize_args(hipStream_t s, float *data, size_t n, const float *args);
 size_t nz_pool_automata_mask_words(int res);
 int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res, unsigned *mask);
 int32_t nz_launch_pool_automata_clean(hipStream_t s, const float *pool, int res, unsigned *mask);

@@ -604,6 +604,38 @@ extern "C" int32_t nz_map_normalize_values(nz_ctx *ctx, float *src, float *tmp, 
     return nz_ctx_finish(ctx, out);
 }
 
+// GetMapRangeJob.Schedule, Filter/NormalizeJob.cs:45-53: res = DEVICE {min, max, max - min}
+extern "C" int32_t nz_get_map_range(nz_ctx *ctx, const float *map, size_t n_floats, float *res, float lim_min, float lim_max,
+                                    nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(map && res, "map/res is NULL");
+    NZ_REQUIRE(n_floats >= 1, "empty map");
+    float *scratch = nullptr;
+    NZ_TRY(nz_ctx_scratch(ctx, nz_map_range_scratch_floats(), &scratch));
+    NZ_TRY(nz_launch_map_range(ctx->stream, map, n_floats, lim_min, lim_max, res, scratch));
+    return nz_ctx_finish(ctx, out);
+}
+
+// MapNormalizeValuesDelegate with `args` left in device memory by nz_get_map_range (the reference's NativeSlice<float> args)
+extern "C" int32_t nz_map_normalize_values_dev(nz_ctx *ctx, float *src, float *tmp, const float *args, int32_t resolution,
+                                               nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_res(resolution));
+    NZ_REQUIRE(src && args, "src/args is NULL");
+    (void)tmp;  // element-wise: done in place, no flush copy
+    NZ_TRY(nz_launch_normalize_args(ctx->stream, src, (size_t)resolution * resolution, args));
+    return nz_ctx_finish(ctx, out);
+}
+
+// The same on any contiguous run of cells (a stripe's owned rows)
+extern "C" int32_t nz_normalize_cells_dev(nz_ctx *ctx, float *data, size_t n_floats, const float *args, nz_handle dep,
+                                          nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_REQUIRE(data && args, "data/args is NULL");
+    NZ_TRY(nz_launch_normalize_args(ctx->stream, data, n_floats, args));
+    return nz_ctx_finish(ctx, out);
+}
+
 extern "C" size_t nz_flowmap_stage_work_floats(int32_t resolution) {
     return resolution > 0 ? (size_t)11 * resolution * resolution : 0;  // the reference stage's 11 planes
 }

@@ -354,6 +354,45 @@ class HipStripeOps:
                    int(last), normMin, normMax)
 
 
+    def map_range(self, buf, n, res, lim_min=float("inf"), lim_max=float("-inf")):
+        """GetMapRangeJob over the first n floats of `buf` into the 3-float device buffer `res`."""
+        self._call("nz_get_map_range", buf.data_ptr(), n, res.data_ptr(), lim_min, lim_max)
+
+    def normalize_args(self, buf, plan, args):
+        """NormalizeMap on the stripe's owned rows with args = device {min, max, range}."""
+        owned = buf.data_ptr() + plan.own0 * plan.cols * 4
+        self._call("nz_normalize_cells_dev", owned, plan.nown * plan.cols, args.data_ptr())
+
+
+def map_range_work_floats(world):
+    return 5 * world + 6
+
+
+def global_map_range(ops, dist, plane, plan, res, work, lim_min=float("inf"), lim_max=float("-inf")):
+    """{min, max, range} of the WHOLE grid in every rank's `res` (3 floats): GetMapRangeJob (Filter/NormalizeJob.cs:17-55)
+    over the owned rows of `plane`, one all-gather of the per-rank {min, max, range}, and the same fold over the
+    gathered minima and maxima in rank order -- which is the order the monolithic job walks the grid in, so the result
+    (down to the sign of a zero extreme) is the monolithic one.  The one collective of the path: data-dependent
+    normalisation needs every rank's extremes.  `work` = map_range_work_floats(world) floats on the device of `res`.
+    The limits must not be NaN."""
+    w = plan.world
+    gathered, mins, maxs = work[:3 * w], work[3 * w:4 * w], work[4 * w:5 * w]
+    lo, hi = work[5 * w:5 * w + 3], work[5 * w + 3:5 * w + 6]
+    ops.map_range(plane[plan.own0:plan.own1], plan.nown * plan.cols, res)
+    if dist is not None:  # one rank included: the collective is the same call at every world size
+        dist.all_gather_into_tensor(gathered, res)
+    else:
+        gathered.copy_(res)
+    mins.copy_(gathered.view(w, 3)[:, 0])
+    maxs.copy_(gathered.view(w, 3)[:, 1])
+    ops.map_range(mins, w, lo, lim_min, float("-inf"))
+    ops.map_range(maxs, w, hi, float("inf"), lim_max)
+    res[0:1].copy_(lo[0:1])
+    res[1:2].copy_(hi[1:2])
+    res[2:3].copy_(res[1:2] - res[0:1])  # IEEE fp32 subtraction, as `max_ - min_` in the job
+    return res
+
+
 class TorchComm:
     """Neighbour halo exchange with torch.distributed P2P (backend `nccl` = RCCL over xGMI on the GPU
     box, `gloo` in the CPU tests).  Each exchange is one grouped batch: at most two neighbours."""

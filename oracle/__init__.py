@@ -73,6 +73,8 @@ def lib():
         L.nzo_water_step.argtypes = [f32p] * 6 + [i, i]
         L.nzo_velocity.argtypes = [f32p] * 5 + [i, i]
         L.nzo_normalize.argtypes = [f32p, f32p, f32p, i, i]
+        L.nzo_get_map_range.argtypes = [f32p, C.c_size_t, C.c_float, C.c_float, f32p]
+        L.nzo_get_map_range.restype = None
         L.nzo_flowmap.argtypes = [f32p, i, i, i, f, f]
         L.nzo_mesh_heightmap.argtypes = [i, f32p, i, i, i, f, f, f32p, u32p]
         L.nzo_mesh_square_grid.argtypes = [i, f32p, u32p]
@@ -281,6 +283,23 @@ def normalize(a, nmin, nmax):
     a = _plane(a).copy()
     tmp = np.empty_like(a)
     args = np.array([nmin, nmax, np.float32(nmax) - np.float32(nmin)], np.float32)
+    lib().nzo_normalize(_p(a), _p(tmp), _p(args), *a.shape)
+    return a
+
+
+def get_map_range(a, lim_min=np.inf, lim_max=-np.inf):
+    """GetMapRangeJob: float32 [min, max, max - min] of the cells, folded in index order from the two limits."""
+    a = np.ascontiguousarray(a, np.float32).reshape(-1)
+    res = np.empty(3, np.float32)
+    lib().nzo_get_map_range(_p(a), a.size, lim_min, lim_max, _p(res))
+    return res
+
+
+def normalize_args(a, args):
+    """NormalizeMap with explicit args = [min, max, range]."""
+    a = _plane(a).copy()
+    tmp = np.empty_like(a)
+    args = np.ascontiguousarray(args, np.float32)
     lib().nzo_normalize(_p(a), _p(tmp), _p(args), *a.shape)
     return a
 

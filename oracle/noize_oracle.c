@@ -776,6 +776,20 @@ void nzo_normalize(float *src, float *tmp, const float *args, int rows, int cols
     flush_write_slice(src, tmp, (size_t)rows * cols);
 }
 
+/* GetMapRangeJob.Execute Filter/NormalizeJob.cs:33-43: one thread, in index order; math.min / math.max of
+ * Unity.Mathematics 1.2.1 (`IsNaN(y) || x < y ? x : y`): a NaN cell is skipped, on a tie the later operand stays */
+void nzo_get_map_range(const float *map, size_t n, float lim_min, float lim_max, float *res) {
+    float min_ = lim_min, max_ = lim_max;
+    for (size_t i = 0; i < n; i++) {
+        float y = map[i];
+        min_ = (y != y) || min_ < y ? min_ : y;
+        max_ = (y != y) || max_ > y ? max_ : y;
+    }
+    res[0] = min_;
+    res[1] = max_;
+    res[2] = max_ - min_;
+}
+
 /* FlowMapStage.ScheduleAll FlowMapStage.cs:124-195.  The reference leaves the flux planes
  * uninitialised (:55-62); this build defines them as zero at the start of every run. */
 int nzo_flowmap(float *src, int rows, int cols, int iterations, float normMin, float normMax) {

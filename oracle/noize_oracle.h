@@ -24,6 +24,7 @@
 #ifndef NOIZE_ORACLE_H
 #define NOIZE_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -120,6 +121,7 @@ void nzo_velocity(float *dst, const float *fN, const float *fS, const float *fE,
                   int rows, int cols);
 /* MapNormalizeValues.ScheduleParallel NormalizeJob.cs:70-90; args = {min,max,range} */
 void nzo_normalize(float *src, float *tmp, const float *args, int rows, int cols);
+void nzo_get_map_range(const float *map, size_t n, float lim_min, float lim_max, float *res);
 /* FlowMapStage.ScheduleAll FlowMapStage.cs:124-195; flux planes zero-initialised per run */
 int nzo_flowmap(float *src, int rows, int cols, int iterations, float normMin, float normMax);
 

@@ -65,3 +65,10 @@ class OracleStripeOps:
             S_out[0].numpy()[plan.own0:plan.own1] = w[sl]
             for i in range(4):
                 S_out[1 + i].numpy()[plan.own0:plan.own1] = fl[i][sl]
+
+    def map_range(self, buf, n, res, lim_min=float("inf"), lim_max=float("-inf")):
+        res.numpy()[:] = O.get_map_range(buf.numpy().reshape(-1)[:n], lim_min, lim_max)
+
+    def normalize_args(self, buf, plan, args):
+        own = buf.numpy()[plan.own0:plan.own1]
+        own[:] = O.normalize_args(own, args.numpy())

@@ -46,6 +46,16 @@ def _worker(rank, world, port, grows, cols, pkw, out_path):
     dist.all_gather(parts, mine)
     if rank == 0:
         np.save(out_path, torch.cat(parts, 0).cpu().numpy())
+    # the path's one collective: per-rank GetMapRangeJob -> all-gather over RCCL -> fold in rank order -> normalise
+    rng_res = torch.empty(3, device="cuda")
+    work = torch.empty(sh.map_range_work_floats(world), device="cuda")
+    sh.global_map_range(ops, dist, res, plan, rng_res, work)
+    ops.normalize_args(res, plan, rng_res)
+    torch.cuda.synchronize()
+    dist.all_gather(parts, res[plan.own0:plan.own1].contiguous())
+    if rank == 0:
+        np.save(out_path + ".range.npy", rng_res.cpu().numpy())
+        np.save(out_path + ".norm.npy", torch.cat(parts, 0).cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
     ctx.close()
@@ -65,6 +75,9 @@ def test_nccl_sharded_equals_monolithic(oracle, tmp_path, mode):
     mp.spawn(_worker, args=(world, _free_port(), grows, cols, pkw, out), nprocs=world, join=True)
     want = oracle.pipeline(grows, cols, octaves=8, noise_size=300, xpos=100, zpos=900)
     assert np.array_equal(np.load(out), want)
+    rng_want = oracle.get_map_range(want)
+    assert np.load(out + ".range.npy").view(np.uint32).tolist() == rng_want.view(np.uint32).tolist()
+    assert np.array_equal(np.load(out + ".norm.npy"), oracle.normalize_args(want, rng_want))
 
 
 def _single_rank_worker(rank, port, grows, cols, pkw, out_path):
@@ -108,6 +121,16 @@ def _single_rank_worker(rank, port, grows, cols, pkw, out_path):
     dist.all_reduce(t)   # a collective on the same group for good measure
     np.save(out_path, full.cpu().numpy())
     assert t.item() == moved[0] and moved[0] > 0
+    # the path's one collective: GetMapRangeJob -> all-gather over RCCL -> fold -> normalise with device args
+    whole = sh.StripePlan(0, 1, grows, cols, 0)
+    plane = full.clone()
+    rng_res = torch.empty(3, device="cuda")
+    work = torch.empty(sh.map_range_work_floats(1), device="cuda")
+    sh.global_map_range(ops, dist, plane, whole, rng_res, work)
+    ops.normalize_args(plane, whole, rng_res)
+    torch.cuda.synchronize()
+    np.save(out_path + ".range.npy", rng_res.cpu().numpy())
+    np.save(out_path + ".norm.npy", plane.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
     ctx.close()
@@ -133,3 +156,6 @@ def test_nccl_single_rank_halo_exchange_through_rccl(oracle, tmp_path):
     assert proc.exitcode == 0
     want = oracle.pipeline(grows, cols, octaves=8, noise_size=300, xpos=100, zpos=900)
     assert np.array_equal(np.load(out), want)
+    rng_want = oracle.get_map_range(want)
+    assert np.load(out + ".range.npy").view(np.uint32).tolist() == rng_want.view(np.uint32).tolist()
+    assert np.array_equal(np.load(out + ".norm.npy"), oracle.normalize_args(want, rng_want))

@@ -622,6 +622,37 @@ def test_pool_automata_runs_match_the_row_walk(nj, ctx, oracle, res, cover):
     assert np.array_equal(d_pool.ToArray((res, res)), oracle.pool_automata(pool, height, 2))
 
 
+@pytest.mark.parametrize("n", [1, 3, 255, 1024, 4099, 300 * 300, 2048 * 2048 + 5])
+def test_get_map_range_and_device_args_normalise(nj, ctx, oracle, n):
+    # GetMapRangeJob (Filter/NormalizeJob.cs:17-55) -> {min, max, range} in device memory -> NormalizeMap reading them
+    rng = np.random.default_rng(n)
+    for case in range(6):
+        a = (rng.random(n, dtype=f32) * f32(4) - f32(1.5)).astype(f32)
+        lim = (np.inf, -np.inf)
+        if case == 1:            # NaN cells are skipped
+            a[rng.random(n) < 0.3] = np.nan
+        elif case == 2:          # minimum zero: the sign of the LAST zero cell stays
+            a = np.abs(a); a[rng.integers(0, n, 5)] = f32(0.0); a[rng.integers(0, n, 5)] = f32(-0.0)
+        elif case == 3:          # maximum zero
+            a = -np.abs(a); a[rng.integers(0, n, 5)] = f32(-0.0); a[rng.integers(0, n, 5)] = f32(0.0)
+        elif case == 4:          # limits inside the data's range, and a zero limit with no zero cell
+            a = np.abs(a) + f32(0.25); lim = (-0.0, 1.0)
+        elif case == 5:          # nothing but NaN
+            a[:] = np.nan; lim = (2.0, -3.0)
+        d, res = ctx.from_host(a), ctx.alloc(3)
+        ctx.call("nz_get_map_range", d.ptr, n, res.ptr, lim[0], lim[1]).Complete()
+        want = oracle.get_map_range(a, *lim)
+        got = res.ToArray((3,))
+        assert got.view(np.uint32).tolist() == want.view(np.uint32).tolist(), (case, got, want)
+    side = int(np.sqrt(n))
+    if side >= 2 and side * side == n:
+        a = rng.random((side, side), dtype=f32)
+        d, res = ctx.from_host(a), ctx.alloc(3)
+        h = ctx.call("nz_get_map_range", d.ptr, n, res.ptr, np.inf, -np.inf)
+        ctx.call("nz_map_normalize_values_dev", d.ptr, d.ptr, res.ptr, side, dep=h).Complete()
+        assert np.array_equal(d.ToArray((side, side)), oracle.normalize_args(a, oracle.get_map_range(a)))
+
+
 def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):
     # BasicDemo "ParallelFlowMap": Perlin fBm -> Invert (curve) -> FlowMapStage -> CurveBoostContrast
     res = 128

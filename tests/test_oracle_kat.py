@@ -498,3 +498,23 @@ def test_pool_automata_known_answers(oracle):
     pool = np.zeros((res, res), f32)
     pool[2, 2] = 5e-4
     assert np.array_equal(oracle.pool_automata(pool, flat, 4), pool)
+
+
+def test_get_map_range_known_answers(oracle):
+    # GetMapRangeJob (Filter/NormalizeJob.cs:33-43): sequential fold with math.min / math.max from the two limits
+    f = np.float32
+    r = oracle.get_map_range(np.array([3, -2, 7, 0.5], f))
+    assert r.tolist() == [-2.0, 7.0, 9.0]
+    r = oracle.get_map_range(np.array([3, np.nan, 7], f))                      # NaN cells are skipped
+    assert r.tolist() == [3.0, 7.0, 4.0]
+    r = oracle.get_map_range(np.array([3, 4], f), lim_min=1.0, lim_max=10.0)   # the limits take part in the fold
+    assert r.tolist() == [1.0, 10.0, 9.0]
+    r = oracle.get_map_range(np.array([np.nan, np.nan], f))                    # nothing but NaN: the limits stay
+    assert r[0] == np.inf and r[1] == -np.inf
+    # on a tie the later operand stays: among the zeros of a plane whose minimum is zero, the LAST one gives the sign
+    r = oracle.get_map_range(np.array([0.0, 5, -0.0, 2], f))
+    assert r[0] == 0 and np.signbit(r[0]) and r[1] == 5
+    r = oracle.get_map_range(np.array([-0.0, 5, 0.0, 2], f))
+    assert r[0] == 0 and not np.signbit(r[0])
+    r = oracle.get_map_range(np.array([-3, 0.0, -0.0, -1], f))                 # ... and of a maximum that is zero
+    assert r[1] == 0 and np.signbit(r[1]) and r[0] == -3

@@ -65,6 +65,58 @@ def test_sharded_schedule_equals_monolithic(oracle, tmp_path, world, grows, cols
     assert np.array_equal(got, want)
 
 
+def _range_worker(rank, world, port, grows, cols, case, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from noize_job_amd import sharded as sh
+    from oracle_stripe_ops import OracleStripeOps
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    ops = OracleStripeOps()
+    plan = sh.StripePlan(rank, world, grows, cols, 2)
+    full = torch.from_numpy(_range_case(case, grows, cols))
+    plane = torch.full((plan.rows, cols), float("nan"))
+    plane[plan.own0:plan.own1] = full[plan.g0:plan.g0 + plan.nown]
+    res, work = torch.empty(3), torch.empty(sh.map_range_work_floats(world))
+    sh.global_map_range(ops, dist, plane, plan, res, work, *_RANGE_LIMS[case])
+    ops.normalize_args(plane, plan, res)
+    parts = [None] * world
+    dist.all_gather_object(parts, (plan.g0, res.numpy().copy(), plane[plan.own0:plan.own1].numpy().copy()))
+    if rank == 0:
+        parts.sort(key=lambda t: t[0])
+        np.savez(out_path, res=np.stack([r for _, r, _ in parts]), full=np.concatenate([a for _, _, a in parts], axis=0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+_RANGE_LIMS = {"plain": (np.inf, -np.inf), "zeros": (np.inf, -np.inf), "nan_rank": (np.inf, -np.inf), "limits": (0.25, 0.5)}
+
+
+def _range_case(case, grows, cols):
+    rng = np.random.default_rng(len(case))
+    a = rng.random((grows, cols), dtype=np.float32)
+    if case == "zeros":       # the minimum is zero: the sign of the LAST zero of the whole grid stays
+        a[3, 5] = -0.0; a[grows // 2 + 1, 2] = 0.0; a[grows - 2, 7] = -0.0
+    if case == "nan_rank":    # one rank holds nothing but NaN
+        a[:grows // 3] = np.nan
+    return a
+
+
+@pytest.mark.parametrize("world,case", [(2, "plain"), (3, "zeros"), (3, "nan_rank"), (2, "limits")])
+def test_global_map_range_all_gather_equals_monolithic(oracle, tmp_path, world, case):
+    # the one collective of the path: GetMapRangeJob per rank, all-gather, the same fold in rank order; every rank
+    # ends with the monolithic {min, max, range} bit for bit and normalises its rows with it
+    grows, cols = 30, 17
+    out = str(tmp_path / "range.npz")
+    mp.spawn(_range_worker, args=(world, _free_port(), grows, cols, case, out), nprocs=world, join=True)
+    got = np.load(out)
+    a = _range_case(case, grows, cols)
+    want = oracle.get_map_range(a, *_RANGE_LIMS[case])
+    for r in got["res"]:
+        assert r.view(np.uint32).tolist() == want.view(np.uint32).tolist(), (r, want)
+    assert np.array_equal(got["full"], oracle.normalize_args(a, want), equal_nan=True)
+
+
 def test_overlapped_exchange_splits_a_launch_into_interior_and_border_rows():
     # with an asynchronous comm the launch that needs ghost rows runs rows [own0 + up, own1 - down) first -- they read
     # no ghost row -- and the border rows after finish(); a window thinner than its halos runs whole, after finish()

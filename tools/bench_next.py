@@ -111,10 +111,14 @@ def main():
         rng = np.random.default_rng(0)
         pool = ctx.from_host(np.where(rng.random((res, res)) < 0.3, rng.random((res, res), dtype=np.float32) * 0.3, 0).astype(np.float32))
         flow, track = ctx.alloc(cells), ctx.alloc(cells)
+        rng3 = ctx.alloc(3)
         for name, fn, bpc, note in (
+                ("map range (min, max, range of a plane)", lambda: ctx.call("nz_get_map_range", data.ptr, cells, rng3.ptr, float("inf"), float("-inf")), 4,
+                 "GetMapRangeJob: one read of the plane, result stays in device memory"),
+                ("normalise with device args", lambda: ctx.call("nz_map_normalize_values_dev", data.ptr, data.ptr, rng3.ptr, res), 8, ""),
                 ("live erosion: flow from track", lambda: ctx.call("nz_update_flow_from_track", pool.ptr, flow.ptr, track.ptr, 0.05, 0.1, 1000.0, res), 24, ""),
                 ("live erosion: pool automaton x1 (4 colour passes)", lambda: ctx.call("nz_pool_automata", pool.ptr, data.ptr, 1, res), 4 * 8,
-                 "sequential along every row, as in the reference: res/2 threads per pass")):
+                 "parallel runs of acting steps; 30 % of the cells under water")):
             fn()
             ctx.synchronize()
             h0 = ctx.record()

@@ -44,7 +44,7 @@ def main():
 
     alone = {k: loop([(sa[k], wa)]) for k in sa}
     print("alone (ms): " + "  ".join("%s %.4f" % kv for kv in alone.items()))
-    for x, y in (("noise", "gauss"), ("noise", "flow"), ("gauss", "flow"), ("noise", "noise"), ("gauss", "gauss")):
+    for x, y in (("noise", "gauss"), ("noise", "flow"), ("gauss", "flow"), ("noise", "noise"), ("gauss", "gauss"), ("flow", "flow")):
         t = loop([(sa[x], wa), (sb[y], wb)])
         print("%s || %s: %.4f ms per pair = %.3f of the sum (perfect overlap %.3f)" %
               (x, y, t, t / (alone[x] + alone[y]), max(alone[x], alone[y]) / (alone[x] + alone[y])))
