@@ -442,6 +442,23 @@ __device__ __forceinline__ map_range_part map_range_block(map_range_part p, map_
     return p;  // thread 0 holds the block's
 }
 
+__device__ __forceinline__ void map_range_finish(const map_range_part &p, float lim_min, float lim_max, float *__restrict__ res) {
+    float mn = lim_min, mx = lim_max;
+    if (!(p.mn == __builtin_inff() && p.mx == -__builtin_inff())) {  // some element was not NaN
+        mn = umin(lim_min, p.mn);
+        mx = umax(lim_max, p.mx);
+        const bool last_is_neg = p.last_nz > p.last_pz;  // both -2: no zero in the plane, the limit's own zero stays
+        if (mn == 0.0f && (p.last_pz >= 0 || p.last_nz >= 0)) mn = last_is_neg ? -0.0f : 0.0f;
+        if (mx == 0.0f && (p.last_pz >= 0 || p.last_nz >= 0)) mx = last_is_neg ? -0.0f : 0.0f;
+    }
+    res[0] = mn;
+    res[1] = mx;
+    res[2] = mx - mn;
+}
+
+// Two launches: every workgroup folds its share into a partial, then one workgroup folds the partials.  (One launch
+// with the last workgroup to arrive doing the second fold is slower: 2048 arrivals on one counter serialise, 0.042 ms;
+// with 512 workgroups 0.028 ms against 0.024 ms for this form.)
 __global__ __launch_bounds__(CT) void map_range_partial_kernel(const float *__restrict__ map, size_t n, int vec,
                                                               map_range_part *__restrict__ parts) {
     __shared__ map_range_part s_part[CT / 64];
@@ -449,12 +466,22 @@ __global__ __launch_bounds__(CT) void map_range_partial_kernel(const float *__re
     const size_t stride = (size_t)gridDim.x * CT;
     if (vec) {
         const size_t n4 = n / 4;
-        for (size_t i = (size_t)blockIdx.x * CT + threadIdx.x; i < n4; i += stride) {
-            const float4 t = reinterpret_cast<const float4 *>(map)[i];
-            map_range_take(p, t.x, (long long)(4 * i));
-            map_range_take(p, t.y, (long long)(4 * i + 1));
-            map_range_take(p, t.z, (long long)(4 * i + 2));
-            map_range_take(p, t.w, (long long)(4 * i + 3));
+        constexpr int U = 4;  // loads in flight per thread
+        for (size_t i0 = (size_t)blockIdx.x * CT + threadIdx.x; i0 < n4; i0 += U * stride) {
+            float4 t[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const size_t i = i0 + u * stride;
+                t[u] = i < n4 ? reinterpret_cast<const float4 *>(map)[i] : make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {  // ascending indices: the last zero a thread meets is its highest
+                const long long b = (long long)(4 * (i0 + u * stride));
+                map_range_take(p, t[u].x, b);
+                map_range_take(p, t[u].y, b + 1);
+                map_range_take(p, t[u].z, b + 2);
+                map_range_take(p, t[u].w, b + 3);
+            }
         }
         for (size_t i = n4 * 4 + (size_t)blockIdx.x * CT + threadIdx.x; i < n; i += stride) map_range_take(p, map[i], (long long)i);
     } else {
@@ -470,28 +497,28 @@ __global__ __launch_bounds__(CT) void map_range_final_kernel(const map_range_par
     map_range_part p{__builtin_inff(), -__builtin_inff(), -2, -2};
     for (int i = threadIdx.x; i < nparts; i += CT) map_range_merge(p, parts[i]);
     p = map_range_block(p, s_part);
-    if (threadIdx.x != 0) return;
-    float mn = lim_min, mx = lim_max;
-    if (!(p.mn == __builtin_inff() && p.mx == -__builtin_inff())) {  // some element was not NaN
-        mn = umin(lim_min, p.mn);
-        mx = umax(lim_max, p.mx);
-        const bool last_is_neg = p.last_nz > p.last_pz;  // both -2: no zero in the plane, the limit's own zero stays
-        if (mn == 0.0f && (p.last_pz >= 0 || p.last_nz >= 0)) mn = last_is_neg ? -0.0f : 0.0f;
-        if (mx == 0.0f && (p.last_pz >= 0 || p.last_nz >= 0)) mx = last_is_neg ? -0.0f : 0.0f;
-    }
-    res[0] = mn;
-    res[1] = mx;
-    res[2] = mx - mn;
+    if (threadIdx.x == 0) map_range_finish(p, lim_min, lim_max, res);
 }
 
 // NormalizeMap with its args in device memory ({min, max, range}: what GetMapRangeJob leaves), NormalizeJob.cs:57-92
-__global__ __launch_bounds__(CT) void normalize_args_kernel(float *__restrict__ data, size_t n, const float *__restrict__ args) {
-    const size_t i = (size_t)blockIdx.x * CT + threadIdx.x;
-    if (i >= n) return;
-    const float nmin = args[0], nrange = args[2];
-    float v = data[i];
+__device__ __forceinline__ float normalize_cell(float v, float nmin, float nrange) {
     if (nrange < 1e-12f) v = 0.0f;
-    data[i] = (v - nmin) / nrange;
+    return (v - nmin) / nrange;
+}
+__global__ __launch_bounds__(CT) void normalize_args_kernel(float *__restrict__ data, size_t n, int vec,
+                                                           const float *__restrict__ args) {
+    const float nmin = args[0], nrange = args[2];
+    const size_t i = (size_t)blockIdx.x * CT + threadIdx.x;
+    if (vec && 4 * i + 4 <= n) {
+        float4 t = reinterpret_cast<float4 *>(data)[i];
+        t.x = normalize_cell(t.x, nmin, nrange);
+        t.y = normalize_cell(t.y, nmin, nrange);
+        t.z = normalize_cell(t.z, nmin, nrange);
+        t.w = normalize_cell(t.w, nmin, nrange);
+        reinterpret_cast<float4 *>(data)[i] = t;
+    } else {
+        for (size_t j = 4 * i; j < n && j < 4 * i + 4; j++) data[j] = normalize_cell(data[j], nmin, nrange);
+    }
 }
 
 // CropJob (Filter/Sample/CropJob.cs:34-41): out(x,z) = in(clamp(x + Offset), clamp(z + Offset)); the reference never
@@ -654,7 +681,8 @@ int32_t nz_launch_map_range(hipStream_t s, const float *map, size_t n, float lim
 
 int32_t nz_launch_normalize_args(hipStream_t s, float *data, size_t n, const float *args) {
     if (n == 0) return NZ_OK;
-    hipLaunchKernelGGL(normalize_args_kernel, dim3((unsigned)((n + CT - 1) / CT)), dim3(CT), 0, s, data, n, args);
+    const int vec = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
+    hipLaunchKernelGGL(normalize_args_kernel, dim3((unsigned)(((n + 3) / 4 + CT - 1) / CT)), dim3(CT), 0, s, data, n, vec, args);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
