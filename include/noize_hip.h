@@ -380,7 +380,9 @@ int32_t nz_particle_queue_upload(nz_ctx *ctx, nz_particle_queue *queue, const nz
 int32_t nz_clear_particle_queue(nz_ctx *ctx, nz_particle_queue *queue, nz_handle dep, nz_handle *out);
 int32_t nz_erosive_events_create(nz_ctx *ctx, int32_t resolution, nz_erosive_events **out);
 int32_t nz_erosive_events_destroy(nz_ctx *ctx, nz_erosive_events *events);
-float *nz_erosive_events_sediment(nz_erosive_events *events); /* device plane, x * res + z */
+/* device plane, x * res + z: the per-cell sediment events nz_process_beyer_erosive_events left.  READ ONLY for hosts:
+ * nz_erode_height_maps finds the events through the cycle's cell list, not by scanning this plane */
+float *nz_erosive_events_sediment(nz_erosive_events *events);
 int32_t nz_erosive_events_count(nz_ctx *ctx, nz_erosive_events *events, int32_t *count); /* events of the last descent */
 
 /* FillBeyerQueueJob.ScheduleParallel(particles, ep, tm, generationRound, res, maxParticles, deps, concurrency),
@@ -398,7 +400,8 @@ int32_t nz_queued_beyer_cycle(nz_ctx *ctx, const float *height, const float *poo
 int32_t nz_process_beyer_erosive_events(nz_ctx *ctx, float *height, float *pool, float *flow, float *track,
                                         nz_erosive_events *events, const nz_erosion_params *ep,
                                         const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out);
-/* ErodeHeightMaps.ScheduleRun(height, erosions, ep, tm, res, deps), :459-479 */
+/* ErodeHeightMaps.ScheduleRun(height, erosions, ep, tm, res, deps), :459-479: applies the events of the LAST
+ * nz_process_beyer_erosive_events on `events` (in place on `height`) */
 int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *events, const nz_erosion_params *ep,
                              const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out);
 /* PoolAutomataJob.Schedule(pool, height, particleQueue, ep, tm, iterations, res, drainParticles, deps), :289-325:
