@@ -567,6 +567,44 @@ __global__ __launch_bounds__(CT) void thermal_phase_kernel(float *data, int reso
     data[i0] = vx; data[i0 + 1] = vy; data[i2] = vz; data[i2 + 1] = vw;
 }
 
+// Phases 0 and 1 relax blocks of the SAME row pairs (z, z + 1), z even, at x offsets 1 and 2; phases 2 and 3 those of the
+// odd pairs.  A row pair depends on no other row pair within such a pair of phases, so one workgroup takes a row pair
+// through both phases in LDS: one read and one write of the plane instead of two, in place.
+__global__ __launch_bounds__(1024) void thermal_pair_kernel(float *data, int resolution, int zodd, float maxDiff,
+                                                         float increment, int vec) {
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];  // [2][resolution]
+    const int z = (blockIdx.x + 1) * 2 - zodd, nt = blockDim.x;
+    float *g0 = data + (size_t)z * resolution;
+    float *s0 = s_rows, *s1 = s_rows + resolution;
+    if (vec) {  // resolution % 4 == 0 and the plane 16-byte aligned: both rows are
+        for (int i = threadIdx.x; i < resolution / 2; i += nt)  // 2 rows x resolution / 4 float4s, contiguous in memory and in LDS
+            reinterpret_cast<float4 *>(s_rows)[i] = reinterpret_cast<const float4 *>(g0)[i];
+    } else {
+        for (int i = threadIdx.x; i < 2 * resolution; i += nt) s_rows[i] = g0[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int offset = 1; offset <= 2; offset++) {
+        for (int x = offset + 2 * (int)threadIdx.x; x < resolution - 1; x += 2 * nt) {
+            float vx = s0[x], vy = s0[x + 1], vz = s1[x], vw = s1[x + 1];
+            thermal_rectify(vx, vy, maxDiff, increment);
+            thermal_rectify(vx, vz, maxDiff, increment);
+            thermal_rectify(vx, vw, maxDiff, increment);
+            thermal_rectify(vy, vz, maxDiff, increment);
+            thermal_rectify(vy, vw, maxDiff, increment);
+            thermal_rectify(vz, vw, maxDiff, increment);
+            s0[x] = vx; s0[x + 1] = vy; s1[x] = vz; s1[x + 1] = vw;
+        }
+        __syncthreads();
+    }
+    if (vec) {
+        for (int i = threadIdx.x; i < resolution / 2; i += nt)
+            reinterpret_cast<float4 *>(g0)[i] = reinterpret_cast<const float4 *>(s_rows)[i];
+    } else {
+        for (int i = threadIdx.x; i < 2 * resolution; i += nt) g0[i] = s_rows[i];
+    }
+}
+
 unsigned blocks_for(size_t n) { return (unsigned)((n + (size_t)CT * 4 - 1) / ((size_t)CT * 4)); }
 
 }  // namespace
@@ -691,6 +729,22 @@ int32_t nz_launch_crop(hipStream_t s, const float *in, int in_res, float *out, i
     if (out_res <= 0) return NZ_OK;
     dim3 grid((out_res + CT - 1) / CT, out_res);
     hipLaunchKernelGGL(crop_kernel, grid, dim3(CT), 0, s, in, in_res, out, out_res, 0);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+// phases (0, 1) for zodd = 0, (2, 3) for zodd = 1; false if a row pair does not fit the LDS (resolution > 16384)
+bool nz_thermal_pair_fits(int resolution) { return (size_t)resolution * 8 <= 128 * 1024; }
+int32_t nz_launch_thermal_pair(hipStream_t s, float *data, int resolution, int zodd, float maxDiff, float increment) {
+    int jobs = resolution / 2 - 1;
+    if (jobs <= 0 || resolution < 3) return NZ_OK;
+    const int vec = resolution % 4 == 0 && (reinterpret_cast<uintptr_t>(data) & 15) == 0;
+    const size_t lds = (size_t)resolution * 8;
+    if (lds > 64 * 1024)
+        NZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(thermal_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // a row pair of 2 x resolution cells per workgroup: enough threads to keep the loads of a 64 KB pair in flight
+    const int nt = resolution >= 8192 ? 1024 : (resolution >= 2048 ? 512 : 256);
+    hipLaunchKernelGGL(thermal_pair_kernel, dim3((unsigned)jobs), dim3(nt), lds, s, data, resolution, zodd, maxDiff, increment, vec);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

@@ -220,4 +220,6 @@ int32_t *nz_particle_queue_hdr(nz_particle_queue *q);
 nz_particle *nz_particle_queue_data(nz_particle_queue *q);
 int32_t nz_launch_crop(hipStream_t s, const float *in, int in_res, float *out, int out_res);
 int32_t nz_launch_curve(hipStream_t s, float *data, size_t n, const float *curve, int curveSize);
+bool nz_thermal_pair_fits(int resolution);
+int32_t nz_launch_thermal_pair(hipStream_t s, float *data, int resolution, int zodd, float maxDiff, float increment);
 int32_t nz_launch_thermal_phase(hipStream_t s, float *data, int resolution, int flip, float maxDiff, float increment);

@@ -1086,8 +1086,15 @@ extern "C" int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, floa
     NZ_REQUIRE(iterations >= 0, "iterations < 0");
     float t = (talus / 90.0f) * 3.14159f / 2.0f;                             // :131
     float maxDiff = (tanf(t) * meshHeightWidthRatio) / (float)resolution;   // :132
-    for (int i = 0; i < iterations; i++)
-        for (int flip = 0; flip < 4; flip++)
-            NZ_TRY(nz_launch_thermal_phase(ctx->stream, src, resolution, flip, maxDiff, incrementRatio));
+    static const int pairs = [] { const char *e = getenv("NZ_THERMAL_PAIRS"); return e ? atoi(e) : 1; }();
+    for (int i = 0; i < iterations; i++) {
+        if (pairs && nz_thermal_pair_fits(resolution)) {  // two phases per pass over the plane
+            NZ_TRY(nz_launch_thermal_pair(ctx->stream, src, resolution, 0, maxDiff, incrementRatio));
+            NZ_TRY(nz_launch_thermal_pair(ctx->stream, src, resolution, 1, maxDiff, incrementRatio));
+        } else {
+            for (int flip = 0; flip < 4; flip++)
+                NZ_TRY(nz_launch_thermal_phase(ctx->stream, src, resolution, flip, maxDiff, incrementRatio));
+        }
+    }
     return nz_ctx_finish(ctx, out);
 }

@@ -671,7 +671,7 @@ def test_demo_pipeline_with_invert_curve(nj, ctx, oracle):
 
 
 def test_thermal_erosion_stage(nj, ctx, oracle):
-    for res in (2, 3, 8, 65, 256):
+    for res in (2, 3, 4, 5, 8, 65, 256, 1030, 2048):   # 1030: rows not 16-byte aligned; 2048: more blocks than threads
         t = np.random.default_rng(res).random((res, res), dtype=f32)
         for iters, talus, inc, ratio in ((1, 45, 0.5, 0.75), (3, 20, 0.25, 0.3), (2, 80, 0.5, 2.0)):
             got = run(nj.StageThermalErosion(ctx, iters, talus, inc, ratio), nj, gen(nj, ctx, res, host=t))
