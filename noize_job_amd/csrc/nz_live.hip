@@ -190,9 +190,19 @@ struct live_planes {
     size_t n;
 };
 
-__device__ __forceinline__ void emit(const live_planes &P, int idx, float dTrack, float dPool, float dSed) {
+// `first`: this event is the cell's first of the cycle (the caller's atomicAdd on P.touched returned 0, issued at the top
+// of the step so that its round trip overlaps the step's loads).  The cell joins the cycle's list; the lanes that arrive
+// here together share ONE increment of the list counter (160 k single increments of one word serialise in the L2).
+__device__ __forceinline__ void emit(const live_planes &P, int idx, bool first, float dTrack, float dPool, float dSed) {
     long long a = to_fix(dPool), b = to_fix(dTrack), c = to_fix(dSed);
-    if (atomicAdd(&P.touched[idx], 1) == 0) P.list[atomicAdd(&P.counters[P.list_slot], 1)] = idx;
+    const unsigned long long firsts = __ballot(first);
+    if (first) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)firsts) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&P.counters[P.list_slot], __popcll(firsts));
+        base = __shfl(base, leader);
+        P.list[base + __popcll(firsts & ((1ull << lane) - 1ull))] = idx;
+    }
     if (a) atomicAdd(&P.acc[idx], (unsigned long long)a);
     if (b) atomicAdd(&P.acc[P.n + idx], (unsigned long long)b);
     if (c) atomicAdd(&P.acc[2 * P.n + idx], (unsigned long long)c);
@@ -216,17 +226,18 @@ __global__ __launch_bounds__(64) void descent_kernel(live_planes P, const int32_
         events++;
         const int ix = (int)rintf(posx), iz = (int)rintf(posz);
         const int idx = ix * res + iz;
+        const bool first = atomicAdd(&P.touched[idx], 1) == 0;  // every way out of this step emits one event at idx
         float eTrack = 0.0f, ePool = 0.0f, eSed = 0.0f;
         int heading = heading_from(dirx, dirz);
         if (water < .01f) {
             eSed = sediment / HEIGHT;
-            emit(P, idx, eTrack, ePool, eSed);
+            emit(P, idx, first, eTrack, ePool, eSed);
             break;
         }
         if (age >= ep.MAXAGE) {
             ePool = water / HEIGHT;
             eSed = sediment / HEIGHT;
-            emit(P, idx, eTrack, ePool, eSed);
+            emit(P, idx, first, eTrack, ePool, eSed);
             break;
         }
         const int sidx = clampi((int)posx, 0, res - 1) * res + clampi((int)posz, 0, res - 1);
@@ -249,7 +260,10 @@ __global__ __launch_bounds__(64) void descent_kernel(live_planes P, const int32_
         const int ai = heading_adj_idx(heading);
         const int hl = adj_heading(ai + 7), hr = adj_heading(ai + 1);
         const int wl = heading_wt_idx(hl), wc = heading_wt_idx(heading), wr = heading_wt_idx(hr);
-        if (ai >= 8 || wl < 0 || wc < 0 || wr < 0) break;  // unreachable: the drain direction is never (0, 0)
+        if (ai >= 8 || wl < 0 || wc < 0 || wr < 0) {  // unreachable: the drain direction is never (0, 0)
+            emit(P, idx, first, 0.0f, 0.0f, 0.0f);
+            break;
+        }
         float hx = 0.0f, hy = 0.0f, hz = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; k++) {  // nb[] stays in registers: select, do not index
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(64) void descent_kernel(live_planes P, const int32_
             if (hDiff > 0.0f) {
                 ePool = water / HEIGHT;
                 eSed = sediment / HEIGHT;
-                emit(P, idx, eTrack, ePool, eSed);
+                emit(P, idx, first, eTrack, ePool, eSed);
                 break;
             }
         }
@@ -293,7 +307,7 @@ __global__ __launch_bounds__(64) void descent_kernel(live_planes P, const int32_
         dirz = (float)drainDz;
         const float pnx = posx + dirx, pnz = posz + dirz;
         if ((int)pnx < 0 || (int)pnz < 0 || (int)pnx >= res || (int)pnz >= res) {
-            emit(P, idx, eTrack, ePool, eSed);
+            emit(P, idx, first, eTrack, ePool, eSed);
             break;
         }
         const float vDiff = fabsf(hDiff);
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(64) void descent_kernel(live_planes P, const int32_
         if (thetaD < 3.0f && vel < 1.0f) {
             ePool += water / HEIGHT;
             eSed += sediment / HEIGHT;
-            emit(P, idx, eTrack, ePool, eSed);
+            emit(P, idx, first, eTrack, ePool, eSed);
             break;
         }
         const float currentCapacity = vel * water * ep.CAPACITY;
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(64) void descent_kernel(live_planes P, const int32_
         posx = pnx;
         posz = pnz;
         age++;
-        emit(P, idx, eTrack, ePool, eSed);
+        emit(P, idx, first, eTrack, ePool, eSed);
     }
     atomicAdd(&P.counters[3], events);
 }
