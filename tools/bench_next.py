@@ -100,7 +100,7 @@ def main():
         run("curve LUT 256", nj.CurveStage(ctx, lambda t: 1.0 - t, 256), gd, 8)
         seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
         run("thermal erosion x1 (4 phases)", nj.StageThermalErosion(ctx, 1), gd, 8 * 4,
-            "in place, 4 dependent colour phases")
+            "in place; the four colour phases as two passes over the plane")
         seed.Schedule(nj.PipelineWorkItem(gd), nj.JobHandle())
         vb = 4 + (48.0 * (res - 7) ** 2 + 24.0 * (res - 8) ** 2) / cells
         run("mesh Overshoot %d^2" % (res - 8), nj.MeshTileStage(ctx, nj.MeshType.OvershootSquareGridHeightMap), md, vb,
