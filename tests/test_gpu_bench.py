@@ -54,3 +54,23 @@ def test_stripe_rehearsal_line():
     d = _run("--steps", "4", "--warmup", "1", "--as-rank", "1", "4", "--stripe-rows", "256", "--cols", "1024")
     assert d["n_gpus"] == 1 and "cpu_baseline" not in d and "roofline" in d
     assert "rehearsal of rank 1 of 4" in d["config"]["parallelism"] and d["config"]["cells"] == 256 * 1024
+
+
+@pytest.mark.timeout(400, method="thread")
+@pytest.mark.parametrize("halo", ["exchange", "exchange_once"])
+def test_launched_like_the_driver_at_n_gt_1(halo):
+    # the launcher the driver uses for N > 1 (torch.distributed.run, one rank per GPU, backend nccl), with the one rank a
+    # one-GPU box has: process group on RCCL, the context on torch's stream, the stripe schedule with asynchronous
+    # exchanges, the strong-scaling grid beside it, ONE line on rank 0's stdout
+    port = 29600 + os.getpid() % 300
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--sharded", "--halo", halo, "--steps", "4", "--warmup", "1",
+                          "--stripe-rows", "384", "--cols", "1024", "--grid", "1024", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=380, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["cells"] == 384 * 1024 and d["value"] > 0
+    assert "row-stripe" in d["config"]["parallelism"] and d["grid_1024"]["recompute"]["Mcells/s"] > 0
