@@ -203,20 +203,24 @@ def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, til
 
 
 @pytest.mark.gpu
-def test_config4_reduced_live_erosion_equals_oracle(nj, ctx, oracle):
-    # BASELINE config 4 at a size the oracle finishes in seconds: cellular fBm 13 octaves -> LiveErosion, the driver loop
+@pytest.mark.parametrize("res,particles,updates,cycles,water_steps", [(512, 10000, 3, 3, 5), (2048, 40000, 1, 2, 10),
+                                                                      (8192, 10000, 1, 2, 10)])  # the last: config 4 itself
+def test_config4_live_erosion_equals_oracle(nj, ctx, oracle, res, particles, updates, cycles, water_steps):
+    # BASELINE config 4 at sizes the oracle finishes in seconds: cellular fBm 13 octaves -> LiveErosion, the driver loop
     # of TriggerQueuedBeyerMT (thermal -> spawn -> descent -> event reduce -> sediment -> flow from track -> pool
-    # automaton with drains), 3 Updates x 3 cycles, control textures included
-    res, particles, th = 512, 10000, 1000
+    # automaton with drains), control textures included.  2048^2: 32 mask words per automaton walk, the bits cleaned
+    # nine times per cycle, WATER_STEPS at the config's 10.  8192^2, 10 000 particles per cycle, WATER_STEPS 10 IS
+    # BASELINE config 4: every plane and the particle queue bit-equal to the oracle after two cycles.
+    th = 1000
     h = oracle.fractal(oracle.CELLULAR, res, res, 0.4, 1.0, 2.0, 0.0, 13, 0, 0, 1700)
-    es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, CYCLES=3, WATER_STEPS=5)
+    es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, CYCLES=cycles, WATER_STEPS=water_steps)
     tm = nj.tile_set_meta(res, height=th, tile_size=2000, tile_res=res - 16, margin=8)
     G = nj.LiveErosion(ctx, ctx.from_host(h), tm, es)
     G.EnableControlTextures()
     L = oracle.LiveErosionOracle(h, _params(oracle, es), tile_height=th, patch_res=float(tm.PATCH_RES[0]))
     shape = (res, res)
     gen = 0
-    for update in range(3):
+    for update in range(updates):
         seeds = [40000 * update + 11 * c + 3 for c in range(es.CYCLES)]
         G.TriggerQueuedBeyerMT(seeds).Complete()
         for c in range(es.CYCLES):
