@@ -12,15 +12,32 @@ using System;
 
 namespace xshazwar.noize.hip {
 
-    public enum ErosionMode { ALL_EROSION, ONLY_FLOW_WATER, ONLY_THERMAL_EROSION, ONLY_PARTICLE_EROSION }   // LiveErosionDataTypes.cs:29-34
-    public enum ColorChannelByte { R, G, B, A }                                                             // :1235-1241
+    public enum ErosionMode { ALL_EROSION, ONLY_THERMAL_EROSION, THERMAL_FLOW_WATER, ONLY_FLOW_WATER }   // LiveErosionDataTypes.cs:28-33
+    public enum ColorChannelByte { R, G, B, A }                                                         // :1235-1241
 
     public class ErosionSettings {               // ScriptableObject/ErosionSettings.cs:5-124 (defaults = Reset())
+        public int CYCLES = 3, PARTICLES_PER_CYCLE = 1000;
         public ErosionMode BEHAVIOR = ErosionMode.ALL_EROSION;
-        public int PARTICLES_PER_CYCLE = 1000, CYCLES = 1, WATER_STEPS = 10, THERMAL_CYCLES = 1;
+        public float INERTIA = 0.5f, GRAVITY = 1f, DRAG = 0.001f, FRICTION = 0.01f, EVAP = 0.01f, EROSION = 1f, DEPOSITION = 0.1f;
+        public float FLOW_HEIGHT_CONTRIBUTION = 25f, SLOW_CULL_ANGLE = 3f, SLOW_CULL_SPEED = 0.11f, CAPACITY = 3f;
+        public int MAXAGE = 100, WATER_STEPS = 10;
+        public float SURFACE_EVAPORATION_RATE = 0.1f, POOL_PLACEMENT_MULTIPLIER = 0.5f, TRACK_PLACEMENT_MULTIPLIER = 80f, FLOW_LOSS_RATE = 0.05f;
+        public int PILING_RADIUS = 15;
+        public float MIN_PILE_INCREMENT = 1f, PILE_THRESHOLD = 2f;
         public bool ENABLE_THERMAL = true;
-        public float TALUS = 45f, THERMAL_STEP = 0.5f;
-        public NzErosionParams parameters;       // AsParameters() :96-123
+        public float TALUS = 55f, THERMAL_STEP = 0.6f;
+        public int THERMAL_CYCLES = 1;
+
+        public NzErosionParams AsParameters() {  // :96-123
+            return new NzErosionParams {
+                INERTIA = INERTIA, GRAVITY = GRAVITY, DRAG = DRAG, FRICTION = FRICTION, EVAP = EVAP, EROSION = EROSION, DEPOSITION = DEPOSITION,
+                FLOW_HEIGHT_CONTRIBUTION = FLOW_HEIGHT_CONTRIBUTION, SLOW_CULL_ANGLE = SLOW_CULL_ANGLE, SLOW_CULL_SPEED = SLOW_CULL_SPEED,
+                CAPACITY = BEHAVIOR == ErosionMode.ALL_EROSION ? CAPACITY : 0f,
+                MAXAGE = MAXAGE, TERMINAL_VELOCITY = 1f / DRAG, SURFACE_EVAPORATION_RATE = SURFACE_EVAPORATION_RATE,
+                POOL_PLACEMENT_MULTIPLIER = BEHAVIOR == ErosionMode.ONLY_THERMAL_EROSION ? 0f : POOL_PLACEMENT_MULTIPLIER,
+                TRACK_PLACEMENT_MULTIPLIER = TRACK_PLACEMENT_MULTIPLIER, FLOW_LOSS_RATE = FLOW_LOSS_RATE, PILING_RADIUS = PILING_RADIUS,
+                MIN_PILE_INCREMENT = MIN_PILE_INCREMENT, PILE_THRESHOLD = PILE_THRESHOLD };
+        }
     }
 
     public sealed class ParticleQueue : IDisposable {
@@ -87,7 +104,7 @@ namespace xshazwar.noize.hip {
         // TriggerQueuedBeyerMT :378-436.  seeds: one per cycle.
         public GpuJobHandle TriggerQueuedBeyerMT(int[] seeds) {
             ErosionSettings es = erosionSettings;
-            NzErosionParams ep = es.parameters;
+            NzErosionParams ep = es.AsParameters();
             NzTileSetMeta tm = tileMeta;
             ulong h = 0;
             IntPtr c = ctx.Handle;

@@ -4,6 +4,8 @@
 //          host_demo <resolution> <out.f32> reduce      (ReducePipeline: simplex x cellular, MULTIPLY)
 //          host_demo <resolution> <out.f32> context     (producer -> context buffer -> consumer, parked until written)
 //          host_demo <resolution> <out.f32> batch <n>   (n tiles at xpos = k * resolution through the batched stage bodies)
+//          host_demo <resolution> <out.f32> live <particles> <cycles>   (cellular fBm -> LiveErosion, seeds 3, 14, 25, ...:
+//                                                                         height, pool, flow planes back to back)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,13 +25,51 @@ int main(int argc, char **argv) {
     const bool context = argc > 3 && std::strcmp(argv[3], "context") == 0;
     const int batch = argc > 4 && std::strcmp(argv[3], "batch") == 0 ? std::atoi(argv[4]) : 0;
     // `rw`: the tile is a READ / WRITE plane pair and the stencil stages swap it instead of flushing (nz_*_rw)
+    const bool live = argc > 5 && std::strcmp(argv[3], "live") == 0;
     const bool rw = argc > 3 && std::strcmp(argv[3], "rw") == 0;
     if (rw) argc = 3;
     int G = argc > 3 ? std::atoi(argv[3]) : 17, F = argc > 4 ? std::atoi(argv[4]) : 5, E = argc > 5 ? std::atoi(argv[5]) : 5;
     try {
         nz_ctx *ctx = nullptr;
         check(nz_ctx_create(0, &ctx), "nz_ctx_create");
-        if (context) {
+        if (live) {  // BASELINE config 4's shape: cellular fBm 13 octaves -> LiveErosion.TriggerQueuedBeyerMT
+            DeviceTile height(ctx, (size_t)res * res);
+            NoiseStage noise(ctx);
+            noise.noiseType = FractalNoise::Cellular;
+            noise.hurst = 0.4f;
+            noise.octaves = 13;
+            noise.noiseSize = 1700;
+            GeneratorData gd;
+            gd.uuid = "live";
+            gd.data = &height;
+            gd.resolution = res;
+            PipelineWorkItem wi{&gd, nullptr, nullptr, JobHandle(), nullptr};
+            noise.Schedule(wi, JobHandle());
+            ErosionSettings es;
+            es.PARTICLES_PER_CYCLE = std::atoi(argv[4]);
+            es.CYCLES = std::atoi(argv[5]);
+            es.WATER_STEPS = 5;
+            nz_tile_set_meta tm{};
+            tm.TILE_RES[0] = tm.TILE_RES[1] = res - 16;
+            tm.TILE_SIZE[0] = tm.TILE_SIZE[1] = 2000;
+            tm.GENERATOR_RES[0] = tm.GENERATOR_RES[1] = res;
+            tm.PATCH_RES[0] = tm.PATCH_RES[1] = 2000.0f / (float)(res - 16);
+            tm.HEIGHT = 1000;
+            tm.HEIGHT_F = 1000.0f;
+            tm.MARGIN = 8;
+            check(nz_ctx_synchronize(ctx), "nz_ctx_synchronize");
+            LiveErosion erosion(ctx, &height, tm, es);
+            std::vector<int> seeds;
+            for (int c = 0; c < es.CYCLES; c++) seeds.push_back(11 * c + 3);
+            erosion.TriggerQueuedBeyerMT(seeds).Complete();
+            std::vector<float> host(3 * (size_t)res * res);
+            height.CopyTo(host.data());
+            erosion.poolMap.CopyTo(host.data() + (size_t)res * res);
+            erosion.streamMap.CopyTo(host.data() + 2 * (size_t)res * res);
+            FILE *f = std::fopen(argv[2], "wb");
+            if (!f || std::fwrite(host.data(), sizeof(float), host.size(), f) != host.size()) throw std::runtime_error("write failed");
+            std::fclose(f);
+        } else if (context) {
             PipelineStateManager mgr(ctx);
             DeviceTile src(ctx, (size_t)res * res), dst(ctx, (size_t)res * res);
             NoiseStage noise(ctx);

@@ -769,4 +769,107 @@ class ReducePipeline : public BasePipeline {
     std::function<void(StageIO *)> action;
 };
 
+// ---- live erosion (BASELINE config 4): Component/LiveErosion.cs:200-436 without the MonoBehaviour ----------------
+enum class ErosionMode { ALL_EROSION, ONLY_THERMAL_EROSION, THERMAL_FLOW_WATER, ONLY_FLOW_WATER };  // LiveErosionDataTypes.cs:28-33
+
+struct ErosionSettings {  // ScriptableObject/ErosionSettings.cs:5-124 (defaults = Reset())
+    int CYCLES = 3, PARTICLES_PER_CYCLE = 1000;
+    ErosionMode BEHAVIOR = ErosionMode::ALL_EROSION;
+    float INERTIA = 0.5f, GRAVITY = 1.0f, DRAG = 0.001f, FRICTION = 0.01f, EVAP = 0.01f, EROSION = 1.0f, DEPOSITION = 0.1f;
+    float FLOW_HEIGHT_CONTRIBUTION = 25.0f, SLOW_CULL_ANGLE = 3.0f, SLOW_CULL_SPEED = 0.11f, CAPACITY = 3.0f;
+    int MAXAGE = 100, WATER_STEPS = 10;
+    float SURFACE_EVAPORATION_RATE = 0.1f, POOL_PLACEMENT_MULTIPLIER = 0.5f, TRACK_PLACEMENT_MULTIPLIER = 80.0f,
+          FLOW_LOSS_RATE = 0.05f;
+    int PILING_RADIUS = 15;
+    float MIN_PILE_INCREMENT = 1.0f, PILE_THRESHOLD = 2.0f;
+    bool ENABLE_THERMAL = true;
+    float TALUS = 55.0f, THERMAL_STEP = 0.6f;
+    int THERMAL_CYCLES = 1;
+
+    nz_erosion_params AsParameters() const {  // :96-123
+        nz_erosion_params ep{};
+        ep.INERTIA = INERTIA; ep.GRAVITY = GRAVITY; ep.DRAG = DRAG; ep.FRICTION = FRICTION; ep.EVAP = EVAP;
+        ep.EROSION = EROSION; ep.DEPOSITION = DEPOSITION; ep.FLOW_HEIGHT_CONTRIBUTION = FLOW_HEIGHT_CONTRIBUTION;
+        ep.SLOW_CULL_ANGLE = SLOW_CULL_ANGLE; ep.SLOW_CULL_SPEED = SLOW_CULL_SPEED;
+        ep.CAPACITY = BEHAVIOR == ErosionMode::ALL_EROSION ? CAPACITY : 0.0f;
+        ep.MAXAGE = MAXAGE;
+        ep.TERMINAL_VELOCITY = 1.0f / DRAG;
+        ep.SURFACE_EVAPORATION_RATE = SURFACE_EVAPORATION_RATE;
+        ep.POOL_PLACEMENT_MULTIPLIER = BEHAVIOR == ErosionMode::ONLY_THERMAL_EROSION ? 0.0f : POOL_PLACEMENT_MULTIPLIER;
+        ep.TRACK_PLACEMENT_MULTIPLIER = TRACK_PLACEMENT_MULTIPLIER; ep.FLOW_LOSS_RATE = FLOW_LOSS_RATE;
+        ep.PILING_RADIUS = PILING_RADIUS; ep.MIN_PILE_INCREMENT = MIN_PILE_INCREMENT; ep.PILE_THRESHOLD = PILE_THRESHOLD;
+        return ep;
+    }
+};
+
+// Owns poolMap / streamMap / particleTrack (planes indexed x * res + z), the particle queue and the erosive events, and
+// chains one Update's worth of jobs on the context's stream.  `seeds`: one per cycle (the reference draws them from
+// UnityEngine.Random, MultiThreadErosionJob.cs:50): the same seeds give the same planes on every run.
+class LiveErosion {
+  public:
+    LiveErosion(nz_ctx *c, DeviceTile *height, const nz_tile_set_meta &tm, const ErosionSettings &es, bool perform = true)
+        : ctx(c), heightMap(height), tileMeta(tm), erosionSettings(es), performErosion(perform), res(tm.GENERATOR_RES[0]),
+          poolMap(c, (size_t)tm.GENERATOR_RES[0] * tm.GENERATOR_RES[0]), streamMap(c, poolMap.Length),
+          particleTrack(c, poolMap.Length) {
+        if (height->Length != poolMap.Length) throw std::runtime_error("heightMap is not GENERATOR_RES^2 cells");
+        std::vector<float> zeros(poolMap.Length, 0.0f);
+        poolMap.CopyFrom(zeros.data());
+        streamMap.CopyFrom(zeros.data());
+        particleTrack.CopyFrom(zeros.data());
+        QUEUE_SIZE = perform ? es.PARTICLES_PER_CYCLE : 1;  // :215-219
+        const int n = res * res;
+        check(nz_particle_queue_create(ctx, std::max(std::max(4 * QUEUE_SIZE, QUEUE_SIZE + n / 8), 1024), &particleQueue),
+              "nz_particle_queue_create");
+        check(nz_erosive_events_create(ctx, res, &events), "nz_erosive_events_create");
+    }
+    LiveErosion(const LiveErosion &) = delete;
+    ~LiveErosion() {
+        jobHandle.Complete();
+        if (particleQueue) nz_particle_queue_destroy(ctx, particleQueue);
+        if (events) nz_erosive_events_destroy(ctx, events);
+    }
+
+    JobHandle TriggerQueuedBeyerMT(const std::vector<int> &seeds) {  // :378-436
+        const ErosionSettings &es = erosionSettings;
+        const nz_erosion_params ep = es.AsParameters();
+        const nz_tile_set_meta &tm = tileMeta;
+        nz_handle h = 0;
+        if (performErosion) {
+            if ((int)seeds.size() < es.CYCLES) throw std::runtime_error("one seed per cycle");
+            for (int i = 0; i < es.CYCLES; i++) {
+                if (es.ENABLE_THERMAL && es.BEHAVIOR != ErosionMode::ONLY_FLOW_WATER)  // `TILE_SIZE.x / HEIGHT`: int / int (:386)
+                    check(nz_thermal_erosion(ctx, heightMap->ptr, es.TALUS, es.THERMAL_STEP, (float)(tm.TILE_SIZE[0] / tm.HEIGHT),
+                                             es.THERMAL_CYCLES, res, h, &h), "nz_thermal_erosion");
+                if (es.BEHAVIOR != ErosionMode::ONLY_FLOW_WATER)
+                    check(nz_fill_beyer_queue(ctx, particleQueue, &ep, &tm, particleGenerationID % 4, res, QUEUE_SIZE, seeds[i],
+                                              std::min(10, QUEUE_SIZE), h, &h), "nz_fill_beyer_queue");
+                check(nz_queued_beyer_cycle(ctx, heightMap->ptr, poolMap.ptr, streamMap.ptr, particleTrack.ptr, particleQueue, events,
+                                            &ep, &tm, EVENT_LIMIT, res, h, &h), "nz_queued_beyer_cycle");
+                check(nz_process_beyer_erosive_events(ctx, heightMap->ptr, poolMap.ptr, streamMap.ptr, particleTrack.ptr, events, &ep,
+                                                      &tm, res, h, &h), "nz_process_beyer_erosive_events");
+                check(nz_clear_particle_queue(ctx, particleQueue, h, &h), "nz_clear_particle_queue");
+                check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, h, &h), "nz_erode_height_maps");
+                check(nz_update_flow_from_track(ctx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
+                                                ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, h, &h), "nz_update_flow_from_track");
+                check(nz_pool_automata_job(ctx, poolMap.ptr, heightMap->ptr, particleQueue, &ep, &tm, es.WATER_STEPS, res,
+                                           performErosion ? 1 : 0, h, &h), "nz_pool_automata_job");
+            }
+        }
+        jobHandle = JobHandle{ctx, h};
+        particleGenerationID += 1;  // Update() :341
+        return jobHandle;
+    }
+
+    nz_ctx *ctx;
+    DeviceTile *heightMap;
+    nz_tile_set_meta tileMeta;
+    ErosionSettings erosionSettings;
+    bool performErosion;
+    int res, QUEUE_SIZE = 0, particleGenerationID = 0, EVENT_LIMIT = 1500;
+    DeviceTile poolMap, streamMap, particleTrack;
+    nz_particle_queue *particleQueue = nullptr;
+    nz_erosive_events *events = nullptr;
+    JobHandle jobHandle;
+};
+
 }  // namespace noize

@@ -384,6 +384,19 @@ def test_cpp_host_mirror_runs_the_metric_pipeline(oracle, tmp_path):
     got = np.fromfile(out, dtype=np.float32).reshape(128, 128)
     noise = oracle.fractal(oracle.SIMPLEX, 128, 128, 0.4, 1.0, 2.0, 0.0, 8, 64, 32, 200)
     assert np.array_equal(got, oracle.kernel_filter(noise, 2, 3))
+    # the live erosion driver of the C++ mirror (LiveErosion::TriggerQueuedBeyerMT): config 4's shape at 384^2
+    res, particles, cycles = 384, 4000, 2
+    subprocess.check_call([exe, str(res), out, "live", str(particles), str(cycles)])
+    got = np.fromfile(out, dtype=np.float32).reshape(3, res, res)
+    h = oracle.fractal(oracle.CELLULAR, res, res, 0.4, 1.0, 2.0, 0.0, 13, 0, 0, 1700)
+    nj_settings = dict(PARTICLES_PER_CYCLE=particles, CYCLES=cycles, WATER_STEPS=5)
+    import noize_job_amd as nj
+    from test_live_erosion import _params
+    st = nj.ErosionSettings(**nj_settings)
+    L = oracle.LiveErosionOracle(h, _params(oracle, st), tile_height=1000, patch_res=float(np.float32(2000.0) / np.float32(res - 16)))
+    for c in range(cycles):
+        L.cycle(0, particles, 11 * c + 3, water_steps=5, thermal=(st.TALUS, st.THERMAL_STEP, 2.0, st.THERMAL_CYCLES))
+    assert np.array_equal(got[0], L.height) and np.array_equal(got[1], L.pool) and np.array_equal(got[2], L.flow)
     # batched stage bodies from the C++ mirror: 3 tiles of 96^2 at (k * 96, -3 k)
     subprocess.check_call([exe, "96", out, "batch", "3"])
     got = np.fromfile(out, dtype=np.float32).reshape(3, 96, 96)
