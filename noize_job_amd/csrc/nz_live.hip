@@ -477,8 +477,8 @@ __global__ __launch_bounds__(CT) void disperse_frame_kernel(float *__restrict__ 
 // them cannot see each other.  The grid is cut into such blocks, 4-coloured by (bx & 1, bz & 1); one launch per colour,
 // one wave per block; inside a block the events keep the canonical order (z ascending, x ascending inside).  (The
 // reference runs all of them on one thread in whatever order its parallel queue writers produced.)
-// Per pile the wave loads the vertex values side by side (SetPile), lane 0 walks DepositSediment -- sequential by
-// nature: a running remainder -- over LDS, and commits the modified vertices in vertex order (the ManhattanVertex list
+// Per pile the wave loads the vertex values side by side (SetPile), walks DepositSediment -- sequential by nature: a
+// running remainder -- over the vertices that qualify (found 64 at a time), and commits the modified vertices in vertex order (the ManhattanVertex list
 // names the centre four times and many ring cells twice, each copy with a value of its own: the LAST copy wins).
 __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__restrict__ sediment,
                                                  const int32_t *__restrict__ pile_blocks,
@@ -493,10 +493,28 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
     const int lane = threadIdx.x;
     const int x0 = bx * B, z0 = bz * B, x1 = min(x0 + B, res), z1 = min(z0 + B, res);
     if (!pile_blocks[bx * nb + bz]) return;  // no pile event in this block (disperse_list_kernel flags them)
+    // the block's sediment events into LDS first, lanes along z (the planes' fast index), all loads in flight together:
+    // walking the block row by row straight from memory cost one dependent round trip per row (32 of them)
+    float *s_sed = reinterpret_cast<float *>(s_raw + (((size_t)nverts * 9 + 15) & ~(size_t)15));
+    const int bw = x1 - x0, bh = z1 - z0;  // <= B each
+    for (int i0 = lane; i0 < bw * bh; i0 += 64 * 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {  // eight loads in flight per lane
+            const int i = i0 + 64 * u, xo = i / bh, zo = i - xo * bh;
+            t[u] = i < bw * bh ? sediment[(size_t)(x0 + xo) * res + z0 + zo] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 64 * u, xo = i / bh, zo = i - xo * bh;
+            if (i < bw * bh) s_sed[xo * B + zo] = t[u];
+        }
+    }
+    __syncthreads();
     for (int z = z0; z < z1; z++) {
         for (int xb = x0; xb < x1; xb += 64) {
             const int x = xb + lane;
-            const float val = x < x1 ? sediment[(size_t)x * res + z] : 0.0f;
+            const float val = x < x1 ? s_sed[(x - x0) * B + (z - z0)] : 0.0f;
             const bool is_pile = val != 0.0f && !(val < 0.0f || val <= pileThreshold);
             unsigned long long todo = __ballot(is_pile);
             while (todo) {  // wave-uniform
@@ -504,15 +522,36 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
                 todo &= todo - 1;
                 const int px = xb + src_lane, pz = z;
                 const float amount = __shfl(val, src_lane);
-                for (int i = lane; i < nverts; i += 64) {  // SetPile
-                    const int vx = px + ofs[i].x, vz = pz + ofs[i].y;
-                    const bool ok = vx >= 0 && vz >= 0 && vx < res && vz < res;
-                    s_flag[i] = ok ? 1 : 0;
-                    s_idx[i] = ok ? vx * res + vz : 0;
-                    s_val[i] = ok ? height[(size_t)vx * res + vz] : 0.0f;
+                for (int i0 = lane; i0 < nverts; i0 += 64 * 8) {  // SetPile, eight vertices per lane in flight
+                    short2 o[8];
+                    float hv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) o[u] = ofs[min(i0 + 64 * u, nverts - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int vx = px + o[u].x, vz = pz + o[u].y;
+                        const bool ok = i0 + 64 * u < nverts && vx >= 0 && vz >= 0 && vx < res && vz < res;
+                        hv[u] = ok ? height[(size_t)vx * res + vz] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int i = i0 + 64 * u;
+                        if (i >= nverts) break;
+                        const int vx = px + o[u].x, vz = pz + o[u].y;
+                        const bool ok = vx >= 0 && vz >= 0 && vx < res && vz < res;
+                        s_flag[i] = ok ? 1 : 0;
+                        s_idx[i] = ok ? vx * res + vz : 0;
+                        s_val[i] = hv[u];
+                    }
                 }
                 __syncthreads();  // one wave per workgroup: orders the LDS traffic
-                if (lane == 0) {
+                // DepositSediment: a running remainder handed to the vertices below the round's level, in vertex order --
+                // sequential by nature, but only over the vertices that QUALIFY.  The wave tests 64 vertices at a time
+                // (a vertex's value changes within a round only at its own visit, so the test at the round's start is the
+                // test at its visit) and walks the ballot's set bits in order with the reference's arithmetic; every
+                // scalar below is wave-uniform, lane 0 writes.  A pile that used to cost one lane ~8 000 LDS round trips
+                // (15 rounds x up to 540 vertices) costs a few ballots per round.
+                {
                     float remaining = amount;
                     int cmax = -1;
                     for (int guard = 0; remaining > 0.0f && increment > 0.0f && guard < 4096; guard++) {
@@ -521,27 +560,40 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
                         bool done = false;
                         for (int round = 1; round <= maxDistance && !done; round++) {
                             const float level = s_val[0] + (increment * (float)round);
-                            int c = -1;
-                            for (int dist = 0; dist < round && !done; dist++)
-                                for (int dir = 0; dir < 4 && !done; dir++)
-                                    for (int i = 0; i <= dist + 1; i++) {
-                                        c++;
-                                        if (!(s_flag[c] & 1)) continue;
-                                        const float v = s_val[c];
-                                        if (!(v < level)) continue;
-                                        const float inc = lminf(increment, rem);
+                            const int nv = 2 * round * (round + 3);  // vertices of the rings dist < round: sum of 4 (dist + 2)
+                            for (int base = 0; base < nv && !done; base += 64) {
+                                const int cl = base + lane;
+                                const bool below = cl < nv && (s_flag[cl] & 1) && s_val[cl] < level;
+                                unsigned long long mask = __ballot(below);
+                                while (mask && !done) {
+                                    const int c = base + __ffsll((long long)mask) - 1;
+                                    mask &= mask - 1;
+                                    const float v = s_val[c];
+                                    const float inc = lminf(increment, rem);
+                                    if (lane == 0) {
                                         s_flag[c] |= 2;
                                         s_val[c] = v + inc;
-                                        cmax = max(cmax, c);
-                                        deposited += inc;
-                                        rem = amt - deposited;
-                                        if (rem <= 0.0f) { done = true; break; }
                                     }
+                                    cmax = max(cmax, c);
+                                    deposited += inc;
+                                    rem = amt - deposited;
+                                    if (rem <= 0.0f) done = true;
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();  // lane 0's LDS stores before the next round's tests
                         }
                         remaining = done ? 0.0f : rem;
                     }
-                    for (int c = 0; c <= cmax; c++)  // CommitChanges, in vertex order
-                        if ((s_flag[c] & 3) == 3) height[s_idx[c]] = s_val[c];
+                    // CommitChanges, in vertex order (a cell listed twice keeps its LAST copy): only modified vertices
+                    for (int base = 0; base <= cmax; base += 64) {
+                        const int cl = base + lane;
+                        unsigned long long mod = __ballot(cl <= cmax && (s_flag[cl] & 3) == 3);
+                        while (mod) {
+                            const int c = base + __ffsll((long long)mod) - 1;
+                            mod &= mod - 1;
+                            if (lane == 0) height[s_idx[c]] = s_val[c];
+                        }
+                    }
                     __threadfence_block();
                 }
                 __syncthreads();  // the next pile of this block reads the committed heights
@@ -833,7 +885,9 @@ extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_e
             events->pile_scratch_bytes = bytes;
         }
         const int nverts = (int)ofs.size();
-        const size_t lds = (size_t)nverts * 9;
+        const size_t lds = (((size_t)nverts * 9 + 15) & ~(size_t)15) + (size_t)B * B * 4;  // vertices + the block's sediment
+        if (lds > 64 * 1024)
+            NZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         for (int colour = 0; colour < 4; colour++) {
             const int cx = colour & 1, cz = colour >> 1;
             const int bxn = (nb - cx + 1) / 2, bzn = (nb - cz + 1) / 2;
