@@ -264,14 +264,14 @@ __global__ __launch_bounds__(64) void descent_kernel(live_planes P, const int32_
             emit(P, idx, first, 0.0f, 0.0f, 0.0f);
             break;
         }
-        float hx = 0.0f, hy = 0.0f, hz = 0.0f;
+        int il = 0, ic = 0, ir = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {  // nb[] stays in registers: select, do not index
-            const float v = (float)nb[k] / 100.0f;
-            hx = (k == wl) ? v : hx;
-            hy = (k == wc) ? v : hy;
-            hz = (k == wr) ? v : hz;
+        for (int k = 0; k < 8; k++) {  // nb[] stays in registers: select, do not index; three divisions, not eight
+            il = (k == wl) ? nb[k] : il;
+            ic = (k == wc) ? nb[k] : ic;
+            ir = (k == wr) ? nb[k] : ir;
         }
+        const float hx = (float)il / 100.0f, hy = (float)ic / 100.0f, hz = (float)ir / 100.0f;
         float headingHeight;
         int flowH;
         if (hx < hy && hx < hz) { headingHeight = hx; flowH = hl; }
