@@ -280,27 +280,42 @@ __global__ __launch_bounds__(256) void pool_masks_clean_kernel(const float *__re
     const int k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.z;
     if (k >= pm.walks) return;
     const int z = 2 * k + (c & 1);
-    for (int w = blockIdx.y * PCW; w < min((int)blockIdx.y * PCW + PCW, pm.words); w++) {
-        unsigned *word = pm.m + ((size_t)c * pm.words + w) * pm.walks + k;
-        const unsigned m = *word;
-        if (m == 0) continue;
-        const int x0 = (c >> 1) + (k & 1) + 64 * w;
-        unsigned keep = m;
-        for (unsigned rest = m; rest; rest &= rest - 1) {
-            const int b = __builtin_ctz(rest);
-            if (!pool_step_acts(pool[(size_t)(x0 + 2 * b) * res + z])) keep &= ~(1u << b);
+    const int w0 = blockIdx.y * PCW;
+    unsigned m[PCW];
+#pragma unroll
+    for (int u = 0; u < PCW; u++)  // the words first, all loads in flight
+        m[u] = w0 + u < pm.words ? pm.m[((size_t)c * pm.words + w0 + u) * pm.walks + k] : 0u;
+#pragma unroll
+    for (int u = 0; u < PCW; u++) {
+        if (m[u] == 0) continue;
+        const int x0 = (c >> 1) + (k & 1) + 64 * (w0 + u);
+        unsigned keep = m[u];
+        for (unsigned rest = m[u]; rest;) {  // eight cells per round trip (a word of a lake has all 32 bits set)
+            int b[8];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                b[e] = rest ? __builtin_ctz(rest) : -1;
+                rest &= rest - 1;  // 0 stays 0
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = b[e] >= 0 ? pool[(size_t)(x0 + 2 * b[e]) * res + z] : 1.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (b[e] >= 0 && !pool_step_acts(v[e])) keep &= ~(1u << b[e]);
         }
-        if (keep != m) *word = keep;
+        if (keep != m[u]) pm.m[((size_t)c * pm.words + w0 + u) * pm.walks + k] = keep;
     }
 }
 
+constexpr int PRT = 256;  // threads per workgroup: a pass is 50 tiny launches, 4x fewer workgroups dispatch faster
 template <bool DRAIN>
-__global__ __launch_bounds__(64) void pool_runs_kernel(float *pool, const float *__restrict__ height, pool_masks pm,
+__global__ __launch_bounds__(PRT) void pool_runs_kernel(float *pool, const float *__restrict__ height, pool_masks pm,
                                                       int res, int xoff, int zoff, int32_t *drain_hdr,
                                                       nz_particle *drain_data) {
     const int walks = pm.walks, words = pm.words;
     const unsigned *mask = pm.m + (size_t)(2 * xoff + zoff) * words * walks;  // read-only for the whole pass
-    const int k = blockIdx.x * 64 + threadIdx.x, w = blockIdx.y;
+    const int k = blockIdx.x * PRT + threadIdx.x, w = blockIdx.y;
     if (k >= walks) return;
     const unsigned m0 = mask[(size_t)w * walks + k];
     if (m0 == 0) return;
@@ -685,12 +700,12 @@ int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *he
     dim3 grid((unsigned)((jobs + 63) / 64));
     if (mask) {
         pool_masks pm{mask, ((res + 1) / 2 + 31) / 32, jobs};
-        grid.y = (unsigned)pm.words;
+        dim3 rgrid((unsigned)((jobs + PRT - 1) / PRT), (unsigned)pm.words);
         if (drain_hdr)
-            hipLaunchKernelGGL(pool_runs_kernel<true>, grid, dim3(64), 0, s, pool, height, pm, res, xoff, zoff, drain_hdr,
+            hipLaunchKernelGGL(pool_runs_kernel<true>, rgrid, dim3(PRT), 0, s, pool, height, pm, res, xoff, zoff, drain_hdr,
                                drain_data);
         else
-            hipLaunchKernelGGL(pool_runs_kernel<false>, grid, dim3(64), 0, s, pool, height, pm, res, xoff, zoff, drain_hdr,
+            hipLaunchKernelGGL(pool_runs_kernel<false>, rgrid, dim3(PRT), 0, s, pool, height, pm, res, xoff, zoff, drain_hdr,
                                drain_data);
     } else if (drain_hdr) {
         hipLaunchKernelGGL(pool_automata_pass_kernel<true>, grid, dim3(64), 0, s, pool, height, res, xoff, zoff, drain_hdr,
