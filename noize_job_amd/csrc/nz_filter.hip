@@ -376,8 +376,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
     if (l > 0) {
         const int Tp = ch.T[l - 1], Hp = Tp * O, HXp = (Hp + 3) & ~3;
         const int OWp = TW - 2 * HXp, OHp = TH - 2 * Hp;
-        const int ix0 = max(ox0 - HX, 0), ix1 = min(ox0 - HX + TW - 1, g.cols - 1);
-        const int iz0 = max(oz0 - H, g.or0), iz1 = min(oz0 - H + TH - 1, g.or1 - 1);
+        // Awaited: the launch-(l-1) tiles whose interior meets this tile's input window (their stores are read here) or
+        // lies within THEIR halo of this tile's interior (they read the cells this tile overwrites: the ping-pong plane
+        // is shared).  The second set is inside the first while H(l-1) <= H(l), which the host guarantees; the window is
+        // widened to the larger halo all the same, so the protocol does not rest on that order.
+        const int Hw = max(H, Hp), HXw = max(HX, HXp);
+        const int ix0 = max(ox0 - HXw, 0), ix1 = min(ox0 + OW + HXw - 1, g.cols - 1);
+        const int iz0 = max(oz0 - Hw, g.or0), iz1 = min(oz0 + OH + Hw - 1, g.or1 - 1);
         const int px0 = ix0 / OWp, px1 = ix1 / OWp, py0 = (iz0 - g.or0) / OHp, py1 = (iz1 - g.or0) / OHp;
         const int nx = px1 - px0 + 1, nd = nx * (py1 - py0 + 1);
         if ((int)threadIdx.x < nd) {

@@ -244,8 +244,11 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     const bool chain_on = chain_mode == 2 ? L >= 2 : (chain_mode == 1 && L >= 3 && t.ksize >= 5);
     if (chain_on && L <= 8 && g.count == 1 && (size_t)g.rows * g.pitch * 4 < ((size_t)1 << 32) &&
         (swapped || !(L & 1))) {
+        // T must not decrease along the chain: a tile of launch l + 1 waits for the launch-l tiles whose INTERIOR meets
+        // its input window (read after write); its own stores land in the plane launch l reads, and the launch-l tiles
+        // that read that region are all among the awaited ones only while H(l) <= H(l + 1) (write after read)
         int Ts[8];
-        for (int i = 0; i < L; i++) Ts[i] = base + (i < rem ? 1 : 0);
+        for (int i = 0; i < L; i++) Ts[i] = base + (i >= L - rem ? 1 : 0);
         int *flags = nullptr;
         unsigned *ctl = nullptr, epoch = 0;
         NZ_TRY_(nz_ctx_chain_state(ctx, (size_t)nz_conv_chain_items(t.ksize, g, Ts, L), &flags, &ctl, &epoch));

@@ -61,7 +61,7 @@ def test_metric_pipeline_4096_rw_pair_equals_oracle(nj, ctx, oracle):
 
 def test_config4_base_8192_cellular13_equals_oracle(nj, ctx, oracle):
     # BASELINE config 4's source plane: 8192^2 cellular fBm, 13 octaves (the particle erosion that follows it is
-    # covered at reduced size by tests/test_gpu_erosion.py)
+    # covered by tests/test_live_erosion.py, up to this size)
     res = 8192
     d = nj.GeneratorData("c4", ctx.alloc(res * res), res, 0, 0)
     _run(nj, nj.NoiseStage(ctx, nj.FractalNoise.Cellular, 0.4, 1.0, 13, 2.0, 0.0, 1700), d)
