@@ -473,6 +473,22 @@ __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__r
 // fill of a row segment (iteration i starts 2(n - i) + 1 rows above the segment): 108 / 128 x S / (S + 2n) of the
 // executed cell-iterations are stored ones, 0.70 for the 51-row segments that give every SIMD of the chip three waves
 // at 4096^2 (0.47 for the tile kernel).  Same per-cell functions, same operand order: bit-identical results.
+// -DNZ_FLOW_PROBE: lane 0 of every wave stamps s_memrealtime (100 MHz) and s_memtime (shader clock) at its start, after
+// the pipeline fill and at its end, plus HW_ID / XCC_ID, into a caller-supplied buffer (tools/probe_flow_stream.py).
+// Never built by the Makefile.
+#ifdef NZ_FLOW_PROBE
+__device__ unsigned long long *nz_flow_probe_buf = nullptr;  // [wave][8]
+#define NZ_FPROBE(slot, val)                                                                                        \
+    do {                                                                                                            \
+        if (threadIdx.x == 0 && nz_flow_probe_buf)                                                                  \
+            nz_flow_probe_buf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = (val);                  \
+    } while (0)
+#else
+#define NZ_FPROBE(slot, val)
+#endif
+#ifndef NZ_FS_PRIO
+#define NZ_FS_PRIO 1
+#endif
 constexpr int FS_RING = 16;   // rows of height kept per wave (needs 2n - 1 <= 9)
 constexpr int FS_TW = 128;    // columns per strip, halo included
 
@@ -490,13 +506,17 @@ struct fs_bounds {
 };
 
 // One step: every stage advances one row.
-//   COND : stages outside their row range are skipped (pipeline fill and drain), and a cell in the grid's first / last row
-//          takes its own value for the clamped z-neighbour -- the steps in between run without either test;
+//   NACT : only stages 0 .. NACT-1 compute (pipeline fill of a segment away from the grid's first row: stage i joins four
+//          steps after stage i - 1); stage NACT's windows are kept moving so that it finds its rows when it joins.  A
+//          stage that has just joined updates water / stores velocity two rows early: values nobody reads, stores
+//          masked by the row test;
+//   COND : stages outside their row range are skipped (fill and drain of the segments on the grid's first / last rows),
+//          and a cell in the grid's first / last row takes its own value for the clamped z-neighbour;
 //   XEDGE: the strip touches the grid's first / last column: the lane that holds it takes its own value for the clamped
 //          x-neighbour (column 0 is the first of its lane's two columns; the last column the second, or the first when the row length is odd).
 // Cells outside the grid are computed like any other and never read by a cell inside it.
-template <int NST, bool COND, bool XEDGE, bool VEC>
-__device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const float2 hp, float2 *ring,
+template <int NST, int NACT, bool COND, bool XEDGE, bool VEC>
+__device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const float2 hp, const float2 hn, float2 *ring,
                                         const fs_bounds &b, const int gx, const bool lane_x0, const bool lane_x1, const bool lane_x1o,
                                         const nz_geom &g, const float nmin, const float nrange,
                                         float *__restrict__ dst, const bool store_lane) {
@@ -505,8 +525,23 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
     float FCprev[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
     for (int i = 0; i < NST; i++) {
+        if (i > NACT) continue;
+        if (i == NACT) {  // not computing yet: its windows follow what stage NACT - 1 hands on
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                st.Tm[i][e] = st.T0[i][e]; st.T0[i][e] = Tp[e];
+                st.Wm[i][e] = st.W0[i][e]; st.W0[i][e] = Wp[e];
+            }
+            continue;
+        }
         const int r = t - 2 * i;
         float FC[2][4];
+        // height of the row whose water this stage updates (read from the ring ahead of the outflow arithmetic)
+        float2 hh = make_float2(0.0f, 0.0f);
+        if (i < NST - 1) hh = ring[((r - 1) & (FS_RING - 1)) * 64];
+        // The prefetched row h(t + 2) goes into the ring here, before the last stage's stores: waiting for that load behind
+        // a (conditional) store would mean waiting for the store as well -- vmcnt counts both, in order.
+        if (i == NACT - 1) ring[((t + 2) & (FS_RING - 1)) * 64] = hn;
         // ---- outflow of row r (ComputeFlowStep)
         const bool fa = !COND || (r >= b.loF[i] && r < b.hiF[i]);
         if (fa) {
@@ -571,7 +606,6 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
                 }
             }
             if (i < NST - 1) {
-                const float2 hh = ring[(rw & (FS_RING - 1)) * 64];
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const float inE = e == 0 ? eW : st.FB[i][0][1];
@@ -599,7 +633,7 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
                     if (nrange < 1e-12f) v = 0.0f;
                     out[e] = (v - nmin) / nrange;
                 }
-                if (store_lane) {
+                if (store_lane && (COND || rw >= b.loW[NST - 1])) {
                     float *p = dst + (size_t)rw * g.pitch + gx;
                     if (VEC) {
                         *reinterpret_cast<float2 *>(p) = make_float2(out[0], out[1]);
@@ -624,9 +658,21 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
     for (int e = 0; e < 2; e++)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            st.FA[NST - 1][e][k] = st.FB[NST - 1][e][k];
-            st.FB[NST - 1][e][k] = FCprev[e][k];
+            st.FA[NACT - 1][e][k] = st.FB[NACT - 1][e][k];
+            st.FB[NACT - 1][e][k] = FCprev[e][k];
         }
+}
+
+// Waves of a SIMD are served oldest first: left alone, the three waves of a SIMD finish one after the other and the last
+// one runs alone (at most one VALU instruction per four cycles) for a quarter of the launch.  Priority by progress keeps
+// them together: a wave that is a step ahead of another (modulo 4) yields to it.
+__device__ __forceinline__ void fs_prio(int step) {
+    switch (step & 3) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+    }
 }
 
 template <bool VEC>
@@ -675,16 +721,40 @@ __device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__re
         st.T0[0][0] = 0.0001f + h0.x; st.T0[0][1] = 0.0001f + h0.y;
     }
     float2 hp = fs_load_row<VEC>(h, g, min(t0 + 1, g.zc1), gx);
+    ring[((t0 + 1) & (FS_RING - 1)) * 64] = hp;
     int t = t0;
-    // pipeline fill: stage i joins at row max(zc0, s0 - m_i); the last stage stores its first row, s0, at t = s0 + H - 1
-    // (and the last stage's row zc0 + 1, the first whose z-neighbours are both real, is reached at t = zc0 + H - 1)
-    const int tfill = min(t1, max(s0, g.zc0 + 1) + H - 1);
-    for (; t < tfill; t++) {
-        const float2 hn = fs_load_row<VEC>(h, g, min(t + 2, g.zc1), gx);
-        ring[((t + 1) & (FS_RING - 1)) * 64] = hp;
-        fs_step<NST, true, XEDGE, VEC>(st, t, hp, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, dst, store_lane);
-        hp = hn;
+#define NZ_FS_STEP(NA, C, T, HP, HN)                                                                              \
+    do {                                                                                                          \
+        if (NZ_FS_PRIO) fs_prio((T) - t0);                                                                        \
+        fs_step<NST, NA, C, XEDGE, VEC>(st, T, HP, HN, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, dst, \
+                                        store_lane);                                                              \
+    } while (0)
+#define NZ_FS_PHASE(K)                                                            \
+    if (NST > K) {                                                                \
+        for (int q = 0; q < 4 && t < t1; q++, t++) {                              \
+            const float2 hn = fs_load_row<VEC>(h, g, min(t + 2, g.zc1), gx);      \
+            NZ_FS_STEP((K < NST ? K : NST), false, t, hp, hn);                    \
+            hp = hn;                                                              \
+        }                                                                         \
     }
+    if (s0 - (H - 1) > g.zc0 && s1 + H - 1 <= g.zc1) {
+        // pipeline fill away from the grid's first and last rows: stage i joins at row s0 - m_i, four steps after stage i - 1
+        NZ_FS_PHASE(1)
+        NZ_FS_PHASE(2)
+        NZ_FS_PHASE(3)
+        NZ_FS_PHASE(4)
+    } else {
+        // on the grid's first rows stage i joins at row zc0 (two steps apart) and border cells need their clamped
+        // z-neighbours: the last stage's row zc0 + 1, the first whose z-neighbours are both real, is reached at t = zc0 + H - 1
+        const int tfill = min(t1, max(s0, g.zc0 + 1) + H - 1);
+        for (; t < tfill; t++) {
+            const float2 hn = fs_load_row<VEC>(h, g, min(t + 2, g.zc1), gx);
+            NZ_FS_STEP(NST, true, t, hp, hn);
+            hp = hn;
+        }
+    }
+    NZ_FPROBE(2, __builtin_amdgcn_s_memrealtime());
+    NZ_FPROBE(3, __builtin_amdgcn_s_memtime());
     // steady state: every stage is inside its row range and no stage is on the grid's first or last row (the first stage
     // reaches the last row, zc1, at t = zc1).  Three steps per trip: a row window is three registers deep while a step runs
     // (rows r - 1, r and the incoming r + 1), so after three steps every value is back in the register it started in and
@@ -692,23 +762,21 @@ __device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__re
     const int tsteady = min(t1, g.zc1);
     for (; t + 2 < tsteady; t += 3) {
         const float2 hn = fs_load_row<VEC>(h, g, t + 2, gx);
-        ring[((t + 1) & (FS_RING - 1)) * 64] = hp;
-        fs_step<NST, false, XEDGE, VEC>(st, t, hp, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, dst, store_lane);
+        NZ_FS_STEP(NST, false, t, hp, hn);
         const float2 hn2 = fs_load_row<VEC>(h, g, min(t + 3, g.zc1), gx);
-        ring[((t + 2) & (FS_RING - 1)) * 64] = hn;
-        fs_step<NST, false, XEDGE, VEC>(st, t + 1, hn, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, dst, store_lane);
+        NZ_FS_STEP(NST, false, t + 1, hn, hn2);
         const float2 hn3 = fs_load_row<VEC>(h, g, min(t + 4, g.zc1), gx);
-        ring[((t + 3) & (FS_RING - 1)) * 64] = hn2;
-        fs_step<NST, false, XEDGE, VEC>(st, t + 2, hn2, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, dst, store_lane);
+        NZ_FS_STEP(NST, false, t + 2, hn2, hn3);
         hp = hn3;
     }
     // the last one or two steps of an inner segment; the drain of a segment that ends on the grid's last row
     for (; t < t1; t++) {
         const float2 hn = fs_load_row<VEC>(h, g, min(t + 2, g.zc1), gx);
-        ring[((t + 1) & (FS_RING - 1)) * 64] = hp;
-        fs_step<NST, true, XEDGE, VEC>(st, t, hp, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, dst, store_lane);
+        NZ_FS_STEP(NST, true, t, hp, hn);
         hp = hn;
     }
+#undef NZ_FS_PHASE
+#undef NZ_FS_STEP
 }
 
 template <int NST>
@@ -723,8 +791,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NST >= 4 ? 3
     const size_t off = blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
     const bool inner = aligned && lx0 > 0 && lx0 + FS_TW < g.cols;
     float2 *ring = s_ring + threadIdx.x;
+    NZ_FPROBE(0, __builtin_amdgcn_s_memrealtime());
+    NZ_FPROBE(1, __builtin_amdgcn_s_memtime());
+    NZ_FPROBE(6, (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)));   // HW_ID
+    NZ_FPROBE(7, (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) | ((unsigned long long)inner << 32));  // XCC_ID
     if (inner) flow_stream_body<NST, false>(ring, h + off, dst + off, g, lx0, s0, s1, nmin, nrange);
     else flow_stream_body<NST, true>(ring, h + off, dst + off, g, lx0, s0, s1, nmin, nrange);
+    NZ_FPROBE(4, __builtin_amdgcn_s_memrealtime());
+    NZ_FPROBE(5, __builtin_amdgcn_s_memtime());
 }
 
 }  // namespace
@@ -872,3 +946,8 @@ int32_t nz_launch_normalize(hipStream_t s, const float *src, float *dst, size_t 
     return NZ_OK;
 }
 
+#ifdef NZ_FLOW_PROBE
+extern "C" int32_t nz_debug_set_flow_probe(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(nz_flow_probe_buf), &buf, sizeof buf) == hipSuccess ? 0 : -3;
+}
+#endif
