@@ -197,6 +197,10 @@ int nz_flow_fused_max();
 int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const in[5], float *const out[5], float *dst,
                              float *h_out, const nz_geom &g, int n, int first, int last, float nmin, float nrange);
 
+// the whole stage (first && last) as one row-streaming launch (nz_flow_stream.hip)
+bool nz_flow_stream_wanted(const nz_geom &g, int n);
+int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const nz_geom &g, int n, float nmin, float nrange);
+
 int32_t nz_launch_mesh_planar(hipStream_t s, void *vertices, uint32_t *indices, int res);
 int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *indices, int res, int in_res,
                        float tile_height, float tile_size, const float *heights, int count = 1, int index16 = 0);
