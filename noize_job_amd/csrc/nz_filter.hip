@@ -805,6 +805,7 @@ int32_t nz_launch_conv_fused(hipStream_t s, const float *src, float *dst, const 
         return NZ_ERR_INVALID;
     }
     if (g.or1 <= g.or0) return NZ_OK;
+    if (nz_conv_stream_wanted(g, k.ksize, T)) return nz_launch_conv_stream(s, src, dst, g, k, T);
     switch (k.ksize) {
         case 3: return launch_fused<3>(s, src, dst, g, k, T);
         case 5: return launch_fused<5>(s, src, dst, g, k, T);

@@ -366,7 +366,8 @@ bool nz_flow_stream_wanted(const nz_geom &g, int n) {
     static const int mode = getenv("NZ_FLOW_STREAM") ? atoi(getenv("NZ_FLOW_STREAM")) : 1;
     if (mode == 0 || n < 1 || n > FT_MAX_N) return false;
     if (mode == 2) return true;  // test matrix: every size
-    return (long long)g.cols * (g.or1 - g.or0) * g.count >= 1024ll * 1024;
+    // 4096^2: 0.160 against 0.205 ms for the tile kernel, 8192^2: 0.667 against 0.848; 2048^2: 0.084 against 0.075
+    return (long long)g.cols * (g.or1 - g.or0) * g.count >= 8ll * 1024 * 1024;
 }
 
 int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const nz_geom &g, int n, float nmin,

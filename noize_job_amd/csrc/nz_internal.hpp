@@ -161,6 +161,10 @@ int nz_conv_max_fused(int ksize);
 // T fused applications of (X pass, Z pass) src -> dst on rows [or0, or1)
 int32_t nz_launch_conv_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g,
                              const nz_kernel_taps &k, int T);
+// the same as one row-streaming launch (nz_conv_stream.hip; 3 and 5 taps)
+int nz_conv_stream_max(int ksize);
+bool nz_conv_stream_wanted(const nz_geom &g, int ksize, int T);
+int32_t nz_launch_conv_stream(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T);
 // L launches as one grid with tile-level dependencies; see nz_filter.hip
 int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L);
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,

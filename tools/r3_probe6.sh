@@ -1,0 +1,11 @@
+set -x
+mkdir -p gpurun_out
+NZ_CONV_STREAM=2 NZ_FLOW_STREAM=2 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/t3.log 2>&1; echo "rc stream-all $?" >> gpurun_out/t3.log
+tail -n 5 gpurun_out/t3.log
+rm -f gpurun_out/stage.txt
+for W in 3072 4096 6144 8192 12288; do echo "WAVES $W" >> gpurun_out/stage.txt; NZ_CONV_STREAM_WAVES=$W python tools/bench_stage.py gauss --reps 300 >> gpurun_out/stage.txt 2>&1; done
+echo "TILE" >> gpurun_out/stage.txt; NZ_CONV_STREAM=0 python tools/bench_stage.py gauss --reps 300 >> gpurun_out/stage.txt 2>&1
+for C in 3 4 6; do echo "TCAP $C" >> gpurun_out/stage.txt; NZ_CONV_TCAP=$C python tools/bench_stage.py gauss --reps 300 >> gpurun_out/stage.txt 2>&1; done
+grep -v amdgpu.ids gpurun_out/stage.txt
+python bench.py --no-extras --no-cpu-baseline > gpurun_out/bench2.json 2> gpurun_out/bench2.err; python -c "
+import json;d=json.loads(open('gpurun_out/bench2.json').read().strip().split('\n')[-1]);print(d['value'],d['ms_per_step'],{k:v['ms'] for k,v in d['stages'].items()})"
