@@ -4,12 +4,16 @@
 A step = one pass of the metric pipeline (simplex fBm 13 oct -> Gauss5 x17 -> FlowMap x5 -> value
 erosion x5) over one device-resident grid; nothing crosses PCIe inside the timed region.
   N = 1 : the 4096^2 tile BASELINE.json's metric is quoted on.
-  N > 1 : one process per GPU (torch.distributed, backend nccl = RCCL); the grid is row-stripe
-          sharded, 2048 x 16384 cells per rank (N = 8 is BASELINE config 5, 16384^2) -> "scaling":
-          "weak".  The stripes are independent: the source is closed-form noise, so every rank
-          recomputes the 49 ghost rows per side the stencils consume (--halo recompute, default; no
-          data-path collective).  --halo exchange swaps ghost rows with the neighbour ranks over
-          RCCL before every stencil launch instead (the form an uploaded height map would need).
+  N > 1 : one process per GPU (torch.distributed, backend nccl = RCCL); BASELINE config 5's 16384^2 grid,
+          row-stripe sharded over the N ranks (16384 / N rows each) -> "scaling": "strong" (the same grid at
+          every N; the N = 1 line carries the whole grid on one GPU as `grid_16384`, the denominator).  The
+          ranks exchange the ghost rows every stencil launch consumes with their neighbour ranks over RCCL
+          (--halo exchange, the default at N > 1: P2P batches on the process group's stream, overlapped with
+          the launch's interior rows); `comm` says what RCCL ran and what the exchanges cost.  --halo
+          recompute: every rank recomputes its 49 ghost rows per side from the closed-form noise instead (no
+          data-path communication); it is reported beside the headline in `grid_16384`.
+  `python bench.py --gpus N` without a launcher starts its own: N ranks through torch.distributed.run, before
+  this process touches the GPU, and relays rank 0's line.
 Rank 0 prints ONE JSON line:
   * `stages`  : per stage, launch time from HIP events recorded on the kernels' stream inside the timed steps, and
                 -- from the counter summary profiles/*_counters.json that belongs to THESE kernel sources -- the
@@ -46,7 +50,12 @@ BYTES = {"noise": 4.0, "gauss": 8.0 * G_IT, "flow": 24.0 + 44.0 * (F_IT - 1) + 2
 STAGES = ["noise", "gauss", "flow", "erosion"]
 # kernel of each stage as rocprofv3 names it (prefixes; the first that the counter summary holds)
 KERNEL_PREFIX = {"noise": ("fractal_simplex_tab_kernel",), "gauss": ("conv_chain_kernel<5", "conv_reg_kernel<5"),
-                 "flow": ("flow_fused_kernel",), "erosion": ("erosion_reg_kernel",)}
+                 "flow": ("flow_stream_kernel", "flow_fused_kernel"), "erosion": ("erosion_reg_kernel",)}
+# algorithmic fp32 lane-operations per cell (no FMA contraction anywhere, so a multiply-add is two): fBm 13
+# octaves x ~85; one 5-tap application = 2 passes x (5 mul + 4 add); one flow iteration ~40 + velocity / normalise ~15; one
+# value-erosion application = 2 min.  useful_valu_frac = this x cells / (SQ_INSTS_VALU x 64): what the halo recompute,
+# selects, moves and address arithmetic leave of the instructions executed
+ALGO_LANE_OPS = {"noise": 13 * 85.0, "gauss": G_IT * 18.0, "flow": F_IT * 40.0 + 15.0, "erosion": E_IT * 2.0}
 
 CPU_PASSES = 11         # ~10 s of host work on the GPU box's 32 cores (0.9-1.0 s per 4096^2 pass)
 PREHEAT_MIN_STEPS = 50  # untimed passes before the timed region, warm-up included (clock settling)
@@ -61,16 +70,21 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--res", type=int, default=4096, help="tile resolution at N=1")
-    ap.add_argument("--stripe-rows", type=int, default=2048, help="rows per rank at N>1")
+    ap.add_argument("--stripe-rows", type=int, default=0,
+                    help="rows per rank at N>1 (0: --grid / N, strong scaling; a fixed count gives weak scaling)")
     ap.add_argument("--cols", type=int, default=16384, help="grid columns at N>1")
     ap.add_argument("--grid", type=int, default=16384,
                     help="side of the strong-scaling grid reported as grid_16384 at every N (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational measurements after the timed steps")
     ap.add_argument("--sharded", action="store_true", help="run the row-stripe path even with one rank (rehearsal)")
-    ap.add_argument("--halo", choices=("recompute", "exchange", "exchange_once"), default="recompute",
-                    help="N>1: ghost rows recomputed from the closed-form noise (no data-path communication) or "
-                         "exchanged with the neighbour ranks over RCCL before every launch")
+    ap.add_argument("--halo", choices=("recompute", "exchange", "exchange_once"), default=None,
+                    help="N>1 (default exchange): ghost rows exchanged with the neighbour ranks over RCCL before every "
+                         "launch, or recomputed from the closed-form noise (no data-path communication; the default "
+                         "of the one-rank rehearsals)")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="go through the launcher even with one rank (what --gpus N > 1 does when no launcher set "
+                         "WORLD_SIZE): the ranks are children started with torch.distributed.run")
     ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "P"), default=None,
                     help="one-process rehearsal of rank R of a P-rank job (needs --halo recompute)")
     ap.add_argument("--flush", choices=("swap", "copy"), default="swap",
@@ -227,8 +241,11 @@ class TimedComm:
     def __init__(self, comm, ctx):
         self.comm, self.ctx, self.spans = comm, ctx, []
         self.overlap = getattr(comm, "overlap", False)
+        self.enabled = True  # markers only while set (the handle ring holds 4096 markers)
 
     def exchange(self, planes, plan, up_rows, down_rows):
+        if not self.enabled:
+            return self.comm.exchange(planes, plan, up_rows, down_rows)
         a = self.ctx.record()
         self.comm.exchange(planes, plan, up_rows, down_rows)
         self.spans.append((a, self.ctx.record()))
@@ -237,6 +254,8 @@ class TimedComm:
         return self.comm.begin(planes, plan, up_rows, down_rows)
 
     def finish(self, reqs):
+        if not self.enabled:
+            return self.comm.finish(reqs)
         a = self.ctx.record()
         self.comm.finish(reqs)
         self.spans.append((a, self.ctx.record()))
@@ -324,8 +343,41 @@ def cpu_baseline(res):
                       "read-write pass" % (CPU_PASSES, res, res, dt, flags)}, plane
 
 
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` as the driver runs N = 1, with no launcher around it: start the N ranks as children
+    (python -m torch.distributed.run, rendezvous on 127.0.0.1) BEFORE this process has touched the GPU -- a process that
+    has initialised HIP must never exec or be replaced -- relay their stdout (rank 0's one JSON line) and exit with the
+    launcher's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+          [a for a in argv if a != "--self-launch"]
+    print("bench.py: no launcher (WORLD_SIZE unset): starting %d rank(s): %s" % (gpus, " ".join(cmd)), file=sys.stderr)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    last = None
+    for line in child.stdout:
+        if line.startswith("{"):
+            last = line
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if last is not None:
+        sys.stdout.write(last)
+        sys.stdout.flush()
+    raise SystemExit(rc if rc else (0 if last is not None else 1))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch):
+        self_launch(sys.argv[1:], args.gpus)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -337,10 +389,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.halo is None:
+        args.halo = "exchange" if world > 1 else "recompute"
     # stdout carries the ONE JSON line only: whatever libraries print while they initialise (RCCL's version
     # banner under NCCL_DEBUG=VERSION) is sent to stderr
     sys.stdout.flush()
@@ -398,14 +449,18 @@ def main():
         ops = sh.HipStripeOps(ctx)
         halo = sh.halo_rows_needed(ops, p)
         prank, pworld = args.as_rank if args.as_rank is not None else (rank, world)
-        plan = sh.StripePlan(prank, pworld, args.stripe_rows * pworld, args.cols, halo,
+        strong = args.stripe_rows <= 0  # the same --grid rows at every N, split over the ranks
+        stripe_rows = args.stripe_rows if not strong else max(1, (args.grid or 16384) // pworld)
+        plan = sh.StripePlan(prank, pworld, stripe_rows * pworld, args.cols, halo,
                              neighbours_own_halo=args.halo != "recompute")
         cells = plan.nown * world * plan.cols  # every rank owns stripe_rows rows
         bufs = (torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
                 torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
                 torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
                 torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"))
-        comm = sh.NoComm() if args.halo == "recompute" else sh.TorchComm(dist)
+        # the exchanges are asynchronous (P2P batches on the process group's stream, the launch's interior rows run
+        # meanwhile); TimedComm brackets the compute stream's wait for them with stream markers
+        comm = sh.NoComm() if args.halo == "recompute" else TimedComm(sh.TorchComm(dist), ctx)
 
         def step(record):
             if record:  # stream markers where the stages begin (exchanges of a stage are charged to it)
@@ -420,7 +475,7 @@ def main():
                "recompute": "%d ghost rows per side recomputed from the closed-form noise, no data-path "
                             "communication" % halo}[args.halo]
         workload = "%dx%d grid as %d row stripes of %dx%d (%s): simplex-13oct -> Gauss5_S1 x%d " \
-                   "-> FlowMap x%d -> ValueErosion x%d" % (plan.grows, plan.cols, pworld, args.stripe_rows, plan.cols,
+                   "-> FlowMap x%d -> ValueErosion x%d" % (plan.grows, plan.cols, pworld, stripe_rows, plan.cols,
                                                             how, G_IT, F_IT, E_IT)
         parallelism = "row-stripe dp%d" % world
         if args.as_rank is not None:
@@ -471,15 +526,22 @@ def main():
     for _ in range(args.warmup):
         step(False)
     fence()
+    if sharded and isinstance(comm, TimedComm):
+        comm.total_ms()  # forget the warm-up's exchanges
     t0 = time.perf_counter()
+    ex_steps = min(args.steps, 64)  # exchanges are bracketed with markers in the last steps only
     for i in range(args.steps):
+        if sharded and isinstance(comm, TimedComm):
+            comm.enabled = args.steps - i <= ex_steps
         step(args.steps - i <= MAX_MARKED_STEPS)
     fence()
     dt = time.perf_counter() - t0
+    exchange_ms = None
     if sharded:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        ex = comm.total_ms() / ex_steps if isinstance(comm, TimedComm) else 0.0
+        t = torch.tensor([dt, ex], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, exchange_ms = float(t[0].item()), float(t[1].item())
 
     out = None
     out_lock = threading.Lock()
@@ -490,7 +552,8 @@ def main():
         out = {"metric": "Mcells/s 4096^2 simplex13oct->Gauss5x17->FlowMap->Erosion; %HBM roofline @1/8GPU",
                "value": round(value, 1), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "strong" if (not sharded or strong) else "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
                "config": {"workload": workload, "cells": cells, "parallelism": parallelism, "preheat_steps": preheat,
                           "algorithmic_bytes_per_cell": total_bytes, "flush": flush_note},
                "pipeline_hbm": {"achieved": round(total_bytes * cells / (dt / args.steps) / 1e9 / world, 1),
@@ -500,6 +563,24 @@ def main():
                                         "filter / flow / erosion application) over the step time.  NOT a roofline: the "
                                         "applications are fused on chip, the HBM traffic actually moved is `stages.*."
                                         "hbm_bytes_per_launch`, so this figure may exceed the peak"}}
+        if sharded:
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                rccl = None
+            out["comm"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "rccl_version": rccl,
+                           "halo": args.halo, "overlapped": bool(getattr(comm, "overlap", False)),
+                           "exchange_ms_per_step": None if exchange_ms is None else round(exchange_ms, 4),
+                           "ranks_on_device": "one process per GPU (LOCAL_RANK -> device), %d device(s) visible to rank 0" % ndev,
+                           "note": "exchange_ms_per_step = time the compute stream waits for ghost rows (HIP events around "
+                                   "every wait, max over ranks); 0 ghost-row traffic with --halo recompute"}
+            out["config"]["strong_scaling"] = (
+                "the same %dx%d grid at every N; denominator = `grid_%d`.recompute of the N = 1 line (the whole grid on one "
+                "GPU)" % (plan.grows, plan.cols, plan.grows)) if strong else None
+        else:
+            out["config"]["strong_scaling"] = ("this N = 1 line is the 4096^2 metric tile; the N > 1 lines run the %d^2 grid "
+                                               "split over the ranks, whose one-GPU figure is `grid_%d` below" %
+                                               (args.grid, args.grid)) if args.grid else None
         if cold_ms is not None:
             out["cold_ms"] = round(cold_ms, 4)
             out["config"]["cold_ms_note"] = "one step from an idle chip (0.5 s after the previous one), host-timed"
@@ -562,7 +643,8 @@ def main():
             s["algorithmic_equivalent_GB/s"] = round(gbs, 1)
             hit = counters_for(cnt, n)
             if hit is None:
-                s.update({"kernel": KERNEL_PREFIX[n][0], "valu_issue_frac": None, "hbm_traffic_frac": None, "bound": None})
+                s.update({"kernel": KERNEL_PREFIX[n][0], "valu_issue_frac": None, "hbm_traffic_frac": None, "bound": None,
+                          "useful_valu_frac": None})
                 continue
             name, e = hit
             insts = e["SQ_INSTS_VALU"] * cnt["scale"]
@@ -570,6 +652,7 @@ def main():
             valu_frac = insts * VALU_CYCLES_PER_INST / (N_SIMD * CLK_HZ) / (launch_ms * 1e-3)
             hbm_frac = hbm / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             valu_floor_ms += launches[n] * insts * VALU_CYCLES_PER_INST / (N_SIMD * CLK_HZ) * 1e3
+            s["useful_valu_frac"] = round(ALGO_LANE_OPS[n] * rcells / (launches[n] * insts * 64.0), 4)
             s.update({"kernel": name, "valu_insts_per_launch": round(insts), "hbm_bytes_per_launch": round(hbm),
                       "valu_issue_frac": round(valu_frac, 4), "hbm_traffic_frac": round(hbm_frac, 4),
                       "bound": "valu-fp32" if valu_frac >= hbm_frac else "hbm"})

@@ -27,7 +27,7 @@ def test_single_gpu_line():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "verified", "cold_ms"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["unit"] == "Mcells/s"
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] == pytest.approx(d["config"]["cells"] / (d["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
     assert d["verified"] is True   # the plane of the last timed step equals the oracle's, bit for bit
@@ -42,6 +42,7 @@ def test_single_gpu_line():
         for s in d["stages"].values():
             assert 0.0 < s["valu_issue_frac"] <= 1.0 and 0.0 < s["hbm_traffic_frac"] <= 1.0
             assert s["bound"] == ("valu-fp32" if s["valu_issue_frac"] >= s["hbm_traffic_frac"] else "hbm")
+            assert 0.0 < s["useful_valu_frac"] <= 1.0  # algorithmic lane-operations over executed ones
         assert 0.0 < d["step_valu"]["frac"] <= 1.0
     else:
         assert r["bound"] == "unknown" and r["frac"] is None
@@ -74,3 +75,42 @@ def test_launched_like_the_driver_at_n_gt_1(halo):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["cells"] == 384 * 1024 and d["value"] > 0
     assert "row-stripe" in d["config"]["parallelism"] and d["grid_1024"]["recompute"]["Mcells/s"] > 0
+
+
+def _self_launched(*args):
+    # plain `python bench.py --gpus N ...`, no launcher around it, exactly as the driver runs N = 1: bench.py starts the
+    # ranks itself (torch.distributed.run) before it touches the GPU and relays rank 0's line
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=380, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one line, got %d" % len(lines)
+    assert "starting" in out.stderr and "torch.distributed.run" in out.stderr
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(400, method="thread")
+def test_bench_starts_its_own_ranks_one_rank():
+    # the one-GPU box drives the self-launch path with one rank: RCCL process group, stripe schedule, exchanges with
+    # the rank's own neighbours absent (first and last stripe at once), `comm` in the line
+    d = _self_launched("--gpus", "1", "--sharded", "--self-launch", "--steps", "4", "--warmup", "1", "--stripe-rows", "384",
+                       "--cols", "1024", "--grid", "1024", "--halo", "exchange", "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["config"]["cells"] == 384 * 1024 and d["value"] > 0
+    c = d["comm"]
+    assert c["backend"] == "nccl" and c["world"] == 1 and c["halo"] == "exchange" and c["overlapped"] is True
+    assert c["exchange_ms_per_step"] is not None and c["exchange_ms_per_step"] >= 0.0 and c["rccl_version"]
+    assert d["grid_1024"]["recompute"]["Mcells/s"] > 0
+
+
+@pytest.mark.timeout(400, method="thread")
+def test_bench_gpus_2_without_a_launcher():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    # N = 2 exactly as the driver would type it: the 2048^2 grid split over two ranks, ghost rows exchanged over RCCL
+    d = _self_launched("--gpus", "2", "--steps", "4", "--warmup", "1", "--grid", "2048", "--cols", "2048", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["cells"] == 2048 * 2048
+    c = d["comm"]
+    assert c["backend"] == "nccl" and c["world"] == 2 and c["halo"] == "exchange" and c["exchange_ms_per_step"] > 0.0
+    assert set(d["grid_2048"]) >= {"recompute", "exchange", "exchange_blocking", "exchange_once"}
