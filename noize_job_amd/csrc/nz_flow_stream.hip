@@ -219,16 +219,21 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
         }
 }
 
-// Waves of a SIMD are served oldest first: left alone, the three waves of a SIMD finish one after the other and the last
-// one runs alone (at most one VALU instruction per four cycles) for a quarter of the launch.  Priority by progress keeps
-// them together: a wave that is a step ahead of another (modulo 4) yields to it.
-__device__ __forceinline__ void fs_prio(int step) {
-    switch (step & 3) {
-        case 0: __builtin_amdgcn_s_setprio(3); break;
-        case 1: __builtin_amdgcn_s_setprio(2); break;
-        case 2: __builtin_amdgcn_s_setprio(1); break;
-        default: __builtin_amdgcn_s_setprio(0); break;
-    }
+// Waves of a SIMD are served oldest first: left alone, the three waves of a SIMD finish one after the other (after 45 %,
+// 70 % and 100 % of the launch) and the last one runs alone, at most one VALU instruction per four cycles, for the last
+// third.  NZ_FS_PRIO rotates the priority among the SIMD's wave slots (slot id from HW_ID):
+//   1: by the wave's own step count -- the order moves on every 2^NZ_FS_PRIO_SHIFT steps;
+//   2: by the 100 MHz real-time counter, the same for every wave -- every slot is first for a third of the time.
+#ifndef NZ_FS_PRIO_SHIFT
+#define NZ_FS_PRIO_SHIFT 8
+#endif
+__device__ __forceinline__ void fs_prio(int step, int slot) {
+    unsigned phase = (unsigned)step >> NZ_FS_PRIO_SHIFT;
+    if (NZ_FS_PRIO == 2) phase = (unsigned)(__builtin_amdgcn_s_memrealtime() >> NZ_FS_PRIO_SHIFT);
+    const unsigned k = ((unsigned)slot + phase) % 3u;
+    if (k == 0) __builtin_amdgcn_s_setprio(2);
+    else if (k == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
 }
 
 template <bool VEC>
@@ -279,9 +284,10 @@ __device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__re
     float2 hp = fs_load_row<VEC>(h, g, min(t0 + 1, g.zc1), gx);
     ring[((t0 + 1) & (FS_RING - 1)) * 64] = hp;
     int t = t0;
+    const int slot = (int)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  /* HW_ID.WAVE_ID */
 #define NZ_FS_STEP(NA, C, T, HP, HN)                                                                              \
     do {                                                                                                          \
-        if (NZ_FS_PRIO) fs_prio((T) - t0);                                                                        \
+        if (NZ_FS_PRIO) fs_prio((T) - t0, slot);                                                                      \
         fs_step<NST, NA, C, XEDGE, VEC>(st, T, HP, HN, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, dst, \
                                         store_lane);                                                              \
     } while (0)
@@ -337,13 +343,29 @@ __device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__re
 
 template <int NST>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NST >= 4 ? 3 : 4))) void flow_stream_kernel(
-    const float *__restrict__ h, float *__restrict__ dst, nz_geom g, int S, int nstrips, float nmin, float nrange,
-    int aligned) {
+    const float *__restrict__ h, float *__restrict__ dst, nz_geom g, int S, int nstrips, int Se, int nseg_edge, float nmin,
+    float nrange, int aligned) {
     __shared__ float2 s_ring[FS_RING * 64];
     constexpr int H = 2 * NST, OW = FS_TW - 2 * H;
-    const int strip = blockIdx.x % nstrips, seg = blockIdx.x / nstrips;
+    // The first blocks are the two border strips (one when the grid is a single strip wide), whose steps carry the border
+    // selects and clamped accesses.  A launch on an idle chip places its blocks breadth first (block b is the (b / number
+    // of SIMDs)-th wave of its SIMD, tools/probe_flow_stream.py) and a SIMD serves its waves oldest first: as the first
+    // wave of their SIMDs the border strips run at full speed and do not finish last (0.158 -> 0.148 ms at 4096^2); they
+    // also get shorter segments (Se rows).  Then the strips away from the grid's first / last column, S rows per segment.
+    int strip, s0, s1;
+    const int ne = min(nstrips, 2), n_edge = ne * nseg_edge;
+    if ((int)blockIdx.x < n_edge) {
+        const int e = (int)blockIdx.x;
+        strip = (e % ne) ? nstrips - 1 : 0;
+        s0 = g.or0 + (e / ne) * Se;
+        s1 = min(s0 + Se, g.or1);
+    } else {
+        const int b = (int)blockIdx.x - n_edge;
+        strip = 1 + b % (nstrips - 2);
+        s0 = g.or0 + (b / (nstrips - 2)) * S;
+        s1 = min(s0 + S, g.or1);
+    }
     const int lx0 = strip * OW - H;
-    const int s0 = g.or0 + seg * S, s1 = min(s0 + S, g.or1);
     const size_t off = blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
     const bool inner = aligned && lx0 > 0 && lx0 + FS_TW < g.cols;
     float2 *ring = s_ring + threadIdx.x;
@@ -382,11 +404,16 @@ int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const n
     if (S < 16) S = 16;
     if (s_env > 0) S = s_env;
     nseg = (rows + S - 1) / S;
+    // border strips: ~12 % shorter segments (their steps are that much longer)
+    int Se = (S * 7 + 7) / 8;
+    if (Se < 8) Se = S;
+    const int nseg_e = (rows + Se - 1) / Se;
+    const int nblocks = (nstrips > 2 ? nstrips - 2 : 0) * nseg + (nstrips < 2 ? nstrips : 2) * nseg_e;
     uintptr_t bits = reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4) |
                      (uintptr_t)(g.bstride * 4);
     const int aligned = (bits & 7) == 0;
-    const dim3 grid((unsigned)(nstrips * nseg), g.count);
-#define NZ_FS(N) hipLaunchKernelGGL((flow_stream_kernel<N>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, nmin, nrange, aligned)
+    const dim3 grid((unsigned)nblocks, g.count);
+#define NZ_FS(N) hipLaunchKernelGGL((flow_stream_kernel<N>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned)
     switch (n) {
         case 1: NZ_FS(1); break;
         case 2: NZ_FS(2); break;

@@ -32,6 +32,7 @@ with nj.Context(0) as ctx:
     nj.FlowMapStage(ctx, 5, 0.0, 0.005).Schedule(nj.PipelineWorkItem(g2), nj.JobHandle())
     ctx.synchronize()
     p = probe.ToArray((NW, 8))
+blk = np.nonzero(p[:, 0] > 0)[0]
 p = p[p[:, 0] > 0]
 t0 = p[:, 0].min()
 start, mid, end = (p[:, 0] - t0) / 100.0, (p[:, 2] - t0) / 100.0, (p[:, 4] - t0) / 100.0  # us (100 MHz)
@@ -65,3 +66,19 @@ print("SIMDs seen %d; waves per SIMD: mean %.2f min %d max %d; resident waves wh
       "the span: mean %.2f min %.2f" % (len(simd), np.mean(cnt), min(cnt), max(cnt), np.mean(conc), np.mean(busy), np.min(busy)))
 hist = collections.Counter(cnt)
 print("waves per SIMD histogram:", dict(sorted(hist.items())))
+slot = p[:, 6] & 0xf
+for k in sorted(set(slot.tolist())):
+    m = slot == k
+    print("  wave slot %d: %5d waves, start mean %.1f us, end mean %.1f us (min %.1f, max %.1f)" % (
+        k, m.sum(), start[m].mean(), end[m].mean(), end[m].min(), end[m].max()))
+# dispatch order (block index) against finishing time: waves of a SIMD are served oldest first
+order = np.argsort(start, kind="stable")
+for q in range(4):
+    m = order[q * len(order) // 4:(q + 1) * len(order) // 4]
+    print("  start-time quartile %d: end mean %.1f us" % (q, end[m].mean()))
+# is the wave slot a function of the block index (breadth-first fill: block b -> slot b // 1024)?
+for lo in range(0, int(blk.max()) + 1, 512):
+    m = (blk >= lo) & (blk < lo + 512)
+    if m.any():
+        h = collections.Counter((p[m, 6] & 0xf).tolist())
+        print("  blocks %4d..%4d: slots %s, end mean %.1f us" % (lo, lo + 511, dict(sorted(h.items())), end[m].mean()))
