@@ -95,6 +95,11 @@ def parse():
                          "rows recomputed from the closed-form noise; the fp32-bound kernels of one stripe overlap "
                          "the HBM-bound kernels of another); 1 = the stage pipeline on one stream")
     ap.add_argument("--cpu-res", type=int, default=0, help="tile side of the CPU baseline (0 = --res)")
+    ap.add_argument("--schedule", choices=("pipeline", "stages"), default="stages",
+                    help="N=1: `stages` = the reference's stage-by-stage hand-over on one stream (BasePipeline's default); "
+                         "`pipeline` = BasePipeline.fuseStages: the stock stage list goes to the library as ONE call "
+                         "(nz_terrain_pipeline: two independent row stripes on two HIP streams of the context, ghost rows "
+                         "recomputed)")
     return ap.parse_args()
 
 
@@ -215,6 +220,7 @@ def in_place_entries(nj, ctx, res, p, steps=60):
     stages = make_stages(nj, ctx, p)
     gd = nj.GeneratorData("inplace", ctx.alloc(cells), res, 0, 0)
     pipe = nj.BasePipeline(stages, "in-place")
+    pipe.fuseStages = False
 
     def one():
         pipe.Schedule(gd)
@@ -232,6 +238,39 @@ def in_place_entries(nj, ctx, res, p, steps=60):
     return {"ms_per_step": round(dt * 1e3, 4), "Mcells/s": round(cells / dt / 1e6, 1),
             "note": "one plane, in-place entries with their flush copies (bench.py --flush copy): results land in "
                     "`data` exactly as in the reference"}
+
+
+def one_call_pipeline(nj, ctx, res, p, steps=60):
+    """Informational: BasePipeline.fuseStages -- the stock stage list handed to the library as ONE call
+    (nz_terrain_pipeline: two independent row stripes on two HIP streams of the context, ghost rows recomputed, result in
+    the tile's own plane) -- what `--schedule pipeline` times as its headline."""
+    cells = res * res
+    stages = make_stages(nj, ctx, p)
+    gd = nj.GeneratorData("one-call", ctx.alloc(cells), res, 0, 0)
+    pipe = nj.BasePipeline(stages, "one-call")
+    pipe.fuseStages = True
+
+    def one():
+        pipe.Schedule(gd)
+        pipe.pipelineRunning = False
+    one()
+    if pipe.fusedMarks is None:
+        pipe.Destroy()
+        gd.data.Dispose()
+        return {"applies": False, "note": "nz_terrain_pipeline does not apply to this tile (too small to split)"}
+    for _ in range(20):
+        one()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pipe.Destroy()
+    gd.data.Dispose()
+    return {"ms_per_step": round(dt * 1e3, 4), "Mcells/s": round(cells / dt / 1e6, 1),
+            "note": "BasePipeline.fuseStages: one nz_terrain_pipeline call per tile, two row stripes on two streams; no "
+                    "WRITE plane, no stage scratch"}
 
 
 class TimedComm:
@@ -428,8 +467,13 @@ def main():
         pipe = nj.BasePipeline(stages, "metric")
         gd = nj.GeneratorData("bench", tile, res, 0, 0, write=ctx.wrap(data_w.data_ptr(), cells) if swap else None)
 
+        pipe.fuseStages = args.schedule == "pipeline"
+        pipe.Schedule(gd)  # one untimed pass: buffers, code objects -- and whether the one-call form applies to this tile
+        pipe.pipelineRunning = False
+        one_call = pipe.fusedMarks is not None
+
         def step(record):
-            if record:
+            if record and not one_call:
                 hs = [ctx.record()]
                 for st in stages:  # same chain BasePipeline.Schedule builds, with a marker between stages
                     st.Schedule(nj.PipelineWorkItem(gd), hs[-1])
@@ -439,11 +483,35 @@ def main():
                 pipe.Schedule(gd)
                 pipe.pipelineRunning = False
 
+        def stage_pass(steps=100, warm=20):
+            """The same stage list scheduled stage by stage on ONE stream, markers between the stages: every kernel has
+            the chip to itself, which is what a launch time and a roofline fraction mean.  Host-timed like the headline."""
+            def one(rec):
+                hs = [ctx.record()]
+                for st in stages:
+                    st.Schedule(nj.PipelineWorkItem(gd), hs[-1])
+                    hs.append(st.jobHandle)
+                if rec:
+                    marks.append(hs)
+            for _ in range(warm):
+                one(False)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one(True)
+            fence()
+            return (time.perf_counter() - t0) / steps
+
         workload = "%dx%d tile: simplex-13oct(h0.4,size1700) -> Gauss5_S1 x%d -> FlowMap x%d (norm 0/0.005) -> " \
                    "ValueErosion x%d" % (res, res, G_IT, F_IT, E_IT)
         parallelism = "single tile"
         flush_note = ("READ/WRITE plane pair, SWAP_RWTILE = pointer swap (nz_*_rw entries)" if swap else
                       "one plane, in-place entries with flush copies")
+        if one_call:
+            parallelism = "single tile; BasePipeline.Schedule = one nz_terrain_pipeline call: two row stripes on two HIP " \
+                          "streams of the context"
+            flush_note = "result lands in the tile's own plane (no WRITE plane, no flush copy); the per-stage figures " \
+                         "come from the stage-by-stage pass (" + flush_note + ")"
     else:
         swap, flush_note = False, "stripe entries (explicit src / dst planes)"
         ops = sh.HipStripeOps(ctx)
@@ -543,6 +611,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, exchange_ms = float(t[0].item()), float(t[1].item())
 
+    stage_by_stage_s, got_one_call = None, None
+    if not sharded and striped is None and one_call:
+        if rank == 0 and not args.no_cpu_baseline and (args.cpu_res or res) == res:
+            # the plane the last timed step (one call, two stripes) left behind, kept for the comparison with the oracle
+            got_one_call = np.empty(cells, np.float32)
+            nj._native.check(nj._native.lib.nz_tile_download(ctx._h, gd.data.ptr, got_one_call.ctypes.data, cells, 0, None),
+                             "download")
+            fence()
+        stage_by_stage_s = stage_pass()
     out = None
     out_lock = threading.Lock()
     if rank == 0:
@@ -581,6 +658,12 @@ def main():
             out["config"]["strong_scaling"] = ("this N = 1 line is the 4096^2 metric tile; the N > 1 lines run the %d^2 grid "
                                                "split over the ranks, whose one-GPU figure is `grid_%d` below" %
                                                (args.grid, args.grid)) if args.grid else None
+        if stage_by_stage_s is not None:
+            out["stage_by_stage"] = {"ms_per_step": round(stage_by_stage_s * 1e3, 4),
+                                     "Mcells/s": round(cells / stage_by_stage_s / 1e6, 1),
+                                     "note": "the same stage list, stage after stage on one stream (bench.py --schedule "
+                                             "stages): `stages` and `roofline` below are measured in this pass, where a "
+                                             "kernel has the chip to itself; `value` is the one-call form"}
         if cold_ms is not None:
             out["cold_ms"] = round(cold_ms, 4)
             out["config"]["cold_ms_note"] = "one step from an idle chip (0.5 s after the previous one), host-timed"
@@ -704,11 +787,16 @@ def main():
             nj._native.check(nj._native.lib.nz_tile_download(ctx._h, src.ptr, got.ctypes.data, cells, 0, None), "download")
             fence()
             same = bool(np.array_equal(got.reshape(res, res), plane))
+            if got_one_call is not None:  # both forms: the one call of the timed steps and the stage-by-stage pass
+                same_one = bool(np.array_equal(got_one_call.reshape(res, res), plane))
+                out["verified_detail"] = {"one_call_plane_equals_oracle": same_one, "stage_by_stage_plane_equals_oracle": same}
+                same = same and same_one
             out["verified"] = same
             if not same:
                 bad = ~(np.abs(got.reshape(res, res) - plane) <= 1e-5 * np.abs(plane) + 1e-6)
-                out["verified_detail"] = {"cells_outside_1e-5_rel": int(bad.sum()),
-                                          "max_abs_diff": float(np.abs(got.reshape(res, res) - plane).max())}
+                out.setdefault("verified_detail", {}).update({
+                    "cells_outside_1e-5_rel": int(bad.sum()),
+                    "max_abs_diff": float(np.abs(got.reshape(res, res) - plane).max())})
         else:
             out["verified"] = None
     extras = not args.no_extras
@@ -729,7 +817,8 @@ def main():
         watchdog = threading.Timer(240.0, bail)
         watchdog.daemon = True
         watchdog.start()
-        for key, fn in (("in_place_entries", lambda: in_place_entries(nj, ctx, res, p) if swap else None),
+        for key, fn in (("one_call_pipeline", lambda: one_call_pipeline(nj, ctx, res, p) if not one_call else None),
+                        ("in_place_entries", lambda: in_place_entries(nj, ctx, res, p) if swap else None),
                         ("two_tiles_in_flight", lambda: two_tiles(nj, ctx, stages, gd, res, p, swap)),
                         ("tile_as_two_stripes", lambda: two_stripes(nj, sh, torch, local_rank, data, res, p))):
             try:

@@ -435,6 +435,34 @@ int32_t nz_crop_job(nz_ctx *ctx, const float *input, int32_t inputResolution, fl
 int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, float incrementRatio, float meshHeightWidthRatio,
                            int32_t iterations, int32_t resolution, nz_handle dep, nz_handle *out);
 
+/* ---- a whole BasePipeline of the stock stages as one call -------------------------------------------------------
+ * BasePipeline.Schedule hands a work item from stage to stage (Pipeline/Executable/Pipeline.cs:91-152,
+ * Pipeline/Stage/PipelineStage.cs:41-48); when the stage list is NoiseStage -> [KernelFilterStage] -> [FlowMapStage] ->
+ * [ErosionKernelJob x n] (README.md:23-32, the metric pipeline) the host may hand the whole list over instead.  The
+ * source is closed-form noise, so the tile is run as two independent row stripes on two HIP streams of the context --
+ * every stripe evaluates the noise on its rows plus the stencil radius of everything downstream and each launch
+ * produces a window that shrinks by the radius it consumed -- and the fp32-bound kernels of one stripe overlap the
+ * memory-bound ones of the other.  Same kernels, same results as the stage-by-stage calls, bit for bit; the result lands
+ * in `data` (the tile's READ plane), no WRITE plane or stage scratch is needed (the context owns the stripes' planes).
+ * An iteration count of 0 leaves a stage out.  `marks` (nullable, 5 handles): markers on the context's stream where the
+ * noise, filter, flow and erosion launches of the FIRST stripe begin, and at the end.
+ * nz_terrain_pipeline_stripes: the number of stripes the call would use on this tile, 0 if it does not apply (tile too
+ * small to split, no stencil stage, a filter or iteration count without a fused kernel): the host then schedules stage by
+ * stage as the reference does. */
+typedef struct nz_terrain_params {
+    int32_t noiseType;            /* NoiseStage.FractalNoise, Noise/NoiseStage.cs:15-24 */
+    float hurst, startingAmplitude, stepdown, detuneRate;
+    int32_t octaves, noiseSize;
+    int32_t filter;               /* KernelFilterType */
+    int32_t filterIterations;     /* KernelFilterStage.iterations, 0 = no filter stage */
+    int32_t flowIterations;       /* FlowMapStage.iterations, 0 = no flow stage */
+    float normMin, normMax;
+    int32_t erosionIterations;    /* ErosionKernelJob applications, 0 = none */
+} nz_terrain_params;
+int32_t nz_terrain_pipeline_stripes(const nz_terrain_params *p, int32_t resolution);
+int32_t nz_terrain_pipeline(nz_ctx *ctx, float *data, int32_t resolution, int32_t xpos, int32_t zpos,
+                            const nz_terrain_params *p, nz_handle *marks, nz_handle dep, nz_handle *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,7 +56,15 @@ class Particle(C.Structure):
     _fields_ = [("px", C.c_int32), ("pz", C.c_int32), ("water", C.c_float), ("pid", C.c_uint32)]
 
 
-ep_p, tm_p = C.POINTER(ErosionParameters), C.POINTER(TileSetMeta)
+class TerrainParams(C.Structure):
+    """nz_terrain_params (include/noize_hip.h): the stock stage list handed over as one call."""
+    _fields_ = [("noiseType", C.c_int32), ("hurst", C.c_float), ("startingAmplitude", C.c_float), ("stepdown", C.c_float),
+                ("detuneRate", C.c_float), ("octaves", C.c_int32), ("noiseSize", C.c_int32), ("filter", C.c_int32),
+                ("filterIterations", C.c_int32), ("flowIterations", C.c_int32), ("normMin", C.c_float),
+                ("normMax", C.c_float), ("erosionIterations", C.c_int32)]
+
+
+ep_p, tm_p, tp_p = C.POINTER(ErosionParameters), C.POINTER(TileSetMeta), C.POINTER(TerrainParams)
 
 NZ_OK, NZ_ERR_INVALID, NZ_ERR_UNSUPPORTED, NZ_ERR_HIP, NZ_ERR_NOMEM, NZ_ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 
@@ -99,6 +107,8 @@ SIGNATURES = {
     "nz_gauss_blur_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _i] + _tail),
     "nz_smooth_blur_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
     "nz_erosion_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
+    "nz_terrain_pipeline_stripes": (_i, [tp_p, _i]),
+    "nz_terrain_pipeline": (_i, [ctx_p, dev_ptr, _i, _i, _i, tp_p, handle_p] + _tail),
     "nz_kernel_filter_halo_rows": (_i, [_i, _i]),
     "nz_kernel_filter_max_fused": (_i, [_i]),
     "nz_erosion_max_fused_iterations": (_i, []),

@@ -234,7 +234,7 @@ int32_t launch_stream(hipStream_t s, const float *src, float *dst, const nz_geom
     constexpr int O = (KS - 1) / 2, HX = (O * T + 1) & ~1, OW = CS_TW - 2 * HX;
     static const int s_env = getenv("NZ_CONV_STREAM_S") ? atoi(getenv("NZ_CONV_STREAM_S")) : 0;
     const int nstrips = (g.cols + OW - 1) / OW, rows = g.or1 - g.or0;
-    const long long per = (long long)nstrips * g.count;
+    const long long per = (long long)nstrips * g.count * (g.chip_div > 1 ? g.chip_div : 1);  // chip_div: its share of the chip
     int nseg = (int)(waves / per > 0 ? waves / per : 1);
     int S = (rows + nseg - 1) / nseg;
     if (S < 16) S = 16;

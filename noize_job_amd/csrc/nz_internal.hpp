@@ -58,6 +58,12 @@ struct nz_ctx {
     size_t chain_flags_n = 0;
     unsigned *chain_ctl = nullptr;
     unsigned chain_epoch = 0;
+    // striped pipeline (nz_terrain_pipeline): a second stream with its fork / join markers and the stripes' planes, all
+    // created on first use
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float *pipe_work = nullptr;
+    size_t pipe_work_floats = 0;
 };
 
 #define NZ_TRY_(expr)             \
@@ -71,6 +77,7 @@ constexpr uint64_t NZ_HANDLE_SEQ_MASK = (1ull << NZ_HANDLE_SEQ_BITS) - 1;
 int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep);           // set device, order the stream after `dep`
 int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out);         // record the JobHandle marker
 int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out);
+int32_t nz_ctx_pipe_state(nz_ctx *ctx, size_t floats, float **work);  // aux stream, fork / join events, stripe planes
 
 // ---- kernel parameter blocks ----------------------------------------------------------------
 constexpr int NZ_MAX_KSIZE = 25;
@@ -115,6 +122,9 @@ struct nz_geom {
     // the kernels take the grid index from blockIdx.y
     int count = 1;
     size_t bstride = 0;
+    // the launch shares the chip with (chip_div - 1) launches like it on other streams: kernels that size their grid to
+    // one round of waves take 1 / chip_div of the chip
+    int chip_div = 1;
 };
 
 inline nz_geom nz_geom_batch(int res, int count) {

@@ -226,6 +226,13 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->chain_flags) (void)hipFree(ctx->chain_flags);
     if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
+    if (ctx->aux) {
+        (void)hipStreamSynchronize(ctx->aux);
+        (void)hipStreamDestroy(ctx->aux);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->pipe_work) (void)hipFree(ctx->pipe_work);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return NZ_OK;
@@ -242,6 +249,7 @@ extern "C" void *nz_ctx_stream(nz_ctx *ctx) { return ctx ? (void *)ctx->stream :
 
 static int32_t ctx_sync_all(nz_ctx *ctx) {
     NZ_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux) NZ_HIP(hipStreamSynchronize(ctx->aux));  // (its work is joined into `stream` before a call returns)
     return NZ_OK;
 }
 static int32_t ctx_chain_check(nz_ctx *ctx);
@@ -252,12 +260,8 @@ static std::vector<nz_ctx *> g_reg;  // index = ctx id - 1; nullptr once destroy
 
 static void registry_add(nz_ctx *ctx) {
     std::lock_guard<std::mutex> lk(g_reg_mx);
-    for (size_t i = 0; i < g_reg.size(); i++)
-        if (!g_reg[i]) {
-            g_reg[i] = ctx;
-            ctx->id = (uint32_t)i + 1;
-            return;
-        }
+    // ids are never reused (24 bits of a handle: 16 M contexts per process): a stale handle of a destroyed context keeps
+    // naming that context, whose slot stays empty, and so reads as completed -- it can never alias a later context's marker
     g_reg.push_back(ctx);
     ctx->id = (uint32_t)g_reg.size();
 }
@@ -326,6 +330,28 @@ int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out) {
     NZ_HIP(hipEventRecord(*ev, ctx->stream));
     ctx->last_seq = q;
     *out = ((uint64_t)ctx->id << NZ_HANDLE_SEQ_BITS) | q;
+    return NZ_OK;
+}
+
+int32_t nz_ctx_pipe_state(nz_ctx *ctx, size_t floats, float **work) {
+    if (!ctx->aux) NZ_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    if (!ctx->ev_fork) NZ_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->ev_join) NZ_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    if (floats > ctx->pipe_work_floats) {
+        if (ctx->pipe_work) {
+            NZ_TRY_(ctx_sync_all(ctx));
+            NZ_HIP(hipFree(ctx->pipe_work));
+            ctx->pipe_work = nullptr;
+            ctx->pipe_work_floats = 0;
+        }
+        hipError_t e = hipMalloc((void **)&ctx->pipe_work, floats * sizeof(float));
+        if (e != hipSuccess) {
+            nz_set_error("hipMalloc(%zu floats): %s", floats, hipGetErrorString(e));
+            return NZ_ERR_NOMEM;
+        }
+        ctx->pipe_work_floats = floats;
+    }
+    *work = ctx->pipe_work;
     return NZ_OK;
 }
 
