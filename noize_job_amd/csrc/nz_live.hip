@@ -217,6 +217,9 @@ __global__ __launch_bounds__(64) void descent_kernel(live_planes P, const int32_
     if (pi >= n) return;
     const int NBDX[8] = {0, 1, 0, -1, 1, 1, -1, -1}, NBDZ[8] = {1, 0, -1, 0, 1, -1, -1, 1};
     const nz_particle src = particles[pi];
+    // a particle uploaded with a position outside the tile (nz_particle_queue_upload cannot know the resolution) is
+    // dropped: its first event would index the per-cell planes out of bounds
+    if ((unsigned)src.px >= (unsigned)res || (unsigned)src.pz >= (unsigned)res) return;
     float posx = (float)src.px, posz = (float)src.pz, dirx = 0.0f, dirz = 0.0f;
     float vel = .01f, water = src.water, sediment = 0.0f;
     int age = 0, events = 0;

@@ -228,8 +228,14 @@ class LiveErosion:
         self.waterControl = self.ctx.from_host(np.zeros(mres * mres * 4, np.uint8))
         self.textureControl = self.ctx.from_host(np.zeros(mres * mres * 4, np.uint8))
 
-    def OnDestroy(self):
+    def CompleteJob(self):
+        """jobHandle.Complete() of Update() (:330-343), plus what a NativeQueue cannot do silently: a queue that a job found
+        too small (drained pools or a top-up beyond its capacity drop particles, which changes the erosion) raises here."""
         self.jobHandle.Complete()
+        self.particleQueue.Count  # NZ_ERR_NOMEM -> exception if a job overflowed the queue
+
+    def OnDestroy(self):
+        self.CompleteJob()
         for t in (self.poolMap, self.streamMap, self.particleTrack, self.waterControl, self.textureControl):
             if t is not None:
                 t.Dispose()

@@ -249,6 +249,37 @@ def test_config4_live_erosion_equals_oracle(nj, ctx, oracle, res, particles, upd
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("res,particles,cycles", [(512, 10000, 300), (2048, 10000, 50)])
+def test_live_erosion_soak_equals_oracle_at_ten_checkpoints(nj, ctx, oracle, res, particles, cycles):
+    # The long-run regime of LiveErosion.TriggerQueuedBeyerMT (Component/LiveErosion.cs:378-436 loops
+    # erosionSettings.CYCLES): hundreds of cycles on one tile -- the terrain is cut down by most of its relief, a tenth of
+    # the cells hold water, pools fill, drain and re-enter the particle queue, piles accumulate -- compared with the
+    # oracle at ten checkpoints: every plane and the particle queue, bit for bit.
+    th, per = 1000, cycles // 10
+    h = oracle.fractal(oracle.CELLULAR, res, res, 0.4, 1.0, 2.0, 0.0, 13, 0, 0, 1700)
+    es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, CYCLES=per, WATER_STEPS=10)
+    tm = nj.tile_set_meta(res, height=th, tile_size=2000, tile_res=res - 16, margin=8)
+    G = nj.LiveErosion(ctx, ctx.from_host(h), tm, es)
+    L = oracle.LiveErosionOracle(h, _params(oracle, es), tile_height=th, patch_res=float(tm.PATCH_RES[0]))
+    shape = (res, res)
+    wet = []
+    for cp in range(10):
+        seeds = [7919 * cp + 13 * c + 1 for c in range(per)]
+        G.TriggerQueuedBeyerMT(seeds).Complete()
+        for c in range(per):
+            L.cycle(cp % 4, particles, seeds[c], water_steps=es.WATER_STEPS,
+                    thermal=(es.TALUS, es.THERMAL_STEP, float(2000 // th), es.THERMAL_CYCLES))
+        for name, got, want in (("height", G.heightMap, L.height), ("pool", G.poolMap, L.pool), ("flow", G.streamMap, L.flow),
+                                ("track", G.particleTrack, L.track)):
+            assert np.array_equal(got.ToArray(shape), want), (cp, name)
+        assert np.array_equal(np.sort(G.particleQueue.ToArray(), order=["px", "pz", "water"]),
+                              np.sort(L.queued(), order=["px", "pz", "water"])), cp
+        wet.append(float((L.pool > 0).mean()))
+    assert float(np.abs(L.height - h).max()) > 0.02 and wet[-1] > 0.001   # the run did leave the fresh-terrain regime
+    G.OnDestroy()
+
+
+@pytest.mark.gpu
 def test_config4_full_size_is_deterministic_and_keeps_its_invariants(nj, ctx, oracle):
     # BASELINE config 4 at its full size, 8192^2 cellular fBm 13 octaves + live erosion: too large to hand to the oracle
     # cycle by cycle in the suite's time, so the size-independent properties -- two runs from the same seeds agree bit

@@ -2,7 +2,10 @@
 """BASELINE config 4 on one MI355X: 8192^2 cellular fBm (13 octaves) base + live particle erosion
 (LiveErosion.TriggerQueuedBeyerMT: thermal -> spawn -> descent -> event reduce -> sediment -> flow from track ->
 pool automaton), per-job GPU time from HIP events on the context's stream, whole cycles per second.
-usage: bench_config4.py [--res 8192] [--particles 10000] [--cycles 20] [--water-steps 10] [--json out.json]"""
+usage: bench_config4.py [--res 8192] [--particles 10000] [--cycles 20] [--water-steps 10] [--json out.json]
+                        [--at 1,100,1000]   per-job times around these cycle counts of ONE long run (the long-run regime:
+                                            relief cut down, a tenth of the cells holding water, pools draining into the
+                                            queue), with the share of cells under water and acting in the automaton"""
 import argparse
 import ctypes as C
 import json
@@ -21,6 +24,8 @@ def main():
     ap.add_argument("--cycles", type=int, default=20)
     ap.add_argument("--water-steps", type=int, default=10)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--at", default="", help="comma-separated cycle counts of one long run at which the per-job times are taken")
+    ap.add_argument("--skip-fresh", action="store_true", help="only the --at run")
     a = ap.parse_args()
     res = a.res
     out = {"config": "%dx%d cellular-13oct base + live particle erosion, %d particles per cycle, WATER_STEPS %d" %
@@ -57,6 +62,53 @@ def main():
             ("pool_automata", lambda: ctx.call("nz_pool_automata_job", G.poolMap.ptr, h.ptr, G.particleQueue._h, epp, tmp_,
                                                a.water_steps, res, 1)),
         ]
+        if a.at:
+            # one long run; around every checkpoint the jobs of 10 cycles are bracketed with stream markers
+            import numpy as np
+            checkpoints = sorted(int(x) for x in a.at.split(",") if x)
+            out["long_run"] = {}
+            done = 0
+            seed = 1
+
+            def one_cycle(timed):
+                nonlocal seed
+                seed += 1
+                jobs[1] = ("spawn", lambda: ctx.call("nz_fill_beyer_queue", G.particleQueue._h, epp, tmp_, (seed // 30) % 4, res,
+                                                     a.particles, seed, 10))
+                marks = [ctx.record()] if timed else None
+                for _, fn in jobs:
+                    fn()
+                    if timed:
+                        marks.append(ctx.record())
+                return marks
+            for cp in checkpoints:
+                while done < cp - 5:
+                    one_cycle(False)
+                    done += 1
+                    if done % 64 == 0:
+                        ctx.synchronize()
+                acc_cp = {n: 0.0 for n, _ in jobs}
+                ev = 0
+                for _ in range(10):
+                    marks = one_cycle(True)
+                    marks[-1].Complete()
+                    for i, (n, _) in enumerate(jobs):
+                        acc_cp[n] += ctx.elapsed_ms(marks[i], marks[i + 1])
+                    ev += G.events.Count
+                    done += 1
+                pool = G.poolMap.ToArray()
+                out["long_run"]["cycle_%d" % cp] = {
+                    "per_job_ms": {n: round(v / 10, 4) for n, v in acc_cp.items()}, "cycle_ms": round(sum(acc_cp.values()) / 10, 4),
+                    "events_per_cycle": ev // 10, "cells_holding_water": round(float((pool > 0).mean()), 5),
+                    "cells_acting_in_the_automaton": round(float((pool >= 1e-3).mean()), 6),
+                    "queue_before_spawn": int(G.particleQueue.Count)}
+            if a.skip_fresh:
+                print(json.dumps(out, indent=1))
+                if a.json:
+                    with open(a.json, "w") as f:
+                        json.dump(out, f, indent=1)
+                G.OnDestroy()
+                return
         acc = {n: 0.0 for n, _ in jobs}
         events = 0
         for cyc in range(a.cycles + 2):
