@@ -309,6 +309,10 @@ __global__ __launch_bounds__(256) void pool_masks_clean_kernel(const float *__re
 }
 
 constexpr int PRT = 256;  // threads per workgroup: a pass is 50 tiny launches, 4x fewer workgroups dispatch faster
+#ifndef NZ_POOL_PR
+#define NZ_POOL_PR 8
+#endif
+constexpr int PR = NZ_POOL_PR;  // steps of a run whose loads are in flight together (all-wet 8192^2: 305 ms one step at a time, 212 with 8, 222 with 16: what is left is the ~1 us instruction stream of a step)
 template <bool DRAIN>
 __global__ __launch_bounds__(PRT) void pool_runs_kernel(float *pool, const float *__restrict__ height, pool_masks pm,
                                                       int res, int xoff, int zoff, int32_t *drain_hdr,
@@ -330,45 +334,54 @@ __global__ __launch_bounds__(PRT) void pool_runs_kernel(float *pool, const float
         int ww = w, bit = first;
         unsigned m = m0;
         int x = xbase + 2 * (32 * w + first);
-        float sw, sh, nh[4], nw[4];
-        {
-            const int xr = min(x + 1, res - 1), xl = max(x - 1, 0);
-            const size_t c = (size_t)x * res;
-            sw = pool[c + z];                       sh = height[c + z];
-            nh[0] = height[c + zu];                 nw[0] = pool[c + zu];                  // up
-            nh[1] = height[(size_t)xr * res + z];   nw[1] = pool[(size_t)xr * res + z];    // right
-            nh[2] = height[c + zd];                 nw[2] = pool[c + zd];                  // down
-            nh[3] = height[(size_t)xl * res + z];   nw[3] = pool[(size_t)xl * res + z];    // left
-        }
+        float carry = 0.0f;
+        bool have_carry = false;  // the run's first step reads its left-hand cell from memory, the later ones carry it
         for (;;) {
-            // does the run go on?  (a step past the end of the row has no bit)
-            bool more;
-            if (bit < 31) {
-                more = (m >> (bit + 1)) & 1u;
-            } else {
-                m = ww + 1 < words ? mask[(size_t)(ww + 1) * walks + k] : 0u;
-                more = m & 1u;
+            // the steps of this run inside the current mask word, PR at a time: their cells are written by no earlier
+            // step of the walk except the left-hand one, which travels in `carry` -- so the loads of PR steps go out
+            // together and a long run (standing water) pays one memory round trip per PR steps, not one per step
+            const unsigned rest = m >> bit;
+            int ones = rest == 0xffffffffu ? 32 : __builtin_ctz(~rest);  // >= 1: bit `bit` is set
+            // a run that reaches the end of the word goes on in the next one: its bits are asked for now
+            const bool to_end = bit + ones == 32 && ww + 1 < words;
+            const unsigned mnext = to_end ? mask[(size_t)(ww + 1) * walks + k] : 0u;
+            while (ones > 0) {
+                const int n = min(ones, PR);
+                float sw[PR], sh[PR], nh[PR][4], nw[PR][4];
+#pragma unroll
+                for (int u = 0; u < PR; u++) {
+                    if (u < n) {
+                        const int xs = x + 2 * u;
+                        const int xr = min(xs + 1, res - 1), xl = max(xs - 1, 0);
+                        const size_t c = (size_t)xs * res;
+                        sw[u] = pool[c + z];                       sh[u] = height[c + z];
+                        nh[u][0] = height[c + zu];                 nw[u][0] = pool[c + zu];                  // up
+                        nh[u][1] = height[(size_t)xr * res + z];   nw[u][1] = pool[(size_t)xr * res + z];    // right
+                        nh[u][2] = height[c + zd];                 nw[u][2] = pool[c + zd];                  // down
+                        nh[u][3] = height[(size_t)xl * res + z];                                             // left
+                        nw[u][3] = (u == 0 && !have_carry) ? pool[(size_t)xl * res + z] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PR; u++) {
+                    if (u < n) {
+                        if (u > 0 || have_carry) nw[u][3] = carry;
+                        carry = nw[u][1];
+                        have_carry = true;
+                        if (pool_step_acts(sw[u]))  // a stale bit: the step stays in its run and does nothing
+                            spread_pool_step<DRAIN, true>(pool, res, x + 2 * u, z, zu, zd, sw[u], sh[u], nh[u], nw[u], carry,
+                                                          drain_hdr, drain_data, pm);
+                    }
+                }
+                x += 2 * n;
+                bit += n;
+                ones -= n;
             }
-            float sw2 = 0.0f, sh2 = 0.0f, nh2[4] = {0.0f, 0.0f, 0.0f, 0.0f}, nw2[3] = {0.0f, 0.0f, 0.0f};
-            if (more) {  // the next step's cells, none of them written by this step -- except its left-hand one
-                const int x2 = x + 2;
-                const int xr = min(x2 + 1, res - 1);
-                const size_t c = (size_t)x2 * res;
-                sw2 = pool[c + z];                       sh2 = height[c + z];
-                nh2[0] = height[c + zu];                 nw2[0] = pool[c + zu];
-                nh2[1] = height[(size_t)xr * res + z];   nw2[1] = pool[(size_t)xr * res + z];
-                nh2[2] = height[c + zd];                 nw2[2] = pool[c + zd];
-                nh2[3] = height[(size_t)(x2 - 1) * res + z];
-            }
-            float carry = nw[1];
-            if (pool_step_acts(sw))  // a stale bit: the step stays in its run and does nothing
-                spread_pool_step<DRAIN, true>(pool, res, x, z, zu, zd, sw, sh, nh, nw, carry, drain_hdr, drain_data, pm);
-            if (!more) break;
-            x += 2;
-            if (bit < 31) bit++; else { bit = 0; ww++; }
-            sw = sw2; sh = sh2;
-            nh[0] = nh2[0]; nh[1] = nh2[1]; nh[2] = nh2[2]; nh[3] = nh2[3];
-            nw[0] = nw2[0]; nw[1] = nw2[1]; nw[2] = nw2[2]; nw[3] = carry;
+            if (!to_end) break;  // the run ended inside this word (or with the row)
+            ww++;
+            m = mnext;
+            bit = 0;
+            if (!(m & 1u)) break;
         }
     }
 }
