@@ -257,15 +257,18 @@ int32_t launch_stream(hipStream_t s, const float *src, float *dst, const nz_geom
 // largest T the streaming form holds (0: this tap count has none)
 int nz_conv_stream_max(int ksize) { return ksize == 3 || ksize == 5 ? 6 : 0; }
 
-// The streaming form wants a grid that fills the chip with waves of at least a few dozen rows, and buffer offsets of 32
-// bits with room for the out-of-range marker (planes below 2 GiB).  NZ_CONV_STREAM=0: never; 2: every size (test matrix).
+// NZ_CONV_STREAM=1: the streaming form for grids of 40 M cells and more; 2: every size (test matrix); default 0: never.
+// Measured against the tile kernels (chained at 4096^2, separate launches elsewhere), Gauss5 x17: 4096^2 0.228 against
+// 0.206 ms (a segment of ~50 rows spends a fifth of its steps filling the pipeline), 8192^2 0.743 against 0.767,
+// 16384^2 2.90 against 2.52, a 2048 x 16384 stripe 0.432 against 0.391: per output cell it executes 7 % fewer
+// instructions, but its per-wave streams (512 B per row, one row stride apart) use HBM worse than tile loads, and four
+// launches of ~3000 long waves each end in a tail of lone waves.  Kept as the barrier-free reference form; buffer offsets
+// are 32 bits with room for the out-of-range marker, so planes must stay below 2 GiB.
 bool nz_conv_stream_wanted(const nz_geom &g, int ksize, int T) {
-    static const int mode = getenv("NZ_CONV_STREAM") ? atoi(getenv("NZ_CONV_STREAM")) : 1;
+    static const int mode = getenv("NZ_CONV_STREAM") ? atoi(getenv("NZ_CONV_STREAM")) : 0;
     if (mode == 0 || T < 1 || T > nz_conv_stream_max(ksize)) return false;
     if ((size_t)g.rows * g.pitch * 4 >= ((size_t)1 << 31)) return false;
     if (mode == 2) return true;
-    // Gauss5 x17: 4096^2 0.228 against 0.206 ms for the chained tile kernel (a segment of ~50 rows spends a fifth of its
-    // steps filling the pipeline), 8192^2 0.743 against 0.767: the row-streaming form pays from ~6000^2 cells on
     return (long long)g.cols * (g.or1 - g.or0) * g.count >= 40ll * 1024 * 1024;
 }
 
