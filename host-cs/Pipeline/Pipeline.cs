@@ -48,6 +48,7 @@ namespace xshazwar.noize.hip {
 
     public abstract class PipelineStage {        // PipelineStage.cs:10-62
         protected readonly GpuContext ctx;
+        public GpuContext Context => ctx;
         public GpuJobHandle jobHandle;
         public Action<PipelineWorkItem, GpuJobHandle> OnStageScheduledAction;
         protected int dataLength = 0;
@@ -113,11 +114,59 @@ namespace xshazwar.noize.hip {
                                                  dependency = dependency });
         }
 
+        // Opt-in: the stock stage list -- NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionStage], README.md:23-32
+        // -- on a tile big enough to split goes to the library as ONE call (nz_terrain_pipeline: two independent row stripes
+        // on two streams of the context, ghost rows recomputed; same plane, bit for bit).  Every stage still gets its
+        // jobHandle, TransformData and scheduled actions; no WRITE plane and no stage scratch are needed.
+        public bool fuseStages = false;
+        public bool lastScheduleWasOneCall = false;
+
         public void Schedule(PipelineWorkItem item) {                                               // :104-120
             activeItem = item;
             if (stage_instances.Count == 0) throw new Exception("No stages in pipeline");
             pipelineBeingScheduled = true;
-            stage_instances[0].ReceiveHandledInput(activeItem, activeItem.dependency);
+            lastScheduleWasOneCall = fuseStages && ScheduleStockList();
+            if (!lastScheduleWasOneCall) stage_instances[0].ReceiveHandledInput(activeItem, activeItem.dependency);
+        }
+
+        bool ScheduleStockList() {
+            if (!(activeItem.data is GeneratorData d) || d is GeneratorDataBatch || stage_instances.Count < 2) return false;
+            if (stage_instances[0].GetType() != typeof(NoiseStage)) return false;
+            NoiseStage n = (NoiseStage) stage_instances[0];
+            KernelFilterStage f = null; FlowMapStage w = null; ErosionStage e = null;
+            int k = 0;                           // the optional stages in this order, each at most once
+            for (int i = 1; i < stage_instances.Count; i++) {
+                PipelineStage s = stage_instances[i];
+                if (!ReferenceEquals(s.Context, n.Context)) return false;
+                if (k < 1 && s.GetType() == typeof(KernelFilterStage)) { f = (KernelFilterStage) s; k = 1; }
+                else if (k < 2 && s.GetType() == typeof(FlowMapStage)) { w = (FlowMapStage) s; k = 2; }
+                else if (k < 3 && s.GetType() == typeof(ErosionStage)) { e = (ErosionStage) s; k = 3; }
+                else return false;
+            }
+            if (f != null && f.filter == KernelFilterType.Sobel3_2D) return false;
+            NzTerrainParams tp = new NzTerrainParams {
+                noiseType = (int) n.noiseType, hurst = n.hurst, startingAmplitude = n.startingAmplitude, stepdown = n.stepdown,
+                detuneRate = n.detuneRate, octaves = n.octaves, noiseSize = n.noiseSize,
+                filter = f != null ? (int) f.filter : 0, filterIterations = f != null ? f.iterations : 0,
+                flowIterations = w != null ? w.iterations : 0, normMin = w != null ? w.normMin : 0f, normMax = w != null ? w.normMax : 0f,
+                erosionIterations = e != null ? e.iterations : 0 };
+            if (Native.nz_terrain_pipeline_stripes(ref tp, d.resolution) <= 0) return false;
+            Native.Check(Native.nz_terrain_pipeline(n.Context.Handle, d.data.Ptr, d.resolution, d.xpos, d.zpos, ref tp, null,
+                                                    activeItem.dependency.id, out ulong h), "nz_terrain_pipeline");
+            GpuJobHandle done = n.Context.Wrap(h);
+            for (int i = 0; i < stage_instances.Count; i++) {
+                PipelineStage s = stage_instances[i];
+                s.jobHandle = done;
+                s.TransformData(activeItem);
+                // every scheduled action except the hand-over to the next stage, which happened inside the call
+                if (s.OnStageScheduledAction == null) continue;
+                foreach (Delegate a in s.OnStageScheduledAction.GetInvocationList()) {
+                    bool chain = i + 1 < stage_instances.Count && ReferenceEquals(a.Target, stage_instances[i + 1]) &&
+                                 a.Method.Name == nameof(PipelineStage.ReceiveHandledInput);
+                    if (!chain) ((Action<PipelineWorkItem, GpuJobHandle>) a)(activeItem, done);
+                }
+            }
+            return true;
         }
 
         void OnPipelineFullyScheduled(PipelineWorkItem res, GpuJobHandle handle) {                  // :122-128

@@ -15,6 +15,19 @@ namespace xshazwar.noize.hip {
     [StructLayout(LayoutKind.Sequential)]
     public struct NzRwTile { public IntPtr read, write; public int resolution, count; }           // nz_rw_tile
 
+    // the stock stage list handed over as one call (nz_terrain_pipeline)
+    [StructLayout(LayoutKind.Sequential)]
+    public struct NzTerrainParams {                                                                  // nz_terrain_params
+        public int noiseType;
+        public float hurst, startingAmplitude, stepdown, detuneRate;
+        public int octaves, noiseSize;
+        public int filter;
+        public int filterIterations;
+        public int flowIterations;
+        public float normMin, normMax;
+        public int erosionIterations;
+    }
+
     // ErosionParameters, Geologic/ParticleErosion/LiveErosionDataTypes.cs:78-100 (field order kept)
     [StructLayout(LayoutKind.Sequential)]
     public struct NzErosionParams {

@@ -27,7 +27,9 @@ int main(int argc, char **argv) {
     // `rw`: the tile is a READ / WRITE plane pair and the stencil stages swap it instead of flushing (nz_*_rw)
     const bool live = argc > 5 && std::strcmp(argv[3], "live") == 0;
     const bool rw = argc > 3 && std::strcmp(argv[3], "rw") == 0;
-    if (rw) argc = 3;
+    // `onecall`: BasePipeline.fuseStages -- the stock stage list as one nz_terrain_pipeline call (tiles of 2048^2 and more)
+    const bool onecall = argc > 3 && std::strcmp(argv[3], "onecall") == 0;
+    if (rw || onecall) argc = 3;
     int G = argc > 3 ? std::atoi(argv[3]) : 17, F = argc > 4 ? std::atoi(argv[4]) : 5, E = argc > 5 ? std::atoi(argv[5]) : 5;
     try {
         nz_ctx *ctx = nullptr;
@@ -197,6 +199,7 @@ int main(int argc, char **argv) {
             ErosionStage erosion(ctx);
             erosion.iterations = E;
             BasePipeline pipe({&noise, &gauss, &flow, &erosion});
+            pipe.fuseStages = onecall;
             GeneratorData gd;
             gd.uuid = "host-demo";
             gd.data = &tile;
@@ -210,6 +213,7 @@ int main(int argc, char **argv) {
             pipe.Enqueue(&gd, nullptr, [&](StageIO *) { completed++; });
             pipe.RunToCompletion();
             if (completed != 1) throw std::runtime_error("completeAction did not fire");
+            if (onecall && !pipe.lastScheduleWasOneCall) throw std::runtime_error("the one-call form did not apply");
             std::vector<float> host((size_t)res * res);
             gd.data->CopyTo(host.data());  // with a pair, `data` is whichever plane the last stage left the result in
             FILE *f = std::fopen(argv[2], "wb");

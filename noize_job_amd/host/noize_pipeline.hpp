@@ -18,6 +18,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <typeinfo>
 #include <vector>
 
 #include "../../include/noize_hip.h"
@@ -171,7 +172,10 @@ class PipelineStateManager {
 };
 
 // ---- PipelineStage ---------------------------------------------------------------------------
+class BasePipeline;
 class PipelineStage {
+    friend class BasePipeline;  // the one-call form of the stock stage list sets the stages' handles itself
+
   public:
     explicit PipelineStage(nz_ctx *c) : ctx(c) {}
     virtual ~PipelineStage() = default;
@@ -608,11 +612,18 @@ class BasePipeline {
                  std::function<void(StageIO *)> completeAction = nullptr, JobHandle dependency = JobHandle()) {
         queue.push_back(PipelineWorkItem{input, completeAction, scheduleAction, dependency, contextManager});
     }
+    // Opt-in: the stock stage list -- NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionStage], README.md:23-32
+    // -- on a tile big enough to split goes to the library as ONE call (nz_terrain_pipeline: two independent row stripes
+    // on two streams of the context, ghost rows recomputed; same plane, bit for bit).  Every stage still gets its
+    // jobHandle, TransformData and scheduled actions; it saves the WRITE plane and the stages' scratch planes.
+    bool fuseStages = false;
+    bool lastScheduleWasOneCall = false;
     void Schedule(PipelineWorkItem wi) {
         activeItem = std::move(wi);
         if (stage_instances.empty()) throw std::runtime_error("No stages in pipeline");
         pipelineBeingScheduled = true;
-        stage_instances[0]->ReceiveHandledInput(activeItem, activeItem.dependency);
+        lastScheduleWasOneCall = fuseStages && ScheduleStockList();
+        if (!lastScheduleWasOneCall) stage_instances[0]->ReceiveHandledInput(activeItem, activeItem.dependency);
     }
     bool WorkIsSchedulable(const PipelineWorkItem &item) {  // Pipeline.cs:256-265
         bool ready = true;
@@ -669,13 +680,21 @@ class BasePipeline {
     }
 
   protected:
+    // the stock list as one call; false: this list / work item / tile keeps the stage-by-stage hand-over
+    bool ScheduleStockList();
+    std::vector<size_t> chainLink;  // per stage: index of the hand-over to the next stage in its OnStageScheduledAction
     void Setup() {
         PipelineStage *previous = nullptr;
+        chainLink.assign(stage_instances.size(), (size_t)-1);
+        size_t i = 0;
         for (auto *stage : stage_instances) {
-            if (previous)
+            if (previous) {
+                chainLink[i - 1] = previous->OnStageScheduledAction.size();
                 previous->OnStageScheduledAction.push_back(
                     [stage](PipelineWorkItem &wi, JobHandle h) { stage->ReceiveHandledInput(wi, h); });
+            }
             previous = stage;
+            i++;
         }
         if (previous)
             previous->OnStageScheduledAction.push_back([this](PipelineWorkItem &wi, JobHandle h) {
@@ -871,5 +890,45 @@ class LiveErosion {
     nz_erosive_events *events = nullptr;
     JobHandle jobHandle;
 };
+
+
+inline bool BasePipeline::ScheduleStockList() {
+    auto *d = dynamic_cast<GeneratorData *>(activeItem.data);
+    if (!d || dynamic_cast<GeneratorDataBatch *>(d) || stage_instances.size() < 2) return false;
+    auto *n = dynamic_cast<NoiseStage *>(stage_instances[0]);
+    if (!n) return false;
+    KernelFilterStage *f = nullptr;
+    FlowMapStage *w = nullptr;
+    ErosionStage *e = nullptr;
+    int k = 0;  // the optional stages must come in this order, each at most once
+    for (size_t i = 1; i < stage_instances.size(); i++) {
+        PipelineStage *s = stage_instances[i];
+        if (s->ctx != n->ctx) return false;
+        if (k < 1 && typeid(*s) == typeid(KernelFilterStage)) { f = static_cast<KernelFilterStage *>(s); k = 1; }
+        else if (k < 2 && typeid(*s) == typeid(FlowMapStage)) { w = static_cast<FlowMapStage *>(s); k = 2; }
+        else if (k < 3 && typeid(*s) == typeid(ErosionStage)) { e = static_cast<ErosionStage *>(s); k = 3; }
+        else return false;
+    }
+    if (typeid(*n) != typeid(NoiseStage) || (f && f->filter == NZ_SOBEL3_2D)) return false;
+    nz_terrain_params tp{};
+    tp.noiseType = (int)n->noiseType;
+    tp.hurst = n->hurst; tp.startingAmplitude = n->startingAmplitude; tp.stepdown = n->stepdown; tp.detuneRate = n->detuneRate;
+    tp.octaves = n->octaves; tp.noiseSize = n->noiseSize;
+    tp.filter = f ? f->filter : 0; tp.filterIterations = f ? f->iterations : 0;
+    tp.flowIterations = w ? w->iterations : 0; tp.normMin = w ? w->normMin : 0.f; tp.normMax = w ? w->normMax : 0.f;
+    tp.erosionIterations = e ? e->iterations : 0;
+    if (nz_terrain_pipeline_stripes(&tp, d->resolution) <= 0) return false;
+    nz_handle h = 0;
+    check(nz_terrain_pipeline(n->ctx, d->data->ptr, d->resolution, d->xpos, d->zpos, &tp, nullptr, activeItem.dependency.id, &h),
+          "nz_terrain_pipeline");
+    for (size_t i = 0; i < stage_instances.size(); i++) {
+        PipelineStage *s = stage_instances[i];
+        s->jobHandle = JobHandle{n->ctx, h};
+        s->TransformData(activeItem);
+        for (size_t a = 0; a < s->OnStageScheduledAction.size(); a++)
+            if (a != chainLink[i]) s->OnStageScheduledAction[a](activeItem, s->jobHandle);  // the hand-over happened inside the call
+    }
+    return true;
+}
 
 }  // namespace noize

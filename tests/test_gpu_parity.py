@@ -373,6 +373,9 @@ def test_cpp_host_mirror_runs_the_metric_pipeline(oracle, tmp_path):
     # the same pipeline on a READ / WRITE plane pair (nz_*_rw entries: SWAP_RWTILE as a pointer swap)
     subprocess.check_call([exe, "256", out, "rw"])
     assert np.array_equal(np.fromfile(out, dtype=np.float32).reshape(256, 256), got)
+    # BasePipeline.fuseStages of the C++ mirror: the stock list as one nz_terrain_pipeline call, at a size it applies to
+    subprocess.check_call([exe, "2048", out, "onecall"])
+    assert np.array_equal(np.fromfile(out, dtype=np.float32).reshape(2048, 2048), oracle.pipeline(2048, 2048))
     # ReducePipeline of the C++ mirror: simplex (left) x cellular (right), MULTIPLY
     subprocess.check_call([exe, "200", out, "reduce"])
     got = np.fromfile(out, dtype=np.float32).reshape(200, 200)

@@ -131,7 +131,7 @@ def test_sequential_structs_match_the_c_structs():
 
     kind = {"int32_t": "int", "float": "float", "uint32_t": "uint"}
     for cname, csname in (("nz_stripe", "NzStripe"), ("nz_rw_tile", "NzRwTile"), ("nz_erosion_params", "NzErosionParams"),
-                          ("nz_tile_set_meta", "NzTileSetMeta")):
+                          ("nz_tile_set_meta", "NzTileSetMeta"), ("nz_terrain_params", "NzTerrainParams")):
         cf, sf = c_fields(cname), cs_fields(csname)
         assert [n for _, n in cf] == [n for _, n in sf], cname
         for (ct, n), (st, _) in zip(cf, sf):
