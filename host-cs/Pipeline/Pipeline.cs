@@ -130,7 +130,7 @@ namespace xshazwar.noize.hip {
         }
 
         bool ScheduleStockList() {
-            if (!(activeItem.data is GeneratorData d) || d is GeneratorDataBatch || stage_instances.Count < 2) return false;
+            if (!(activeItem.data is GeneratorData d) || d.GetType() != typeof(GeneratorData) || stage_instances.Count < 2) return false;
             if (stage_instances[0].GetType() != typeof(NoiseStage)) return false;
             NoiseStage n = (NoiseStage) stage_instances[0];
             KernelFilterStage f = null; FlowMapStage w = null; ErosionStage e = null;
