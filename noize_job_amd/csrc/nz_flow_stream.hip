@@ -42,6 +42,9 @@ __device__ unsigned long long *nz_flow_probe_buf = nullptr;  // [wave][8]
 #else
 #define NZ_FPROBE(slot, val)
 #endif
+#ifndef NZ_FS_WPE
+#define NZ_FS_WPE 3  // waves per SIMD the four- and five-iteration kernels are register-allocated for (2: 176 VGPRs, no spill, same time)
+#endif
 #ifndef NZ_FS_PRIO
 #define NZ_FS_PRIO 0
 #endif
@@ -342,7 +345,7 @@ __device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__re
 }
 
 template <int NST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NST >= 4 ? 3 : 4))) void flow_stream_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NST >= 4 ? NZ_FS_WPE : 4))) void flow_stream_kernel(
     const float *__restrict__ h, float *__restrict__ dst, nz_geom g, int S, int nstrips, int Se, int nseg_edge, float nmin,
     float nrange, int aligned) {
     __shared__ float2 s_ring[FS_RING * 64];
