@@ -318,8 +318,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
 // are dealt so that a class works through a contiguous eighth of every launch's tiles, in launch order), waits until
 // the <= 9 tiles of the previous launch that its input window touches have been stored, and runs the same tile code
 // with sc1 accesses.  Loads of launch l + 1 overlap arithmetic of launch l, and nothing drains in between.
-//   * work items are claimed with an atomic ticket per class, so a workgroup only ever waits for items that were
-//     claimed before its own: the wait cannot deadlock whatever order the hardware starts workgroups in;
+//   * work items are claimed with an atomic ticket per class, so within a class a workgroup only ever waits for items
+//     claimed before its own.  Across classes the producers of an item are claimed by workgroups of OTHER classes, which
+//     must get dispatched: progress rests on the hardware starting workgroups in index order, round-robin over the XCDs
+//     (observed, not promised).  Termination does not: the poll is bounded, see below, and a context whose chained launch
+//     ever timed out runs separate launches from then on (nz_runtime.cpp, ctx_chain_check);
 //   * hand-off: producer = sc1 stores, every wave s_waitcnt vmcnt(0), workgroup barrier, ONE lane stores the tile's
 //     flag (agent scope); consumer = up to nine lanes poll one flag each (sc1 loads), workgroup barrier, sc1 loads;
 //   * the poll is bounded: a workgroup that gives up raises ctl[NZ_CHAIN_ERR] and carries on, so the grid always

@@ -58,6 +58,7 @@ struct nz_ctx {
     size_t chain_flags_n = 0;
     unsigned *chain_ctl = nullptr;
     unsigned chain_epoch = 0;
+    bool chain_off = false;  // a chained launch once timed out on this context: separate launches from then on
     // striped pipeline (nz_terrain_pipeline): a second stream with its fork / join markers and the stripes' planes, all
     // created on first use
     hipStream_t aux = nullptr;

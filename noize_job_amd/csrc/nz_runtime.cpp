@@ -407,7 +407,14 @@ static int32_t ctx_chain_check(nz_ctx *ctx) {
     NZ_HIP(hipMemcpy(&err, ctx->chain_ctl + 9, sizeof err, hipMemcpyDeviceToHost));
     if (err) {
         (void)hipMemset(ctx->chain_ctl, 0, 64);
-        nz_set_error("a chained kernel-filter launch timed out waiting for a producer tile: its results are invalid");
+        // The wait of a chained launch terminates whatever happens (bounded poll), but it only makes PROGRESS while the
+        // hardware starts the grid's workgroups in index order, round-robin over the XCDs -- a consumer's producers belong
+        // to other ticket classes (blockIdx.x & 7), and those are claimed by workgroups that must get dispatched.  That
+        // is observed behaviour, not a contract (CU masking or a partitioned mode could break it): after one timeout the
+        // context falls back to separate launches for good.
+        ctx->chain_off = true;
+        nz_set_error("a chained kernel-filter launch timed out waiting for a producer tile: its results are invalid; this "
+                     "context now runs filter stages as separate launches");
         return NZ_ERR_HIP;
     }
     return NZ_OK;
