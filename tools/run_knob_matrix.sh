@@ -1,7 +1,14 @@
 #!/bin/bash
 # The whole GPU suite under every tuning knob of DESIGN.md section 6 (none of them may change a result).
+#   tools/run_knob_matrix.sh [first [last]]   -- knobs first..last of the list (0-based), default all
 cd "$(dirname "$0")/.."
-for kv in NZ_THERMAL_PAIRS=0 NZ_POOL_RUNS=0 NZ_CONV_CHAIN=0 NZ_CONV_CHAIN=2 NZ_WIDE_BIG_FROM=11 NZ_NOISE_TAB=0 NZ_CONV_TCAP=1 NZ_CONV_TCAP=2 NZ_CONV_TCAP=8 NZ_FLOW_NMAX=1 NZ_FLOW_NMAX=3 NZ_FLOW_OCC=2 NZ_EROSION_EMAX=1 NZ_EROSION_EMAX=4 NZ_EROSION_EMAX=5 NZ_FLOW_STREAM=0 NZ_FLOW_STREAM=2 NZ_CONV_STREAM=2 "NZ_FLOW_STREAM=2 NZ_FLOW_STREAM_WAVES=512" NZ_PIPELINE_STRIPES=0; do
+KNOBS=(NZ_THERMAL_PAIRS=0 NZ_POOL_RUNS=0 NZ_CONV_CHAIN=0 NZ_CONV_CHAIN=2 NZ_WIDE_BIG_FROM=11 NZ_NOISE_TAB=0 NZ_CONV_TCAP=1
+       NZ_CONV_TCAP=2 NZ_CONV_TCAP=8 NZ_FLOW_NMAX=1 NZ_FLOW_NMAX=3 NZ_FLOW_OCC=2 NZ_EROSION_EMAX=1 NZ_EROSION_EMAX=4
+       NZ_EROSION_EMAX=5 NZ_FLOW_STREAM=0 NZ_FLOW_STREAM=2 NZ_CONV_STREAM=2 "NZ_FLOW_STREAM=2 NZ_FLOW_STREAM_WAVES=512"
+       NZ_PIPELINE_STRIPES=0 "NZ_CONV_STREAM=2 NZ_CONV_STREAM_WAVES=700")
+first=${1:-0}; last=${2:-$((${#KNOBS[@]} - 1))}
+for ((i = first; i <= last && i < ${#KNOBS[@]}; i++)); do
+  kv=${KNOBS[$i]}
   echo "== $kv"
   env $kv timeout -k 10 300 python3 -m pytest tests -m gpu -q 2>&1 | tail -1
 done
