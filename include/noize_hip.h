@@ -435,6 +435,12 @@ int32_t nz_crop_job(nz_ctx *ctx, const float *input, int32_t inputResolution, fl
 int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, float incrementRatio, float meshHeightWidthRatio,
                            int32_t iterations, int32_t resolution, nz_handle dep, nz_handle *out);
 
+/* Test hook for the chained filter launches (a stage of three or more fused launches runs as ONE grid whose tiles wait
+ * for the tiles of the previous launch they depend on): the workgroup that takes work item `item` (items count through
+ * the chain, launch 0's tiles first) sleeps `sleeps` x ~3.4 us before it loads its tile -- a straggler that reads a plane
+ * later launches overwrite.  Results must not change.  item < 0: off. */
+int32_t nz_debug_chain_delay(int32_t item, int32_t sleeps);
+
 /* ---- a whole BasePipeline of the stock stages as one call -------------------------------------------------------
  * BasePipeline.Schedule hands a work item from stage to stage (Pipeline/Executable/Pipeline.cs:91-152,
  * Pipeline/Stage/PipelineStage.cs:41-48); when the stage list is NoiseStage -> [KernelFilterStage] -> [FlowMapStage] ->

@@ -107,6 +107,7 @@ SIGNATURES = {
     "nz_gauss_blur_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _i] + _tail),
     "nz_smooth_blur_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
     "nz_erosion_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
+    "nz_debug_chain_delay": (_i, [_i, _i]),
     "nz_terrain_pipeline_stripes": (_i, [tp_p, _i]),
     "nz_terrain_pipeline": (_i, [ctx_p, dev_ptr, _i, _i, _i, tp_p, handle_p] + _tail),
     "nz_kernel_filter_halo_rows": (_i, [_i, _i]),

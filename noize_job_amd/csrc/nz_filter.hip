@@ -340,6 +340,10 @@ struct nz_chain {
     int *flags;       // one per work item, indexed first[l] + tile
     unsigned *ctl;
     float *plane[2];  // launch l reads plane[l & 1] and writes plane[(l + 1) & 1]
+    // test hook (nz_debug_chain_delay): the workgroup that claims work item `delay_item` sleeps `delay_sleeps` x ~1 us
+    // between its dependency wait and its loads -- a straggler among the readers of a plane that later launches
+    // overwrite; -1: nobody
+    int delay_item, delay_sleeps;
 };
 
 __host__ __device__ __forceinline__ int chain_class_count(int n, int c) { return n > c ? (n - c + 7) >> 3 : 0; }  // #{vb < n : vb % 8 == c}
@@ -402,6 +406,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
         }
         __syncthreads();
     }
+    if (ch.first[l] + tile == ch.delay_item)
+        for (int i = 0; i < ch.delay_sleeps; i++) __builtin_amdgcn_s_sleep(127);  // 127 x 64 clocks ~ 3.4 us
     conv_tile<KS, UNIT, NT, true>(ch.plane[l & 1], ch.plane[(l + 1) & 1], g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
     __syncthreads();
@@ -722,6 +728,8 @@ int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom 
     return NZ_OK;
 }
 
+int g_chain_delay_item = -1, g_chain_delay_sleeps = 0;  // nz_debug_chain_delay
+
 template <int KS>
 int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
                      int L, int *flags, unsigned *ctl, unsigned epoch) {
@@ -743,6 +751,8 @@ int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom 
     ch.ctl = ctl;
     ch.plane[0] = plane0;
     ch.plane[1] = plane1;
+    ch.delay_item = g_chain_delay_item;
+    ch.delay_sleeps = g_chain_delay_sleeps;
     int aligned = ((reinterpret_cast<uintptr_t>(plane0) | reinterpret_cast<uintptr_t>(plane1) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
     if (k.factor == 1.0f)
         hipLaunchKernelGGL((conv_chain_kernel<KS, true, NT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned);
@@ -888,3 +898,11 @@ extern "C" int32_t nz_debug_set_conv_probe(void *buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(nz_probe_buf), &buf, sizeof buf) == hipSuccess ? 0 : -3;
 }
 #endif
+
+// Test hook: the workgroup that claims work item `item` of every chained launch from now on (items count through the
+// launches of a chain: launch 0's tiles first) sleeps `sleeps` x ~3.4 us before it loads its tile; item < 0 switches it off.
+extern "C" int32_t nz_debug_chain_delay(int32_t item, int32_t sleeps) {
+    g_chain_delay_item = item;
+    g_chain_delay_sleeps = sleeps < 0 ? 0 : sleeps;
+    return NZ_OK;
+}

@@ -247,3 +247,28 @@ def test_striped_tile_random_shapes(nj, ctx, oracle, seed):
         want = oracle.pipeline(rows, cols, xpos=p.xpos, zpos=p.zpos, gauss_iterations=p.gaussIterations,
                                flow_iterations=p.flowIterations, erosion_iterations=p.erosionIterations)
         assert np.array_equal(got, want), (n, rows, cols, vars(p))
+
+
+def test_chained_filter_launches_tolerate_a_straggling_tile(nj, ctx, oracle):
+    # The launches of a filter stage run as ONE grid whose tiles wait for the previous launch's tiles they read -- and
+    # overwrite the plane that launch read.  A tile held up before its loads (nz_debug_chain_delay: ~0.3 ms, several
+    # launches' worth) must still find its input intact: the tiles of the next launch that store into its window are made
+    # to wait for it (write after read), whatever the fusion depths along the chain are.
+    lib = nj._native.lib
+    res = 1536
+    h = oracle.fractal(oracle.SIMPLEX, res, res, 0.4, 1.0, 2.0, 0.0, 6, 0, 0, 300)
+    want = oracle.kernel_filter(h, int(nj.KernelFilterType.Gauss5_S1), 17)
+    tiles0 = -(-res // 112) ** 2   # launch 0 of 17 = 4 + 4 + 4 + 5 applications: 112 x 112 interiors
+    data, write = ctx.from_host(h), ctx.alloc(res * res)
+    stage = nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17)
+    try:
+        for item in (0, 7, tiles0 // 2 + 3, tiles0 - 1, tiles0 + 5, 2 * tiles0 + 11, 3 * tiles0 - 2):
+            assert lib.nz_debug_chain_delay(item, 90) == 0
+            data.CopyFrom(h)
+            gd = nj.GeneratorData("t", data, res, 0, 0, write=write)
+            stage.ReceiveHandledInput(nj.PipelineWorkItem(gd), nj.JobHandle())
+            stage.jobHandle.Complete()
+            assert np.array_equal(gd.data.ToArray((res, res)), want), item
+    finally:
+        lib.nz_debug_chain_delay(-1, 0)
+    stage.OnDestroy()
