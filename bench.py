@@ -127,7 +127,9 @@ def load_counters(res, flush):
                 d = json.load(f)
         except (OSError, ValueError):
             continue
-        c = d.get("config", {})
+        c = d.get("config", {}) if isinstance(d, dict) else {}
+        if not isinstance(c, dict) or "kernels" not in d:  # another tool's summary (e.g. *_config4_counters.json)
+            continue
         if c.get("kernel_sources_sha") == sha and c.get("flush") == flush and not c.get("sharded"):
             best = (path, d)
     if best is None:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel times and counters of BASELINE config 4's cycle in its long-run regime (around cycle 100 of one run), on the
-# GPU box:   tools/collect_config4.sh <tag>   ->  gpurun_out/<tag>_config4_kernel_stats.csv, <tag>_config4_counters.json
+# GPU box:   tools/collect_config4.sh <tag>   ->  gpurun_out/<tag>_config4_kernel_stats.csv, <tag>_config4_kernel_counters.json
 # Every counter group is its own rocprofv3 run with --kernel-trace only.
 set -e
 TAG=${1:-r03_vX}
@@ -20,7 +20,7 @@ for GROUP in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAV
   echo "group $i done"
 done
 cp "$(find "$P/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_config4_kernel_stats.csv"
-python3 - "$P" "$OUT/${TAG}_config4_counters.json" "$OUT/${TAG}_config4_kernel_stats.csv" <<'PY'
+python3 - "$P" "$OUT/${TAG}_config4_kernel_counters.json" "$OUT/${TAG}_config4_kernel_stats.csv" <<'PY'
 import collections, csv, glob, json, re, sys
 def short(name):
     name = name.replace("(anonymous namespace)::", "")
