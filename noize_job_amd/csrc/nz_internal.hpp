@@ -54,11 +54,10 @@ struct nz_ctx {
     size_t scratch_floats = 0;
     // chained launches (nz_launch_conv_chain): tile flags (grown on demand, never cleared: they carry an epoch) and
     // the control block {8 tickets, done, error, ...}
-    // (two sets: the second stream of the striped pipeline runs chained launches of its own at the same time)
-    int *chain_flags[2] = {nullptr, nullptr};
-    size_t chain_flags_n[2] = {0, 0};
-    unsigned *chain_ctl[2] = {nullptr, nullptr};
-    unsigned chain_epoch[2] = {0, 0};
+    int *chain_flags = nullptr;
+    size_t chain_flags_n = 0;
+    unsigned *chain_ctl = nullptr;
+    unsigned chain_epoch = 0;
     bool chain_off = false;  // a chained launch once timed out on this context: separate launches from then on
     // striped pipeline (nz_terrain_pipeline): a second stream with its fork / join markers and the stripes' planes, all
     // created on first use
@@ -181,8 +180,7 @@ int32_t nz_launch_conv_stream(hipStream_t s, const float *src, float *dst, const
 int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L);
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
                              const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch);
-int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch, int set = 0,
-                           hipStream_t stream = nullptr);
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch);
 // one whole application of a wide odd kernel (11..25 taps), src -> dst
 bool nz_conv_has_wide(int ksize);
 int32_t nz_launch_conv_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k);

@@ -224,10 +224,8 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     if (ctx->d_rgrad) (void)hipFree(ctx->d_rgrad);
     if (ctx->d_simplex) (void)hipFree(ctx->d_simplex);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    for (int k = 0; k < 2; k++) {
-        if (ctx->chain_flags[k]) (void)hipFree(ctx->chain_flags[k]);
-        if (ctx->chain_ctl[k]) (void)hipFree(ctx->chain_ctl[k]);
-    }
+    if (ctx->chain_flags) (void)hipFree(ctx->chain_flags);
+    if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
     if (ctx->aux) {
         (void)hipStreamSynchronize(ctx->aux);
         (void)hipStreamDestroy(ctx->aux);
@@ -378,49 +376,46 @@ int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out) {
 
 // The flags / control block of the chained launches.  Flags are compared with an epoch that grows by one per launch, so
 // stale contents never match; a (re)allocated array is zeroed and the epoch restarts above zero.
-int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch, int k, hipStream_t stream) {
-    if (!stream) stream = ctx->stream;
-    if (!ctx->chain_ctl[k]) {
-        NZ_HIP(hipMalloc((void **)&ctx->chain_ctl[k], 64));
-        NZ_HIP(hipMemsetAsync(ctx->chain_ctl[k], 0, 64, stream));
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch) {
+    if (!ctx->chain_ctl) {
+        NZ_HIP(hipMalloc((void **)&ctx->chain_ctl, 64));
+        NZ_HIP(hipMemsetAsync(ctx->chain_ctl, 0, 64, ctx->stream));
     }
-    if (items > ctx->chain_flags_n[k]) {
-        if (ctx->chain_flags[k]) {
+    if (items > ctx->chain_flags_n) {
+        if (ctx->chain_flags) {
             NZ_TRY_(ctx_sync_all(ctx));
-            NZ_HIP(hipFree(ctx->chain_flags[k]));
-            ctx->chain_flags[k] = nullptr;
-            ctx->chain_flags_n[k] = 0;
+            NZ_HIP(hipFree(ctx->chain_flags));
+            ctx->chain_flags = nullptr;
+            ctx->chain_flags_n = 0;
         }
         size_t n = items + items / 2 + 1024;
-        NZ_HIP(hipMalloc((void **)&ctx->chain_flags[k], n * sizeof(int)));
-        NZ_HIP(hipMemsetAsync(ctx->chain_flags[k], 0, n * sizeof(int), stream));
-        ctx->chain_flags_n[k] = n;
+        NZ_HIP(hipMalloc((void **)&ctx->chain_flags, n * sizeof(int)));
+        NZ_HIP(hipMemsetAsync(ctx->chain_flags, 0, n * sizeof(int), ctx->stream));
+        ctx->chain_flags_n = n;
     }
-    if (++ctx->chain_epoch[k] == 0) ctx->chain_epoch[k] = 1;  // 0 is what a fresh flag holds
-    *flags = ctx->chain_flags[k];
-    *ctl = ctx->chain_ctl[k];
-    *epoch = ctx->chain_epoch[k];
+    if (++ctx->chain_epoch == 0) ctx->chain_epoch = 1;  // 0 is what a fresh flag holds
+    *flags = ctx->chain_flags;
+    *ctl = ctx->chain_ctl;
+    *epoch = ctx->chain_epoch;
     return NZ_OK;
 }
 
 // a chained launch that gave up waiting for a producer tile has raised ctl[9]: reported wherever the host waits
 static int32_t ctx_chain_check(nz_ctx *ctx) {
-    for (int k = 0; k < 2; k++) {
-        if (!ctx->chain_ctl[k]) continue;
-        int err = 0;
-        NZ_HIP(hipMemcpy(&err, ctx->chain_ctl[k] + 9, sizeof err, hipMemcpyDeviceToHost));
-        if (err) {
-            (void)hipMemset(ctx->chain_ctl[k], 0, 64);
-            // The wait of a chained launch terminates whatever happens (bounded poll), but it only makes PROGRESS while the
-            // hardware starts the grid's workgroups in index order, round-robin over the XCDs -- a consumer's producers
-            // belong to other ticket classes (blockIdx.x & 7), and those are claimed by workgroups that must get dispatched.
-            // That is observed behaviour, not a contract (CU masking or a partitioned mode could break it): after one
-            // timeout the context falls back to separate launches for good.
-            ctx->chain_off = true;
-            nz_set_error("a chained kernel-filter launch timed out waiting for a producer tile: its results are invalid; this "
-                         "context now runs filter stages as separate launches");
-            return NZ_ERR_HIP;
-        }
+    if (!ctx->chain_ctl) return NZ_OK;
+    int err = 0;
+    NZ_HIP(hipMemcpy(&err, ctx->chain_ctl + 9, sizeof err, hipMemcpyDeviceToHost));
+    if (err) {
+        (void)hipMemset(ctx->chain_ctl, 0, 64);
+        // The wait of a chained launch terminates whatever happens (bounded poll), but it only makes PROGRESS while the
+        // hardware starts the grid's workgroups in index order, round-robin over the XCDs -- a consumer's producers belong
+        // to other ticket classes (blockIdx.x & 7), and those are claimed by workgroups that must get dispatched.  That
+        // is observed behaviour, not a contract (CU masking or a partitioned mode could break it): after one timeout the
+        // context falls back to separate launches for good.
+        ctx->chain_off = true;
+        nz_set_error("a chained kernel-filter launch timed out waiting for a producer tile: its results are invalid; this "
+                     "context now runs filter stages as separate launches");
+        return NZ_ERR_HIP;
     }
     return NZ_OK;
 }

@@ -1217,38 +1217,7 @@ extern "C" int32_t nz_terrain_pipeline(nz_ctx *ctx, float *data, int32_t resolut
     }
     int up_left = need_up, down_left = need_down, kind = 0;
     bool in_A[2] = {true, true};
-    // The filter launches of a stripe as one chained grid (conv_chain_kernel: tile-level dependencies instead of launch
-    // boundaries), under the stage's own rule (three launches or more of a 5..9-tap kernel).  The chain runs every launch
-    // on ONE window, so it takes the first launch's: the later launches then also produce ghost rows that nothing reads
-    // (their values near the buffer's ends are clamped against rows the buffer does not hold -- never within reach of the
-    // rows a later launch keeps).  An odd chain leaves the result in B.
-    size_t n_filter = 0;
-    while (n_filter < plan.size() && plan[n_filter].kind == 1) n_filter++;
-    static const int chain_mode = getenv("NZ_CONV_CHAIN") ? atoi(getenv("NZ_CONV_CHAIN")) : 1;
-    const bool chain = !ctx->chain_off && n_filter >= 3 && n_filter <= 8 && taps.ksize >= 5 && chain_mode != 0 &&
-                       n_filter < plan.size() && (size_t)R * R * 4 < ((size_t)1 << 32) &&
-                       !nz_conv_stream_wanted(geom(sp[0], 0, 0), taps.ksize, plan[0].n);
-    size_t first = 0;
-    if (chain) {
-        NZ_TRY(mark(1));
-        kind = 1;
-        int Ts[8];
-        for (size_t i = 0; i < n_filter; i++) Ts[i] = plan[n_filter - 1 - i].n;  // non-decreasing along the chain (tp_plan puts the larger first)
-        for (size_t i = 0; i < n_filter; i++) { up_left -= plan[i].up; down_left -= plan[i].down; }
-        for (int s = 0; s < P; s++) {
-            const stripe &q = sp[s];
-            // the window of the first launch: everything the launches after the filter still need, plus the later filter
-            // launches' own radii
-            const nz_geom g = geom(q, need_up - plan[n_filter - 1].up, need_down - plan[n_filter - 1].down);
-            int *flags = nullptr;
-            unsigned *ctl = nullptr, epoch = 0;
-            NZ_TRY(nz_ctx_chain_state(ctx, (size_t)nz_conv_chain_items(taps.ksize, g, Ts, (int)n_filter), &flags, &ctl, &epoch, s, q.st));
-            NZ_TRY(nz_launch_conv_chain(q.st, q.A, q.B, g, taps, Ts, (int)n_filter, flags, ctl, epoch));
-            in_A[s] = (n_filter & 1) == 0;
-        }
-        first = n_filter;
-    }
-    for (size_t i = first; i < plan.size(); i++) {
+    for (size_t i = 0; i < plan.size(); i++) {
         const tp_launch &l = plan[i];
         if (l.kind != kind) {
             kind = l.kind;
