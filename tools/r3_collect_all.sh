@@ -1,7 +1,7 @@
 set -x
 TAG=$1
 mkdir -p gpurun_out
-C=$(cat gpurun_out/.commit 2>/dev/null || echo unknown)
+C=${2:-unknown}
 bash tools/collect_profiles.sh $TAG $C swap > gpurun_out/collect_$TAG.log 2>&1; tail -n 6 gpurun_out/collect_$TAG.log
 bash tools/collect_stalls.sh $TAG > gpurun_out/${TAG}_stalls.txt 2>&1; tail -n 3 gpurun_out/${TAG}_stalls.txt
 python bench.py --flush copy --no-cpu-baseline > gpurun_out/${TAG}_bench_flush_copy.json 2>/dev/null
