@@ -101,6 +101,9 @@ namespace xshazwar.noize.hip {
             waterControl.CopyFrom(zeros); textureControl.CopyFrom(zeros);
         }
 
+        public bool parallelBranch = false;      // true: ErodeHeightMaps || UpdateFlowFromTrackJob on two streams, as in the reference's job graph (measured slower)
+        GpuContext branchCtx;                    // created on first use
+
         // TriggerQueuedBeyerMT :378-436.  seeds: one per cycle.
         public GpuJobHandle TriggerQueuedBeyerMT(int[] seeds) {
             ErosionSettings es = erosionSettings;
@@ -122,10 +125,21 @@ namespace xshazwar.noize.hip {
                                                               events.Handle, ref ep, ref tm, EVENT_LIMIT, res, h, out h), "nz_queued_beyer_cycle");
                     Native.Check(Native.nz_process_beyer_erosive_events(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, events.Handle,
                                                                         ref ep, ref tm, res, h, out h), "nz_process_beyer_erosive_events");
-                    h = particleQueue.Clear(ctx.Wrap(h)).id;
-                    Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
-                    Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
-                                                                  ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out h), "nz_update_flow_from_track");
+                    // CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all behind the event reduction
+                    // (:408-412): the flow job runs on a stream of its own (a second context), beside the sediment job
+                    if (parallelBranch) {
+                        if (branchCtx == null) branchCtx = new GpuContext();
+                        Native.Check(Native.nz_update_flow_from_track(branchCtx.Handle, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
+                                                                      ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out ulong flow), "nz_update_flow_from_track");
+                        h = particleQueue.Clear(ctx.Wrap(h)).id;
+                        Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
+                        Native.Check(Native.nz_handle_combine(c, new ulong[] { h, flow }, 2, out h), "nz_handle_combine");
+                    } else {
+                        h = particleQueue.Clear(ctx.Wrap(h)).id;
+                        Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
+                        Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
+                                                                      ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out h), "nz_update_flow_from_track");
+                    }
                     Native.Check(Native.nz_pool_automata_job(c, poolMap.Ptr, heightMap.Ptr, particleQueue.Handle, ref ep, ref tm, es.WATER_STEPS, res,
                                                              performErosion ? 1 : 0, h, out h), "nz_pool_automata_job");
                 }
@@ -149,6 +163,7 @@ namespace xshazwar.noize.hip {
             foreach (DeviceTile t in new[] { poolMap, streamMap, particleTrack, waterControl, textureControl }) t?.Dispose();
             particleQueue.Dispose();
             events.Dispose();
+            branchCtx?.Dispose();
         }
     }
 }

@@ -846,6 +846,7 @@ class LiveErosion {
         jobHandle.Complete();
         if (particleQueue) nz_particle_queue_destroy(ctx, particleQueue);
         if (events) nz_erosive_events_destroy(ctx, events);
+        if (branchCtx) nz_ctx_destroy(branchCtx);
     }
 
     JobHandle TriggerQueuedBeyerMT(const std::vector<int> &seeds) {  // :378-436
@@ -866,10 +867,24 @@ class LiveErosion {
                                             &ep, &tm, EVENT_LIMIT, res, h, &h), "nz_queued_beyer_cycle");
                 check(nz_process_beyer_erosive_events(ctx, heightMap->ptr, poolMap.ptr, streamMap.ptr, particleTrack.ptr, events, &ep,
                                                       &tm, res, h, &h), "nz_process_beyer_erosive_events");
-                check(nz_clear_particle_queue(ctx, particleQueue, h, &h), "nz_clear_particle_queue");
-                check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, h, &h), "nz_erode_height_maps");
-                check(nz_update_flow_from_track(ctx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
-                                                ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, h, &h), "nz_update_flow_from_track");
+                // CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all behind the event reduction
+                // (:408-412): the flow job runs on a stream of its own (a second context), beside the sediment job
+                if (parallelBranch) {
+                    if (!branchCtx) check(nz_ctx_create(0, &branchCtx), "nz_ctx_create");
+                    nz_handle flow = 0, both[2];
+                    check(nz_update_flow_from_track(branchCtx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
+                                                    ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, h, &flow), "nz_update_flow_from_track");
+                    check(nz_clear_particle_queue(ctx, particleQueue, h, &h), "nz_clear_particle_queue");
+                    check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, h, &h), "nz_erode_height_maps");
+                    both[0] = h;
+                    both[1] = flow;
+                    check(nz_handle_combine(ctx, both, 2, &h), "nz_handle_combine");
+                } else {
+                    check(nz_clear_particle_queue(ctx, particleQueue, h, &h), "nz_clear_particle_queue");
+                    check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, h, &h), "nz_erode_height_maps");
+                    check(nz_update_flow_from_track(ctx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
+                                                    ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, h, &h), "nz_update_flow_from_track");
+                }
                 check(nz_pool_automata_job(ctx, poolMap.ptr, heightMap->ptr, particleQueue, &ep, &tm, es.WATER_STEPS, res,
                                            performErosion ? 1 : 0, h, &h), "nz_pool_automata_job");
             }
@@ -880,6 +895,8 @@ class LiveErosion {
     }
 
     nz_ctx *ctx;
+    bool parallelBranch = false;    // true: ErodeHeightMaps || UpdateFlowFromTrackJob on two streams, as in the reference's job graph (measured slower)
+    nz_ctx *branchCtx = nullptr;    // (created on first use; destroyed with the component)
     DeviceTile *heightMap;
     nz_tile_set_meta tileMeta;
     ErosionSettings erosionSettings;
