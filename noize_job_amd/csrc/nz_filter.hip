@@ -88,6 +88,9 @@ __device__ unsigned long long *nz_probe_buf = nullptr;  // [workgroup][16]
 // 512-thread workgroups per CU (6 waves per SIMD, 80 VGPRs, one edge buffer of 32 KB each) so one workgroup's
 // load/store phase overlaps the others' VALU phases: 5 % faster than two workgroups at 121 VGPRs; the 7- and
 // 9-tap windows do not fit 80 registers without spilling and stay at two.
+#ifndef NZ_CONV5_NBUF
+#define NZ_CONV5_NBUF 1  // 2: double-buffered edge rows for the 5-tap kernel (one barrier per application, 64 KB of LDS: two workgroups per CU)
+#endif
 #ifndef NZ_CONV5_WAVES
 #define NZ_CONV5_WAVES 6
 #endif
@@ -134,7 +137,7 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
     // boundary rows of every 8-row block: [parity][block][top|bottom][o][column group].  Double buffered
     // (one barrier per application) for the 3-tap kernel; the others keep one buffer and pay a second barrier
     // instead of giving up a resident workgroup (5 taps: 3 x 32 KB; 7/9 taps: 2 x 48/64 KB).
-    constexpr int NBUF = O >= 2 ? 1 : 2;
+    constexpr int NBUF = (O == 2 && NZ_CONV5_NBUF == 2) ? 2 : (O >= 2 ? 1 : 2);
     float4 (*s_edge)[TH / RB][2][O][TW / 4] = reinterpret_cast<float4 (*)[TH / RB][2][O][TW / 4]>(s_edge_raw);
 
     const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
                                                      nz_kernel_taps taps, int T, int aligned) {
     constexpr int O = (KS - 1) / 2;
     constexpr int TH = NT / 32 * RB;
-    constexpr int NBUF = O >= 2 ? 1 : 2;
+    constexpr int NBUF = (O == 2 && NZ_CONV5_NBUF == 2) ? 2 : (O >= 2 ? 1 : 2);
     __shared__ float4 s_edge[NBUF][TH / RB][2][O][TW / 4];
     const int H = T * O, HX = (H + 3) & ~3;
     src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
                                                                                                                   nz_chain ch, int aligned) {
     constexpr int O = (KS - 1) / 2;
     constexpr int TH = NT / 32 * RB;
-    constexpr int NBUF = O >= 2 ? 1 : 2;
+    constexpr int NBUF = (O == 2 && NZ_CONV5_NBUF == 2) ? 2 : (O >= 2 ? 1 : 2);
     __shared__ float4 s_edge[NBUF][TH / RB][2][O][TW / 4];
     __shared__ int s_item[2];
     if (threadIdx.x == 0) {

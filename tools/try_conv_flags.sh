@@ -10,5 +10,5 @@ for extra in "" "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE $extra -c nz_filter.hip -o build/nz_filter.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libnoize_hip.so
   echo "== flags: [$extra]"
-  python3 "$ROOT/tools/bench_stage.py" gauss --reps 40 2>/dev/null | tail -1
+  python3 "$ROOT/tools/bench_stage.py" gauss --reps 300 2>/dev/null | tail -1
 done
