@@ -576,8 +576,8 @@ __global__ __launch_bounds__(CT) void conv_pass_z_kernel(const float *__restrict
 // Filter/Kernel/Blur/BlurJob.cs:11-52).  A workgroup of NT threads produces an (NT/8) x 128 output tile.  Source rows
 // [z0-O, z0+32+O) x columns [x0-16, x0+144), clamped to the grid (RWTileData.GetData), are staged in LDS
 // as 160-float rows: 16-byte loads, five whole 128-byte lines per row.  The X pass runs on all 32+2O rows
-// into a second LDS plane, 8 consecutive outputs per thread from one register window; the Z pass reads
-// that plane column-wise, 4 columns x 4 rows per thread, and stores 16 bytes per lane.  Clamped source
+// in place (see s_a), 8 consecutive outputs per thread from one register window; the Z pass reads
+// those columns row after row, 4 columns x 4 rows per thread, and stores 16 bytes per lane.  Clamped source
 // rows give the X-pass value of the clamped row, which is what the reference's Z pass reads after the flush.
 constexpr int WD_W = 128, WD_XH = 16, WD_AP = WD_W + 2 * WD_XH;
 
@@ -590,8 +590,11 @@ __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restric
     constexpr int OFF = WD_XH - O;            // first window column of output column 0
     constexpr int OFA = OFF & ~3, SH = OFF & 3;
     constexpr int NF = (SH + 8 + 2 * O + 3) / 4;  // float4s per X window
+    // One LDS plane: the X pass writes a row's results back over that row's source columns [WD_XH, WD_XH + 128).
+    // The 16 threads of a row are lanes of one wave, whose LDS loads of the row all precede its stores in program
+    // order, so no lane reads a column another lane has already replaced; half the LDS lets twice the workgroups
+    // (of other tiles, in other phases) share the CU.
     __shared__ float4 s_a[NR * WD_AP / 4];
-    __shared__ float4 s_b[NR * WD_W / 4];
     const int tid = threadIdx.x;
     src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
     dst += blockIdx.y * g.bstride;
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restric
                 for (int kk = 1; kk < KS; kk++) total += w[SH + e + kk] * taps.kx[kk];
                 o[e] = UNIT ? total : total * taps.factor;
             }
-            float4 *b = s_b + (r * WD_W + 8 * tx) / 4;
+            float4 *b = s_a + (r * WD_AP + WD_XH + 8 * tx) / 4;
             b[0] = make_float4(o[0], o[1], o[2], o[3]);
             b[1] = make_float4(o[4], o[5], o[6], o[7]);
         }
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restric
         float v[4 + 2 * O][4];
 #pragma unroll
         for (int i = 0; i < 4 + 2 * O; i++) {
-            float4 t = s_b[((rg * 4 + i) * WD_W) / 4 + cg];
+            float4 t = s_a[((rg * 4 + i) * WD_AP + WD_XH) / 4 + cg];
             v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
         }
         const int gx = x0 + 4 * cg;
