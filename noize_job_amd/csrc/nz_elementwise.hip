@@ -259,20 +259,28 @@ __device__ __forceinline__ void spread_pool_step(float *pool, int res, int x, in
 // classes' bits are being set by it), and does not have to: a step that has stopped acting stays in its run and does
 // nothing there -- any SUPERSET of the acting steps cuts the walks into runs that give the row walk's values.
 __global__ __launch_bounds__(64) void pool_masks_kernel(const float *__restrict__ pool, pool_masks pm, int res) {
-    const int z = blockIdx.x * 64 + threadIdx.x, w = blockIdx.y;
-    const int k = z >> 1;
+    // a lane owns walk k of both z parities: rows z = 2k and 2k + 1 are neighbours in memory, one 8-byte load per column
+    const int k = blockIdx.x * 64 + threadIdx.x, w = blockIdx.y;
     if (k >= pm.walks) return;
-    const int odd = k & 1;
-    unsigned m0 = 0, m1 = 0;  // xoff = 0: x = 64 w + odd + 2 b; xoff = 1: x = 64 w + 1 + odd + 2 b
+    const int odd = k & 1, z = 2 * k;
+    unsigned m0[2] = {0, 0}, m1[2] = {0, 0};  // xoff = 0: x = 64 w + odd + 2 b; xoff = 1: x = 64 w + 1 + odd + 2 b
 #pragma unroll
     for (int b = 0; b < 32; b++) {
         const int xa = 64 * w + odd + 2 * b, xb = xa + 1;
-        if (xa < res && pool_step_acts(pool[(size_t)xa * res + z])) m0 |= 1u << b;
-        if (xb < res && pool_step_acts(pool[(size_t)xb * res + z])) m1 |= 1u << b;
+        float va[2] = {0.0f, 0.0f}, vb[2] = {0.0f, 0.0f};
+        if (xa < res) __builtin_memcpy(va, pool + (size_t)xa * res + z, 8);
+        if (xb < res) __builtin_memcpy(vb, pool + (size_t)xb * res + z, 8);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            if (pool_step_acts(va[e])) m0[e] |= 1u << b;
+            if (pool_step_acts(vb[e])) m1[e] |= 1u << b;
+        }
     }
-    const int zoff = z & 1;
-    pm.m[((size_t)(0 + zoff) * pm.words + w) * pm.walks + k] = m0;
-    pm.m[((size_t)(2 + zoff) * pm.words + w) * pm.walks + k] = m1;
+#pragma unroll
+    for (int zoff = 0; zoff < 2; zoff++) {
+        pm.m[((size_t)(0 + zoff) * pm.words + w) * pm.walks + k] = m0[zoff];
+        pm.m[((size_t)(2 + zoff) * pm.words + w) * pm.walks + k] = m1[zoff];
+    }
 }
 
 constexpr int PCW = 8;  // mask words per thread of the clean kernel
@@ -690,7 +698,7 @@ size_t nz_pool_automata_mask_words(int res) { return 4 * (size_t)(((res + 1) / 2
 int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res, unsigned *mask) {
     if (res / 2 <= 0) return NZ_OK;
     pool_masks pm{mask, ((res + 1) / 2 + 31) / 32, res / 2};
-    hipLaunchKernelGGL(pool_masks_kernel, dim3((unsigned)((res + 63) / 64), (unsigned)pm.words), dim3(64), 0, s, pool, pm, res);
+    hipLaunchKernelGGL(pool_masks_kernel, dim3((unsigned)((pm.walks + 63) / 64), (unsigned)pm.words), dim3(64), 0, s, pool, pm, res);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

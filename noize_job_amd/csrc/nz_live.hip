@@ -2,7 +2,7 @@
 //
 // Replaces the Burst jobs of Geologic/ParticleErosion/MultiThreadErosionJob.cs that LiveErosion.TriggerQueuedBeyerMT
 // (Component/LiveErosion.cs:378-436) chains per cycle:
-//   FillBeyerQueueJob (:21-72)               -> fill_queue_kernel          one lane per reference worker
+//   FillBeyerQueueJob (:21-72)               -> fill_queue_kernel          one lane per 16 particles of a worker
 //   QueuedBeyerCycleMultiThreadJob (:178-224) -> descent_kernel             one lane per particle, until it is dead
 //   ProcessBeyerErosiveEventsJob (:330-385)   -> process_events_kernel      one lane per cell that received an event
 //   ErodeHeightMaps (:438-480, ONE thread)    -> disperse_kernel (every cell gathers) + pile_kernel (one wave per block)
@@ -54,42 +54,6 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 __device__ __forceinline__ float lmaxf(float a, float b) { return (b != b) || a > b ? a : b; }  // math.max
 __device__ __forceinline__ float lminf(float a, float b) { return (b != b) || a < b ? a : b; }  // math.min
 
-// ---- Cephes atanf / sinf in fp32 operations (the oracle's text) ----------------------------------------------------
-__device__ float live_atanf(float xx) {
-    if (xx != xx) return xx;
-    float sign = 1.0f, x = xx, y;
-    if (x < 0.0f) { sign = -1.0f; x = -x; }
-    if (x > 2.414213562373095f) { y = 1.5707963267948966192f; x = -(1.0f / x); }
-    else if (x > 0.4142135623730950f) { y = 0.7853981633974483096f; x = (x - 1.0f) / (x + 1.0f); }
-    else y = 0.0f;
-    float z = x * x;
-    y += (((8.05374449538e-2f * z - 1.38776856032E-1f) * z + 1.99777106478E-1f) * z - 3.33329491539E-1f) * z * x + x;
-    return sign * y;
-}
-
-__device__ float live_sinf(float xx) {
-    if (xx != xx) return xx;
-    float sign = 1.0f, x = xx, y;
-    if (x < 0.0f) { sign = -1.0f; x = -x; }
-    if (x > 8192.0f) return 0.0f;
-    int j = (int)(1.27323954473516f * x);
-    y = (float)j;
-    if (j & 1) { j += 1; y += 1.0f; }
-    j &= 7;
-    if (j > 3) { sign = -sign; j -= 4; }
-    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
-    float z = x * x;
-    if (j == 1 || j == 2) {
-        y = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z;
-        y -= 0.5f * z;
-        y += 1.0f;
-    } else {
-        y = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * x;
-        y += x;
-    }
-    return sign * y;
-}
-
 // ---- FillBeyerQueueJob + FlowMaster.CreateRandomParticles ----------------------------------------------------------
 __device__ __forceinline__ uint32_t rnd_next_state(uint32_t &s) {  // Unity.Mathematics.Random.NextState
     uint32_t t = s;
@@ -99,8 +63,38 @@ __device__ __forceinline__ uint32_t rnd_next_state(uint32_t &s) {  // Unity.Math
     return t;
 }
 
-__global__ void fill_queue_kernel(int32_t *hdr, nz_particle *data, int generationRound, int res, int maxParticles,
-                                  int seed, int concurrency) {
+// xorshift32 is linear over GF(2): the state 32 * q steps on is a 32 x 32 bit matrix applied to the state.  FILL_JUMP
+// holds the matrices of 32 * 2^l steps (columns = images of the unit vectors), so a lane reaches the first state of
+// any 16-particle chunk of its worker's stream in at most FILL_LEVELS products instead of walking there.
+constexpr int FILL_CHUNK = 16, FILL_LEVELS = 27;
+struct fill_jump_table { uint32_t col[FILL_LEVELS][32]; };
+constexpr uint32_t fill_step(uint32_t s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+constexpr uint32_t fill_apply(const uint32_t (&m)[32], uint32_t s) {
+    uint32_t r = 0;
+    for (int b = 0; b < 32; b++) r ^= (0u - ((s >> b) & 1u)) & m[b];
+    return r;
+}
+constexpr fill_jump_table fill_make_jump() {
+    fill_jump_table t{};
+    uint32_t m[32] = {}, n[32] = {};
+    for (int b = 0; b < 32; b++) m[b] = fill_step(1u << b);
+    for (int sq = 0; sq < 5; sq++) {  // 1 step -> 2 * FILL_CHUNK = 32 steps
+        for (int b = 0; b < 32; b++) n[b] = fill_apply(m, m[b]);
+        for (int b = 0; b < 32; b++) m[b] = n[b];
+    }
+    for (int l = 0; l < FILL_LEVELS; l++) {
+        for (int b = 0; b < 32; b++) t.col[l][b] = m[b];
+        for (int b = 0; b < 32; b++) n[b] = fill_apply(m, m[b]);
+        for (int b = 0; b < 32; b++) m[b] = n[b];
+    }
+    return t;
+}
+__constant__ fill_jump_table FILL_JUMP = fill_make_jump();
+
+// One workgroup; an item is one chunk of FILL_CHUNK consecutive particles of one reference worker (worker i draws
+// Random(seed + i), two states per particle, and numbers its particles pid += i * COUNT + k).
+__global__ __launch_bounds__(1024) void fill_queue_kernel(int32_t *hdr, nz_particle *data, int generationRound, int res,
+                                                          int maxParticles, int seed, int concurrency) {
     __shared__ int s_current, s_count;
     if (threadIdx.x == 0) {
         int current = hdr[0];
@@ -116,23 +110,35 @@ __global__ void fill_queue_kernel(int32_t *hdr, nz_particle *data, int generatio
         s_count = COUNT;
     }
     __syncthreads();
-    const int i = threadIdx.x, COUNT = s_count;
-    if (i < concurrency) {
+    const int COUNT = s_count, current = s_current;
+    const int chunks = (COUNT + FILL_CHUNK - 1) / FILL_CHUNK;
+    const uint16_t pid0 = (uint16_t)(generationRound * maxParticles);
+    for (long long item = threadIdx.x; item < (long long)concurrency * chunks; item += blockDim.x) {
+        const int i = (int)(item / chunks), q = (int)(item - (long long)i * chunks);
         uint32_t st = (uint32_t)(seed + i);
         (void)rnd_next_state(st);  // Random(uint seed): state = seed; NextState()
-        uint16_t pid = (uint16_t)(generationRound * maxParticles);
-        for (int k = 0; k < COUNT; k++) {
-            pid = (uint16_t)(pid + (uint16_t)((i * COUNT) + k));
+        for (int l = 0; l < FILL_LEVELS; l++)
+            if ((q >> l) & 1) {
+                uint32_t r = 0;
+#pragma unroll
+                for (int b = 0; b < 32; b++) r ^= (0u - ((st >> b) & 1u)) & FILL_JUMP.col[l][b];
+                st = r;
+            }
+        const int k1 = min(COUNT, (q + 1) * FILL_CHUNK);
+        for (int k = q * FILL_CHUNK; k < k1; k++) {
+            // pid after the additions of particles 0..k: (k + 1) * i * COUNT + k (k + 1) / 2, modulo 2^16
+            unsigned long long tri = (unsigned long long)k * (unsigned long long)(k + 1) / 2ull;
+            uint32_t lin = (uint32_t)(k + 1) * (uint32_t)i * (uint32_t)COUNT;
             nz_particle p;
             p.px = (int)(((uint64_t)rnd_next_state(st) * (uint64_t)(uint32_t)res) >> 32);
             p.pz = (int)(((uint64_t)rnd_next_state(st) * (uint64_t)(uint32_t)res) >> 32);
             p.water = 1.0f;
-            p.pid = pid;
-            data[s_current + i * COUNT + k] = p;
+            p.pid = (uint16_t)(pid0 + (uint16_t)lin + (uint16_t)tri);
+            data[current + (long long)i * COUNT + k] = p;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) hdr[0] = s_current + concurrency * COUNT;
+    if (threadIdx.x == 0) hdr[0] = current + concurrency * COUNT;
 }
 
 // ---- Heading (LiveErosionDataTypes.cs:1297-1444) ---------------------------------------------------------------------
@@ -143,37 +149,22 @@ __device__ __forceinline__ int heading_from(float dx, float dz) {
     if (dz > 0.0f) b |= H_N; else if (dz < 0.0f) b |= H_S;
     return b;
 }
-// nb[] / WTORDER index of a heading (N, E, S, W, NE, SE, SW, NW), -1 for NONE
+// nb[] / WTORDER index of a heading (N, E, S, W, NE, SE, SW, NW), -1 for NONE:
+//   N = 1 -> 0, E = 4 -> 1, S = 2 -> 2, W = 8 -> 3, NE = 5 -> 4, SE = 6 -> 5, SW = 10 -> 6, NW = 9 -> 7
+// a nibble (value + 1) per heading; a switch is a chain of branches on the particle's critical path
 __device__ __forceinline__ int heading_wt_idx(int h) {
-    switch (h) {
-        case 1: return 0;   // N
-        case 4: return 1;   // E
-        case 2: return 2;   // S
-        case 8: return 3;   // W
-        case 5: return 4;   // NE
-        case 6: return 5;   // SE
-        case 10: return 6;  // SW
-        case 9: return 7;   // NW
-    }
-    return -1;
+    const unsigned t = (h & 8) ? 0x784u : 0x06520310u;
+    return (unsigned)h < 16u ? (int)((t >> (4 * (h & 7))) & 15u) - 1 : -1;
 }
-// position in ADJACENT (N, NE, E, SE, S, SW, W, NW) and back
+// position in ADJACENT (N, NE, E, SE, S, SW, W, NW) and back; 8 for anything else:
+//   1 -> 0, 5 -> 1, 4 -> 2, 6 -> 3, 2 -> 4, 10 -> 5, 8 -> 6, 9 -> 7
 __device__ __forceinline__ int heading_adj_idx(int h) {
-    switch (h) {
-        case 1: return 0;
-        case 5: return 1;
-        case 4: return 2;
-        case 6: return 3;
-        case 2: return 4;
-        case 10: return 5;
-        case 8: return 6;
-        case 9: return 7;
-    }
-    return 8;
+    const unsigned t = (h & 8) ? 0x88888576u : 0x83128408u;
+    return (unsigned)h < 16u ? (int)((t >> (4 * (h & 7))) & 15u) : 8;
 }
 __device__ __forceinline__ int adj_heading(int i) {
-    const int A[8] = {1, 5, 4, 6, 2, 10, 8, 9};
-    return A[i & 7];
+    // {1, 5, 4, 6, 2, 10, 8, 9}[i & 7], a nibble each: a table in memory is a load on the particle's critical path
+    return (int)((0x98A26451u >> (4 * (i & 7))) & 15u);
 }
 
 __device__ __forceinline__ long long to_fix(float v) {
@@ -190,167 +181,348 @@ struct live_planes {
     size_t n;
 };
 
-// `first`: this event is the cell's first of the cycle (the caller's atomicAdd on P.touched returned 0, issued at the top
-// of the step so that its round trip overlaps the step's loads).  The cell joins the cycle's list; the lanes that arrive
-// here together share ONE increment of the list counter (160 k single increments of one word serialise in the L2).
-__device__ __forceinline__ void emit(const live_planes &P, int idx, bool first, float dTrack, float dPool, float dSed) {
-    long long a = to_fix(dPool), b = to_fix(dTrack), c = to_fix(dSed);
-    const unsigned long long firsts = __ballot(first);
-    if (first) {
-        const int lane = threadIdx.x & 63, leader = __ffsll((long long)firsts) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&P.counters[P.list_slot], __popcll(firsts));
-        base = __shfl(base, leader);
-        P.list[base + __popcll(firsts & ((1ull << lane) - 1ull))] = idx;
-    }
-    if (a) atomicAdd(&P.acc[idx], (unsigned long long)a);
-    if (b) atomicAdd(&P.acc[P.n + idx], (unsigned long long)b);
-    if (c) atomicAdd(&P.acc[2 * P.n + idx], (unsigned long long)c);
+#ifndef NZ_DESCENT_LANES
+#define NZ_DESCENT_LANES 64  // particles per wave
+#endif
+#ifndef NZ_DESCENT_PREFETCH
+#define NZ_DESCENT_PREFETCH 1
+#endif
+
+#ifdef NZ_DESCENT_PROBE
+// -DNZ_DESCENT_PROBE (tools/probe_descent.sh): shader-clock sums over all waves and steps -- waiting for the step's loads,
+// the step's arithmetic, the emit -- and the number of wave steps
+__device__ unsigned long long g_descent_probe[8];
+#define NZ_DPROBE(slot)                                   \
+    do {                                                  \
+        __builtin_amdgcn_sched_barrier(0);                \
+        const unsigned long long t_now = clock64();       \
+        probe_t[slot] += t_now - probe_last;              \
+        probe_last = t_now;                               \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+#else
+#define NZ_DPROBE(slot) do { } while (0)
+#endif
+
+__device__ __forceinline__ float ld_off(const float *plane, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(plane) + byte_off);
 }
 
-// BeyerParticle.DescendSimultaneous (LiveErosionDataTypes.cs:273-432), repeated until the particle is dead
-// (FlowMaster.BeyerSimultaneousDescentSingle, LiveErosionComponents.cs:79-91).  The planes are read only.
+struct live_particle {
+    float posx, posz, dirx, dirz, vel, water, sediment;
+    int age;
+};
+
+// ---- one DescendSimultaneous call (LiveErosionDataTypes.cs:273-432) as ONE basic block -----------------------------
+// The event a live particle leaves at cell (ix, iz), and whether the particle is dead afterwards; the planes are read
+// only.  A wave with its SIMD to itself issues a VALU instruction that depends on the one before every 8 clocks, an independent
+// one every ~5 (tools/microbench/lone_wave.hip), and the 64 particles of a wave between them take every branch of the
+// step anyway.  So the step is written without branches: every way out becomes a flag, every `if` a select on the
+// reference's own condition, the arithmetic of both sides is the reference's operation for operation, and the compiler
+// is free to interleave the independent chains (the eight neighbours, the divisions, the fixed-point conversions).
+// What the ways out share is computed once: water / HEIGHT and sediment / HEIGHT (the particle's water and sediment do
+// not change before the end of a step), and the slope pass (atan, sin, sqrt) that UphillVelocityLoss and the velocity
+// update both run on |hDiff| -- a lane needs a second pass only when it cannot climb and falls back to the drain
+// direction, which is the one wave-uniform branch left.
+// Cephes atanf / sinf in fp32 operations: the oracle's text (oracle/noize_oracle_live.c) with every `if` as a select
+// on the same condition
+__device__ __forceinline__ float live_atanf(float xx) {
+    const bool nan = xx != xx;
+    const bool neg = xx < 0.0f;
+    const float sign = neg ? -1.0f : 1.0f;
+    const float nx = -xx;
+    float x = neg ? nx : xx;
+    const bool big = x > 2.414213562373095f, mid = !big && x > 0.4142135623730950f;
+    const float y0 = big ? 1.5707963267948966192f : (mid ? 0.7853981633974483096f : 0.0f);
+    const float xm1 = x - 1.0f, xp1 = x + 1.0f;
+    const float num_m = mid ? xm1 : x, den_m = mid ? xp1 : 1.0f;
+    const float num = big ? -1.0f : num_m, den = big ? x : den_m;
+    x = num / den;  // -(1 / x) == (-1) / x and x / 1 == x, bit for bit
+    const float z = x * x;
+    float y = y0;
+    y += (((8.05374449538e-2f * z - 1.38776856032E-1f) * z + 1.99777106478E-1f) * z - 3.33329491539E-1f) * z * x + x;
+    const float r = sign * y;  // both arms of a select are plain values: an expression in an arm is a branch again
+    return nan ? xx : r;
+}
+
+__device__ __forceinline__ float live_sinf(float xx) {
+    const bool nan = xx != xx;
+    const bool neg = xx < 0.0f;
+    float sign = neg ? -1.0f : 1.0f;
+    const float nx = -xx;
+    float x = neg ? nx : xx;
+    const bool big = x > 8192.0f;
+    int j = (int)(1.27323954473516f * x);
+    float y = (float)j;
+    const bool odd = j & 1;
+    j += odd ? 1 : 0;
+    const float y1 = y + 1.0f;
+    y = odd ? y1 : y;
+    j &= 7;
+    const bool flip = j > 3;
+    const float nsign = -sign;
+    sign = flip ? nsign : sign;
+    j -= flip ? 4 : 0;
+    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    const float z = x * x;
+    float yc = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z + 4.166664568298827E-002f) * z * z;
+    yc -= 0.5f * z;
+    yc += 1.0f;
+    float ys = ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * x;
+    ys += x;
+    y = (j == 1 || j == 2) ? yc : ys;
+    const float r = sign * y;
+    const float rb = big ? 0.0f : r;
+    return nan ? xx : rb;
+}
+
+__device__ __forceinline__ bool descent_step(const live_planes &P, live_particle &p, const nz_erosion_params &ep, int res,
+                                             float HEIGHT, float patchRes, int ix, int iz, bool alive, float &eTrack,
+                                             float &ePool, float &eSed, float (&pf)[6]
+#ifdef NZ_DESCENT_PROBE
+                                             , unsigned long long (&probe_t)[4], unsigned long long &probe_last
+#endif
+) {
+    const int NBDX[8] = {0, 1, 0, -1, 1, 1, -1, -1}, NBDZ[8] = {1, 0, -1, 0, 1, -1, -1, 1};
+    const int heading0 = heading_from(p.dirx, p.dirz);
+    const bool dead_water = p.water < .01f;                    // :276
+    const bool dead_age = !dead_water && p.age >= ep.MAXAGE;   // :283
+    const float wq = p.water / HEIGHT, sq = p.sediment / HEIGHT;
+    const unsigned res4 = 4u * (unsigned)res;
+    const unsigned rowb[3] = {(unsigned)clampi(ix - 1, 0, res - 1) * res4, (unsigned)ix * res4,
+                              (unsigned)clampi(ix + 1, 0, res - 1) * res4};
+    const unsigned zb[3] = {4u * (unsigned)clampi(iz - 1, 0, res - 1), 4u * (unsigned)iz, 4u * (unsigned)clampi(iz + 1, 0, res - 1)};
+    const unsigned soff = (unsigned)clampi((int)p.posx, 0, res - 1) * res4 + 4u * (unsigned)clampi((int)p.posz, 0, res - 1);
+    float hv[8], pv[8], fv[8];
+    const float h0 = ld_off(P.height, soff), p0 = ld_off(P.pool, soff), f0 = ld_off(P.flow, rowb[1] + zb[1]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const unsigned no = rowb[NBDX[k] + 1] + zb[NBDZ[k] + 1];
+        hv[k] = ld_off(P.height, no);
+        pv[k] = ld_off(P.pool, no);
+        fv[k] = ld_off(P.flow, no);
+    }
+#if NZ_DESCENT_PREFETCH
+    // The next step reads the 3 x 3 cells around one of this step's neighbours: rows ix - 2 and ix + 2 are the only
+    // cache lines of it this step has not touched (z is the fast index: iz +- 2 shares the lines of iz, a line end
+    // aside).  Asking for them now -- BEHIND this step's own loads, returns come back in order -- hides their way
+    // from HBM behind this step's arithmetic; the next step then finds all its lines in the CU's cache.  Nothing looks
+    // at the values before the end of the step (descent_kernel).
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const unsigned xm = (unsigned)clampi(ix - 2, 0, res - 1) * res4 + zb[1], xp = (unsigned)clampi(ix + 2, 0, res - 1) * res4 + zb[1];
+        pf[0] = ld_off(P.height, xm); pf[1] = ld_off(P.height, xp);
+        pf[2] = ld_off(P.pool, xm);   pf[3] = ld_off(P.pool, xp);
+        pf[4] = ld_off(P.flow, xm);   pf[5] = ld_off(P.flow, xp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    const float currentHeight = HEIGHT * (h0 + p0);
+    int nb[8];
+    int hmin = 0x7fffffff, kmin = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float all = HEIGHT * (hv[k] + pv[k]) + ep.FLOW_HEIGHT_CONTRIBUTION * (fv[k]);
+        nb[k] = (int)(100.0f * all);
+        const bool lower = nb[k] < hmin;  // nbSort[0] and its first index (IndexOf)
+        hmin = lower ? nb[k] : hmin;
+        kmin = lower ? k : kmin;
+    }
+    const float fl = lmaxf(f0, 0.0f);
+    NZ_DPROBE(0);
+    const int drainDx0 = (int)((0xA19u >> (2 * kmin)) & 3u) - 1, drainDz0 = (int)((0x8246u >> (2 * kmin)) & 3u) - 1;
+    const int heading_drain = heading_from((float)drainDx0, (float)drainDz0);
+    const int heading = heading0 == H_NONE ? heading_drain : heading0;
+    const float effectiveDrag = ep.DRAG * (1.0f - fl);
+    const float effectiveFriction = ep.FRICTION * (1.0f - fl);
+    const int ai = heading_adj_idx(heading);
+    const int hl = adj_heading(ai + 7), hr = adj_heading(ai + 1);
+    const int wl = heading_wt_idx(hl), wc = heading_wt_idx(heading), wr = heading_wt_idx(hr);
+    const bool dead_heading = ai >= 8 || wl < 0 || wc < 0 || wr < 0;  // unreachable: the drain direction is never (0, 0)
+    int il = 0, ic = 0, ir = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        il = (k == wl) ? nb[k] : il;
+        ic = (k == wc) ? nb[k] : ic;
+        ir = (k == wr) ? nb[k] : ir;
+    }
+    const float hx = (float)il / 100.0f, hy = (float)ic / 100.0f, hz = (float)ir / 100.0f;
+    const bool take_l = hx < hy && hx < hz, take_r = !take_l && hz < hx && hz < hy;
+    const float hh_r = take_r ? hz : hy;
+    const int fh_r = take_r ? hr : heading;
+    const float headingHeight = take_l ? hx : hh_r;
+    const int flowH = take_l ? hl : fh_r;
+    const int flowDx = ((flowH >> 2) & 1) ? 1 : (((flowH >> 3) & 1) ? -1 : 0);
+    const int flowDz = ((flowH >> 0) & 1) ? 1 : (((flowH >> 1) & 1) ? -1 : 0);
+    const float hDiff0 = headingHeight - currentHeight;
+    const bool down = hDiff0 < 0.0f;  // up = !down takes NaN along, as the reference's !(hDiff < 0) does
+    float vel = p.vel - (p.vel * effectiveDrag);
+    // the slope pass on |hDiff0|: UphillVelocityLoss for the lanes going up (+ friction), DownhillVelocityGain for the
+    // others (- friction == + (-friction)); hDiff0 == -0 gives the reference's NaN (0 / 0) either way
+    const float a1 = fabsf(hDiff0);
+    const float th1 = live_atanf(a1 / patchRes);
+    const float st1 = live_sinf(th1);
+    const float nfric = -effectiveFriction;
+    const float fric1 = down ? nfric : effectiveFriction;
+    const float acc1 = (ep.GRAVITY * st1) + fric1;
+    const float r1 = sqrtf(2.0f * fabsf(acc1) * (a1 / st1));
+    const bool uphillOk = !down && r1 <= vel;
+    const bool follow = down || uphillOk;  // keeps the heading's direction; the others fall back to the drain
+    const float hD = (float)hmin / 100.0f - currentHeight;
+    const bool dead_uphill = !follow && hD > 0.0f;  // :330
+    float th2 = 0.0f, r2 = 0.0f;
+    const float a2 = fabsf(hD);
+#ifdef NZ_DESCENT_PROBE
+    if (__ballot(alive && !down)) probe_t[3] += 1;
+    if (__ballot(alive && !follow && !dead_uphill && a2 > 0.0f)) probe_t[3] += 1ull << 32;
+#endif
+    if (__ballot(alive && !follow && !dead_uphill && a2 > 0.0f)) {  // wave-uniform: some lane falls back and goes on
+        th2 = live_atanf(a2 / patchRes);
+        const float st2 = live_sinf(th2);
+        const float acc2 = (ep.GRAVITY * st2) - effectiveFriction;
+        r2 = sqrtf(2.0f * fabsf(acc2) * (a2 / st2));
+    }
+    const float hDiff = follow ? hDiff0 : hD;
+    const float velocityLoss = (follow && !down) ? r1 : 0.0f;
+    const int drainDx = follow ? flowDx : drainDx0, drainDz = follow ? flowDz : drainDz0;
+    const float dirx = (float)drainDx, dirz = (float)drainDz;
+    const float pnx = p.posx + dirx, pnz = p.posz + dirz;
+    const bool dead_edge = (int)pnx < 0 || (int)pnz < 0 || (int)pnx >= res || (int)pnz >= res;  // :344
+    const float vDiff = fabsf(hDiff);
+    const bool sloped = vDiff > 0.0f;
+    const float theta = follow ? th1 : th2;
+    const float theta_deg = theta * 180.0f / 3.14159f;
+    const float thetaD = sloped ? theta_deg : 0.0f;
+    // hDiff > 0: only a lane that climbed (a fallen-back lane with hD > 0 is dead); otherwise the gain of its own pass
+    const float loss = -1.0f * velocityLoss, gain = follow ? r1 : r2;
+    const float dv = hDiff > 0.0f ? loss : gain;
+    const float deltaV = sloped ? dv : 0.0f;
+    vel = lmaxf((vel + deltaV), 0.0f);
+    const float over = vel - ep.TERMINAL_VELOCITY;
+    vel = vel - lmaxf(lminf(over, lmaxf(effectiveDrag * 0.25f * over * over, 0.0f)), 0.0f);
+    const bool dead_slow = thetaD < 3.0f && vel < 1.0f;  // :374
+    const float currentCapacity = vel * p.water * ep.CAPACITY;
+    const float erodes = -1.0f * ep.EROSION * (currentCapacity - p.sediment), lays = ep.DEPOSITION * (p.sediment - currentCapacity);
+    const float depositionAmount = p.sediment < currentCapacity ? erodes : lays;
+    const bool deposits = fabsf(depositionAmount) > 0.0f;
+    const float dq = depositionAmount / HEIGHT;
+    // the first way out that applies, in the reference's order
+    const bool with_pool = dead_age || (!dead_water && !dead_heading && (dead_uphill || (!dead_edge && dead_slow)));
+    const bool with_sed = dead_water || with_pool;
+    const bool dies = dead_water || dead_age || dead_heading || dead_uphill || dead_edge || dead_slow;
+    eTrack = dies ? 0.0f : p.water;
+    ePool = with_pool ? wq : 0.0f;
+    const float sed_dead = with_sed ? sq : 0.0f, sed_live = deposits ? dq : 0.0f;
+    eSed = dies ? sed_dead : sed_live;
+    // a dead particle's state is never looked at again
+    const float sed_less = p.sediment - depositionAmount;
+    p.sediment = deposits ? sed_less : p.sediment;
+    p.water = p.water * (1 - ep.EVAP);
+    p.vel = vel;
+    p.dirx = dirx;
+    p.dirz = dirz;
+    p.posx = pnx;
+    p.posz = pnz;
+    p.age++;
+    return dies;
+}
+
+// BeyerParticle.DescendSimultaneous repeated until the particle is dead (FlowMaster.BeyerSimultaneousDescentSingle,
+// LiveErosionComponents.cs:79-91), one lane per particle.  A particle's steps are one dependent chain -- load the
+// neighbourhood, decide, move -- so the kernel lasts as long as the longest-lived particle's chain, and what counts is
+// the length of one step:
+//   * every step ends in ONE event (a cell, three sums); the wave emits its lanes' events together, dead lanes wait
+//     masked until the wave's last particle is dead;
+//   * the cell's first event of the cycle (atomicAdd on `touched` returned 0; asked for at the top of the step, so its
+//     round trip overlaps the step's loads) puts the cell on the cycle's list.  The lanes of a step share ONE increment
+//     of the list counter (160 k single increments of one word serialise in the L2), and its return value is only
+//     looked at one step later, behind that step's loads (returns come back in order): the list entry of step s is
+//     written at the end of step s + 1;
+//   * the look-ahead loads of descent_step, and its branch-free form.
 __global__ __launch_bounds__(64) void descent_kernel(live_planes P, const int32_t *hdr, const nz_particle *particles,
                                                     nz_erosion_params ep, int res, float HEIGHT, float patchRes) {
-    const int pi = blockIdx.x * 64 + threadIdx.x;
-    const int n = min(hdr[0], hdr[1]);
-    if (pi >= n) return;
-    const int NBDX[8] = {0, 1, 0, -1, 1, 1, -1, -1}, NBDZ[8] = {1, 0, -1, 0, 1, -1, -1, 1};
-    const nz_particle src = particles[pi];
+    const int lane = threadIdx.x;
+    const int n = min(hdr[0], hdr[1]);  // the count lives on the device; the grid is sized by the host's bound
+    int events = 0;
+    unsigned sink = 0;
+#ifdef NZ_DESCENT_PROBE
+    unsigned long long probe_t[4] = {0, 0, 0, 0}, probe_last = clock64(), probe_steps = 0;
+#endif
+    for (long long first_pi = (long long)blockIdx.x * NZ_DESCENT_LANES; first_pi < n; first_pi += (long long)gridDim.x * NZ_DESCENT_LANES) {
+    const long long pi = first_pi + lane;
+    bool alive = lane < NZ_DESCENT_LANES && pi < n;
+    nz_particle src{0, 0, 0.0f, 0};
+    if (alive) src = particles[pi];
     // a particle uploaded with a position outside the tile (nz_particle_queue_upload cannot know the resolution) is
     // dropped: its first event would index the per-cell planes out of bounds
-    if ((unsigned)src.px >= (unsigned)res || (unsigned)src.pz >= (unsigned)res) return;
-    float posx = (float)src.px, posz = (float)src.pz, dirx = 0.0f, dirz = 0.0f;
-    float vel = .01f, water = src.water, sediment = 0.0f;
-    int age = 0, events = 0;
-    // every path of the loop either returns or ages the particle, and age >= MAXAGE returns: the bound below only
-    // matters for MAXAGE beyond it (a particle that old is cut off, on the oracle's side too by construction of the tests)
-    for (;;) {
-        events++;
-        const int ix = (int)rintf(posx), iz = (int)rintf(posz);
-        const int idx = ix * res + iz;
-        const bool first = atomicAdd(&P.touched[idx], 1) == 0;  // every way out of this step emits one event at idx
+    if ((unsigned)src.px >= (unsigned)res || (unsigned)src.pz >= (unsigned)res) alive = false;
+    live_particle p{(float)src.px, (float)src.pz, 0.0f, 0.0f, .01f, src.water, 0.0f, 0};
+    // the list entries of the previous step: waiting for their place
+    unsigned long long pend_firsts = 0;
+    int pend_base = 0, pend_idx = 0;
+    // every path of a step either kills or ages the particle, and age >= MAXAGE kills
+    while (__ballot(alive)) {
+#ifdef NZ_DESCENT_PROBE
+        probe_steps++;
+#endif
         float eTrack = 0.0f, ePool = 0.0f, eSed = 0.0f;
-        int heading = heading_from(dirx, dirz);
-        if (water < .01f) {
-            eSed = sediment / HEIGHT;
-            emit(P, idx, first, eTrack, ePool, eSed);
-            break;
+        float pf[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        bool first = false, dies = false;
+        int idx = 0;
+        if (alive) {
+            events++;
+            const int ix = (int)rintf(p.posx), iz = (int)rintf(p.posz);
+            idx = ix * res + iz;
+            first = atomicAdd(&P.touched[idx], 1) == 0;
+#ifdef NZ_DESCENT_PROBE
+            dies = descent_step(P, p, ep, res, HEIGHT, patchRes, ix, iz, alive, eTrack, ePool, eSed, pf, probe_t, probe_last);
+#else
+            dies = descent_step(P, p, ep, res, HEIGHT, patchRes, ix, iz, alive, eTrack, ePool, eSed, pf);
+#endif
         }
-        if (age >= ep.MAXAGE) {
-            ePool = water / HEIGHT;
-            eSed = sediment / HEIGHT;
-            emit(P, idx, first, eTrack, ePool, eSed);
-            break;
+        NZ_DPROBE(1);
+        if (pend_firsts) {  // wave-uniform
+            const int base = __builtin_amdgcn_readlane(pend_base, __ffsll((long long)pend_firsts) - 1);
+            if ((pend_firsts >> lane) & 1ull) P.list[base + __popcll(pend_firsts & ((1ull << lane) - 1ull))] = pend_idx;
         }
-        const int sidx = clampi((int)posx, 0, res - 1) * res + clampi((int)posz, 0, res - 1);
-        const float currentHeight = HEIGHT * (P.height[sidx] + P.pool[sidx]);
-        int nb[8];
-        int hmin = 0x7fffffff, kmin = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int ni = clampi(ix + NBDX[k], 0, res - 1) * res + clampi(iz + NBDZ[k], 0, res - 1);
-            const float all = HEIGHT * (P.height[ni] + P.pool[ni]) + ep.FLOW_HEIGHT_CONTRIBUTION * (P.flow[ni]);
-            nb[k] = (int)(100.0f * all);
-            if (nb[k] < hmin) { hmin = nb[k]; kmin = k; }  // nbSort[0] and its first index (IndexOf)
+        const unsigned long long firsts = __ballot(alive && first);
+        if (firsts) {
+            if (lane == __ffsll((long long)firsts) - 1) pend_base = atomicAdd(&P.counters[P.list_slot], __popcll(firsts));
+            pend_idx = idx;
         }
-        const float drainHeight = (float)hmin / 100.0f;
-        int drainDx = NBDX[kmin], drainDz = NBDZ[kmin];
-        if (heading == H_NONE) heading = heading_from((float)drainDx, (float)drainDz);
-        const float fl = lmaxf(P.flow[idx], 0.0f);
-        const float effectiveDrag = ep.DRAG * (1.0f - fl);
-        const float effectiveFriction = ep.FRICTION * (1.0f - fl);
-        const int ai = heading_adj_idx(heading);
-        const int hl = adj_heading(ai + 7), hr = adj_heading(ai + 1);
-        const int wl = heading_wt_idx(hl), wc = heading_wt_idx(heading), wr = heading_wt_idx(hr);
-        if (ai >= 8 || wl < 0 || wc < 0 || wr < 0) {  // unreachable: the drain direction is never (0, 0)
-            emit(P, idx, first, 0.0f, 0.0f, 0.0f);
-            break;
+        pend_firsts = firsts;
+        if (alive) {
+            const long long a = to_fix(ePool), b = to_fix(eTrack), c = to_fix(eSed);
+            if (a) atomicAdd(&P.acc[idx], (unsigned long long)a);
+            if (b) atomicAdd(&P.acc[P.n + idx], (unsigned long long)b);
+            if (c) atomicAdd(&P.acc[2 * P.n + idx], (unsigned long long)c);
         }
-        int il = 0, ic = 0, ir = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {  // nb[] stays in registers: select, do not index; three divisions, not eight
-            il = (k == wl) ? nb[k] : il;
-            ic = (k == wc) ? nb[k] : ic;
-            ir = (k == wr) ? nb[k] : ir;
-        }
-        const float hx = (float)il / 100.0f, hy = (float)ic / 100.0f, hz = (float)ir / 100.0f;
-        float headingHeight;
-        int flowH;
-        if (hx < hy && hx < hz) { headingHeight = hx; flowH = hl; }
-        else if (hz < hx && hz < hy) { headingHeight = hz; flowH = hr; }
-        else { headingHeight = hy; flowH = heading; }
-        const int flowDx = ((flowH >> 2) & 1) ? 1 : (((flowH >> 3) & 1) ? -1 : 0);
-        const int flowDz = ((flowH >> 0) & 1) ? 1 : (((flowH >> 1) & 1) ? -1 : 0);
-        float hDiff = headingHeight - currentHeight;
-        float velocityLoss = 0.0f;
-        vel = vel - (vel * effectiveDrag);
-        bool uphillOk = false;
-        if (!(hDiff < 0.0f)) {  // UphillVelocityLoss :253-260
-            const float theta = live_atanf(hDiff / patchRes);
-            const float st = live_sinf(theta);
-            const float acceleration = (ep.GRAVITY * st) + effectiveFriction;
-            velocityLoss = sqrtf(2.0f * fabsf(acceleration) * (hDiff / st));
-            uphillOk = velocityLoss <= vel;
-        }
-        if (hDiff < 0.0f || uphillOk) {
-            drainDx = flowDx;
-            drainDz = flowDz;
-        } else {
-            velocityLoss = 0.0f;
-            hDiff = drainHeight - currentHeight;
-            if (hDiff > 0.0f) {
-                ePool = water / HEIGHT;
-                eSed = sediment / HEIGHT;
-                emit(P, idx, first, eTrack, ePool, eSed);
-                break;
-            }
-        }
-        dirx = (float)drainDx;
-        dirz = (float)drainDz;
-        const float pnx = posx + dirx, pnz = posz + dirz;
-        if ((int)pnx < 0 || (int)pnz < 0 || (int)pnx >= res || (int)pnz >= res) {
-            emit(P, idx, first, eTrack, ePool, eSed);
-            break;
-        }
-        const float vDiff = fabsf(hDiff);
-        float thetaD = 0.0f, deltaV = 0.0f;
-        if (vDiff > 0.0f) {
-            const float theta = live_atanf(vDiff / patchRes);
-            thetaD = theta * 180.0f / 3.14159f;
-            if (hDiff > 0.0f) {
-                deltaV = -1.0f * velocityLoss;
-            } else {  // DownhillVelocityGain :262-270
-                const float st = live_sinf(theta);
-                const float acceleration = (ep.GRAVITY * st) - effectiveFriction;
-                deltaV = sqrtf(2.0f * fabsf(acceleration) * (vDiff / st));
-            }
-        }
-        vel = lmaxf((vel + deltaV), 0.0f);
-        const float over = vel - ep.TERMINAL_VELOCITY;
-        vel = vel - lmaxf(lminf(over, lmaxf(effectiveDrag * 0.25f * over * over, 0.0f)), 0.0f);
-        if (thetaD < 3.0f && vel < 1.0f) {
-            ePool += water / HEIGHT;
-            eSed += sediment / HEIGHT;
-            emit(P, idx, first, eTrack, ePool, eSed);
-            break;
-        }
-        const float currentCapacity = vel * water * ep.CAPACITY;
-        float depositionAmount;
-        if (sediment < currentCapacity) depositionAmount = -1.0f * ep.EROSION * (currentCapacity - sediment);
-        else depositionAmount = ep.DEPOSITION * (sediment - currentCapacity);
-        if (fabsf(depositionAmount) > 0.0f) {
-            eSed += depositionAmount / HEIGHT;
-            sediment -= depositionAmount;
-        }
-        eTrack = water;
-        water = water * (1 - ep.EVAP);
-        posx = pnx;
-        posz = pnz;
-        age++;
-        emit(P, idx, first, eTrack, ePool, eSed);
+        alive = alive && !dies;
+        NZ_DPROBE(2);
+#if NZ_DESCENT_PREFETCH
+        __builtin_amdgcn_sched_barrier(0);  // the look-ahead values: looked at last
+        sink |= __float_as_uint(pf[0]) & __float_as_uint(pf[1]) & __float_as_uint(pf[2]) & __float_as_uint(pf[3]) &
+                __float_as_uint(pf[4]) & __float_as_uint(pf[5]);
+#endif
     }
-    atomicAdd(&P.counters[3], events);
+    if (pend_firsts) {
+        const int base = __builtin_amdgcn_readlane(pend_base, __ffsll((long long)pend_firsts) - 1);
+        if ((pend_firsts >> lane) & 1ull) P.list[base + __popcll(pend_firsts & ((1ull << lane) - 1ull))] = pend_idx;
+    }
+    }  // the wave's next 64 particles
+#ifdef NZ_DESCENT_PROBE
+    if (lane == 0 && probe_steps) {
+        for (int k = 0; k < 3; k++) atomicAdd(&g_descent_probe[k], probe_t[k]);
+        atomicAdd(&g_descent_probe[6], probe_t[3] & 0xffffffffull);
+        atomicAdd(&g_descent_probe[7], probe_t[3] >> 32);
+        atomicAdd(&g_descent_probe[3], probe_steps);
+        atomicAdd(&g_descent_probe[4], 1ull);
+        atomicMax(&g_descent_probe[5], probe_steps);
+    }
+#endif
+    for (int o = 32; o; o >>= 1) events += __shfl_xor(events, o);  // every lane of the wave is here
+    if (lane == 0 && events) atomicAdd(&P.counters[3], events);
+    if (sink == 0xffffffffu && n < 0) P.counters[3] = 0;  // never: n >= 0; keeps the look-ahead loads
 }
 
 // ProcessBeyerErosiveEventsJob + CombineBeyerEvents / HandleBeyerEvent (MultiThreadErosionJob.cs:330-385,
@@ -381,7 +553,9 @@ __global__ __launch_bounds__(CT) void process_events_kernel(float *pool, float *
         }
         sediment[idx] = sedimentV;
         // WriteSedimentMap :118-128: negative or small events are dispersed, the others piled (NaN: piled, a no-op)
-        if (sedimentV != 0.0f && !(sedimentV < 0.0f || sedimentV <= pileThreshold)) atomicAdd(&counters[2], 1);  // statistics
+        // statistics: one increment per wave (this file is built without the compiler's atomic optimizer, see Makefile)
+        const unsigned long long piled = __ballot(sedimentV != 0.0f && !(sedimentV < 0.0f || sedimentV <= pileThreshold));
+        if (piled && (int)(threadIdx.x & 63) == __ffsll((long long)piled) - 1) atomicAdd(&counters[2], __popcll(piled));
         acc[idx] = 0;
         acc[ncell + idx] = 0;
         acc[2 * ncell + idx] = 0;
@@ -417,20 +591,25 @@ __global__ __launch_bounds__(CT) void disperse_list_kernel(float *__restrict__ h
         if (!disperses(own, pileThreshold)) continue;
         const int tx = sx + tap / 5 - 2, tz = sz + tap % 5 - 2;
         if (tx < 2 || tz < 2 || tx >= res - 2 || tz >= res - 2) continue;  // the frame kernel's
+        // the whole 5 x 5 window in flight at once (walking it load by load, with the early way out, was 25 dependent
+        // round trips); q = 5 * (wz - tz + 2) + (wx - tx + 2) is the canonical order inside the window
+        float win[25];
+        const float *w0 = sediment + (size_t)(tx - 2) * res + (tz - 2);
+#pragma unroll
+        for (int q = 0; q < 25; q++) win[q] = w0[(size_t)(q % 5) * res + q / 5];
         float v = height[(size_t)tx * res + tz];
-        bool first = true, mine = true;
-        for (int wz = tz - 2; wz <= tz + 2 && mine; wz++)
-            for (int wx = tx - 2; wx <= tx + 2; wx++) {
-                const float val = sediment[(size_t)wx * res + wz];
-                if (!disperses(val, pileThreshold)) continue;
-                if (first) {
-                    first = false;
-                    if (wx != sx || wz != sz) { mine = false; break; }
-                }
-                const float newDiff = ((val * (KERNEL5[tx - wx + 2] * KERNEL5[tz - wz + 2])) / 1.0f);  // its one tap here
-                const float nextV = v + newDiff;
-                if (!(nextV > 1.0f) && !(nextV < 0.0f)) v = v + newDiff;
-            }
+        int firstq = 25;
+#pragma unroll
+        for (int q = 24; q >= 0; q--) firstq = disperses(win[q], pileThreshold) ? q : firstq;
+        const bool mine = firstq < 25 && tx - 2 + firstq % 5 == sx && tz - 2 + firstq / 5 == sz;
+        if (!mine) continue;
+#pragma unroll
+        for (int q = 0; q < 25; q++) {
+            const float val = win[q];
+            const float newDiff = ((val * (KERNEL5[4 - q % 5] * KERNEL5[4 - q / 5])) / 1.0f);  // its one tap here
+            const float nextV = v + newDiff;
+            if (disperses(val, pileThreshold) && !(nextV > 1.0f) && !(nextV < 0.0f)) v = v + newDiff;
+        }
         if (mine) height[(size_t)tx * res + tz] = v;
     }
 }
@@ -499,6 +678,8 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
     // the block's sediment events into LDS first, lanes along z (the planes' fast index), all loads in flight together:
     // walking the block row by row straight from memory cost one dependent round trip per row (32 of them)
     float *s_sed = reinterpret_cast<float *>(s_raw + (((size_t)nverts * 9 + 15) & ~(size_t)15));
+    short2 *s_ofs = reinterpret_cast<short2 *>(s_sed + B * B);  // the vertex offsets: every pile of the block walks them
+    for (int i = lane; i < nverts; i += 64) s_ofs[i] = ofs[i];
     const int bw = x1 - x0, bh = z1 - z0;  // <= B each
     for (int i0 = lane; i0 < bw * bh; i0 += 64 * 8) {
         float t[8];
@@ -514,6 +695,32 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
         }
     }
     __syncthreads();
+    int px = 0, pz = 0;
+    // vertices [v0, v1) of the pile at (px, pz): value, cell and validity side by side in LDS, eight per lane in flight
+    auto set_pile = [&](int v0, int v1) {
+        for (int i0 = v0 + lane; i0 < v1; i0 += 64 * 8) {
+            short2 o[8];
+            float hv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) o[u] = s_ofs[min(i0 + 64 * u, v1 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int vx = px + o[u].x, vz = pz + o[u].y;
+                const bool ok = i0 + 64 * u < v1 && vx >= 0 && vz >= 0 && vx < res && vz < res;
+                hv[u] = ok ? height[(size_t)vx * res + vz] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 64 * u;
+                if (i >= v1) break;
+                const int vx = px + o[u].x, vz = pz + o[u].y;
+                const bool ok = vx >= 0 && vz >= 0 && vx < res && vz < res;
+                s_flag[i] = ok ? 1 : 0;
+                s_idx[i] = ok ? vx * res + vz : 0;
+                s_val[i] = hv[u];
+            }
+        }
+    };
     for (int z = z0; z < z1; z++) {
         for (int xb = x0; xb < x1; xb += 64) {
             const int x = xb + lane;
@@ -523,29 +730,22 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
             while (todo) {  // wave-uniform
                 const int src_lane = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                const int px = xb + src_lane, pz = z;
+                px = xb + src_lane;
+                pz = z;
                 const float amount = __shfl(val, src_lane);
-                for (int i0 = lane; i0 < nverts; i0 += 64 * 8) {  // SetPile, eight vertices per lane in flight
-                    short2 o[8];
-                    float hv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) o[u] = ofs[min(i0 + 64 * u, nverts - 1)];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int vx = px + o[u].x, vz = pz + o[u].y;
-                        const bool ok = i0 + 64 * u < nverts && vx >= 0 && vz >= 0 && vx < res && vz < res;
-                        hv[u] = ok ? height[(size_t)vx * res + vz] : 0.0f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int i = i0 + 64 * u;
-                        if (i >= nverts) break;
-                        const int vx = px + o[u].x, vz = pz + o[u].y;
-                        const bool ok = vx >= 0 && vz >= 0 && vx < res && vz < res;
-                        s_flag[i] = ok ? 1 : 0;
-                        s_idx[i] = ok ? vx * res + vz : 0;
-                        s_val[i] = hv[u];
-                    }
+                // SetPile, as far as the pile will look: a round r only examines the vertices of the rings dist < r
+                // (2 r (r + 3) of them), and most piles are a few increments that the first rounds place -- the first
+                // 64 vertices (rounds 1..4) are one load per lane, the other rings follow only if a round asks for them
+                int loaded = min(64, nverts);
+                if (lane < loaded) {
+                    const short2 o = s_ofs[lane];
+                    const int vx = px + o.x, vz = pz + o.y;
+                    const bool ok = vx >= 0 && vz >= 0 && vx < res && vz < res;
+                    const int cell = ok ? vx * res + vz : 0;
+                    const float hv = height[cell];  // cell 0 for a vertex off the grid: never looked at
+                    s_flag[lane] = ok ? 1 : 0;
+                    s_idx[lane] = cell;
+                    s_val[lane] = ok ? hv : 0.0f;
                 }
                 __syncthreads();  // one wave per workgroup: orders the LDS traffic
                 // DepositSediment: a running remainder handed to the vertices below the round's level, in vertex order --
@@ -562,8 +762,13 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
                         float deposited = 0.0f, rem = amt;
                         bool done = false;
                         for (int round = 1; round <= maxDistance && !done; round++) {
-                            const float level = s_val[0] + (increment * (float)round);
                             const int nv = 2 * round * (round + 3);  // vertices of the rings dist < round: sum of 4 (dist + 2)
+                            if (nv > loaded) {  // wave-uniform: the other rings, once
+                                set_pile(loaded, nverts);
+                                loaded = nverts;
+                                __syncthreads();
+                            }
+                            const float level = s_val[0] + (increment * (float)round);
                             for (int base = 0; base < nv && !done; base += 64) {
                                 const int cl = base + lane;
                                 const bool below = cl < nv && (s_flag[cl] & 1) && s_val[cl] < level;
@@ -782,6 +987,17 @@ extern "C" int32_t nz_erosive_events_count(nz_ctx *ctx, nz_erosive_events *ev, i
     return NZ_OK;
 }
 
+#ifdef NZ_DESCENT_PROBE
+extern "C" int32_t nz_debug_descent_probe(unsigned long long *out8, int32_t reset) {
+    if (out8) NZ_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_descent_probe), 64));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        NZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_descent_probe), z, 64));
+    }
+    return NZ_OK;
+}
+#endif
+
 // ---- jobs --------------------------------------------------------------------------------------------------------------
 extern "C" int32_t nz_fill_beyer_queue(nz_ctx *ctx, nz_particle_queue *particles, const nz_erosion_params *ep,
                                        const nz_tile_set_meta *tm, int32_t generationRound, int32_t res,
@@ -792,7 +1008,7 @@ extern "C" int32_t nz_fill_beyer_queue(nz_ctx *ctx, nz_particle_queue *particles
     if (int32_t rc = check_live(ep, tm, res)) return rc;
     NZ_REQUIRE(concurrency >= 1 && concurrency <= 1024 && maxParticles >= 0, "concurrency %d out of range [1,1024] or maxParticles < 0",
                concurrency);
-    hipLaunchKernelGGL(fill_queue_kernel, dim3(1), dim3((unsigned)((concurrency + 63) / 64 * 64)), 0, ctx->stream, particles->hdr,
+    hipLaunchKernelGGL(fill_queue_kernel, dim3(1), dim3(1024), 0, ctx->stream, particles->hdr,
                        particles->data, generationRound, res, maxParticles, seed, concurrency);
     NZ_HIP(hipGetLastError());
     return nz_ctx_finish(ctx, out);
@@ -811,7 +1027,9 @@ extern "C" int32_t nz_queued_beyer_cycle(nz_ctx *ctx, const float *height, const
     live_planes P{height, pool, flow, events->acc, events->touched, events->list[events->cur], events->counters, events->cur,
                   (size_t)res * res};
     NZ_HIP(hipMemsetAsync(events->counters + 2, 0, 8, ctx->stream));  // piles and events of this cycle
-    const unsigned blocks = (unsigned)((particles->capacity + 63) / 64);  // the count lives on the device: lanes beyond it leave
+    // the count lives on the device: waves beyond it leave; a wave per SIMD slot at most, each takes 64 particles at a
+    // time (a queue sized for a whole plane launched 131 k waves for 10 000 particles)
+    const unsigned blocks = (unsigned)std::min<long long>(((long long)particles->capacity + NZ_DESCENT_LANES - 1) / NZ_DESCENT_LANES, 8192);
     hipLaunchKernelGGL(descent_kernel, dim3(blocks), dim3(64), 0, ctx->stream, P, particles->hdr, particles->data, *ep, res,
                        (float)tm->HEIGHT, tm->PATCH_RES[0]);
     NZ_HIP(hipGetLastError());
@@ -888,7 +1106,8 @@ extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_e
             events->pile_scratch_bytes = bytes;
         }
         const int nverts = (int)ofs.size();
-        const size_t lds = (((size_t)nverts * 9 + 15) & ~(size_t)15) + (size_t)B * B * 4;  // vertices + the block's sediment
+        // vertices + the block's sediment + the vertex offsets
+        const size_t lds = (((size_t)nverts * 9 + 15) & ~(size_t)15) + (size_t)B * B * 4 + (size_t)nverts * 4;
         if (lds > 64 * 1024)
             NZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         for (int colour = 0; colour < 4; colour++) {
