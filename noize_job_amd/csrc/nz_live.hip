@@ -679,14 +679,21 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
     // walking the block row by row straight from memory cost one dependent round trip per row (32 of them)
     float *s_sed = reinterpret_cast<float *>(s_raw + (((size_t)nverts * 9 + 15) & ~(size_t)15));
     short2 *s_ofs = reinterpret_cast<short2 *>(s_sed + B * B);  // the vertex offsets: every pile of the block walks them
-    for (int i = lane; i < nverts; i += 64) s_ofs[i] = ofs[i];
+    for (int i0 = lane; i0 < nverts; i0 += 64 * 16) {  // sixteen loads in flight per lane: a loop of single loads waits for each
+        short2 t[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) t[u] = ofs[min(i0 + 64 * u, nverts - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            if (i0 + 64 * u < nverts) s_ofs[i0 + 64 * u] = t[u];
+    }
     const int bw = x1 - x0, bh = z1 - z0;  // <= B each
     for (int i0 = lane; i0 < bw * bh; i0 += 64 * 8) {
         float t[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {  // eight loads in flight per lane
-            const int i = i0 + 64 * u, xo = i / bh, zo = i - xo * bh;
-            t[u] = i < bw * bh ? sediment[(size_t)(x0 + xo) * res + z0 + zo] : 0.0f;
+        for (int u = 0; u < 8; u++) {  // eight loads in flight per lane (no load behind a condition: each would be waited for)
+            const int i = min(i0 + 64 * u, bw * bh - 1), xo = i / bh, zo = i - xo * bh;
+            t[u] = sediment[(size_t)(x0 + xo) * res + z0 + zo];
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -707,7 +714,7 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
             for (int u = 0; u < 8; u++) {
                 const int vx = px + o[u].x, vz = pz + o[u].y;
                 const bool ok = i0 + 64 * u < v1 && vx >= 0 && vz >= 0 && vx < res && vz < res;
-                hv[u] = ok ? height[(size_t)vx * res + vz] : 0.0f;
+                hv[u] = height[ok ? (size_t)vx * res + vz : 0];  // cell 0 for a vertex off the grid: never looked at
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -717,7 +724,7 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
                 const bool ok = vx >= 0 && vz >= 0 && vx < res && vz < res;
                 s_flag[i] = ok ? 1 : 0;
                 s_idx[i] = ok ? vx * res + vz : 0;
-                s_val[i] = hv[u];
+                s_val[i] = ok ? hv[u] : 0.0f;
             }
         }
     };
@@ -752,7 +759,7 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
                 // sequential by nature, but only over the vertices that QUALIFY.  The wave tests 64 vertices at a time
                 // (a vertex's value changes within a round only at its own visit, so the test at the round's start is the
                 // test at its visit) and walks the ballot's set bits in order with the reference's arithmetic; every
-                // scalar below is wave-uniform, lane 0 writes.  A pile that used to cost one lane ~8 000 LDS round trips
+                // scalar below is wave-uniform.  A pile that used to cost one lane ~8 000 LDS round trips
                 // (15 rounds x up to 540 vertices) costs a few ballots per round.
                 {
                     float remaining = amount;
@@ -771,35 +778,51 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
                             const float level = s_val[0] + (increment * (float)round);
                             for (int base = 0; base < nv && !done; base += 64) {
                                 const int cl = base + lane;
-                                const bool below = cl < nv && (s_flag[cl] & 1) && s_val[cl] < level;
-                                unsigned long long mask = __ballot(below);
-                                while (mask && !done) {
-                                    const int c = base + __ffsll((long long)mask) - 1;
-                                    mask &= mask - 1;
-                                    const float v = s_val[c];
+                                const float myv = cl < nv ? s_val[cl] : 0.0f;
+                                const bool below = cl < nv && (s_flag[cl] & 1) && myv < level;
+                                const unsigned long long mask = __ballot(below);
+                                if (!mask) continue;
+                                // the running remainder is a chain of float operations, one vertex after the other -- but
+                                // a chain of wave-uniform registers only: step k's increment goes to lane k of `incs`, and
+                                // the vertices take theirs all at once afterwards (each copy's value is its own)
+                                float incs = 0.0f;
+                                int served = 0;
+                                for (unsigned long long m = mask; m && !done; m &= m - 1) {
+                                    const int c = base + __ffsll((long long)m) - 1;
                                     const float inc = lminf(increment, rem);
-                                    if (lane == 0) {
-                                        s_flag[c] |= 2;
-                                        s_val[c] = v + inc;
-                                    }
+                                    incs = lane == served ? inc : incs;
+                                    served++;
                                     cmax = max(cmax, c);
                                     deposited += inc;
                                     rem = amt - deposited;
                                     if (rem <= 0.0f) done = true;
                                 }
+                                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                                const float mine = __shfl(incs, rank);
+                                if (below && rank < served) {
+                                    s_flag[cl] |= 2;
+                                    s_val[cl] = myv + mine;
+                                }
                             }
-                            __builtin_amdgcn_wave_barrier();  // lane 0's LDS stores before the next round's tests
+                            __builtin_amdgcn_wave_barrier();  // the LDS stores before the next round's tests
                         }
                         remaining = done ? 0.0f : rem;
                     }
-                    // CommitChanges, in vertex order (a cell listed twice keeps its LAST copy): only modified vertices
+                    // CommitChanges, in vertex order (a cell listed twice keeps its LAST copy): only modified vertices.  The
+                    // wave reads 64 vertices' cells and values at once; lane 0 then stores them one after the other from
+                    // scalar copies (stores of one lane stay in order, none of them is waited for)
                     for (int base = 0; base <= cmax; base += 64) {
                         const int cl = base + lane;
-                        unsigned long long mod = __ballot(cl <= cmax && (s_flag[cl] & 3) == 3);
+                        const bool is_mod = cl <= cmax && (s_flag[cl] & 3) == 3;
+                        const int mycell = cl <= cmax ? s_idx[cl] : 0;
+                        const float myval = cl <= cmax ? s_val[cl] : 0.0f;
+                        unsigned long long mod = __ballot(is_mod);
                         while (mod) {
-                            const int c = base + __ffsll((long long)mod) - 1;
+                            const int l = __ffsll((long long)mod) - 1;
                             mod &= mod - 1;
-                            if (lane == 0) height[s_idx[c]] = s_val[c];
+                            const int cell = __builtin_amdgcn_readlane(mycell, l);
+                            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), l));
+                            if (lane == 0) height[cell] = v;
                         }
                     }
                     __threadfence_block();

@@ -38,6 +38,10 @@ with nj.Context(0) as ctx:
     print("cells with a sediment event %d: dispersed %d, piled %d; pile amounts: median %.3g max %.3g (increment %.3g)" % (
         ev.sum(), disp.sum(), pile.sum(), np.median(sed[pile]) if pile.any() else 0, sed[pile].max() if pile.any() else 0,
         es.MIN_PILE_INCREMENT / tm.HEIGHT))
+    inc = es.MIN_PILE_INCREMENT / tm.HEIGHT
+    steps = (np.where(pile, np.ceil(sed / inc), 0)).reshape(nb, B, nb, B).sum(axis=(1, 3))
+    print("increments to place: %d in all; per block: median %d, 99 %% %d, max %d (that block holds %d piles)" % (
+        steps.sum(), np.median(steps[per > 0]), np.percentile(steps[per > 0], 99), steps.max(), per.flat[steps.argmax()]))
     for colour in range(4):
         cx, cz = colour & 1, colour >> 1
         sub = per[cx::2, cz::2]
