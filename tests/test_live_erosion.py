@@ -153,6 +153,25 @@ def test_spawn_matches_oracle(nj, ctx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("particles,workers", [(12345, 7), (200000, 1), (70000, 1024), (999, 64), (16, 3), (1, 10)])
+def test_spawn_jumps_ahead_in_the_workers_streams(nj, ctx, oracle, particles, workers):
+    """The kernel reaches a worker's k-th particle by jumping 32 * (k / 16) xorshift steps ahead (GF(2) matrices), the
+    oracle walks there: worker counts that do not divide the particles, chunks that are not full, more chunks than
+    threads, a second call on a part-filled queue, ids that wrap at 16 bits."""
+    es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles)
+    cap = 1 << 19
+    G = _gpu_state(nj, ctx, np.zeros((300, 300), f32), es, 1000, 1.0, capacity=cap)
+    L = oracle.LiveErosionOracle(np.zeros((300, 300), f32), _params(oracle, es), capacity=cap)
+    ep, tm = es.AsParameters(), G.tileMeta
+    for gen, seed, want in ((0, 99, particles), (3, 2 ** 31 - 7, particles), (1, 5, particles + particles // 3 + 1)):
+        G.ctx.call("nz_fill_beyer_queue", G.particleQueue._h, C.byref(ep), C.byref(tm), gen, 300, want, seed, workers)
+        L.fill_queue(gen, want, seed, workers)
+        got, ref = G.particleQueue.ToArray(), L.queued()
+        assert len(got) == len(ref) and np.array_equal(got, ref)
+    G.OnDestroy()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("res,particles,tile_height,patch", [(256, 3000, 1000, 1.0), (384, 6000, 500, 2.5),
                                                              (40, 600, 1000, 1.0)])  # 40: a third of the cells in the frame
 def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, tile_height, patch):
@@ -199,6 +218,46 @@ def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, til
         G.ctx.call("nz_pool_automata_job", G.poolMap.ptr, G.heightMap.ptr, G.particleQueue._h, epp, tmp_, 4, res, 1)
         L.pool_automata(4, drain=True)
         assert np.array_equal(G.poolMap.ToArray(shape), L.pool) and np.array_equal(G.streamMap.ToArray(shape), L.flow)
+    G.OnDestroy()
+
+
+@pytest.mark.gpu
+def test_descent_on_hostile_planes_matches_oracle(nj, ctx, oracle):
+    """The descent step is written without branches (every way out a flag, every `if` a select): planes that push
+    particles through all of them at once -- plateaus (slope 0: the 0 / 0 of the velocity model), spikes and pits of
+    +-10^4, negative zero, denormals, negative pools, flow outside [0, 1] -- must still give the oracle's events."""
+    res, th = 160, 1000
+    rng = np.random.default_rng(11)
+    h = terrain(oracle, res).copy()
+    h[20:60, 30:90] = f32(0.37)                       # a plateau
+    h[100:140, 100:140] = np.round(h[100:140, 100:140] * 50) / 50  # terraces
+    r = rng.random((res, res))
+    h[r < 0.01] = f32(1e4); h[(r >= 0.01) & (r < 0.02)] = f32(-1e4)
+    h[(r >= 0.02) & (r < 0.03)] = f32(-0.0); h[(r >= 0.03) & (r < 0.04)] = f32(1e-40)
+    pool0 = np.where(rng.random((res, res)) < 0.05, (rng.random((res, res), dtype=f32) - f32(0.3)) * f32(0.01), 0).astype(f32)
+    flow0 = (rng.random((res, res), dtype=f32) * f32(2.0) - f32(0.5)).astype(f32)
+    es = nj.ErosionSettings(PARTICLES_PER_CYCLE=4000)
+    G = _gpu_state(nj, ctx, h, es, th, 1.0)
+    L = oracle.LiveErosionOracle(h, _params(oracle, es), tile_height=th, patch_res=1.0)
+    G.poolMap.CopyFrom(pool0); G.streamMap.CopyFrom(flow0)
+    L.pool[:] = pool0; L.flow[:] = flow0
+    ep, tm = es.AsParameters(), G.tileMeta
+    epp, tmp_ = C.byref(ep), C.byref(tm)
+    shape = (res, res)
+    for cyc in range(3):
+        G.ctx.call("nz_fill_beyer_queue", G.particleQueue._h, epp, tmp_, cyc, res, 4000, 31 + cyc, 10)
+        L.fill_queue(cyc, 4000, 31 + cyc, 10)
+        G.ctx.call("nz_queued_beyer_cycle", G.heightMap.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
+                   G.particleQueue._h, G.events._h, epp, tmp_, 1500, res)
+        n = L.descend()
+        assert G.events.Count == n
+        G.ctx.call("nz_process_beyer_erosive_events", G.heightMap.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
+                   G.events._h, epp, tmp_, res)
+        L.process_events()
+        assert np.array_equal(G.events.sediment(), L.sediment, equal_nan=True), cyc
+        assert np.array_equal(G.poolMap.ToArray(shape), L.pool, equal_nan=True)
+        assert np.array_equal(G.particleTrack.ToArray(shape), L.track, equal_nan=True)
+        G.particleQueue.Clear(); L.count.value = 0
     G.OnDestroy()
 
 
