@@ -84,24 +84,44 @@ __global__ __launch_bounds__(CT) void curve_kernel(float *data, size_t n, const 
 
 // ---- live erosion: the deterministic grid jobs (planes indexed x * res + z, LiveErosionDataTypes.cs:608-610) -------
 // WorldTile.UpdateFlowMapFromTrack, LiveErosionDataTypes.cs:869-886 (UpdateFlowFromTrackJob)
+__device__ __forceinline__ float flow_from_track_cell(float pv, float tv, float poolV, float flowLossRate) {
+    const float MINFLOWPOOL = .00005f;
+    if (poolV > MINFLOWPOOL) return ((1.0f - 0.1f * flowLossRate) * pv);
+    if (tv > 0.0f) return ((1.0f - flowLossRate) * pv) + (flowLossRate * 50.0f * tv) / (1.0f + 50.0f * tv);
+    return (1.0f - flowLossRate) * pv;
+}
+
+// Four cells per lane, 16-byte accesses.  The flow plane decays everywhere, but the track is zero wherever no particle
+// went this cycle and the pool wherever no water stands -- nearly everywhere -- and zeroing a zero or drying a dry cell
+// changes no bit: those stores are left out (a quad is stored when any of its four cells changes), 16 instead of 24
+// bytes per cell.
 __global__ __launch_bounds__(CT) void flow_from_track_kernel(float *__restrict__ pool, float *__restrict__ flow,
                                                             float *__restrict__ track, size_t n, float flowLossRate,
-                                                            float evaporation /* SURFACE_EVAPORATION_RATE / tm.HEIGHT */) {
-    size_t i = (size_t)blockIdx.x * CT + threadIdx.x;
+                                                            float evaporation /* SURFACE_EVAPORATION_RATE / tm.HEIGHT */,
+                                                            int aligned) {
+    const size_t i = ((size_t)blockIdx.x * CT + threadIdx.x) * 4;
     if (i >= n) return;
-    const float MINFLOWPOOL = .00005f;
-    float pv = flow[i], tv = track[i], poolV = pool[i];
-    float f;
-    if (poolV > MINFLOWPOOL) {
-        f = ((1.0f - 0.1f * flowLossRate) * pv);
-    } else if (tv > 0.0f) {
-        f = ((1.0f - flowLossRate) * pv) + (flowLossRate * 50.0f * tv) / (1.0f + 50.0f * tv);
+    if (aligned && i + 4 <= n) {
+        const float4 pv = *reinterpret_cast<const float4 *>(flow + i), tv = *reinterpret_cast<const float4 *>(track + i),
+                     po = *reinterpret_cast<const float4 *>(pool + i);
+        const float4 f = make_float4(flow_from_track_cell(pv.x, tv.x, po.x, flowLossRate), flow_from_track_cell(pv.y, tv.y, po.y, flowLossRate),
+                                     flow_from_track_cell(pv.z, tv.z, po.z, flowLossRate), flow_from_track_cell(pv.w, tv.w, po.w, flowLossRate));
+        const float4 pn = make_float4(fmaxf(po.x - evaporation, 0.0f), fmaxf(po.y - evaporation, 0.0f), fmaxf(po.z - evaporation, 0.0f),
+                                      fmaxf(po.w - evaporation, 0.0f));
+        *reinterpret_cast<float4 *>(flow + i) = f;
+        const unsigned track_bits = __float_as_uint(tv.x) | __float_as_uint(tv.y) | __float_as_uint(tv.z) | __float_as_uint(tv.w);
+        if (track_bits) *reinterpret_cast<float4 *>(track + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const unsigned pool_diff = (__float_as_uint(pn.x) ^ __float_as_uint(po.x)) | (__float_as_uint(pn.y) ^ __float_as_uint(po.y)) |
+                                   (__float_as_uint(pn.z) ^ __float_as_uint(po.z)) | (__float_as_uint(pn.w) ^ __float_as_uint(po.w));
+        if (pool_diff) *reinterpret_cast<float4 *>(pool + i) = pn;
     } else {
-        f = (1.0f - flowLossRate) * pv;
+        for (size_t k = i; k < n && k < i + 4; k++) {
+            const float pv = flow[k], tv = track[k], poolV = pool[k];
+            flow[k] = flow_from_track_cell(pv, tv, poolV, flowLossRate);
+            track[k] = 0.0f;
+            pool[k] = fmaxf(poolV - evaporation, 0.0f);
+        }
     }
-    flow[i] = f;
-    track[i] = 0.0f;
-    pool[i] = fmaxf(poolV - evaporation, 0.0f);
 }
 
 // FloodedNeighbor ordering (LiveErosionDataTypes.cs:1013-1050): by the hash of height + water = the float's bits as a
@@ -612,9 +632,19 @@ __global__ __launch_bounds__(1024) void thermal_pair_kernel(float *data, int res
     const int z = (blockIdx.x + 1) * 2 - zodd, nt = blockDim.x;
     float *g0 = data + (size_t)z * resolution;
     float *s0 = s_rows, *s1 = s_rows + resolution;
+    // what this thread loaded stays in registers: a quad the relaxation left as it was is not written back (on terrain at
+    // rest -- most of a long run's plane -- that is nearly every quad, and the pass moves 4 bytes per cell instead of 8)
+    constexpr int QMAX = 8;  // float4s per thread: resolution / 2 / nt <= 8 for the thread counts of nz_launch_thermal_pair
+    float4 orig[QMAX];
     if (vec) {  // resolution % 4 == 0 and the plane 16-byte aligned: both rows are
-        for (int i = threadIdx.x; i < resolution / 2; i += nt)  // 2 rows x resolution / 4 float4s, contiguous in memory and in LDS
-            reinterpret_cast<float4 *>(s_rows)[i] = reinterpret_cast<const float4 *>(g0)[i];
+#pragma unroll
+        for (int k = 0; k < QMAX; k++) {  // 2 rows x resolution / 4 float4s, contiguous in memory and in LDS
+            const int i = threadIdx.x + k * nt;
+            if (i < resolution / 2) {
+                orig[k] = reinterpret_cast<const float4 *>(g0)[i];
+                reinterpret_cast<float4 *>(s_rows)[i] = orig[k];
+            }
+        }
     } else {
         for (int i = threadIdx.x; i < 2 * resolution; i += nt) s_rows[i] = g0[i];
     }
@@ -634,8 +664,16 @@ __global__ __launch_bounds__(1024) void thermal_pair_kernel(float *data, int res
         __syncthreads();
     }
     if (vec) {
-        for (int i = threadIdx.x; i < resolution / 2; i += nt)
-            reinterpret_cast<float4 *>(g0)[i] = reinterpret_cast<const float4 *>(s_rows)[i];
+#pragma unroll
+        for (int k = 0; k < QMAX; k++) {
+            const int i = threadIdx.x + k * nt;
+            if (i < resolution / 2) {
+                const float4 v = reinterpret_cast<const float4 *>(s_rows)[i];
+                const unsigned diff = (__float_as_uint(v.x) ^ __float_as_uint(orig[k].x)) | (__float_as_uint(v.y) ^ __float_as_uint(orig[k].y)) |
+                                      (__float_as_uint(v.z) ^ __float_as_uint(orig[k].z)) | (__float_as_uint(v.w) ^ __float_as_uint(orig[k].w));
+                if (diff) reinterpret_cast<float4 *>(g0)[i] = v;
+            }
+        }
     } else {
         for (int i = threadIdx.x; i < 2 * resolution; i += nt) g0[i] = s_rows[i];
     }
@@ -686,8 +724,9 @@ int32_t nz_launch_curve(hipStream_t s, float *data, size_t n, const float *curve
 int32_t nz_launch_flow_from_track(hipStream_t s, float *pool, float *flow, float *track, size_t n, float flowLossRate,
                                   float evaporation) {
     if (n == 0) return NZ_OK;
-    hipLaunchKernelGGL(flow_from_track_kernel, dim3((unsigned)((n + CT - 1) / CT)), dim3(CT), 0, s, pool, flow, track, n,
-                       flowLossRate, evaporation);
+    const int aligned = ((reinterpret_cast<uintptr_t>(pool) | reinterpret_cast<uintptr_t>(flow) | reinterpret_cast<uintptr_t>(track)) & 15) == 0;
+    hipLaunchKernelGGL(flow_from_track_kernel, dim3((unsigned)(((n + 3) / 4 + CT - 1) / CT)), dim3(CT), 0, s, pool, flow, track, n,
+                       flowLossRate, evaporation, aligned);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
