@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ is where the oracle may be used
 sys.path.insert(0, ROOT)
 import noize_job_amd as nj  # noqa: E402
 import oracle  # noqa: E402  (the checker: tools and tests only)
