@@ -278,9 +278,13 @@ __device__ __forceinline__ void spread_pool_step(float *pool, int res, int x, in
 // A pass cannot clear bits itself (its own class's bits are what the other threads cut their runs by, and the other
 // classes' bits are being set by it), and does not have to: a step that has stopped acting stays in its run and does
 // nothing there -- any SUPERSET of the acting steps cuts the walks into runs that give the row walk's values.
-__global__ __launch_bounds__(64) void pool_masks_kernel(const float *__restrict__ pool, pool_masks pm, int res) {
-    // a lane owns walk k of both z parities: rows z = 2k and 2k + 1 are neighbours in memory, one 8-byte load per column
-    const int k = blockIdx.x * 64 + threadIdx.x, w = blockIdx.y;
+#ifndef NZ_POOL_MASKS_NT
+#define NZ_POOL_MASKS_NT 256
+#endif
+__global__ __launch_bounds__(NZ_POOL_MASKS_NT) void pool_masks_kernel(const float *__restrict__ pool, pool_masks pm, int res) {
+    // a lane owns walk k of both z parities: rows z = 2k and 2k + 1 are neighbours in memory, one 8-byte load per column;
+    // a workgroup's waves sit side by side in z, so every row is read in pieces of NT * 8 bytes
+    const int k = blockIdx.x * NZ_POOL_MASKS_NT + threadIdx.x, w = blockIdx.y;
     if (k >= pm.walks) return;
     const int odd = k & 1, z = 2 * k;
     unsigned m0[2] = {0, 0}, m1[2] = {0, 0};  // xoff = 0: x = 64 w + odd + 2 b; xoff = 1: x = 64 w + 1 + odd + 2 b
@@ -737,7 +741,8 @@ size_t nz_pool_automata_mask_words(int res) { return 4 * (size_t)(((res + 1) / 2
 int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res, unsigned *mask) {
     if (res / 2 <= 0) return NZ_OK;
     pool_masks pm{mask, ((res + 1) / 2 + 31) / 32, res / 2};
-    hipLaunchKernelGGL(pool_masks_kernel, dim3((unsigned)((pm.walks + 63) / 64), (unsigned)pm.words), dim3(64), 0, s, pool, pm, res);
+    hipLaunchKernelGGL(pool_masks_kernel, dim3((unsigned)((pm.walks + NZ_POOL_MASKS_NT - 1) / NZ_POOL_MASKS_NT), (unsigned)pm.words),
+                       dim3(NZ_POOL_MASKS_NT), 0, s, pool, pm, res);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
