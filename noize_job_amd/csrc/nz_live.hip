@@ -36,7 +36,7 @@ struct nz_erosive_events {
     unsigned long long *acc = nullptr;  // [3][res^2]: pool, track, sediment sums (2^-40 fixed point, two's complement)
     int32_t *touched = nullptr;         // [res^2] events per cell this cycle
     int32_t *list[2] = {nullptr, nullptr};  // cells touched this cycle / last cycle
-    int32_t *counters = nullptr;        // {n_list[0], n_list[1], n_piles, events}
+    int32_t *counters = nullptr;        // {n_list[0], n_list[1], (unused), events}
     float *sediment = nullptr;          // [res^2] the per-cell ErosiveEvent.deltaSediment (0 where none)
     int cur = 0;
     void *pile_scratch = nullptr;       // the ManhattanVertex offsets of the current PILING_RADIUS
@@ -533,10 +533,13 @@ __global__ __launch_bounds__(CT) void forget_kernel(float *sediment, const int32
     for (int i = blockIdx.x * CT + threadIdx.x; i < n; i += gridDim.x * CT) sediment[list[i]] = 0.0f;
 }
 
+#ifndef NZ_EVENTS_BLOCKS
+#define NZ_EVENTS_BLOCKS 2048  // a cell's eight scattered lines per lane: many lanes in flight
+#endif
 __global__ __launch_bounds__(CT) void process_events_kernel(float *pool, float *track, float *sediment,
                                                            unsigned long long *acc, int32_t *touched, const int32_t *list,
                                                            int32_t *counters, int slot, size_t ncell, float poolMul,
-                                                           float trackMul, float pileThreshold) {
+                                                           float trackMul) {
     const int n = counters[slot];
     for (int i = blockIdx.x * CT + threadIdx.x; i < n; i += gridDim.x * CT) {
         const int idx = list[i];
@@ -552,10 +555,6 @@ __global__ __launch_bounds__(CT) void process_events_kernel(float *pool, float *
             track[idx] = last;
         }
         sediment[idx] = sedimentV;
-        // WriteSedimentMap :118-128: negative or small events are dispersed, the others piled (NaN: piled, a no-op)
-        // statistics: one increment per wave (this file is built without the compiler's atomic optimizer, see Makefile)
-        const unsigned long long piled = __ballot(sedimentV != 0.0f && !(sedimentV < 0.0f || sedimentV <= pileThreshold));
-        if (piled && (int)(threadIdx.x & 63) == __ffsll((long long)piled) - 1) atomicAdd(&counters[2], __popcll(piled));
         acc[idx] = 0;
         acc[ncell + idx] = 0;
         acc[2 * ncell + idx] = 0;
@@ -1071,9 +1070,9 @@ extern "C" int32_t nz_process_beyer_erosive_events(nz_ctx *ctx, float *height, f
     const int cur = events->cur, prev = cur ^ 1;
     hipLaunchKernelGGL(forget_kernel, dim3(512), dim3(CT), 0, ctx->stream, events->sediment, events->list[prev], events->counters, prev);
     NZ_HIP(hipMemsetAsync(events->counters + prev, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(process_events_kernel, dim3(512), dim3(CT), 0, ctx->stream, pool, track, events->sediment,
+    hipLaunchKernelGGL(process_events_kernel, dim3(NZ_EVENTS_BLOCKS), dim3(CT), 0, ctx->stream, pool, track, events->sediment,
                        events->acc, events->touched, events->list[cur], events->counters, cur, (size_t)res * res,
-                       ep->POOL_PLACEMENT_MULTIPLIER, ep->TRACK_PLACEMENT_MULTIPLIER, ep->PILE_THRESHOLD / (float)tm->HEIGHT);
+                       ep->POOL_PLACEMENT_MULTIPLIER, ep->TRACK_PLACEMENT_MULTIPLIER);
     NZ_HIP(hipGetLastError());
     events->cur = prev;  // the next cycle's events go to the other list; this one is forgotten then
     return nz_ctx_finish(ctx, out);
