@@ -36,7 +36,8 @@ enum nz_status {
     NZ_ERR_UNSUPPORTED = -2, /* combination without an implementation (e.g. Sobel3_2D in a batched launch) */
     NZ_ERR_HIP = -3,         /* HIP runtime error */
     NZ_ERR_NOMEM = -4,
-    NZ_ERR_NO_DEVICE = -5    /* no gfx950 device / HIP runtime unavailable */
+    NZ_ERR_NO_DEVICE = -5,   /* no gfx950 device / HIP runtime unavailable */
+    NZ_ERR_COMM = -6         /* RCCL error, or librccl.so.1 could not be opened */
 };
 
 /* NoiseStage.FractalNoise, Noise/NoiseStage.cs:15-24 */
@@ -468,6 +469,110 @@ typedef struct nz_terrain_params {
 int32_t nz_terrain_pipeline_stripes(const nz_terrain_params *p, int32_t resolution);
 int32_t nz_terrain_pipeline(nz_ctx *ctx, float *data, int32_t resolution, int32_t xpos, int32_t zpos,
                             const nz_terrain_params *p, nz_handle *marks, nz_handle dep, nz_handle *out);
+
+/* ---- one large grid over the GPUs of a node: row stripes + RCCL neighbour halo exchange (new-framework feature,
+ * SURVEY.md 8e; the reference only has independent clamped tiles, Scripts/MeshTileGenerator.cs:166-192, which a host
+ * requests one by one through BasePipeline.Schedule, Pipeline/Executable/Pipeline.cs:104-128).  One process per GPU;
+ * every process creates a context on its device and joins ONE communicator.  RCCL (librccl.so.1) is opened when the
+ * first communicator entry is called: a host that never shards never loads it.
+ *
+ * nz_comm_unique_id  = ncclGetUniqueId: called by ONE rank, the 128 bytes travel to the others out of band (a file, a
+ *                      socket, the launcher's store);
+ * nz_comm_init       = ncclCommInitRank on ctx's device (blocks until all `world` ranks have called it) plus the
+ *                      communicator's own HIP stream: exchanges run there, ordered against ctx's stream by events, so that
+ *                      kernels which read no ghost row overlap them. */
+typedef struct nz_comm nz_comm;
+#define NZ_COMM_ID_BYTES 128
+int32_t nz_comm_unique_id(uint8_t *id_out /* NZ_COMM_ID_BYTES */);
+int32_t nz_comm_init(nz_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world, nz_comm **out);
+int32_t nz_comm_destroy(nz_comm *comm);
+int32_t nz_comm_rank(const nz_comm *comm);
+int32_t nz_comm_world(const nz_comm *comm);
+int32_t nz_comm_rccl_version(int32_t *version); /* ncclGetVersion of the library actually loaded, e.g. 22606 */
+
+/* Neighbour halo exchange of the stripe `st` that rank comm->rank holds of a grid split into comm->world row stripes
+ * (rank r above rank r + 1): for each of the n_planes planes (all of the stripe's shape) the `up_rows` ghost rows above
+ * the owned rows are received from rank - 1, which sends the last up_rows rows it owns, and the `down_rows` ghost rows
+ * below from rank + 1 (its first down_rows owned rows) -- ncclGroupStart; ncclSend / ncclRecv with rank +- 1;
+ * ncclGroupEnd on the communicator's stream, behind everything enqueued on ctx's stream so far.  Ranks at the global
+ * border have no neighbour on that side (clamp-to-edge applies there).  Every rank must make the same call.
+ *   nz_halo_exchange_begin  : posts the batch and returns; kernels enqueued on ctx afterwards run concurrently with it
+ *                             (they must not touch the ghost rows);
+ *   nz_halo_exchange_finish : ctx's stream waits for the batch; `out` completes after it;
+ *   nz_halo_exchange        : begin + finish. */
+int32_t nz_halo_exchange_begin(nz_ctx *ctx, nz_comm *comm, float *const *planes, int32_t n_planes, const nz_stripe *st,
+                               int32_t up_rows, int32_t down_rows, nz_handle dep);
+int32_t nz_halo_exchange_finish(nz_ctx *ctx, nz_comm *comm, nz_handle *out);
+int32_t nz_halo_exchange(nz_ctx *ctx, nz_comm *comm, float *const *planes, int32_t n_planes, const nz_stripe *st,
+                         int32_t up_rows, int32_t down_rows, nz_handle dep, nz_handle *out);
+
+/* GetMapRangeJob (Filter/NormalizeJob.cs:17-55) of a grid whose rows are spread over the ranks: `res` = DEVICE {min,
+ * max, max - min} of the WHOLE grid on every rank.  Each rank folds its `n_floats` cells (nz_get_map_range), one
+ * ncclAllGather carries the per-rank triples, and the same fold runs over the gathered minima and maxima in rank order
+ * -- the order the monolithic job walks the grid in, so the result is the monolithic one down to the sign of a zero
+ * extreme.  The path's one collective.  comm == NULL: one rank. */
+int32_t nz_comm_allgather_range(nz_ctx *ctx, nz_comm *comm, const float *map, size_t n_floats, float *res, float lim_min,
+                                float lim_max, nz_handle dep, nz_handle *out);
+
+/* The stock stage list (nz_terrain_params) on a grows x cols grid cut into `stripes` row stripes over all ranks; rank r
+ * holds stripes [r * S, (r + 1) * S), S = stripes / world.  The object owns the stripes' planes and the launch plan,
+ * which is compiled once: nz_sharded_pipeline replays it.  haloMode:
+ *   NZ_HALO_RECOMPUTE     every stripe evaluates the noise on its rows plus the stencil radius of everything downstream
+ *                         and each launch produces a window that shrinks by the radius it consumed: no data-path
+ *                         communication (closed-form source only);
+ *   NZ_HALO_EXCHANGE      before each launch the stripes exchange exactly the ghost rows it consumes; with `overlap` the
+ *                         launch's interior rows, which read no ghost row, are enqueued while the rows travel, its border
+ *                         rows after the wait;
+ *   NZ_HALO_EXCHANGE_ONCE the source plane's ghost rows for the whole pipeline are exchanged once, then as RECOMPUTE.
+ * Transfers between stripes of different ranks AND between two stripes of one rank go through ncclSend / ncclRecv (RCCL
+ * runs a send and its matching receive on one device), so that a one-GPU box executes the very code path of a node;
+ * comm == NULL (one rank, no RCCL): device copies on the context's stream.
+ * externalSource != 0: no noise stage; the caller fills the owned rows of every stripe's source plane (an uploaded
+ * height map) before nz_sharded_pipeline.  asRank / asWorld (asWorld > 0): rehearsal on one rank of the geometry rank
+ * asRank of asWorld would have; neighbours beyond the process are played by its own stripes (timing only).
+ * Same kernels, same operation order as the single-tile entries: the sharded result equals the monolithic grid bit for
+ * bit (the only clamps are at the global border). */
+typedef struct nz_sharded nz_sharded;
+enum nz_halo_mode { NZ_HALO_RECOMPUTE = 0, NZ_HALO_EXCHANGE = 1, NZ_HALO_EXCHANGE_ONCE = 2 };
+typedef struct nz_sharded_desc {
+    int32_t grows, cols;    /* the global grid */
+    int32_t stripes;        /* over all ranks; a multiple of the world size */
+    int32_t haloMode;       /* enum nz_halo_mode */
+    int32_t overlap;        /* exchange modes: != 0 splits a launch into interior rows (before the wait) and border rows */
+    int32_t xpos, zpos;     /* GeneratorData.xpos / zpos of the grid's first cell */
+    int32_t externalSource;
+    int32_t asRank, asWorld;
+} nz_sharded_desc;
+int32_t nz_sharded_create(nz_ctx *ctx, nz_comm *comm, const nz_sharded_desc *desc, const nz_terrain_params *params,
+                          nz_sharded **out);
+int32_t nz_sharded_destroy(nz_sharded *sh);
+int32_t nz_sharded_local_stripes(const nz_sharded *sh);
+/* geometry of local stripe i, its source plane (what the noise stage fills, or the caller) and the plane whose owned
+ * rows hold the result after nz_sharded_pipeline; any pointer may be NULL */
+int32_t nz_sharded_stripe(const nz_sharded *sh, int32_t i, nz_stripe *st, float **source, float **result);
+/* The compiled plan as records of 8 int32 {op, local stripe (-1: all), n, a, b, own0, own1, planes}:
+ *   op 1 noise                       rows [own0, own1) of plane `planes`
+ *   op 2 exchange begin              n = planes per stripe, a = up_rows, b = down_rows, planes = first plane id
+ *   op 3 exchange finish
+ *   op 4 kernel filter   n = fused applications, rows [own0, own1), planes = src | dst << 8
+ *   op 5 flow map        n = fused iterations, a = first, b = last, planes = src | dst << 8 | state_in << 16 | state_out << 24
+ *   op 6 value erosion   n = fused applications
+ *   op 7 stage marker    n = 0 noise, 1 filter, 2 flow, 3 erosion, 4 end
+ * `records` may be NULL to query the count. */
+int32_t nz_sharded_plan(const nz_sharded *sh, int32_t *records, int32_t max_records, int32_t *count);
+/* one pass of the pipeline on every local stripe (enqueue only); `marks` (nullable, 5 handles) as nz_terrain_pipeline */
+int32_t nz_sharded_pipeline(nz_ctx *ctx, nz_sharded *sh, nz_handle *marks, nz_handle dep, nz_handle *out);
+/* exchanges and payload bytes this rank sends per pass */
+int32_t nz_sharded_traffic(const nz_sharded *sh, int32_t *exchanges, size_t *bytes_sent);
+/* with timing on, every wait of the compute stream for an exchange is bracketed by events; nz_sharded_exchange_ms sums
+ * and forgets the brackets recorded so far (host blocks until they have completed; at most 1024 are kept) */
+int32_t nz_sharded_set_timing(nz_sharded *sh, int32_t on);
+int32_t nz_sharded_exchange_ms(nz_sharded *sh, float *ms);
+/* GetMapRangeJob + MapNormalizeValues over the result planes of the whole grid (nz_comm_allgather_range over all
+ * stripes of all ranks, then NormalizeMap on the owned rows with the device args) */
+int32_t nz_sharded_map_range(nz_ctx *ctx, nz_sharded *sh, float *res, float lim_min, float lim_max, nz_handle dep,
+                             nz_handle *out);
+int32_t nz_sharded_normalize(nz_ctx *ctx, nz_sharded *sh, const float *args, nz_handle dep, nz_handle *out);
 
 #ifdef __cplusplus
 }

@@ -64,9 +64,19 @@ class TerrainParams(C.Structure):
                 ("normMax", C.c_float), ("erosionIterations", C.c_int32)]
 
 
-ep_p, tm_p, tp_p = C.POINTER(ErosionParameters), C.POINTER(TileSetMeta), C.POINTER(TerrainParams)
+class ShardedDesc(C.Structure):
+    """nz_sharded_desc (include/noize_hip.h): one grid cut into row stripes over the ranks of a node."""
+    _fields_ = [("grows", C.c_int32), ("cols", C.c_int32), ("stripes", C.c_int32), ("haloMode", C.c_int32),
+                ("overlap", C.c_int32), ("xpos", C.c_int32), ("zpos", C.c_int32), ("externalSource", C.c_int32),
+                ("asRank", C.c_int32), ("asWorld", C.c_int32)]
 
-NZ_OK, NZ_ERR_INVALID, NZ_ERR_UNSUPPORTED, NZ_ERR_HIP, NZ_ERR_NOMEM, NZ_ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+
+ep_p, tm_p, tp_p = C.POINTER(ErosionParameters), C.POINTER(TileSetMeta), C.POINTER(TerrainParams)
+sd_p = C.POINTER(ShardedDesc)
+
+NZ_OK, NZ_ERR_INVALID, NZ_ERR_UNSUPPORTED, NZ_ERR_HIP, NZ_ERR_NOMEM, NZ_ERR_NO_DEVICE, NZ_ERR_COMM = 0, -1, -2, -3, -4, -5, -6
+NZ_COMM_ID_BYTES = 128
+NZ_HALO_RECOMPUTE, NZ_HALO_EXCHANGE, NZ_HALO_EXCHANGE_ONCE = 0, 1, 2
 
 _i, _f, _sz = C.c_int32, C.c_float, C.c_size_t
 _tail = [handle_t, handle_p]  # (dep, out)
@@ -170,6 +180,28 @@ SIGNATURES = {
     "nz_heightmap_mesh16": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _i, _i, _i, _f, _f, dev_ptr] + _tail),
     "nz_square_grid_mesh": (_i, [ctx_p, dev_ptr, dev_ptr, _i] + _tail),
     "nz_heightmap_mesh_batch": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _i, _i, _i, _f, _f, dev_ptr, _i] + _tail),
+    # one grid over the GPUs of a node (nz_comm.cpp)
+    "nz_comm_unique_id": (_i, [C.c_void_p]),
+    "nz_comm_init": (_i, [ctx_p, C.c_void_p, _i, _i, C.POINTER(C.c_void_p)]),
+    "nz_comm_destroy": (_i, [C.c_void_p]),
+    "nz_comm_rank": (_i, [C.c_void_p]),
+    "nz_comm_world": (_i, [C.c_void_p]),
+    "nz_comm_rccl_version": (_i, [C.POINTER(_i)]),
+    "nz_halo_exchange_begin": (_i, [ctx_p, C.c_void_p, C.POINTER(dev_ptr), _i, stripe_p, _i, _i, handle_t]),
+    "nz_halo_exchange_finish": (_i, [ctx_p, C.c_void_p, handle_p]),
+    "nz_halo_exchange": (_i, [ctx_p, C.c_void_p, C.POINTER(dev_ptr), _i, stripe_p, _i, _i] + _tail),
+    "nz_comm_allgather_range": (_i, [ctx_p, C.c_void_p, dev_ptr, _sz, dev_ptr, _f, _f] + _tail),
+    "nz_sharded_create": (_i, [ctx_p, C.c_void_p, sd_p, tp_p, C.POINTER(C.c_void_p)]),
+    "nz_sharded_destroy": (_i, [C.c_void_p]),
+    "nz_sharded_local_stripes": (_i, [C.c_void_p]),
+    "nz_sharded_stripe": (_i, [C.c_void_p, _i, stripe_p, C.POINTER(dev_ptr), C.POINTER(dev_ptr)]),
+    "nz_sharded_plan": (_i, [C.c_void_p, C.POINTER(_i), _i, C.POINTER(_i)]),
+    "nz_sharded_pipeline": (_i, [ctx_p, C.c_void_p, handle_p] + _tail),
+    "nz_sharded_traffic": (_i, [C.c_void_p, C.POINTER(_i), C.POINTER(_sz)]),
+    "nz_sharded_set_timing": (_i, [C.c_void_p, _i]),
+    "nz_sharded_exchange_ms": (_i, [C.c_void_p, C.POINTER(_f)]),
+    "nz_sharded_map_range": (_i, [ctx_p, C.c_void_p, dev_ptr, _f, _f] + _tail),
+    "nz_sharded_normalize": (_i, [ctx_p, C.c_void_p, dev_ptr] + _tail),
 }
 
 
@@ -182,15 +214,21 @@ def _share_hip_runtime_with_torch():
     system runtime in /opt/rocm is used."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
-        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    # RCCL is opened lazily by the library (nz_comm.cpp, first communicator call): the copy that was built against the
+    # HIP runtime in use -- the wheel's -- not /opt/rocm's
+    rccl = os.path.join(libdir, "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("NZ_RCCL_LIB", rccl)
+    if "torch" in sys.modules:
+        return
+    cand = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(cand):
         try:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)

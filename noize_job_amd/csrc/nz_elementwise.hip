@@ -581,6 +581,22 @@ __global__ __launch_bounds__(CT) void normalize_args_kernel(float *__restrict__ 
     }
 }
 
+// the sharded GetMapRangeJob (nz_comm_allgather_range): the ranks' {min, max, range} triples as one array of minima and
+// one of maxima, which the same fold then walks in rank order; and the triple it leaves
+__global__ void range_split_kernel(const float *__restrict__ triples, int n, float *__restrict__ mins, float *__restrict__ maxs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        mins[i] = triples[3 * i];
+        maxs[i] = triples[3 * i + 1];
+    }
+}
+__global__ void range_compose_kernel(const float *__restrict__ lo, const float *__restrict__ hi, float *__restrict__ res) {
+    const float mn = lo[0], mx = hi[1];
+    res[0] = mn;
+    res[1] = mx;
+    res[2] = mx - mn;  // `max_ - min_` of the job, IEEE fp32
+}
+
 // CropJob (Filter/Sample/CropJob.cs:34-41): out(x,z) = in(clamp(x + Offset), clamp(z + Offset)); the reference never
 // sets Offset, so it is 0 (top-left crop).  One thread per output cell; rows of different pitch on either side.
 __global__ __launch_bounds__(CT) void crop_kernel(const float *__restrict__ in, int in_res, float *__restrict__ out,
@@ -801,6 +817,19 @@ int32_t nz_launch_normalize_args(hipStream_t s, float *data, size_t n, const flo
     if (n == 0) return NZ_OK;
     const int vec = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
     hipLaunchKernelGGL(normalize_args_kernel, dim3((unsigned)(((n + 3) / 4 + CT - 1) / CT)), dim3(CT), 0, s, data, n, vec, args);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_range_split(hipStream_t s, const float *triples, int n, float *mins, float *maxs) {
+    if (n <= 0) return NZ_OK;
+    hipLaunchKernelGGL(range_split_kernel, dim3((n + 63) / 64), dim3(64), 0, s, triples, n, mins, maxs);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_range_compose(hipStream_t s, const float *lo, const float *hi, float *res) {
+    hipLaunchKernelGGL(range_compose_kernel, dim3(1), dim3(1), 0, s, lo, hi, res);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

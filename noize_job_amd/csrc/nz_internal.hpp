@@ -162,6 +162,12 @@ inline int32_t launch_on_ctx(nz_ctx *ctx, const nz_geom &g, F launch) {
 
 int32_t nz_check_stripe(const nz_stripe *st, int halo, int halo_below = -1);  // rows needed above / below the owned ones
 
+// nz_stages.cpp, for the sharded plan (nz_comm.cpp)
+int32_t nz_filter_taps(int32_t filter, nz_kernel_taps *t);  // KernelFilterType -> taps
+int nz_conv_tcap(int ksize);                                // applications fused per launch (0: no fused kernel)
+int32_t nz_fractal_rows(nz_ctx *ctx, hipStream_t stream, int noiseType, float *dst, int rows, int cols, int pitch, float hurst,
+                        float amp, float stepdown, float detune, int octaves, int xpos, int zpos_first_row, int noiseSize);
+
 // ---- launchers (defined in the .hip files) ---------------------------------------------------
 // `positions` (nullable, device): {xpos, zpos} per grid of a batched launch of `count` grids `bstride` floats apart
 int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, int cols, int pitch,
@@ -229,6 +235,9 @@ int32_t nz_launch_flow_from_track(hipStream_t s, float *pool, float *flow, float
 size_t nz_map_range_scratch_floats();
 int32_t nz_launch_map_range(hipStream_t s, const float *map, size_t n, float lim_min, float lim_max, float *res, void *scratch);
 int32_t nz_launch_normalize_args(hipStream_t s, float *data, size_t n, const float *args);
+// gathered {min, max, range} triples -> mins[n], maxs[n]; {lo[0], hi[1]} -> res = {min, max, max - min}
+int32_t nz_launch_range_split(hipStream_t s, const float *triples, int n, float *mins, float *maxs);
+int32_t nz_launch_range_compose(hipStream_t s, const float *lo, const float *hi, float *res);
 size_t nz_pool_automata_mask_words(int res);
 int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res, unsigned *mask);
 int32_t nz_launch_pool_automata_clean(hipStream_t s, const float *pool, int res, unsigned *mask);

@@ -327,6 +327,15 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
     return NZ_OK;
 }
 
+// what nz_comm.cpp (the sharded plan) needs of the above
+int32_t nz_filter_taps(int32_t filter, nz_kernel_taps *t) { return filter_taps(filter, t); }
+int nz_conv_tcap(int ksize) { return conv_tcap(ksize); }
+int32_t nz_fractal_rows(nz_ctx *ctx, hipStream_t stream, int noiseType, float *dst, int rows, int cols, int pitch, float hurst,
+                        float amp, float stepdown, float detune, int octaves, int xpos, int zpos_first_row, int noiseSize) {
+    return fractal_impl(ctx, stream, noiseType, dst, rows, cols, pitch, hurst, amp, stepdown, detune, octaves, xpos,
+                        zpos_first_row, noiseSize);
+}
+
 #define NZ_BEGIN(ctx, dep)                   \
     do {                                     \
         int32_t rc_ = nz_ctx_begin(ctx, dep); \
@@ -1219,10 +1228,7 @@ extern "C" int32_t nz_terrain_pipeline(nz_ctx *ctx, float *data, int32_t resolut
     bool in_A[2] = {true, true};
     for (size_t i = 0; i < plan.size(); i++) {
         const tp_launch &l = plan[i];
-        if (l.kind != kind) {
-            kind = l.kind;
-            NZ_TRY(mark(kind));
-        }
+        while (kind < l.kind) NZ_TRY(mark(++kind));  // a stage left out: an empty interval
         up_left -= l.up;
         down_left -= l.down;
         const bool last = i + 1 == plan.size();

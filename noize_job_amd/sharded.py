@@ -432,3 +432,234 @@ class NoComm:
 
     def exchange(self, planes, plan, up_rows, down_rows):
         pass
+
+
+# ---- the same schedule behind the C ABI (nz_comm.cpp): what a C# / C++ host calls ----------------------------------------
+HALO_MODES = {"recompute": N.NZ_HALO_RECOMPUTE, "exchange": N.NZ_HALO_EXCHANGE, "exchange_once": N.NZ_HALO_EXCHANGE_ONCE}
+# record layout of nz_sharded_plan
+OP_NOISE, OP_XBEGIN, OP_XFINISH, OP_FILTER, OP_FLOW, OP_EROSION, OP_MARK = 1, 2, 3, 4, 5, 6, 7
+
+
+def rccl_version():
+    v = C.c_int32(0)
+    N.check(N.lib.nz_comm_rccl_version(C.byref(v)), "nz_comm_rccl_version")
+    return v.value
+
+
+class NativeComm:
+    """nz_comm: an RCCL communicator (ncclCommInitRank) on the context's device plus its own stream.  `unique_id()` is
+    made by ONE rank and handed to the others out of band (bench.py broadcasts it through torch.distributed)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * N.NZ_COMM_ID_BYTES)()
+        N.check(N.lib.nz_comm_unique_id(buf), "nz_comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, ctx, uid, rank, world):
+        assert len(uid) == N.NZ_COMM_ID_BYTES
+        self.ctx = ctx
+        h = C.c_void_p()
+        buf = (C.c_uint8 * N.NZ_COMM_ID_BYTES).from_buffer_copy(uid)
+        N.check(N.lib.nz_comm_init(ctx._h, buf, rank, world, C.byref(h)), "nz_comm_init")
+        self._h = h
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self._h:
+            N.lib.nz_comm_destroy(self._h)
+            self._h = None
+
+    # the TorchComm interface on top of nz_halo_exchange (one stripe per rank): lets run_pipeline drive the Python schedule
+    # over the native exchange
+    overlap = True
+
+    def begin(self, planes, plan, up_rows, down_rows):
+        arr = (N.dev_ptr * len(planes))(*[t.data_ptr() for t in planes])
+        st = plan.stripe()
+        N.check(N.lib.nz_halo_exchange_begin(self.ctx._h, self._h, arr, len(planes), C.byref(st), up_rows, down_rows, 0),
+                "nz_halo_exchange_begin")
+        return True
+
+    def finish(self, reqs):
+        N.check(N.lib.nz_halo_exchange_finish(self.ctx._h, self._h, None), "nz_halo_exchange_finish")
+
+    def exchange(self, planes, plan, up_rows, down_rows):
+        self.finish(self.begin(planes, plan, up_rows, down_rows))
+
+    def allgather_range(self, map_ptr, n_floats, res_ptr, lim_min=float("inf"), lim_max=float("-inf")):
+        N.check(N.lib.nz_comm_allgather_range(self.ctx._h, self._h, map_ptr, n_floats, res_ptr, lim_min, lim_max, 0, None),
+                "nz_comm_allgather_range")
+
+
+def terrain_params(p):
+    """PipelineParams -> nz_terrain_params."""
+    return N.TerrainParams(p.noiseType, p.hurst, p.startingAmplitude, p.stepdown, p.detuneRate, p.octaves, p.noiseSize,
+                           p.filter, p.gaussIterations, p.flowIterations, p.normMin, p.normMax, p.erosionIterations)
+
+
+class ShardedGrid:
+    """nz_sharded: the stock stage list on a grows x cols grid cut into `stripes` row stripes over all ranks of `comm`
+    (None: one rank, device copies instead of RCCL).  The library owns the planes and the launch plan; `run()` replays
+    it (one C call per pass)."""
+
+    def __init__(self, ctx, comm, grows, cols, p, stripes=None, overlap=True, external_source=False, as_rank=None):
+        world = comm.world if comm is not None else 1
+        if as_rank is not None:
+            world = as_rank[1]
+        self.ctx, self.comm, self.p = ctx, comm, p
+        self.desc = N.ShardedDesc(grows, cols, stripes if stripes is not None else world, HALO_MODES[p.haloMode],
+                                  int(bool(overlap)), p.xpos, p.zpos, int(bool(external_source)),
+                                  as_rank[0] if as_rank is not None else 0, as_rank[1] if as_rank is not None else 0)
+        self.tp = terrain_params(p)
+        h = C.c_void_p()
+        # ctx None: a plan-only object (no planes, cannot run): the launch plan of rank as_rank[0] of as_rank[1]
+        N.check(N.lib.nz_sharded_create(ctx._h if ctx is not None else None, comm._h if comm is not None else None,
+                                        C.byref(self.desc), C.byref(self.tp), C.byref(h)), "nz_sharded_create")
+        self._h = h
+        self.local_stripes = N.lib.nz_sharded_local_stripes(h)
+
+    def close(self):
+        if self._h:
+            N.lib.nz_sharded_destroy(self._h)
+            self._h = None
+
+    def stripe(self, i):
+        """(nz_stripe, source plane address, result plane address) of local stripe i."""
+        st, src, res = N.Stripe(), N.dev_ptr(), N.dev_ptr()
+        N.check(N.lib.nz_sharded_stripe(self._h, i, C.byref(st), C.byref(src), C.byref(res)), "nz_sharded_stripe")
+        return st, src.value, res.value
+
+    def plan(self):
+        """The compiled plan as tuples (op, stripe, n, a, b, own0, own1, planes) -- see include/noize_hip.h."""
+        n = C.c_int32(0)
+        N.check(N.lib.nz_sharded_plan(self._h, None, 0, C.byref(n)), "nz_sharded_plan")
+        rec = (C.c_int32 * (8 * n.value))()
+        N.check(N.lib.nz_sharded_plan(self._h, rec, n.value, C.byref(n)), "nz_sharded_plan")
+        return [tuple(rec[8 * i:8 * i + 8]) for i in range(n.value)]
+
+    def run(self, marks=False, dep=0):
+        """One pass (enqueue only).  marks: also return the five stage-boundary handles."""
+        from .runtime import JobHandle
+        out = N.handle_t(0)
+        if marks:
+            m = (N.handle_t * 5)()
+            N.check(N.lib.nz_sharded_pipeline(self.ctx._h, self._h, m, dep, C.byref(out)), "nz_sharded_pipeline")
+            return JobHandle(self.ctx, out.value), [JobHandle(self.ctx, v) for v in m]
+        N.check(N.lib.nz_sharded_pipeline(self.ctx._h, self._h, None, dep, C.byref(out)), "nz_sharded_pipeline")
+        return JobHandle(self.ctx, out.value)
+
+    def traffic(self):
+        n, b = C.c_int32(0), C.c_size_t(0)
+        N.check(N.lib.nz_sharded_traffic(self._h, C.byref(n), C.byref(b)), "nz_sharded_traffic")
+        return n.value, b.value
+
+    def set_timing(self, on):
+        N.check(N.lib.nz_sharded_set_timing(self._h, int(bool(on))), "nz_sharded_set_timing")
+
+    def exchange_ms(self):
+        ms = C.c_float(0)
+        N.check(N.lib.nz_sharded_exchange_ms(self._h, C.byref(ms)), "nz_sharded_exchange_ms")
+        return ms.value
+
+    def map_range(self, res_ptr, lim_min=float("inf"), lim_max=float("-inf")):
+        N.check(N.lib.nz_sharded_map_range(self.ctx._h, self._h, res_ptr, lim_min, lim_max, 0, None), "nz_sharded_map_range")
+
+    def normalize(self, args_ptr):
+        N.check(N.lib.nz_sharded_normalize(self.ctx._h, self._h, args_ptr, 0, None), "nz_sharded_normalize")
+
+    def owned_rows(self, i):
+        """Host copy of local stripe i's result rows: (first global row, array [rows, cols])."""
+        import numpy as np
+        st, _, res = self.stripe(i)
+        n = (st.own1 - st.own0) * st.cols
+        out = np.empty(n, np.float32)
+        N.check(N.lib.nz_tile_download(self.ctx._h, res + st.own0 * st.cols * 4, out.ctypes.data, n, 0, None), "download")
+        self.ctx.synchronize()
+        return st.grow0 + st.own0, out.reshape(st.own1 - st.own0, st.cols)
+
+
+class _PlanRecorder:
+    """A stripe-ops object that launches nothing: it writes down what pipeline_steps asks for, in the record layout of
+    nz_sharded_plan -- the Python schedule as the specification the native plan is checked against."""
+
+    def __init__(self, lib=None):
+        self.lib = lib or N.lib
+        self.records = []
+        self.ids = {}
+
+    def kernel_filter_halo_rows(self, filter, iterations):
+        return self.lib.nz_kernel_filter_halo_rows(filter, iterations)
+
+    def kernel_filter_max_fused(self, filter):
+        return self.lib.nz_kernel_filter_max_fused(filter)
+
+    def erosion_max_fused(self):
+        return self.lib.nz_erosion_max_fused_iterations()
+
+    def flow_fused_max(self):
+        return self.lib.nz_flow_fused_max_iterations()
+
+    def _id(self, buf):
+        return self.ids[id(buf)]
+
+    def fractal(self, buf, plan, p):
+        if plan.own1 > plan.own0:
+            self.records.append((OP_NOISE, 0, 0, 0, plan.own0, plan.own1, self._id(buf) | (self._id(buf) << 8)))
+
+    def kernel_filter(self, src, dst, plan, filter, T):
+        if plan.own1 > plan.own0:
+            self.records.append((OP_FILTER, T, 0, 0, plan.own0, plan.own1, self._id(src) | (self._id(dst) << 8)))
+
+    def erosion(self, src, dst, plan, E):
+        if plan.own1 > plan.own0:
+            self.records.append((OP_EROSION, E, 0, 0, plan.own0, plan.own1, self._id(src) | (self._id(dst) << 8)))
+
+    def flow_fused(self, h, S_in, S_out, dst, plan, n, first, last, normMin, normMax):
+        if plan.own1 > plan.own0:
+            self.records.append((OP_FLOW, n, int(first), int(last), plan.own0, plan.own1,
+                                 self._id(h) | (self._id(dst) << 8) | (self._id(S_in) << 16) | (self._id(S_out) << 24)))
+
+
+class _Named:
+    def __init__(self, planes=None):
+        self.planes = planes
+
+    def __getitem__(self, k):
+        return self.planes[k]
+
+
+def python_plan(rank, world, grows, cols, p, overlap=True):
+    """What pipeline_steps does for stripe `rank` of `world`, as records (op, n, a, b, own0, own1, planes) comparable with
+    ShardedGrid.plan() (whose records also carry the local stripe index)."""
+    rec = _PlanRecorder()
+    halo = halo_rows_needed(rec, p)
+    plan = StripePlan(rank, world, grows, cols, halo, neighbours_own_halo=p.haloMode != "recompute")
+    A, B = _Named(), _Named()
+    S0, S1 = _Named([_Named() for _ in range(FLOW_PLANES)]), _Named([_Named() for _ in range(FLOW_PLANES)])
+    rec.ids = {id(A): 0, id(B): 1, id(S0): 0, id(S1): 1}
+    first_plane = {id(A): 0, id(B): 1}
+    for k in range(FLOW_PLANES):
+        first_plane[id(S0[k])] = 2 + k
+        first_plane[id(S1[k])] = 7 + k
+    marks = {"noise": 0, "gauss": 1, "flow": 2, "erosion": 3, "end": 4}
+    result = []
+    gen = pipeline_steps(rec, plan, p, (A, B, S0, S1), result,
+                         on_stage=lambda name: rec.records.append((OP_MARK, marks[name], 0, 0, 0, 0, 0)))
+    try:
+        req = next(gen)
+        while True:
+            if req == ("finish",):
+                rec.records.append((OP_XFINISH, 0, 0, 0, 0, 0, 0))
+                req = next(gen)
+                continue
+            planes, up_rows, down_rows = req
+            rec.records.append((OP_XBEGIN, len(planes), up_rows, down_rows, 0, 0, first_plane[id(planes[0])]))
+            if overlap:
+                req = gen.send("async")
+            else:
+                rec.records.append((OP_XFINISH, 0, 0, 0, 0, 0, 0))
+                req = next(gen)
+    except StopIteration:
+        pass
+    return rec.records, rec.ids[id(result[0])], plan
