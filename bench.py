@@ -86,7 +86,18 @@ def parse():
                     help="go through the launcher even with one rank (what --gpus N > 1 does when no launcher set "
                          "WORLD_SIZE): the ranks are children started with torch.distributed.run")
     ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "P"), default=None,
-                    help="one-process rehearsal of rank R of a P-rank job (needs --halo recompute)")
+                    help="one-process rehearsal of rank R of a P-rank job: --halo recompute, or (native schedule) --halo "
+                         "exchange / exchange_once with the neighbour ranks played by the rank itself through RCCL")
+    ap.add_argument("--overlap", type=int, choices=(0, 1, 2), default=0,
+                    help="native exchange schedule: 0 = RCCL transfers on the compute stream between the launches; 1 = a launch's "
+                         "interior rows while its ghost rows travel, border rows after; 2 = border rows first, the NEXT "
+                         "launch's exchange travels while the interior runs")
+    ap.add_argument("--marked-steps", type=int, default=200,
+                    help="sharded runs: stage markers (five event records per step) in the last this-many timed steps only")
+    ap.add_argument("--impl", choices=("native", "python"), default="native",
+                    help="sharded runs: `native` = the stripe schedule and the RCCL exchange behind the C ABI "
+                         "(nz_sharded_pipeline: one call per step, ncclSend / ncclRecv on the library's communicator "
+                         "stream); `python` = the same schedule in noize_job_amd/sharded.py over torch.distributed P2P")
     ap.add_argument("--flush", choices=("swap", "copy"), default="swap",
                     help="N=1: the tile is a READ / WRITE plane pair and TileHelpers.SWAP_RWTILE is a pointer swap "
                          "(nz_*_rw entries), or one plane with the in-place entries and their flush copies")
@@ -307,54 +318,94 @@ class TimedComm:
         return t
 
 
-def strong_grid(nj, sh, torch, dist, ctx, grid, rank, world, steps=20, warm=5):
+def make_native_comm(sh, torch, dist, ctx, rank, world):
+    """nz_comm for this rank: rank 0 draws the ncclUniqueId (nz_comm_unique_id), torch.distributed carries its 128 bytes to
+    the other ranks (out-of-band plumbing), every rank joins with nz_comm_init."""
+    uid = [sh.NativeComm.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)
+    return sh.NativeComm(ctx, uid[0], rank, world)
+
+
+def strong_grid(nj, sh, torch, dist, ctx, grid, rank, world, impl="native", ncomm=None, steps=20, warm=5):
     """BASELINE config 5's grid (grid^2) split into `world` row stripes, one per rank: the quantity the >= 6x target is
     defined on, measured at EVERY N (N = 1: the whole grid on one GPU).  Ghost rows recomputed from the closed-form
     noise (no communication) and, at N > 1, exchanged with the neighbour ranks over RCCL before every launch, with the
     time the compute stream spends in the exchanges split out.  Barrier + synchronize on both sides, max over ranks."""
     out = {}
     ops = sh.HipStripeOps(ctx)
-    modes = ("recompute", "exchange", "exchange_blocking", "exchange_once") if world > 1 else ("recompute",)
+    # native: "exchange" = the transfers on the compute stream between the launches (overlap 0, the default);
+    # "exchange_interior_first" / "exchange_border_first" = the two overlapped schedules (overlap 1 / 2).
+    # python: "exchange" = overlapped P2P batches, "exchange_blocking" = the exchange completes first
+    if world <= 1:
+        modes = ("recompute",)
+    elif impl == "native":
+        modes = ("recompute", "exchange", "exchange_interior_first", "exchange_border_first", "exchange_once")
+    else:
+        modes = ("recompute", "exchange", "exchange_blocking", "exchange_once")
     for label in modes:
-        mode = "exchange" if label == "exchange_blocking" else label
+        mode = "exchange" if label.startswith("exchange_") and label != "exchange_once" else label
         p = sh.PipelineParams(gaussIterations=G_IT, flowIterations=F_IT, erosionIterations=E_IT, haloMode=mode)
-        halo = sh.halo_rows_needed(ops, p)
-        plan = sh.StripePlan(rank, world, grid, grid, halo, neighbours_own_halo=mode != "recompute")
-        bufs = (torch.zeros(plan.rows, grid, dtype=torch.float32, device="cuda"),
-                torch.zeros(plan.rows, grid, dtype=torch.float32, device="cuda"),
-                torch.zeros(sh.FLOW_PLANES, plan.rows, grid, dtype=torch.float32, device="cuda"),
-                torch.zeros(sh.FLOW_PLANES, plan.rows, grid, dtype=torch.float32, device="cuda"))
-        # "exchange": the launch that needs the ghost rows runs its interior while they travel (RCCL P2P on the process
-        # group's stream), its border rows after; "exchange_blocking": the exchange completes first
-        comm = sh.NoComm() if mode == "recompute" else TimedComm(sh.TorchComm(dist, overlap=label != "exchange_blocking"), ctx)
 
         def fence():
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
-        for _ in range(warm):
-            sh.run_pipeline(ops, comm, plan, p, bufs)
-        fence()
-        if isinstance(comm, TimedComm):
-            comm.total_ms()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            sh.run_pipeline(ops, comm, plan, p, bufs)
-        fence()
-        dt = time.perf_counter() - t0
-        ex_ms = comm.total_ms() / steps if isinstance(comm, TimedComm) else 0.0
+        host_s = 0.0
+        if impl == "native":
+            g = sh.ShardedGrid(ctx, ncomm if world > 1 else None, grid, grid, p, stripes=world,
+                               overlap={"exchange_interior_first": 1, "exchange_border_first": 2}.get(label, 0))
+            for _ in range(warm):
+                g.run()
+            fence()
+            g.set_timing(mode != "recompute" and world > 1)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                h0 = time.perf_counter()
+                g.run()
+                host_s += time.perf_counter() - h0
+            fence()
+            dt = time.perf_counter() - t0
+            ex_ms = g.exchange_ms() / steps if (mode != "recompute" and world > 1) else 0.0
+            g.close()
+        else:
+            halo = sh.halo_rows_needed(ops, p)
+            plan = sh.StripePlan(rank, world, grid, grid, halo, neighbours_own_halo=mode != "recompute")
+            bufs = (torch.zeros(plan.rows, grid, dtype=torch.float32, device="cuda"),
+                    torch.zeros(plan.rows, grid, dtype=torch.float32, device="cuda"),
+                    torch.zeros(sh.FLOW_PLANES, plan.rows, grid, dtype=torch.float32, device="cuda"),
+                    torch.zeros(sh.FLOW_PLANES, plan.rows, grid, dtype=torch.float32, device="cuda"))
+            # "exchange": the launch that needs the ghost rows runs its interior while they travel (RCCL P2P on the process
+            # group's stream), its border rows after; "exchange_blocking": the exchange completes first
+            comm = sh.NoComm() if mode == "recompute" else TimedComm(sh.TorchComm(dist, overlap=label != "exchange_blocking"), ctx)
+            for _ in range(warm):
+                sh.run_pipeline(ops, comm, plan, p, bufs)
+            fence()
+            if isinstance(comm, TimedComm):
+                comm.total_ms()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                h0 = time.perf_counter()
+                sh.run_pipeline(ops, comm, plan, p, bufs)
+                host_s += time.perf_counter() - h0
+            fence()
+            dt = time.perf_counter() - t0
+            ex_ms = comm.total_ms() / steps if isinstance(comm, TimedComm) else 0.0
+            del bufs
+            torch.cuda.empty_cache()
+        host_ms = host_s / steps * 1e3
         if world > 1:
-            t = torch.tensor([dt, ex_ms], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt, ex_ms, host_ms], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt, ex_ms = float(t[0].item()), float(t[1].item())
-        e = {"ms_per_step": round(dt / steps * 1e3, 4), "Mcells/s": round(grid * grid / (dt / steps) / 1e6, 1)}
+            dt, ex_ms, host_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
+        e = {"ms_per_step": round(dt / steps * 1e3, 4), "Mcells/s": round(grid * grid / (dt / steps) / 1e6, 1),
+             "host_enqueue_ms_per_step": round(host_ms, 4)}
         if mode != "recompute":
             e["exchange_ms_per_step"] = round(ex_ms, 4)
         out[label] = e
-        del bufs
-        torch.cuda.empty_cache()
     out["grid"] = "%dx%d as %d row stripes of %d rows" % (grid, grid, world, grid // world)
     out["steps"] = steps
+    out["impl"] = impl
     out["note"] = ("strong scaling: the same %d^2 grid at every N; speed-up at N GPUs = this figure at N / this figure "
                    "at N = 1" % grid)
     return out
@@ -444,8 +495,9 @@ def main():
     local_rank %= ndev  # a launcher that narrows HIP_VISIBLE_DEVICES per rank leaves one device, index 0
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.sharded or args.as_rank is not None
-    if args.as_rank is not None and (world != 1 or args.halo != "recompute"):
-        raise SystemExit("--as-rank is a single-process rehearsal of the communication-free schedule")
+    if args.as_rank is not None and (world != 1 or (args.halo != "recompute" and args.impl != "native")):
+        raise SystemExit("--as-rank is a single-process rehearsal: --halo recompute, or the native schedule with the "
+                         "neighbour ranks played by the rank itself")
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -524,21 +576,39 @@ def main():
         plan = sh.StripePlan(prank, pworld, stripe_rows * pworld, args.cols, halo,
                              neighbours_own_halo=args.halo != "recompute")
         cells = plan.nown * world * plan.cols  # every rank owns stripe_rows rows
-        bufs = (torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
-                torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
-                torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
-                torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"))
-        # the exchanges are asynchronous (P2P batches on the process group's stream, the launch's interior rows run
-        # meanwhile); TimedComm brackets the compute stream's wait for them with stream markers
-        comm = sh.NoComm() if args.halo == "recompute" else TimedComm(sh.TorchComm(dist), ctx)
+        host_s = [0.0]  # host time spent enqueueing the timed steps
+        ncomm = grid = comm = None
+        if args.impl == "native":
+            # the schedule and the exchange behind the C ABI: one nz_sharded_pipeline call per step
+            if world > 1 or args.halo != "recompute":
+                ncomm = make_native_comm(sh, torch, dist, ctx, rank, world)
+            grid = sh.ShardedGrid(ctx, ncomm, plan.grows, plan.cols, p, stripes=pworld, overlap=args.overlap, as_rank=args.as_rank)
 
-        def step(record):
-            if record:  # stream markers where the stages begin (exchanges of a stage are charged to it)
-                hs = {}
-                sh.run_pipeline(ops, comm, plan, p, bufs, on_stage=lambda name: hs.__setitem__(name, ctx.record()))
-                marks.append([hs[n] for n in ("noise", "gauss", "flow", "erosion", "end")])
-            else:
-                sh.run_pipeline(ops, comm, plan, p, bufs)
+            def step(record):
+                h0 = time.perf_counter()
+                if record:  # stream markers where the stages begin (exchanges of a stage are charged to it)
+                    marks.append(grid.run(marks=True)[1])
+                else:
+                    grid.run()
+                host_s[0] += time.perf_counter() - h0
+        else:
+            bufs = (torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
+                    torch.zeros(plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
+                    torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"),
+                    torch.zeros(sh.FLOW_PLANES, plan.rows, plan.cols, dtype=torch.float32, device="cuda"))
+            # the exchanges are asynchronous (P2P batches on the process group's stream, the launch's interior rows run
+            # meanwhile); TimedComm brackets the compute stream's wait for them with stream markers
+            comm = sh.NoComm() if args.halo == "recompute" else TimedComm(sh.TorchComm(dist), ctx)
+
+            def step(record):
+                h0 = time.perf_counter()
+                if record:  # stream markers where the stages begin (exchanges of a stage are charged to it)
+                    hs = {}
+                    sh.run_pipeline(ops, comm, plan, p, bufs, on_stage=lambda name: hs.__setitem__(name, ctx.record()))
+                    marks.append([hs[n] for n in ("noise", "gauss", "flow", "erosion", "end")])
+                else:
+                    sh.run_pipeline(ops, comm, plan, p, bufs)
+                host_s[0] += time.perf_counter() - h0
 
         how = {"exchange": "ghost rows exchanged over RCCL before every launch",
                "exchange_once": "%d ghost rows per side of the source plane exchanged once over RCCL" % halo,
@@ -598,20 +668,39 @@ def main():
     fence()
     if sharded and isinstance(comm, TimedComm):
         comm.total_ms()  # forget the warm-up's exchanges
+    if sharded:
+        host_s[0] = 0.0
+    timed_exchanges = sharded and args.halo != "recompute" and (grid is not None or isinstance(comm, TimedComm))
     t0 = time.perf_counter()
     ex_steps = min(args.steps, 64)  # exchanges are bracketed with markers in the last steps only
     for i in range(args.steps):
-        if sharded and isinstance(comm, TimedComm):
-            comm.enabled = args.steps - i <= ex_steps
-        step(args.steps - i <= MAX_MARKED_STEPS)
+        if timed_exchanges and args.steps - i == ex_steps:
+            if grid is not None:
+                grid.set_timing(True)
+            else:
+                comm.enabled = True
+        elif timed_exchanges and i == 0 and grid is None:
+            comm.enabled = False
+        step(args.steps - i <= (MAX_MARKED_STEPS if not sharded else min(MAX_MARKED_STEPS, args.marked_steps)))
     fence()
     dt = time.perf_counter() - t0
-    exchange_ms = None
+    exchange_ms = host_enqueue_ms = host_idle_ms = None
     if sharded:
-        ex = comm.total_ms() / ex_steps if isinstance(comm, TimedComm) else 0.0
-        t = torch.tensor([dt, ex], dtype=torch.float64, device="cuda")
+        # the host's own cost of enqueueing a step, measured where the queue cannot push back: eight steps on an idle
+        # stream, each call timed on its own (the timed steps above run against a full queue)
+        probe = []
+        for _ in range(8):
+            h0 = time.perf_counter()
+            step(False)
+            probe.append(time.perf_counter() - h0)
+        fence()
+        host_idle_ms = sorted(probe)[len(probe) // 2] * 1e3
+        ex = 0.0
+        if timed_exchanges:
+            ex = (grid.exchange_ms() if grid is not None else comm.total_ms()) / ex_steps
+        t = torch.tensor([dt, ex, host_s[0] / args.steps * 1e3], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, exchange_ms = float(t[0].item()), float(t[1].item())
+        dt, exchange_ms, host_enqueue_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
 
     stage_by_stage_s, got_one_call = None, None
     if not sharded and striped is None and one_call:
@@ -647,12 +736,34 @@ def main():
                 rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:  # noqa: BLE001
                 rccl = None
+            if grid is not None:
+                n_ex, sent = grid.traffic()
+                impl_note = {"impl": "native: nz_sharded_pipeline (one C-ABI call per step; ncclGroupStart / ncclSend / ncclRecv "
+                                     "/ ncclGroupEnd with rank +- 1, " +
+                                     {0: "on the compute stream between the launch that produced the rows and the launch "
+                                         "that reads them",
+                                      1: "on the library's communicator stream with event hand-offs; interior rows enqueued "
+                                         "before the wait, border rows after",
+                                      2: "on the library's communicator stream with event hand-offs; border rows first, the "
+                                         "next launch's exchange travels while the interior rows run"}[args.overlap] + ")",
+                             "exchanges_per_step": n_ex, "bytes_sent_per_step": sent,
+                             "data_path_rccl": ("librccl %d opened by libnoize_hip.so" % sh.rccl_version()) if ncomm is not None else None}
+            else:
+                impl_note = {"impl": "python: noize_job_amd/sharded.py over torch.distributed batch_isend_irecv"}
             out["comm"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "rccl_version": rccl,
-                           "halo": args.halo, "overlapped": bool(getattr(comm, "overlap", False)),
+                           "halo": args.halo, "overlapped": (args.overlap != 0) if grid is not None else bool(getattr(comm, "overlap", False)),
                            "exchange_ms_per_step": None if exchange_ms is None else round(exchange_ms, 4),
+                           "host_enqueue_ms_per_step": None if host_enqueue_ms is None else round(host_enqueue_ms, 4),
+                           "host_enqueue_ms_idle_queue": None if host_idle_ms is None else round(host_idle_ms, 4),
+                           "overlap_mode": args.overlap if grid is not None else None,
+                           **impl_note,
                            "ranks_on_device": "one process per GPU (LOCAL_RANK -> device), %d device(s) visible to rank 0" % ndev,
                            "note": "exchange_ms_per_step = time the compute stream waits for ghost rows (HIP events around "
-                                   "every wait, max over ranks); 0 ghost-row traffic with --halo recompute"}
+                                   "every wait, max over ranks); 0 ghost-row traffic with --halo recompute; "
+                                   "host_enqueue_ms_per_step = host time inside the step's enqueue calls during the timed steps "
+                                   "(max over ranks; includes the time the full command queue pushes back); "
+                                   "host_enqueue_ms_idle_queue = the same call on an idle stream (median of 8, rank 0): the "
+                                   "host's own cost -- the step is host-bound if THIS approaches ms_per_step"}
             out["config"]["strong_scaling"] = (
                 "the same %dx%d grid at every N; denominator = `grid_%d`.recompute of the N = 1 line (the whole grid on one "
                 "GPU)" % (plan.grows, plan.cols, plan.grows)) if strong else None
@@ -836,15 +947,21 @@ def main():
         if not sharded:  # N = 1 without a process group: the whole grid as one stripe
             g = None
             try:
-                g = strong_grid(nj, sh, torch, None, ctx, args.grid, 0, 1)
+                g = strong_grid(nj, sh, torch, None, ctx, args.grid, 0, 1, impl=args.impl)
             except Exception as e:  # noqa: BLE001  (e.g. not enough free memory next to other processes)
                 g = {"error": "%s: %s" % (type(e).__name__, e)}
             out["grid_%d" % args.grid] = g
         else:
-            g = strong_grid(nj, sh, torch, dist, ctx, args.grid, rank, world)
+            if args.impl == "native" and ncomm is None and world > 1:
+                ncomm = make_native_comm(sh, torch, dist, ctx, rank, world)
+            g = strong_grid(nj, sh, torch, dist, ctx, args.grid, rank, world, impl=args.impl, ncomm=ncomm)
             if rank == 0:
                 out["grid_%d" % args.grid] = g
     if sharded:
+        if grid is not None:
+            grid.close()
+        if ncomm is not None:
+            ncomm.close()
         dist.barrier()
         dist.destroy_process_group()
     if striped is not None:

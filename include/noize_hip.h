@@ -520,9 +520,15 @@ int32_t nz_comm_allgather_range(nz_ctx *ctx, nz_comm *comm, const float *map, si
  *   NZ_HALO_RECOMPUTE     every stripe evaluates the noise on its rows plus the stencil radius of everything downstream
  *                         and each launch produces a window that shrinks by the radius it consumed: no data-path
  *                         communication (closed-form source only);
- *   NZ_HALO_EXCHANGE      before each launch the stripes exchange exactly the ghost rows it consumes; with `overlap` the
- *                         launch's interior rows, which read no ghost row, are enqueued while the rows travel, its border
- *                         rows after the wait;
+ *   NZ_HALO_EXCHANGE      before each launch the stripes exchange exactly the ghost rows it consumes.  `overlap`:
+ *                         0  the transfers are enqueued on the compute stream itself, between the launch that produced the
+ *                            rows and the launch that reads them (no second stream, no event hand-off) -- the fastest form
+ *                            on MI355X: a transfer kernel takes ~14 us, and one running beside a stencil launch that fills
+ *                            the chip does not finish before that launch does (measured);
+ *                         1  on the communicator's stream, while the launch's interior rows, which read no ghost row, run;
+ *                            its border rows follow after the wait;
+ *                         2  a launch produces the rows its neighbours need first, the exchange for the NEXT launch travels
+ *                            while its interior rows run;
  *   NZ_HALO_EXCHANGE_ONCE the source plane's ghost rows for the whole pipeline are exchanged once, then as RECOMPUTE.
  * Transfers between stripes of different ranks AND between two stripes of one rank go through ncclSend / ncclRecv (RCCL
  * runs a send and its matching receive on one device), so that a one-GPU box executes the very code path of a node;
@@ -538,7 +544,7 @@ typedef struct nz_sharded_desc {
     int32_t grows, cols;    /* the global grid */
     int32_t stripes;        /* over all ranks; a multiple of the world size */
     int32_t haloMode;       /* enum nz_halo_mode */
-    int32_t overlap;        /* exchange modes: != 0 splits a launch into interior rows (before the wait) and border rows */
+    int32_t overlap;        /* NZ_HALO_EXCHANGE: 0 inline on the compute stream, 1 interior rows first, 2 border rows first */
     int32_t xpos, zpos;     /* GeneratorData.xpos / zpos of the grid's first cell */
     int32_t externalSource;
     int32_t asRank, asWorld;
@@ -564,8 +570,9 @@ int32_t nz_sharded_plan(const nz_sharded *sh, int32_t *records, int32_t max_reco
 int32_t nz_sharded_pipeline(nz_ctx *ctx, nz_sharded *sh, nz_handle *marks, nz_handle dep, nz_handle *out);
 /* exchanges and payload bytes this rank sends per pass */
 int32_t nz_sharded_traffic(const nz_sharded *sh, int32_t *exchanges, size_t *bytes_sent);
-/* with timing on, every wait of the compute stream for an exchange is bracketed by events; nz_sharded_exchange_ms sums
- * and forgets the brackets recorded so far (host blocks until they have completed; at most 1024 are kept) */
+/* with timing on, every wait of the compute stream for an exchange (overlap 0: every exchange itself) is bracketed by
+ * events; nz_sharded_exchange_ms sums and forgets the brackets recorded so far (host blocks until they have completed; at
+ * most 1024 are kept) */
 int32_t nz_sharded_set_timing(nz_sharded *sh, int32_t on);
 int32_t nz_sharded_exchange_ms(nz_sharded *sh, float *ms);
 /* GetMapRangeJob + MapNormalizeValues over the result planes of the whole grid (nz_comm_allgather_range over all

@@ -118,7 +118,9 @@ namespace {
 
 // Posts one batch behind everything enqueued on ctx's stream so far.  comm == NULL (one rank, no RCCL): device copies on
 // the context's own stream.
-int32_t post_batch(nz_ctx *ctx, nz_comm *comm, const xfer *x, size_t n) {
+// on_ctx_stream: the batch is enqueued on ctx's own stream (no event hand-off, nothing to finish): the launch that follows
+// simply follows.
+int32_t post_batch(nz_ctx *ctx, nz_comm *comm, const xfer *x, size_t n, bool on_ctx_stream = false) {
     if (n == 0) return NZ_OK;
     if (!comm) {
         for (size_t i = 0; i < n; i++) {
@@ -129,12 +131,15 @@ int32_t post_batch(nz_ctx *ctx, nz_comm *comm, const xfer *x, size_t n) {
     }
     NZ_REQUIRE(!comm->pending, "nz_halo_exchange_begin: the previous exchange has not been finished");
     const rccl_api *api = comm->api;
-    NZ_HIP(hipEventRecord(comm->ev_go, ctx->stream));
-    NZ_HIP(hipStreamWaitEvent(comm->stream, comm->ev_go, 0));
+    hipStream_t xs = on_ctx_stream ? ctx->stream : comm->stream;
+    if (!on_ctx_stream) {
+        NZ_HIP(hipEventRecord(comm->ev_go, ctx->stream));
+        NZ_HIP(hipStreamWaitEvent(comm->stream, comm->ev_go, 0));
+    }
     NZ_NCCL(api, api->GroupStart());
     for (size_t i = 0; i < n; i++) {
         if (x[i].src == comm->rank) {
-            ncclResult_t r = api->Send(x[i].send, x[i].floats, ncclFloat, x[i].dst, comm->comm, comm->stream);
+            ncclResult_t r = api->Send(x[i].send, x[i].floats, ncclFloat, x[i].dst, comm->comm, xs);
             if (r != ncclSuccess) {
                 (void)api->GroupEnd();
                 nz_set_error("ncclSend to rank %d failed: %s", x[i].dst, api->GetErrorString(r));
@@ -142,7 +147,7 @@ int32_t post_batch(nz_ctx *ctx, nz_comm *comm, const xfer *x, size_t n) {
             }
         }
         if (x[i].dst == comm->rank) {
-            ncclResult_t r = api->Recv(x[i].recv, x[i].floats, ncclFloat, x[i].src, comm->comm, comm->stream);
+            ncclResult_t r = api->Recv(x[i].recv, x[i].floats, ncclFloat, x[i].src, comm->comm, xs);
             if (r != ncclSuccess) {
                 (void)api->GroupEnd();
                 nz_set_error("ncclRecv from rank %d failed: %s", x[i].src, api->GetErrorString(r));
@@ -151,6 +156,7 @@ int32_t post_batch(nz_ctx *ctx, nz_comm *comm, const xfer *x, size_t n) {
         }
     }
     NZ_NCCL(api, api->GroupEnd());
+    if (on_ctx_stream) return NZ_OK;
     NZ_HIP(hipEventRecord(comm->ev_done, comm->stream));
     comm->pending = true;
     return NZ_OK;
@@ -210,7 +216,11 @@ extern "C" int32_t nz_comm_init(nz_ctx *ctx, const uint8_t *id, int32_t rank, in
         delete c;
         return NZ_ERR_COMM;
     }
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // highest priority: a hardware queue of its own (streams of one priority share a few), and the short transfer
+    // kernels are dispatched ahead of the long stencil launches they run beside
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_go, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -547,6 +557,49 @@ int32_t build_program(nz_sharded &sh, const sh_layout &L) {
         finish();
     }
     int current = 0;
+    // the exchange launch i needs before it runs, with the planes as they are assigned when it starts
+    struct xspec { std::vector<int> planes; int up, down; };
+    auto spec = [&](size_t i, int cur_, int s_cur_) {
+        const launch_rad &r = radii[i];
+        if (r.kind == 2 && (int)i == flow_first) return xspec{{cur_}, flow_widest, flow_widest};  // height: once, read by every flow launch
+        if (r.kind == 2) return xspec{{2 + 5 * s_cur_, 3 + 5 * s_cur_, 4 + 5 * s_cur_, 5 + 5 * s_cur_, 6 + 5 * s_cur_}, r.up, r.down};
+        return xspec{{cur_}, r.up, r.down};
+    };
+    // overlap 2 (border first): a launch produces the rows its neighbours need FIRST, the exchange for the NEXT launch
+    // starts behind them and travels while the launch's interior rows run -- a launch never waits for rows it has just
+    // asked for.  The noise stage is split the same way for the first launch's exchange.
+    const bool border_first = !recompute && sh.d.overlap == 2;
+    bool in_flight = false;  // border_first: the exchange for the launch about to be emitted has been posted
+    if (border_first && !radii.empty() && !sh.prog.empty()) {
+        // redo the noise ops: rows the first exchange sends, then the exchange, then the rest
+        const xspec x0 = spec(0, cur, s_cur);
+        std::vector<sh_op> noise;
+        while (!sh.prog.empty() && sh.prog.back().kind == OP_NOISE) {
+            noise.insert(noise.begin(), sh.prog.back());
+            sh.prog.pop_back();
+        }
+        bool ok = !noise.empty();
+        for (const sh_op &o : noise) ok = ok && (o.own1 - o.own0 > x0.up + x0.down);
+        if (ok) {
+            for (const sh_op &o : noise) {
+                sh_op t = o, b = o;
+                t.own1 = o.own0 + x0.down;
+                b.own0 = o.own1 - x0.up;
+                if (t.own1 > t.own0) emit(t);
+                if (b.own1 > b.own0) emit(b);
+            }
+            exchange(x0.planes, x0.up, x0.down);
+            in_flight = true;
+            for (const sh_op &o : noise) {
+                sh_op m = o;
+                m.own0 = o.own0 + x0.down;
+                m.own1 = o.own1 - x0.up;
+                emit(m);
+            }
+        } else {
+            for (const sh_op &o : noise) emit(o);
+        }
+    }
     for (size_t i = 0; i < radii.size(); i++) {
         const launch_rad &r = radii[i];
         while (current < r.kind) mark(++current);  // a stage left out: an empty interval
@@ -556,11 +609,10 @@ int32_t build_program(nz_sharded &sh, const sh_layout &L) {
         }
         const bool first = (int)i == flow_first, last = (int)i == flow_last;
         bool async = false;
-        if (!recompute) {
-            if (r.kind == 2 && first) exchange({cur}, flow_widest, flow_widest);  // height: exchanged once, read by every flow launch
-            else if (r.kind == 2) exchange({2 + 5 * s_cur, 3 + 5 * s_cur, 4 + 5 * s_cur, 5 + 5 * s_cur, 6 + 5 * s_cur}, r.up, r.down);
-            else exchange({cur}, r.up, r.down);
-            async = sh.d.overlap != 0;
+        if (!recompute && !in_flight) {
+            const xspec x = spec(i, cur, s_cur);
+            exchange(x.planes, x.up, x.down);
+            async = sh.d.overlap == 1;
         }
         // the launch on rows [own0, own1) of stripe j
         auto launch = [&](int j, win w) {
@@ -569,30 +621,58 @@ int32_t build_program(nz_sharded &sh, const sh_layout &L) {
             else if (r.kind == 2) emit(sh_op{OP_FLOW, j, r.n, first, last, w.own0, w.own1, cur, nxt, s_cur, s_nxt, -1});
             else emit(sh_op{OP_EROSION, j, r.n, 0, 0, w.own0, w.own1, cur, nxt, 0, 0, -1});
         };
-        // split_launch (sharded.py): interior rows while the ghost rows travel, border rows after the wait
-        bool split = async;
         std::vector<win> wins(sh.S);
-        for (int j = 0; j < sh.S; j++) {
-            wins[j] = widened(sh, sh.st[j], need_up, need_down);
-            if (wins[j].own1 - r.down <= wins[j].own0 + r.up) split = false;
-        }
-        if (!split) {
-            if (!recompute) finish();
-            for (int j = 0; j < sh.S; j++) launch(j, wins[j]);
+        for (int j = 0; j < sh.S; j++) wins[j] = widened(sh, sh.st[j], need_up, need_down);
+        // planes as launch i + 1 will find them
+        int cur2 = cur, nxt2 = nxt, s_cur2 = s_cur, s_nxt2 = s_nxt;
+        if (r.kind == 2) {
+            std::swap(s_cur2, s_nxt2);
+            if (last) std::swap(cur2, nxt2);
         } else {
-            for (int j = 0; j < sh.S; j++) launch(j, rows_window(wins[j], wins[j].own0 + r.up, wins[j].own1 - r.down));
-            finish();
-            for (int j = 0; j < sh.S; j++) {
-                if (r.up > 0) launch(j, rows_window(wins[j], wins[j].own0, wins[j].own0 + r.up));
-                if (r.down > 0) launch(j, rows_window(wins[j], wins[j].own1 - r.down, wins[j].own1));
+            std::swap(cur2, nxt2);
+        }
+        if (border_first) {
+            finish();  // the rows this launch reads have arrived (posted a launch ago)
+            in_flight = false;
+            bool split = i + 1 < radii.size();
+            xspec xn{{}, 0, 0};
+            if (split) {
+                xn = spec(i + 1, cur2, s_cur2);
+                // the flow stage's later launches exchange state planes a non-last launch writes, its first one the heights,
+                // which no flow launch writes: either way the rows come out of THIS launch, unless it is a flow launch that
+                // hands heights on unchanged
+                for (int j = 0; j < sh.S; j++)
+                    if (wins[j].own1 - wins[j].own0 <= xn.up + xn.down) split = false;
+            }
+            if (split) {
+                for (int j = 0; j < sh.S; j++) {
+                    if (xn.down > 0) launch(j, rows_window(wins[j], wins[j].own0, wins[j].own0 + xn.down));
+                    if (xn.up > 0) launch(j, rows_window(wins[j], wins[j].own1 - xn.up, wins[j].own1));
+                }
+                exchange(xn.planes, xn.up, xn.down);
+                in_flight = true;
+                for (int j = 0; j < sh.S; j++) launch(j, rows_window(wins[j], wins[j].own0 + xn.down, wins[j].own1 - xn.up));
+            } else {
+                for (int j = 0; j < sh.S; j++) launch(j, wins[j]);
+            }
+        } else {
+            // split_launch (sharded.py): interior rows while the ghost rows travel, border rows after the wait
+            bool split = async;
+            for (int j = 0; j < sh.S; j++)
+                if (wins[j].own1 - r.down <= wins[j].own0 + r.up) split = false;
+            if (!split) {
+                if (!recompute) finish();
+                for (int j = 0; j < sh.S; j++) launch(j, wins[j]);
+            } else {
+                for (int j = 0; j < sh.S; j++) launch(j, rows_window(wins[j], wins[j].own0 + r.up, wins[j].own1 - r.down));
+                finish();
+                for (int j = 0; j < sh.S; j++) {
+                    if (r.up > 0) launch(j, rows_window(wins[j], wins[j].own0, wins[j].own0 + r.up));
+                    if (r.down > 0) launch(j, rows_window(wins[j], wins[j].own1 - r.down, wins[j].own1));
+                }
             }
         }
-        if (r.kind == 2) {
-            std::swap(s_cur, s_nxt);
-            if (last) std::swap(cur, nxt);
-        } else {
-            std::swap(cur, nxt);
-        }
+        cur = cur2; nxt = nxt2; s_cur = s_cur2; s_nxt = s_nxt2;
     }
     for (int k = current + 1; k <= 3; k++) mark(k);  // stages left out: empty intervals
     mark(4);
@@ -614,7 +694,17 @@ int32_t run_op(nz_sharded &sh, const sh_op &o, nz_handle *marks) {
         }
         case OP_XBEGIN: {
             const std::vector<xfer> &b = sh.batches[o.batch];
-            return post_batch(ctx, sh.comm, b.data(), b.size());
+            // overlap 0: the transfers run on the compute stream itself, between the launch that produced the rows and the
+            // launch that reads them -- no second stream, no event hand-off
+            const bool inl = sh.d.overlap == 0;
+            if (inl && sh.comm && !b.empty() && sh.timing && sh.ev_used + 2 <= sh.ev_pool.size()) {
+                NZ_HIP(hipEventRecord(sh.ev_pool[sh.ev_used], ctx->stream));
+                NZ_TRY(post_batch(ctx, sh.comm, b.data(), b.size(), true));
+                NZ_HIP(hipEventRecord(sh.ev_pool[sh.ev_used + 1], ctx->stream));
+                sh.ev_used += 2;
+                return NZ_OK;
+            }
+            return post_batch(ctx, sh.comm, b.data(), b.size(), inl);
         }
         case OP_XFINISH: {
             if (!sh.comm || !sh.comm->pending) return NZ_OK;

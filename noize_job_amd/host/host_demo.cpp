@@ -6,9 +6,16 @@
 //          host_demo <resolution> <out.f32> batch <n>   (n tiles at xpos = k * resolution through the batched stage bodies)
 //          host_demo <resolution> <out.f32> live <particles> <cycles>   (cellular fBm -> LiveErosion, seeds 3, 14, 25, ...:
 //                                                                         height, pool, flow planes back to back)
+//          host_demo <resolution> <out.f32> sharded <stripes> [mode overlap]   (ShardedPipeline on ONE rank: the grid as
+//                            <stripes> row stripes whose ghost rows travel through ncclSend / ncclRecv; mode 0 recompute,
+//                            1 exchange, 2 exchange_once)
+//          host_demo <resolution> <out.f32> sharded-rank <rank> <world> <idfile> [mode]   (one process per GPU, device =
+//                            rank; rank 0 writes the ncclUniqueId to <idfile>; every rank writes its rows to <out.f32>.<rank>)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "noize_pipeline.hpp"
@@ -27,14 +34,72 @@ int main(int argc, char **argv) {
     // `rw`: the tile is a READ / WRITE plane pair and the stencil stages swap it instead of flushing (nz_*_rw)
     const bool live = argc > 5 && std::strcmp(argv[3], "live") == 0;
     const bool rw = argc > 3 && std::strcmp(argv[3], "rw") == 0;
+    const bool sharded = argc > 4 && std::strcmp(argv[3], "sharded") == 0;
+    const bool sharded_rank = argc > 6 && std::strcmp(argv[3], "sharded-rank") == 0;
     // `onecall`: BasePipeline.fuseStages -- the stock stage list as one nz_terrain_pipeline call (tiles of 2048^2 and more)
     const bool onecall = argc > 3 && std::strcmp(argv[3], "onecall") == 0;
     if (rw || onecall) argc = 3;
     int G = argc > 3 ? std::atoi(argv[3]) : 17, F = argc > 4 ? std::atoi(argv[4]) : 5, E = argc > 5 ? std::atoi(argv[5]) : 5;
     try {
         nz_ctx *ctx = nullptr;
-        check(nz_ctx_create(0, &ctx), "nz_ctx_create");
-        if (live) {  // BASELINE config 4's shape: cellular fBm 13 octaves -> LiveErosion.TriggerQueuedBeyerMT
+        check(nz_ctx_create(sharded_rank ? std::atoi(argv[4]) : 0, &ctx), "nz_ctx_create");
+        if (sharded || sharded_rank) {
+            // BASELINE config 5's shape: the stock stage list on a res x res grid cut into row stripes, ghost rows over RCCL
+            const int rank = sharded_rank ? std::atoi(argv[4]) : 0, world = sharded_rank ? std::atoi(argv[5]) : 1;
+            const int stripes = sharded ? std::atoi(argv[4]) : world;
+            const int mode = sharded ? (argc > 5 ? std::atoi(argv[5]) : NZ_HALO_EXCHANGE) : (argc > 7 ? std::atoi(argv[7]) : NZ_HALO_EXCHANGE);
+            const int overlap = sharded && argc > 6 ? std::atoi(argv[6]) : 0;
+            std::array<uint8_t, NZ_COMM_ID_BYTES> id{};
+            if (rank == 0) {
+                id = Comm::UniqueId();
+                if (sharded_rank) {  // out of band: a file the other ranks wait for
+                    const std::string tmp = std::string(argv[6]) + ".tmp";
+                    FILE *f = std::fopen(tmp.c_str(), "wb");
+                    if (!f || std::fwrite(id.data(), 1, id.size(), f) != id.size()) throw std::runtime_error("cannot write the id file");
+                    std::fclose(f);
+                    if (std::rename(tmp.c_str(), argv[6]) != 0) throw std::runtime_error("cannot publish the id file");
+                }
+            } else {
+                FILE *f = nullptr;
+                for (int tries = 0; tries < 1200 && !(f = std::fopen(argv[6], "rb")); tries++)
+                    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+                if (!f || std::fread(id.data(), 1, id.size(), f) != id.size()) throw std::runtime_error("no id file from rank 0");
+                std::fclose(f);
+            }
+            {
+                Comm comm(ctx, id, rank, world);
+                NoiseStage noise(ctx);
+                noise.noiseType = FractalNoise::Simplex;
+                noise.hurst = 0.4f;
+                noise.octaves = 13;
+                noise.noiseSize = 1700;
+                KernelFilterStage gauss(ctx);
+                gauss.filter = NZ_GAUSS5_S1;
+                gauss.iterations = 17;
+                FlowMapStage flow(ctx);
+                flow.normMin = 0.0f;
+                flow.normMax = 0.005f;
+                ErosionStage erosion(ctx);
+                erosion.iterations = 5;
+                ShardedPipeline grid(ctx, &comm, {&noise, &gauss, &flow, &erosion}, res, res, stripes, mode, overlap, 100, 900);
+                grid.Schedule().Complete();
+                const std::string path = sharded_rank ? std::string(argv[2]) + "." + std::to_string(rank) : std::string(argv[2]);
+                FILE *f = std::fopen(path.c_str(), "wb");
+                if (!f) throw std::runtime_error("cannot open output");
+                int expect = -1;
+                for (int i = 0; i < grid.LocalStripes(); i++) {
+                    int g0 = 0;
+                    const int rows = grid.OwnedRows(i, &g0);
+                    if (expect >= 0 && g0 != expect) throw std::runtime_error("local stripes are not consecutive");
+                    expect = g0 + rows;
+                    std::vector<float> host((size_t)rows * res);
+                    grid.CopyOwnedRows(i, host.data());
+                    if (std::fwrite(host.data(), sizeof(float), host.size(), f) != host.size()) throw std::runtime_error("write failed");
+                }
+                std::fclose(f);
+                noise.OnDestroy(); gauss.OnDestroy(); flow.OnDestroy(); erosion.OnDestroy();
+            }
+        } else if (live) {  // BASELINE config 4's shape: cellular fBm 13 octaves -> LiveErosion.TriggerQueuedBeyerMT
             DeviceTile height(ctx, (size_t)res * res);
             NoiseStage noise(ctx);
             noise.noiseType = FractalNoise::Cellular;

@@ -12,6 +12,7 @@
 #pragma once
 
 #include <algorithm>
+#include <array>
 #include <deque>
 #include <functional>
 #include <map>
@@ -909,17 +910,18 @@ class LiveErosion {
 };
 
 
-inline bool BasePipeline::ScheduleStockList() {
-    auto *d = dynamic_cast<GeneratorData *>(activeItem.data);
-    if (!d || dynamic_cast<GeneratorDataBatch *>(d) || stage_instances.size() < 2) return false;
-    auto *n = dynamic_cast<NoiseStage *>(stage_instances[0]);
+// The stock stage list NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionStage] (README.md:23-32), all on one
+// context, as nz_terrain_params; false if the list is anything else.
+inline bool stockListParams(const std::vector<PipelineStage *> &stages, nz_terrain_params *tp, NoiseStage **noise) {
+    if (stages.empty()) return false;
+    auto *n = dynamic_cast<NoiseStage *>(stages[0]);
     if (!n) return false;
     KernelFilterStage *f = nullptr;
     FlowMapStage *w = nullptr;
     ErosionStage *e = nullptr;
     int k = 0;  // the optional stages must come in this order, each at most once
-    for (size_t i = 1; i < stage_instances.size(); i++) {
-        PipelineStage *s = stage_instances[i];
+    for (size_t i = 1; i < stages.size(); i++) {
+        PipelineStage *s = stages[i];
         if (s->ctx != n->ctx) return false;
         if (k < 1 && typeid(*s) == typeid(KernelFilterStage)) { f = static_cast<KernelFilterStage *>(s); k = 1; }
         else if (k < 2 && typeid(*s) == typeid(FlowMapStage)) { w = static_cast<FlowMapStage *>(s); k = 2; }
@@ -927,13 +929,23 @@ inline bool BasePipeline::ScheduleStockList() {
         else return false;
     }
     if (typeid(*n) != typeid(NoiseStage) || (f && f->filter == NZ_SOBEL3_2D)) return false;
+    *tp = nz_terrain_params{};
+    tp->noiseType = (int)n->noiseType;
+    tp->hurst = n->hurst; tp->startingAmplitude = n->startingAmplitude; tp->stepdown = n->stepdown; tp->detuneRate = n->detuneRate;
+    tp->octaves = n->octaves; tp->noiseSize = n->noiseSize;
+    tp->filter = f ? f->filter : 0; tp->filterIterations = f ? f->iterations : 0;
+    tp->flowIterations = w ? w->iterations : 0; tp->normMin = w ? w->normMin : 0.f; tp->normMax = w ? w->normMax : 0.f;
+    tp->erosionIterations = e ? e->iterations : 0;
+    if (noise) *noise = n;
+    return true;
+}
+
+inline bool BasePipeline::ScheduleStockList() {
+    auto *d = dynamic_cast<GeneratorData *>(activeItem.data);
+    if (!d || dynamic_cast<GeneratorDataBatch *>(d) || stage_instances.size() < 2) return false;
     nz_terrain_params tp{};
-    tp.noiseType = (int)n->noiseType;
-    tp.hurst = n->hurst; tp.startingAmplitude = n->startingAmplitude; tp.stepdown = n->stepdown; tp.detuneRate = n->detuneRate;
-    tp.octaves = n->octaves; tp.noiseSize = n->noiseSize;
-    tp.filter = f ? f->filter : 0; tp.filterIterations = f ? f->iterations : 0;
-    tp.flowIterations = w ? w->iterations : 0; tp.normMin = w ? w->normMin : 0.f; tp.normMax = w ? w->normMax : 0.f;
-    tp.erosionIterations = e ? e->iterations : 0;
+    NoiseStage *n = nullptr;
+    if (!stockListParams(stage_instances, &tp, &n)) return false;
     if (nz_terrain_pipeline_stripes(&tp, d->resolution) <= 0) return false;
     nz_handle h = 0;
     check(nz_terrain_pipeline(n->ctx, d->data->ptr, d->resolution, d->xpos, d->zpos, &tp, nullptr, activeItem.dependency.id, &h),
@@ -947,5 +959,75 @@ inline bool BasePipeline::ScheduleStockList() {
     }
     return true;
 }
+
+// ---- one large grid over the GPUs of a node (new-framework feature; include/noize_hip.h, nz_comm.cpp) -------------------
+// The reference's host asks for one tile at a time (BasePipeline.Schedule, Pipeline/Executable/Pipeline.cs:104-128;
+// Scripts/MeshTileGenerator.cs:166-192); a grid larger than a tile is cut into row stripes, one process per GPU, and the
+// stock stage list runs on all of them with RCCL neighbour halo exchange.
+class Comm {  // nz_comm: ncclCommInitRank on the context's device + the exchanges' stream
+  public:
+    static std::array<uint8_t, NZ_COMM_ID_BYTES> UniqueId() {  // by ONE rank; the bytes travel out of band
+        std::array<uint8_t, NZ_COMM_ID_BYTES> id{};
+        check(nz_comm_unique_id(id.data()), "nz_comm_unique_id");
+        return id;
+    }
+    Comm(nz_ctx *ctx, const std::array<uint8_t, NZ_COMM_ID_BYTES> &id, int rank, int world) {
+        check(nz_comm_init(ctx, id.data(), rank, world, &h), "nz_comm_init");
+    }
+    ~Comm() { nz_comm_destroy(h); }
+    Comm(const Comm &) = delete;
+    Comm &operator=(const Comm &) = delete;
+    int Rank() const { return nz_comm_rank(h); }
+    int World() const { return nz_comm_world(h); }
+    nz_comm *h = nullptr;
+};
+
+class ShardedPipeline {
+  public:
+    // `stages`: the stock list (stockListParams); comm may be null on one rank (device copies instead of RCCL);
+    // stripes = 0: one per rank
+    ShardedPipeline(nz_ctx *ctx, Comm *comm, const std::vector<PipelineStage *> &stages, int grows, int cols, int stripes = 0,
+                    int haloMode = NZ_HALO_EXCHANGE, int overlap = 0, int xpos = 0, int zpos = 0)
+        : ctx(ctx) {
+        nz_terrain_params tp{};
+        if (!stockListParams(stages, &tp, nullptr)) throw std::runtime_error("ShardedPipeline: not the stock stage list");
+        nz_sharded_desc d{};
+        d.grows = grows;
+        d.cols = cols;
+        d.stripes = stripes > 0 ? stripes : (comm ? comm->World() : 1);
+        d.haloMode = haloMode;
+        d.overlap = overlap;
+        d.xpos = xpos;
+        d.zpos = zpos;
+        check(nz_sharded_create(ctx, comm ? comm->h : nullptr, &d, &tp, &h), "nz_sharded_create");
+    }
+    ~ShardedPipeline() { nz_sharded_destroy(h); }
+    ShardedPipeline(const ShardedPipeline &) = delete;
+    ShardedPipeline &operator=(const ShardedPipeline &) = delete;
+    int LocalStripes() const { return nz_sharded_local_stripes(h); }
+    JobHandle Schedule(JobHandle dependency = JobHandle()) {  // one pass over every local stripe (enqueue only)
+        nz_handle out = 0;
+        check(nz_sharded_pipeline(ctx, h, nullptr, dependency.id, &out), "nz_sharded_pipeline");
+        return JobHandle{ctx, out};
+    }
+    // local stripe i: first owned global row, owned rows, host copy of them (rows x cols floats)
+    int OwnedRows(int i, int *firstGlobalRow = nullptr) const {
+        nz_stripe st{};
+        check(nz_sharded_stripe(h, i, &st, nullptr, nullptr), "nz_sharded_stripe");
+        if (firstGlobalRow) *firstGlobalRow = st.grow0 + st.own0;
+        return st.own1 - st.own0;
+    }
+    void CopyOwnedRows(int i, float *host) const {
+        nz_stripe st{};
+        float *res = nullptr;
+        check(nz_sharded_stripe(h, i, &st, nullptr, &res), "nz_sharded_stripe");
+        const size_t n = (size_t)(st.own1 - st.own0) * st.cols;
+        nz_handle done = 0;
+        check(nz_tile_download(ctx, res + (size_t)st.own0 * st.cols, host, n, 0, &done), "nz_tile_download");
+        check(nz_handle_wait(ctx, done), "nz_handle_wait");
+    }
+    nz_ctx *ctx;
+    nz_sharded *h = nullptr;
+};
 
 }  // namespace noize

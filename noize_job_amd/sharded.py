@@ -503,13 +503,15 @@ class ShardedGrid:
     (None: one rank, device copies instead of RCCL).  The library owns the planes and the launch plan; `run()` replays
     it (one C call per pass)."""
 
-    def __init__(self, ctx, comm, grows, cols, p, stripes=None, overlap=True, external_source=False, as_rank=None):
+    def __init__(self, ctx, comm, grows, cols, p, stripes=None, overlap=0, external_source=False, as_rank=None):
         world = comm.world if comm is not None else 1
         if as_rank is not None:
             world = as_rank[1]
         self.ctx, self.comm, self.p = ctx, comm, p
+        # overlap: 0 = exchanges on the compute stream itself; 1 / True = interior rows first, border rows after the wait;
+        # 2 = border rows first, the exchange for the next launch travels while the interior runs
         self.desc = N.ShardedDesc(grows, cols, stripes if stripes is not None else world, HALO_MODES[p.haloMode],
-                                  int(bool(overlap)), p.xpos, p.zpos, int(bool(external_source)),
+                                  int(overlap), p.xpos, p.zpos, int(bool(external_source)),
                                   as_rank[0] if as_rank is not None else 0, as_rank[1] if as_rank is not None else 0)
         self.tp = terrain_params(p)
         h = C.c_void_p()

@@ -98,7 +98,8 @@ def test_bench_starts_its_own_ranks_one_rank():
                        "--cols", "1024", "--grid", "1024", "--halo", "exchange", "--no-cpu-baseline")
     assert d["n_gpus"] == 1 and d["config"]["cells"] == 384 * 1024 and d["value"] > 0
     c = d["comm"]
-    assert c["backend"] == "nccl" and c["world"] == 1 and c["halo"] == "exchange" and c["overlapped"] is True
+    assert c["backend"] == "nccl" and c["world"] == 1 and c["halo"] == "exchange" and c["overlapped"] is False
+    assert c["impl"].startswith("native") and c["exchanges_per_step"] == 6 and c["host_enqueue_ms_idle_queue"] > 0.0
     assert c["exchange_ms_per_step"] is not None and c["exchange_ms_per_step"] >= 0.0 and c["rccl_version"]
     assert d["grid_1024"]["recompute"]["Mcells/s"] > 0
 
@@ -113,4 +114,5 @@ def test_bench_gpus_2_without_a_launcher():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["cells"] == 2048 * 2048
     c = d["comm"]
     assert c["backend"] == "nccl" and c["world"] == 2 and c["halo"] == "exchange" and c["exchange_ms_per_step"] > 0.0
-    assert set(d["grid_2048"]) >= {"recompute", "exchange", "exchange_blocking", "exchange_once"}
+    assert set(d["grid_2048"]) >= {"recompute", "exchange", "exchange_interior_first", "exchange_border_first", "exchange_once"}
+    assert c["impl"].startswith("native") and c["bytes_sent_per_step"] > 0

@@ -43,13 +43,13 @@ PARAM_SETS = [
 
 
 @pytest.mark.parametrize("mode", ["exchange", "recompute", "exchange_once"])
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [1, 0])   # interior rows first (the Python schedule's overlapped form) / no split
 def test_native_plan_equals_the_python_schedule(nj, mode, overlap):
     from noize_job_amd import sharded as sh
     for kw, (world, grows) in itertools.product(PARAM_SETS, [(1, 300), (2, 700), (4, 4096), (3, 1000), (8, 16384)]):
         p = sh.PipelineParams(haloMode=mode, **kw)
         for rank in sorted({0, world // 2, world - 1}):
-            want, result_plane, plan = sh.python_plan(rank, world, grows, 512, p, overlap=overlap)
+            want, result_plane, plan = sh.python_plan(rank, world, grows, 512, p, overlap=bool(overlap))
             got, stripes = _native_plan(sh, rank, world, grows, 512, p, overlap)
             assert all(r[1] in (-1, 0) for r in got)
             assert _same_marks([(r[0],) + r[2:] for r in got], want) == want, (kw, world, rank)
@@ -66,7 +66,7 @@ def test_native_plan_with_two_stripes_per_rank(nj):
     p = sh.PipelineParams(haloMode="exchange")
     world, grows = 4, 4096
     for rank in range(world):
-        got, stripes = _native_plan(sh, rank, world, grows, 256, p, True, stripes=2 * world)
+        got, stripes = _native_plan(sh, rank, world, grows, 256, p, 1, stripes=2 * world)
         assert len(stripes) == 2
         common = [r for r in got if r[1] == -1]
         for j in range(2):
@@ -75,6 +75,36 @@ def test_native_plan_with_two_stripes_per_rank(nj):
             assert _same_marks(mine, want) == want
             assert (stripes[j].grow0, stripes[j].own0, stripes[j].own1) == (plan.grow0, plan.own0, plan.own1)
         assert [r[0] for r in common].count(sh.OP_XBEGIN) == 6 and [r[0] for r in common].count(sh.OP_XFINISH) == 6
+
+
+def test_border_first_plan_covers_every_row_once(nj):
+    # overlap 2 has no Python counterpart: a launch's rows come out as {rows sent up, rows sent down, the rest}, the
+    # exchange for launch i + 1 is posted behind the first two, and every launch waits for its own exchange first
+    from noize_job_amd import sharded as sh
+    for kw in PARAM_SETS:
+        p = sh.PipelineParams(haloMode="exchange", **kw)
+        ref, _ = _native_plan(sh, 1, 4, 4096, 512, p, 0)
+        got, _ = _native_plan(sh, 1, 4, 4096, 512, p, 2)
+        launches = lambda plan: [r for r in plan if r[0] in (sh.OP_NOISE, sh.OP_FILTER, sh.OP_FLOW, sh.OP_EROSION)]
+        # the same launches over the same rows: merge consecutive pieces of one launch
+        merged = []
+        for r in launches(got):
+            key = (r[0], r[2], r[3], r[4], r[7])
+            if merged and merged[-1][0] == key:
+                merged[-1][1].append((r[5], r[6]))
+            else:
+                merged.append((key, [(r[5], r[6])]))
+        want = [((r[0], r[2], r[3], r[4], r[7]), [(r[5], r[6])]) for r in launches(ref)]
+        assert [k for k, _ in merged] == [k for k, _ in want]
+        for (_, pieces), (_, whole) in zip(merged, want):
+            rows = sorted(pieces)
+            assert rows[0][0] == whole[0][0] and rows[-1][1] == whole[0][1]
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))   # no gap, no overlap
+        # as many exchanges, with the same rows and planes, in the same order
+        assert [r for r in got if r[0] == sh.OP_XBEGIN] == [r for r in ref if r[0] == sh.OP_XBEGIN]
+        # an exchange is finished before the first launch piece that follows the NEXT begin's predecessor launch
+        ops = [r[0] for r in got]
+        assert ops.count(sh.OP_XFINISH) >= ops.count(sh.OP_XBEGIN)
 
 
 def test_sharded_create_rejects_what_cannot_run(nj):
@@ -169,8 +199,8 @@ def _in_child(tmp_path, kind, args, limit=240):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(400, method="thread")
-@pytest.mark.parametrize("mode,overlap,stripes", [("exchange", True, 3), ("exchange", False, 3), ("exchange_once", True, 2),
-                                                  ("recompute", True, 4)])
+@pytest.mark.parametrize("mode,overlap,stripes", [("exchange", 0, 3), ("exchange", 1, 3), ("exchange", 2, 3),
+                                                  ("exchange_once", 0, 2), ("recompute", 0, 4)])
 def test_lockstep_stripes_through_native_rccl_equal_the_oracle(nj, ctx, oracle, tmp_path, mode, overlap, stripes):
     # world 1: every ghost row of the three stripes travels through ncclSend / ncclRecv posted by the library itself
     grows = cols = 384
@@ -200,10 +230,11 @@ def test_flow_state_planes_travel_between_launches(nj, ctx, oracle, tmp_path):
     # 12 flow iterations = three launches: the five state planes are exchanged before the second and the third
     grows = cols = 256
     pkw = dict(octaves=6, noiseSize=200, gaussIterations=3, flowIterations=12, erosionIterations=9, haloMode="exchange")
-    r = _in_child(tmp_path, "grid", (grows, cols, pkw, 2, True))
     want = oracle.pipeline(grows, cols, octaves=6, noise_size=200, gauss_iterations=3, flow_iterations=12,
                            erosion_iterations=9)
-    assert np.array_equal(r["grid"], want)
+    for overlap in (0, 2):
+        r = _in_child(tmp_path, "grid", (grows, cols, pkw, 2, overlap))
+        assert np.array_equal(r["grid"], want), overlap
 
 
 @pytest.mark.gpu
@@ -262,6 +293,36 @@ def test_interior_rank_rehearsal_runs_and_counts_its_traffic(tmp_path, mode):
     else:
         assert exchanges == 6 and sent == 1024 * 4 * (2 * (10 + 8 + 8 + 8) + 2 * 10 + 5)
         assert float(r["exchange_ms"][0]) >= 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400, method="thread")
+def test_cpp_host_mirror_runs_the_sharded_grid(oracle, tmp_path):
+    # noize_pipeline.hpp: Comm + ShardedPipeline from a compiled host with no Python and no torch in the process: RCCL is
+    # the system's (dlopen by libnoize_hip.so), three stripes on one rank, ghost rows through ncclSend / ncclRecv
+    import subprocess
+    exe = os.path.join(ROOT, "noize_job_amd", "host", "host_demo")
+    assert os.path.exists(exe), "host_demo not built (run __graft_entry__.build())"
+    out = str(tmp_path / "grid.f32")
+    want = oracle.pipeline(384, 384, xpos=100, zpos=900)
+    for stripes, mode, overlap in ((3, 1, 0), (3, 1, 2), (2, 2, 0), (4, 0, 0)):
+        subprocess.run([exe, "384", out, "sharded", str(stripes), str(mode), str(overlap)], check=True, timeout=300)
+        assert np.array_equal(np.fromfile(out, dtype=np.float32).reshape(384, 384), want), (stripes, mode, overlap)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400, method="thread")
+def test_cpp_host_mirror_one_process_per_gpu(nj, oracle, tmp_path):
+    import subprocess
+    world = min(nj.Context.device_count(), 4)
+    if world < 2:
+        pytest.skip("needs at least two GPUs (RCCL refuses two ranks on one device)")
+    exe = os.path.join(ROOT, "noize_job_amd", "host", "host_demo")
+    res, out, idfile = 256 * world, str(tmp_path / "grid.f32"), str(tmp_path / "rccl.id")
+    procs = [subprocess.Popen([exe, str(res), out, "sharded-rank", str(r), str(world), idfile]) for r in range(world)]
+    assert all(pr.wait(300) == 0 for pr in procs)
+    got = np.concatenate([np.fromfile("%s.%d" % (out, r), dtype=np.float32).reshape(-1, res) for r in range(world)], axis=0)
+    assert np.array_equal(got, oracle.pipeline(res, res, xpos=100, zpos=900))
 
 
 def _two_gpu_worker(rank, world, idfile, grows, cols, pkw, out_dir):
