@@ -188,6 +188,7 @@ class PipelineStage {
     virtual void TransformData(PipelineWorkItem &) {}
     virtual void OnStageComplete() {}
     virtual void OnDestroy() {}
+    nz_ctx *Context() const { return ctx; }
 
     template <class T>
     T *CheckRequirements(PipelineWorkItem &requirements) {
@@ -922,7 +923,7 @@ inline bool stockListParams(const std::vector<PipelineStage *> &stages, nz_terra
     int k = 0;  // the optional stages must come in this order, each at most once
     for (size_t i = 1; i < stages.size(); i++) {
         PipelineStage *s = stages[i];
-        if (s->ctx != n->ctx) return false;
+        if (s->Context() != n->Context()) return false;
         if (k < 1 && typeid(*s) == typeid(KernelFilterStage)) { f = static_cast<KernelFilterStage *>(s); k = 1; }
         else if (k < 2 && typeid(*s) == typeid(FlowMapStage)) { w = static_cast<FlowMapStage *>(s); k = 2; }
         else if (k < 3 && typeid(*s) == typeid(ErosionStage)) { e = static_cast<ErosionStage *>(s); k = 3; }
