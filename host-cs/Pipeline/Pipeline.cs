@@ -129,14 +129,16 @@ namespace xshazwar.noize.hip {
             if (!lastScheduleWasOneCall) stage_instances[0].ReceiveHandledInput(activeItem, activeItem.dependency);
         }
 
-        bool ScheduleStockList() {
-            if (!(activeItem.data is GeneratorData d) || d.GetType() != typeof(GeneratorData) || stage_instances.Count < 2) return false;
-            if (stage_instances[0].GetType() != typeof(NoiseStage)) return false;
-            NoiseStage n = (NoiseStage) stage_instances[0];
+        // The stock stage list NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionStage] (README.md:23-32), all on
+        // one context, as nz_terrain_params; false if the list is anything else.
+        public static bool StockListParams(IList<PipelineStage> stages, out NzTerrainParams tp, out NoiseStage n) {
+            tp = default(NzTerrainParams); n = null;
+            if (stages.Count == 0 || stages[0].GetType() != typeof(NoiseStage)) return false;
+            n = (NoiseStage) stages[0];
             KernelFilterStage f = null; FlowMapStage w = null; ErosionStage e = null;
             int k = 0;                           // the optional stages in this order, each at most once
-            for (int i = 1; i < stage_instances.Count; i++) {
-                PipelineStage s = stage_instances[i];
+            for (int i = 1; i < stages.Count; i++) {
+                PipelineStage s = stages[i];
                 if (!ReferenceEquals(s.Context, n.Context)) return false;
                 if (k < 1 && s.GetType() == typeof(KernelFilterStage)) { f = (KernelFilterStage) s; k = 1; }
                 else if (k < 2 && s.GetType() == typeof(FlowMapStage)) { w = (FlowMapStage) s; k = 2; }
@@ -144,12 +146,18 @@ namespace xshazwar.noize.hip {
                 else return false;
             }
             if (f != null && f.filter == KernelFilterType.Sobel3_2D) return false;
-            NzTerrainParams tp = new NzTerrainParams {
+            tp = new NzTerrainParams {
                 noiseType = (int) n.noiseType, hurst = n.hurst, startingAmplitude = n.startingAmplitude, stepdown = n.stepdown,
                 detuneRate = n.detuneRate, octaves = n.octaves, noiseSize = n.noiseSize,
                 filter = f != null ? (int) f.filter : 0, filterIterations = f != null ? f.iterations : 0,
                 flowIterations = w != null ? w.iterations : 0, normMin = w != null ? w.normMin : 0f, normMax = w != null ? w.normMax : 0f,
                 erosionIterations = e != null ? e.iterations : 0 };
+            return true;
+        }
+
+        bool ScheduleStockList() {
+            if (!(activeItem.data is GeneratorData d) || d.GetType() != typeof(GeneratorData) || stage_instances.Count < 2) return false;
+            if (!StockListParams(stage_instances, out NzTerrainParams tp, out NoiseStage n)) return false;
             if (Native.nz_terrain_pipeline_stripes(ref tp, d.resolution) <= 0) return false;
             Native.Check(Native.nz_terrain_pipeline(n.Context.Handle, d.data.Ptr, d.resolution, d.xpos, d.zpos, ref tp, null,
                                                     activeItem.dependency.id, out ulong h), "nz_terrain_pipeline");

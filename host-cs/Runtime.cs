@@ -28,6 +28,18 @@ namespace xshazwar.noize.hip {
         public int erosionIterations;
     }
 
+    // one grid over the GPUs of a node (nz_sharded_create): haloMode 0 recompute, 1 exchange, 2 exchange_once
+    [StructLayout(LayoutKind.Sequential)]
+    public struct NzShardedDesc {                                                                    // nz_sharded_desc
+        public int grows, cols;
+        public int stripes;
+        public int haloMode;
+        public int overlap;
+        public int xpos, zpos;
+        public int externalSource;
+        public int asRank, asWorld;
+    }
+
     // ErosionParameters, Geologic/ParticleErosion/LiveErosionDataTypes.cs:78-100 (field order kept)
     [StructLayout(LayoutKind.Sequential)]
     public struct NzErosionParams {

@@ -95,6 +95,11 @@ def test_hand_written_files_call_declared_entries_with_the_right_arity():
         assert re.search(r"class %s\s*:" % cls, stages), cls
     # the other halves of the operator API: the fan-in pipeline and the live-erosion driver with every job of its cycle
     assert re.search(r"class ReducePipeline\s*:\s*BasePipeline", _cs_sources()["Pipeline/ReducePipeline.cs"])
+    # the multi-GPU half: communicator + the sharded stage list, every entry a host needs to run BASELINE config 5
+    sharded = _cs_sources()["Pipeline/ShardedPipeline.cs"]
+    for entry in ("nz_comm_unique_id", "nz_comm_init", "nz_comm_destroy", "nz_sharded_create", "nz_sharded_pipeline",
+                  "nz_sharded_stripe", "nz_sharded_destroy", "nz_sharded_map_range", "nz_sharded_normalize"):
+        assert "Native.%s(" % entry in sharded, entry
     live = _cs_sources()["LiveErosion/LiveErosion.cs"]
     for job in ("nz_thermal_erosion", "nz_fill_beyer_queue", "nz_queued_beyer_cycle", "nz_process_beyer_erosive_events",
                 "nz_clear_particle_queue", "nz_erode_height_maps", "nz_update_flow_from_track", "nz_pool_automata_job",
@@ -131,7 +136,8 @@ def test_sequential_structs_match_the_c_structs():
 
     kind = {"int32_t": "int", "float": "float", "uint32_t": "uint"}
     for cname, csname in (("nz_stripe", "NzStripe"), ("nz_rw_tile", "NzRwTile"), ("nz_erosion_params", "NzErosionParams"),
-                          ("nz_tile_set_meta", "NzTileSetMeta"), ("nz_terrain_params", "NzTerrainParams")):
+                          ("nz_tile_set_meta", "NzTileSetMeta"), ("nz_terrain_params", "NzTerrainParams"),
+                          ("nz_sharded_desc", "NzShardedDesc")):
         cf, sf = c_fields(cname), cs_fields(csname)
         assert [n for _, n in cf] == [n for _, n in sf], cname
         for (ct, n), (st, _) in zip(cf, sf):
