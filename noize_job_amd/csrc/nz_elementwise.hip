@@ -153,14 +153,32 @@ __device__ __forceinline__ bool pool_step_acts(float w) { return w > 0.0f && !(w
 struct pool_masks {
     unsigned *m;
     int words, walks;
+    // the sparse form of a job (pool_sparse_kernel): the non-empty words as a list.  listed[word] != 0: the word has an
+    // entry; list[i] = class | word << 2 | walk << 12; ctl = {entries, done, scan_all}.  NULL: no list is kept.
+    unsigned *listed = nullptr, *list = nullptr;
+    int *ctl = nullptr;
+    int cap = 0;
 };
+__device__ __forceinline__ unsigned pool_list_pack(int c, int w, int k) { return (unsigned)c | ((unsigned)w << 2) | ((unsigned)k << 12); }
+// a word that has just received its first bit (or is found non-empty by the masks kernel) gets its one entry
+__device__ __forceinline__ void pool_list_add(const pool_masks &pm, int c, int w, int k) {
+    const size_t wi = ((size_t)c * pm.words + w) * pm.walks + k;
+    if (__hip_atomic_exchange(pm.listed + wi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    const int slot = __hip_atomic_fetch_add(pm.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (slot < pm.cap) pm.list[slot] = pool_list_pack(c, w, k);  // beyond the capacity: the passes scan every word instead
+}
 __device__ __forceinline__ void pool_mark_acting(const pool_masks &pm, int cx, int cz) {
     const int k = cz >> 1, t = cx - (k & 1);
     if (k >= pm.walks || t < 0) return;  // the last row of an odd plane, column 0 of an odd walk: no pass has a step there
     const int c = 2 * (t & 1) + (cz & 1), st = t >> 1;
+    unsigned *word = pm.m + ((size_t)c * pm.words + (st >> 5)) * pm.walks + k;
+    if (pm.list) {
+        const unsigned old = __hip_atomic_fetch_or(word, 1u << (st & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0u) pool_list_add(pm, c, st >> 5, k);
+        return;
+    }
     // no value comes back: the walk does not wait for it
-    (void)__hip_atomic_fetch_or(pm.m + ((size_t)c * pm.words + (st >> 5)) * pm.walks + k, 1u << (st & 31), __ATOMIC_RELAXED,
-                                __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_or(word, 1u << (st & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <bool DRAIN, bool MARK>
@@ -281,6 +299,7 @@ __device__ __forceinline__ void spread_pool_step(float *pool, int res, int x, in
 #ifndef NZ_POOL_MASKS_NT
 #define NZ_POOL_MASKS_NT 256
 #endif
+template <bool LIST>
 __global__ __launch_bounds__(NZ_POOL_MASKS_NT) void pool_masks_kernel(const float *__restrict__ pool, pool_masks pm, int res) {
     // a lane owns walk k of both z parities: rows z = 2k and 2k + 1 are neighbours in memory, one 8-byte load per column;
     // a workgroup's waves sit side by side in z, so every row is read in pieces of NT * 8 bytes
@@ -302,8 +321,57 @@ __global__ __launch_bounds__(NZ_POOL_MASKS_NT) void pool_masks_kernel(const floa
     }
 #pragma unroll
     for (int zoff = 0; zoff < 2; zoff++) {
-        pm.m[((size_t)(0 + zoff) * pm.words + w) * pm.walks + k] = m0[zoff];
-        pm.m[((size_t)(2 + zoff) * pm.words + w) * pm.walks + k] = m1[zoff];
+        const size_t i0 = ((size_t)(0 + zoff) * pm.words + w) * pm.walks + k, i1 = ((size_t)(2 + zoff) * pm.words + w) * pm.walks + k;
+        pm.m[i0] = m0[zoff];
+        pm.m[i1] = m1[zoff];
+        if (LIST) {  // the non-empty words as a list, one entry each
+            pm.listed[i0] = m0[zoff] != 0u;
+            pm.listed[i1] = m1[zoff] != 0u;
+            if (m0[zoff]) {
+                const int slot = __hip_atomic_fetch_add(pm.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < pm.cap) pm.list[slot] = pool_list_pack(0 + zoff, w, k);
+            }
+            if (m1[zoff]) {
+                const int slot = __hip_atomic_fetch_add(pm.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < pm.cap) pm.list[slot] = pool_list_pack(2 + zoff, w, k);
+            }
+        }
+    }
+}
+
+// a mask word as the other threads of a running kernel have left it: an agent-scope load (atomic ORs land in the L2, a
+// plain load may find an older copy of the line in the CU's L1)
+template <bool COH>
+__device__ __forceinline__ unsigned pool_mask_load(const unsigned *p) {
+    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
+// one word of the clean step: drops the bits of steps that have stopped acting
+template <bool COH>
+__device__ __forceinline__ void pool_clean_word(const float *__restrict__ pool, const pool_masks &pm, int res, int c, int w, int k,
+                                                unsigned mword) {
+    if (mword == 0) return;
+    const int z = 2 * k + (c & 1);
+    const int x0 = (c >> 1) + (k & 1) + 64 * w;
+    unsigned keep = mword;
+    for (unsigned rest = mword; rest;) {  // eight cells per round trip (a word of a lake has all 32 bits set)
+        int b[8];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            b[e] = rest ? __builtin_ctz(rest) : -1;
+            rest &= rest - 1;  // 0 stays 0
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = b[e] >= 0 ? pool[(size_t)(x0 + 2 * b[e]) * res + z] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (b[e] >= 0 && !pool_step_acts(v[e])) keep &= ~(1u << b[e]);
+    }
+    if (keep != mword) {
+        unsigned *word = pm.m + ((size_t)c * pm.words + w) * pm.walks + k;
+        if (COH) __hip_atomic_store(word, keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *word = keep;
     }
 }
 
@@ -311,33 +379,14 @@ constexpr int PCW = 8;  // mask words per thread of the clean kernel
 __global__ __launch_bounds__(256) void pool_masks_clean_kernel(const float *__restrict__ pool, pool_masks pm, int res) {
     const int k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.z;
     if (k >= pm.walks) return;
-    const int z = 2 * k + (c & 1);
+    if (pm.ctl && pm.ctl[1]) return;  // the sparse kernel has already run the whole job
     const int w0 = blockIdx.y * PCW;
     unsigned m[PCW];
 #pragma unroll
     for (int u = 0; u < PCW; u++)  // the words first, all loads in flight
         m[u] = w0 + u < pm.words ? pm.m[((size_t)c * pm.words + w0 + u) * pm.walks + k] : 0u;
 #pragma unroll
-    for (int u = 0; u < PCW; u++) {
-        if (m[u] == 0) continue;
-        const int x0 = (c >> 1) + (k & 1) + 64 * (w0 + u);
-        unsigned keep = m[u];
-        for (unsigned rest = m[u]; rest;) {  // eight cells per round trip (a word of a lake has all 32 bits set)
-            int b[8];
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                b[e] = rest ? __builtin_ctz(rest) : -1;
-                rest &= rest - 1;  // 0 stays 0
-            }
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = b[e] >= 0 ? pool[(size_t)(x0 + 2 * b[e]) * res + z] : 1.0f;
-#pragma unroll
-            for (int e = 0; e < 8; e++)
-                if (b[e] >= 0 && !pool_step_acts(v[e])) keep &= ~(1u << b[e]);
-        }
-        if (keep != m[u]) pm.m[((size_t)c * pm.words + w0 + u) * pm.walks + k] = keep;
-    }
+    for (int u = 0; u < PCW; u++) pool_clean_word<false>(pool, pm, res, c, w0 + u, k, m[u]);
 }
 
 constexpr int PRT = 256;  // threads per workgroup: a pass is 50 tiny launches, 4x fewer workgroups dispatch faster
@@ -345,17 +394,15 @@ constexpr int PRT = 256;  // threads per workgroup: a pass is 50 tiny launches, 
 #define NZ_POOL_PR 8
 #endif
 constexpr int PR = NZ_POOL_PR;  // steps of a run whose loads are in flight together (all-wet 8192^2: 305 ms one step at a time, 212 with 8, 222 with 16: what is left is the ~1 us instruction stream of a step)
-template <bool DRAIN>
-__global__ __launch_bounds__(PRT) void pool_runs_kernel(float *pool, const float *__restrict__ height, pool_masks pm,
-                                                      int res, int xoff, int zoff, int32_t *drain_hdr,
-                                                      nz_particle *drain_data) {
+// thread (walk k, mask word w) of a pass: every run that STARTS among the word's 32 steps, walked to its end
+template <bool DRAIN, bool COH>
+__device__ __forceinline__ void pool_walk_word(float *pool, const float *__restrict__ height, const pool_masks &pm, int res,
+                                               int xoff, int zoff, int k, int w, int32_t *drain_hdr, nz_particle *drain_data) {
     const int walks = pm.walks, words = pm.words;
     const unsigned *mask = pm.m + (size_t)(2 * xoff + zoff) * words * walks;  // read-only for the whole pass
-    const int k = blockIdx.x * PRT + threadIdx.x, w = blockIdx.y;
-    if (k >= walks) return;
-    const unsigned m0 = mask[(size_t)w * walks + k];
+    const unsigned m0 = pool_mask_load<COH>(mask + (size_t)w * walks + k);
     if (m0 == 0) return;
-    const unsigned before = w > 0 ? mask[(size_t)(w - 1) * walks + k] >> 31 : 0u;
+    const unsigned before = w > 0 ? pool_mask_load<COH>(mask + (size_t)(w - 1) * walks + k) >> 31 : 0u;
     unsigned starts = m0 & ~((m0 << 1) | before);
     const int z = 2 * k + zoff;
     const int zu = min(z + 1, res - 1), zd = max(z - 1, 0);  // SafeIdx clamps (:585-589)
@@ -376,7 +423,7 @@ __global__ __launch_bounds__(PRT) void pool_runs_kernel(float *pool, const float
             int ones = rest == 0xffffffffu ? 32 : __builtin_ctz(~rest);  // >= 1: bit `bit` is set
             // a run that reaches the end of the word goes on in the next one: its bits are asked for now
             const bool to_end = bit + ones == 32 && ww + 1 < words;
-            const unsigned mnext = to_end ? mask[(size_t)(ww + 1) * walks + k] : 0u;
+            const unsigned mnext = to_end ? pool_mask_load<COH>(mask + (size_t)(ww + 1) * walks + k) : 0u;
             while (ones > 0) {
                 const int n = min(ones, PR);
                 float sw[PR], sh[PR], nh[PR][4], nw[PR][4];
@@ -415,6 +462,109 @@ __global__ __launch_bounds__(PRT) void pool_runs_kernel(float *pool, const float
             bit = 0;
             if (!(m & 1u)) break;
         }
+    }
+}
+
+template <bool DRAIN>
+__global__ __launch_bounds__(PRT) void pool_runs_kernel(float *pool, const float *__restrict__ height, pool_masks pm,
+                                                      int res, int xoff, int zoff, int32_t *drain_hdr,
+                                                      nz_particle *drain_data) {
+    const int k = blockIdx.x * PRT + threadIdx.x, w = blockIdx.y;
+    if (k >= pm.walks) return;
+    if (pm.ctl && pm.ctl[1]) return;  // the sparse kernel has already run the whole job
+    pool_walk_word<DRAIN, false>(pool, height, pm, res, xoff, zoff, k, w, drain_hdr, drain_data);
+}
+
+// ---- the sparse form of a whole job -----------------------------------------------------------------------------
+// With the reference's settings almost no cell holds enough water to act (a share of 1e-6 ... 2e-4 of the plane over
+// thousands of cycles): the job's `iterations` x 4 colour passes and the cleans between the iterations are
+// then ~50 dependent launches that find nothing to do, ~4.3 us each.  Here ONE workgroup runs them all from the list of
+// non-empty mask words the masks kernel left (and the walks extend when water reaches a word for the first time), with a
+// workgroup barrier where the launches had a kernel boundary: all the plane's cells a pass writes are written by this
+// workgroup, whose waves share one L1, so plain accesses see them across the barrier; mask words, which atomic ORs
+// change in the L2, are read with agent-scope loads.  Same walk code, same order inside every run: same values.
+//   entries <= limit           : the list form; ctl[1] = 1 tells the dense launches that may follow to do nothing
+//   more, dense launches follow: leaves everything to them (ctl[1] = 0)
+//   more, nothing follows      : (the host's hint was out of date) every word of every pass is scanned by this one
+//                                workgroup -- slow, and correct
+// `hint` (mapped host memory): the entry count as this job found it, for the host's choice at the NEXT job.
+constexpr int PST = 1024;
+template <bool DRAIN>
+__global__ __launch_bounds__(PST) void pool_sparse_kernel(float *pool, const float *__restrict__ height, pool_masks pm, int res,
+                                                        int iterations, int limit, int dense_follows, int32_t *drain_hdr,
+                                                        nz_particle *drain_data, unsigned long long *hint,
+                                                        unsigned long long seq) {
+    __shared__ int s_n, s_scan;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const int n = __hip_atomic_load(pm.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_n = n;
+        // (job number, entries) in one 8-byte store to mapped host memory
+        if (hint) __hip_atomic_store(hint, (seq << 32) | (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    const int n0 = s_n;
+    if (n0 > limit && dense_follows) {
+        if (tid == 0) {
+            pm.ctl[1] = 0;
+            pm.ctl[0] = 0;  // the next job's masks kernel counts from zero
+        }
+        return;
+    }
+    bool scan_all = n0 > limit || n0 > pm.cap;
+    const int total = pm.words * pm.walks;
+    for (int it = 0; it < iterations; it++) {
+        if (it > 0) {  // pool_masks_clean_kernel
+            __syncthreads();  // the last pass of the previous iteration is complete
+            if (tid == 0) {
+                const int n = __hip_atomic_load(pm.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_n = n;
+                s_scan = n > pm.cap;
+            }
+            __syncthreads();
+            scan_all = scan_all || s_scan != 0;
+            if (!scan_all) {
+                const int n = min(s_n, pm.cap);
+                for (int i = tid; i < n; i += PST) {
+                    const unsigned e = pm.list[i];
+                    const int c = e & 3, w = (e >> 2) & 1023, k = e >> 12;
+                    pool_clean_word<true>(pool, pm, res, c, w, k, pool_mask_load<true>(pm.m + ((size_t)c * pm.words + w) * pm.walks + k));
+                }
+            } else {
+                for (int c = 0; c < 4; c++)
+                    for (int i = tid; i < total; i += PST)
+                        pool_clean_word<true>(pool, pm, res, c, i / pm.walks, i % pm.walks, pool_mask_load<true>(pm.m + (size_t)c * total + i));
+            }
+        }
+        for (int xoff = 0; xoff < 2; xoff++)
+            for (int zoff = 0; zoff < 2; zoff++) {
+                __syncthreads();  // the previous pass (or the clean) is complete, its stores visible to the workgroup
+                if (tid == 0) {
+                    const int n = __hip_atomic_load(pm.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_n = n;
+                    s_scan = n > pm.cap;
+                }
+                __syncthreads();
+                scan_all = scan_all || s_scan != 0;
+                const int cls = 2 * xoff + zoff;
+                if (!scan_all) {
+                    const int n = s_n;  // entries added during this pass belong to other classes
+                    for (int i = tid; i < n; i += PST) {
+                        const unsigned e = pm.list[i];
+                        if ((int)(e & 3) != cls) continue;
+                        pool_walk_word<DRAIN, true>(pool, height, pm, res, xoff, zoff, (int)(e >> 12), (int)((e >> 2) & 1023), drain_hdr,
+                                                    drain_data);
+                    }
+                } else {
+                    for (int i = tid; i < total; i += PST)
+                        pool_walk_word<DRAIN, true>(pool, height, pm, res, xoff, zoff, i % pm.walks, i / pm.walks, drain_hdr, drain_data);
+                }
+            }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        pm.ctl[1] = 1;
+        pm.ctl[0] = 0;  // the next job's masks kernel counts from zero
     }
 }
 
@@ -751,21 +901,60 @@ int32_t nz_launch_flow_from_track(hipStream_t s, float *pool, float *flow, float
     return NZ_OK;
 }
 
-size_t nz_pool_automata_mask_words(int res) { return 4 * (size_t)(((res + 1) / 2 + 31) / 32) * (size_t)(res / 2); }
 
-// The acting-step bits of a job's four passes, from the plane as the job finds it
-int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res, unsigned *mask) {
+// scratch of a job in its parallel-runs form: the mask words of the four classes, and for the sparse form the `listed`
+// words and the list itself
+constexpr int NZ_POOL_LIST_CAP = 8192;
+static pool_masks pool_masks_of(int res, unsigned *scratch, int *ctl, bool with_list) {
+    pool_masks pm;
+    pm.m = scratch;
+    pm.words = ((res + 1) / 2 + 31) / 32;
+    pm.walks = res / 2;
+    pm.ctl = ctl;
+    if (with_list) {
+        const size_t n = (size_t)4 * pm.words * pm.walks;
+        pm.listed = scratch + n;
+        pm.list = scratch + 2 * n;
+        pm.cap = NZ_POOL_LIST_CAP;
+    }
+    return pm;
+}
+size_t nz_pool_automata_mask_words(int res) {
+    const size_t n = (size_t)4 * (((res + 1) / 2 + 31) / 32) * (size_t)(res / 2);
+    return 2 * n + NZ_POOL_LIST_CAP;
+}
+
+// The acting-step bits of a job's four passes, from the plane as the job finds it (with_list: and the non-empty words
+// as a list, counted in ctl[0])
+int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res, unsigned *mask, int *ctl, int with_list) {
     if (res / 2 <= 0) return NZ_OK;
-    pool_masks pm{mask, ((res + 1) / 2 + 31) / 32, res / 2};
-    hipLaunchKernelGGL(pool_masks_kernel, dim3((unsigned)((pm.walks + NZ_POOL_MASKS_NT - 1) / NZ_POOL_MASKS_NT), (unsigned)pm.words),
-                       dim3(NZ_POOL_MASKS_NT), 0, s, pool, pm, res);
+    const pool_masks pm = pool_masks_of(res, mask, ctl, with_list != 0);
+    const dim3 grid((unsigned)((pm.walks + NZ_POOL_MASKS_NT - 1) / NZ_POOL_MASKS_NT), (unsigned)pm.words);
+    if (with_list) hipLaunchKernelGGL(pool_masks_kernel<true>, grid, dim3(NZ_POOL_MASKS_NT), 0, s, pool, pm, res);
+    else hipLaunchKernelGGL(pool_masks_kernel<false>, grid, dim3(NZ_POOL_MASKS_NT), 0, s, pool, pm, res);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
 
-int32_t nz_launch_pool_automata_clean(hipStream_t s, const float *pool, int res, unsigned *mask) {
+// The whole job from the list (pool_sparse_kernel): one launch of one workgroup
+int32_t nz_launch_pool_automata_sparse(hipStream_t s, float *pool, const float *height, int res, int iterations, int limit,
+                                       int dense_follows, int32_t *drain_hdr, nz_particle *drain_data, unsigned *mask, int *ctl,
+                                       unsigned long long *hint_dev, unsigned long long seq) {
     if (res / 2 <= 0) return NZ_OK;
-    pool_masks pm{mask, ((res + 1) / 2 + 31) / 32, res / 2};
+    const pool_masks pm = pool_masks_of(res, mask, ctl, true);
+    if (drain_hdr)
+        hipLaunchKernelGGL(pool_sparse_kernel<true>, dim3(1), dim3(PST), 0, s, pool, height, pm, res, iterations, limit,
+                           dense_follows, drain_hdr, drain_data, hint_dev, seq);
+    else
+        hipLaunchKernelGGL(pool_sparse_kernel<false>, dim3(1), dim3(PST), 0, s, pool, height, pm, res, iterations, limit,
+                           dense_follows, drain_hdr, drain_data, hint_dev, seq);
+    NZ_HIP(hipGetLastError());
+    return NZ_OK;
+}
+
+int32_t nz_launch_pool_automata_clean(hipStream_t s, const float *pool, int res, unsigned *mask, int *ctl) {
+    if (res / 2 <= 0) return NZ_OK;
+    const pool_masks pm = pool_masks_of(res, mask, ctl, false);
     hipLaunchKernelGGL(pool_masks_clean_kernel, dim3((unsigned)((pm.walks + 255) / 256), (unsigned)((pm.words + PCW - 1) / PCW), 4),
                        dim3(256), 0, s, pool, pm, res);
     NZ_HIP(hipGetLastError());
@@ -773,14 +962,15 @@ int32_t nz_launch_pool_automata_clean(hipStream_t s, const float *pool, int res,
 }
 
 // `mask` = the bits nz_launch_pool_automata_masks prepared (nz_pool_automata_mask_words(res) words, kept up to date by
-// the passes themselves): the pass runs as parallel runs; NULL: one lane per row
+// the passes themselves): the pass runs as parallel runs; NULL: one lane per row.  ctl (nullable): ctl[1] != 0 = the
+// sparse kernel has already run the job, the pass does nothing.
 int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *height, int res, int xoff, int zoff,
-                                     int32_t *drain_hdr, nz_particle *drain_data, unsigned *mask) {
+                                     int32_t *drain_hdr, nz_particle *drain_data, unsigned *mask, int *ctl) {
     int jobs = res / 2;
     if (jobs <= 0) return NZ_OK;
     dim3 grid((unsigned)((jobs + 63) / 64));
     if (mask) {
-        pool_masks pm{mask, ((res + 1) / 2 + 31) / 32, jobs};
+        const pool_masks pm = pool_masks_of(res, mask, ctl, false);
         dim3 rgrid((unsigned)((jobs + PRT - 1) / PRT), (unsigned)pm.words);
         if (drain_hdr)
             hipLaunchKernelGGL(pool_runs_kernel<true>, rgrid, dim3(PRT), 0, s, pool, height, pm, res, xoff, zoff, drain_hdr,

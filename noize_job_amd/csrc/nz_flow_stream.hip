@@ -49,14 +49,21 @@ __device__ unsigned long long *nz_flow_probe_buf = nullptr;  // [wave][8]
 #define NZ_FS_PRIO 0
 #endif
 constexpr int FS_RING = 16;   // rows of height kept per wave (needs 2n - 1 <= 9)
-constexpr int FS_TW = 128;    // columns per strip, halo included
+// NC = columns per lane: 2 (a 128-column strip per wave, 12 registers of state per column and iteration = 120 at n = 5:
+// three waves per SIMD) or 1 (64-column strips: 1.22x the halo columns, half the state per lane -- five waves per SIMD)
 
-template <int NST>
+// a row of the strip: NC cells per lane
+template <int NC>
+struct alignas(4 * NC) fs_row {  // aligned like float2: one 8-byte LDS / global access for two columns
+    float c[NC];
+};
+
+template <int NST, int NC>
 struct fs_state {
     // stage i (0-based) is about to compute the outflow of row r = t - 2i from the state of iteration i - 1:
-    float Tm[NST][2], T0[NST][2];   // total height (water + height) of rows r - 1, r after iteration i - 1
-    float Wm[NST][2], W0[NST][2];   // water of rows r - 1, r after iteration i - 1
-    float FA[NST][2][4], FB[NST][2][4];  // {W, E, S, N} outflow of rows r - 2, r - 1 of iteration i
+    float Tm[NST][NC], T0[NST][NC];   // total height (water + height) of rows r - 1, r after iteration i - 1
+    float Wm[NST][NC], W0[NST][NC];   // water of rows r - 1, r after iteration i - 1
+    float FA[NST][NC][4], FB[NST][NC][4];  // {W, E, S, N} outflow of rows r - 2, r - 1 of iteration i
 };
 
 struct fs_bounds {
@@ -74,29 +81,36 @@ struct fs_bounds {
 //   XEDGE: the strip touches the grid's first / last column: the lane that holds it takes its own value for the clamped
 //          x-neighbour (column 0 is the first of its lane's two columns; the last column the second, or the first when the row length is odd).
 // Cells outside the grid are computed like any other and never read by a cell inside it.
-template <int NST, int NACT, bool COND, bool XEDGE, bool VEC>
-__device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const float2 hp, const float2 hn, float2 *ring,
-                                        const fs_bounds &b, const int gx, const bool lane_x0, const bool lane_x1, const bool lane_x1o,
-                                        const nz_geom &g, const float nmin, const float nrange,
-                                        float *__restrict__ dst, const bool store_lane) {
-    float Tp[2] = {0.0001f + hp.x, 0.0001f + hp.y};  // fillStage (FlowMapStage.cs:129): water 1e-4 everywhere
-    float Wp[2] = {0.0001f, 0.0001f};
-    float FCprev[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+template <int NST, int NC, int NACT, bool COND, bool XEDGE, bool VEC>
+__device__ __forceinline__ void fs_step(fs_state<NST, NC> &st, const int t, const fs_row<NC> hp, const fs_row<NC> hn,
+                                        fs_row<NC> *ring, const fs_bounds &b, const int gx, const bool lane_x0,
+                                        const bool lane_x1, const bool lane_x1o, const nz_geom &g, const float nmin,
+                                        const float nrange, float *__restrict__ dst, const bool store_lane) {
+    float Tp[NC], Wp[NC], FCprev[NC][4];
+#pragma unroll
+    for (int e = 0; e < NC; e++) {
+        Tp[e] = 0.0001f + hp.c[e];  // fillStage (FlowMapStage.cs:129): water 1e-4 everywhere
+        Wp[e] = 0.0001f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) FCprev[e][k] = 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < NST; i++) {
         if (i > NACT) continue;
         if (i == NACT) {  // not computing yet: its windows follow what stage NACT - 1 hands on
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
+            for (int e = 0; e < NC; e++) {
                 st.Tm[i][e] = st.T0[i][e]; st.T0[i][e] = Tp[e];
                 st.Wm[i][e] = st.W0[i][e]; st.W0[i][e] = Wp[e];
             }
             continue;
         }
         const int r = t - 2 * i;
-        float FC[2][4];
+        float FC[NC][4];
         // height of the row whose water this stage updates (read from the ring ahead of the outflow arithmetic)
-        float2 hh = make_float2(0.0f, 0.0f);
+        fs_row<NC> hh;
+#pragma unroll
+        for (int e = 0; e < NC; e++) hh.c[e] = 0.0f;
         if (i < NST - 1) hh = ring[((r - 1) & (FS_RING - 1)) * 64];
         // The prefetched row h(t + 2) goes into the ring here, before the last stage's stores: waiting for that load behind
         // a (conditional) store would mean waiting for the store as well -- vmcnt counts both, in order.
@@ -104,17 +118,17 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
         // ---- outflow of row r (ComputeFlowStep)
         const bool fa = !COND || (r >= b.loF[i] && r < b.hiF[i]);
         if (fa) {
-            float left = wave_prev0(st.T0[i][1]), right = wave_next0(st.T0[i][0]);
+            float left = wave_prev0(st.T0[i][NC - 1]), right = wave_next0(st.T0[i][0]);
             if (XEDGE) {
                 left = lane_x0 ? st.T0[i][0] : left;
-                right = lane_x1 ? st.T0[i][1] : right;
+                right = lane_x1 ? st.T0[i][NC - 1] : right;
             }
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
+            for (int e = 0; e < NC; e++) {
                 const float self = st.T0[i][e];
-                const float tW = e == 0 ? left : st.T0[i][0];
-                float tE = e == 1 ? right : st.T0[i][1];
-                if (XEDGE && e == 0 && lane_x1o) tE = self;
+                const float tW = e == 0 ? left : st.T0[i][e > 0 ? e - 1 : 0];
+                float tE = e == NC - 1 ? right : st.T0[i][e + 1 < NC ? e + 1 : e];
+                if (XEDGE && NC == 2 && e == 0 && lane_x1o) tE = self;
                 float tS = st.Tm[i][e], tN = Tp[e];
                 if (COND) {
                     if (r <= g.zc0) tS = self;
@@ -129,14 +143,14 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 2; e++)
+            for (int e = 0; e < NC; e++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) FC[e][k] = 0.0f;
         }
         // the previous stage's row r (its FA) has now been consumed: its window moves on
         if (i > 0) {
 #pragma unroll
-            for (int e = 0; e < 2; e++)
+            for (int e = 0; e < NC; e++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     st.FA[i > 0 ? i - 1 : 0][e][k] = st.FB[i > 0 ? i - 1 : 0][e][k];
@@ -146,17 +160,19 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
         // ---- row r - 1: water update (UpdateWaterStep), or for the last stage velocity + normalise
         const int rw = r - 1;
         const bool wa = !COND || (rw >= b.loW[i] && rw < b.hiW[i]);
-        float Wn[2] = {0.0f, 0.0f}, Tn[2] = {0.0f, 0.0f};
+        float Wn[NC], Tn[NC];
+#pragma unroll
+        for (int e = 0; e < NC; e++) Wn[e] = Tn[e] = 0.0f;
         if (wa) {
             // own row rw = FB, row rw - 1 = FA (its fN flows in), row rw + 1 = FC (its fS flows in)
-            float eW = wave_prev0(st.FB[i][1][1]), wE = wave_next0(st.FB[i][0][0]);
+            float eW = wave_prev0(st.FB[i][NC - 1][1]), wE = wave_next0(st.FB[i][0][0]);
             if (XEDGE) {
                 eW = lane_x0 ? st.FB[i][0][1] : eW;
-                wE = lane_x1 ? st.FB[i][1][0] : wE;
+                wE = lane_x1 ? st.FB[i][NC - 1][0] : wE;
             }
-            float nS[2], sN[2];  // fN of row rw - 1, fS of row rw + 1
+            float nS[NC], sN[NC];  // fN of row rw - 1, fS of row rw + 1
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
+            for (int e = 0; e < NC; e++) {
                 nS[e] = st.FA[i][e][3];
                 sN[e] = FC[e][2];
                 if (COND) {
@@ -166,22 +182,22 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
             }
             if (i < NST - 1) {
 #pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float inE = e == 0 ? eW : st.FB[i][0][1];
-                    float inW = e == 1 ? wE : st.FB[i][1][0];
-                    if (XEDGE && e == 0 && lane_x1o) inW = st.FB[i][0][0];
+                for (int e = 0; e < NC; e++) {
+                    const float inE = e == 0 ? eW : st.FB[i][e > 0 ? e - 1 : 0][1];
+                    float inW = e == NC - 1 ? wE : st.FB[i][e + 1 < NC ? e + 1 : e][0];
+                    if (XEDGE && NC == 2 && e == 0 && lane_x1o) inW = st.FB[i][0][0];
                     Wn[e] = update_water(st.Wm[i][e], flux4{st.FB[i][e][0], st.FB[i][e][1], st.FB[i][e][2], st.FB[i][e][3]},
                                          inE, inW, nS[e], sN[e]);
-                    Tn[e] = Wn[e] + (e == 0 ? hh.x : hh.y);
+                    Tn[e] = Wn[e] + hh.c[e];
                 }
             } else {
                 // CreateVelocityField + NormalizeMap, FlowMapComponents.cs:120-139,157-165
-                float out[2];
+                float out[NC];
 #pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float fE_w = e == 0 ? eW : st.FB[i][0][1];
-                    float fW_e = e == 1 ? wE : st.FB[i][1][0];
-                    if (XEDGE && e == 0 && lane_x1o) fW_e = st.FB[i][0][0];
+                for (int e = 0; e < NC; e++) {
+                    const float fE_w = e == 0 ? eW : st.FB[i][e > 0 ? e - 1 : 0][1];
+                    float fW_e = e == NC - 1 ? wE : st.FB[i][e + 1 < NC ? e + 1 : e][0];
+                    if (XEDGE && NC == 2 && e == 0 && lane_x1o) fW_e = st.FB[i][0][0];
                     const float dl = fE_w - st.FB[i][e][0];
                     const float dr = st.FB[i][e][1] - fW_e;
                     const float dt = sN[e] - st.FB[i][e][3];
@@ -194,18 +210,21 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
                 }
                 if (store_lane && (COND || rw >= b.loW[NST - 1])) {
                     float *p = dst + (size_t)rw * g.pitch + gx;
-                    if (VEC) {
-                        *reinterpret_cast<float2 *>(p) = make_float2(out[0], out[1]);
+                    if (VEC && NC == 2) {
+                        *reinterpret_cast<float2 *>(p) = make_float2(out[0], out[NC - 1]);
+                    } else if (VEC) {
+                        p[0] = out[0];
                     } else {
-                        if (gx >= 0 && gx < g.cols) p[0] = out[0];
-                        if (gx + 1 >= 0 && gx + 1 < g.cols) p[1] = out[1];
+#pragma unroll
+                        for (int e = 0; e < NC; e++)
+                            if (gx + e >= 0 && gx + e < g.cols) p[e] = out[e];
                     }
                 }
             }
         }
         // the windows of stage i move on; what it produced feeds stage i + 1 (row r - 2) in this same step
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
+        for (int e = 0; e < NC; e++) {
             st.Tm[i][e] = st.T0[i][e]; st.T0[i][e] = Tp[e];
             st.Wm[i][e] = st.W0[i][e]; st.W0[i][e] = Wp[e];
             Tp[e] = Tn[e]; Wp[e] = Wn[e];
@@ -214,7 +233,7 @@ __device__ __forceinline__ void fs_step(fs_state<NST> &st, const int t, const fl
         }
     }
 #pragma unroll
-    for (int e = 0; e < 2; e++)
+    for (int e = 0; e < NC; e++)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             st.FA[NACT - 1][e][k] = st.FB[NACT - 1][e][k];
@@ -239,24 +258,37 @@ __device__ __forceinline__ void fs_prio(int step, int slot) {
     else __builtin_amdgcn_s_setprio(0);
 }
 
-template <bool VEC>
-__device__ __forceinline__ float2 fs_load_row(const float *__restrict__ h, const nz_geom &g, int row, int gx) {
-    if (VEC) return *reinterpret_cast<const float2 *>(h + (size_t)row * g.pitch + gx);
+template <int NC, bool VEC>
+__device__ __forceinline__ fs_row<NC> fs_load_row(const float *__restrict__ h, const nz_geom &g, int row, int gx) {
+    fs_row<NC> o;
+    if (VEC && NC == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(h + (size_t)row * g.pitch + gx);
+        o.c[0] = t.x;
+        o.c[NC - 1] = t.y;
+        return o;
+    }
+    if (VEC) {
+        o.c[0] = h[(size_t)row * g.pitch + gx];
+        return o;
+    }
     const size_t base = (size_t)row * g.pitch;
-    return make_float2(h[base + clampi(gx, 0, g.cols - 1)], h[base + clampi(gx + 1, 0, g.cols - 1)]);
+#pragma unroll
+    for (int e = 0; e < NC; e++) o.c[e] = h[base + clampi(gx + e, 0, g.cols - 1)];
+    return o;
 }
 
-template <int NST, bool XEDGE>
-__device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__restrict__ h, float *__restrict__ dst,
+template <int NST, int NC, bool XEDGE>
+__device__ __forceinline__ void flow_stream_body(fs_row<NC> *ring, const float *__restrict__ h, float *__restrict__ dst,
                                                  const nz_geom &g, const int lx0, const int s0, const int s1,
                                                  const float nmin, const float nrange) {
     constexpr bool VEC = !XEDGE;
-    constexpr int H = 2 * NST;
+    constexpr int H = 2 * NST, FS_TW = 64 * NC;
     const int lane = threadIdx.x;
-    const int gx = lx0 + 2 * lane;
-    // the grid's last column is the second of its lane's two columns when the row length is even, the first when it is odd
-    const bool lane_x0 = gx == 0, lane_x1 = gx + 1 == g.cols - 1, lane_x1o = gx == g.cols - 1;
-    const bool store_lane = 2 * lane >= H && 2 * lane < FS_TW - H;
+    const int gx = lx0 + NC * lane;
+    // the grid's last column is the last of its lane's columns -- or, with two columns per lane and an odd row length,
+    // the first of them
+    const bool lane_x0 = gx == 0, lane_x1 = gx + NC - 1 == g.cols - 1, lane_x1o = NC == 2 && gx == g.cols - 1;
+    const bool store_lane = NC * lane >= H && NC * lane < FS_TW - H;
     fs_bounds b;
 #pragma unroll
     for (int i = 0; i < NST; i++) {
@@ -266,11 +298,11 @@ __device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__re
         b.loW[i] = max(g.zc0, s0 - m + 1);
         b.hiW[i] = min(g.zc1 + 1, s1 + m - 1);
     }
-    fs_state<NST> st;
+    fs_state<NST, NC> st;
 #pragma unroll
     for (int i = 0; i < NST; i++)
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
+        for (int e = 0; e < NC; e++) {
             st.Tm[i][e] = 0.0f; st.T0[i][e] = 0.0f; st.Wm[i][e] = 0.0001f; st.W0[i][e] = 0.0001f;
 #pragma unroll
             for (int k = 0; k < 4; k++) { st.FA[i][e][k] = 0.0f; st.FB[i][e][k] = 0.0f; }
@@ -279,25 +311,28 @@ __device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__re
     // the grid, which the COND steps replace)
     const int t0 = b.loF[0], t1 = s1 + H - 1;
     {
-        const float2 hm = fs_load_row<VEC>(h, g, max(t0 - 1, g.zc0), gx), h0 = fs_load_row<VEC>(h, g, t0, gx);
+        const fs_row<NC> hm = fs_load_row<NC, VEC>(h, g, max(t0 - 1, g.zc0), gx), h0 = fs_load_row<NC, VEC>(h, g, t0, gx);
         ring[(t0 & (FS_RING - 1)) * 64] = h0;
-        st.Tm[0][0] = 0.0001f + hm.x; st.Tm[0][1] = 0.0001f + hm.y;
-        st.T0[0][0] = 0.0001f + h0.x; st.T0[0][1] = 0.0001f + h0.y;
+#pragma unroll
+        for (int e = 0; e < NC; e++) {
+            st.Tm[0][e] = 0.0001f + hm.c[e];
+            st.T0[0][e] = 0.0001f + h0.c[e];
+        }
     }
-    float2 hp = fs_load_row<VEC>(h, g, min(t0 + 1, g.zc1), gx);
+    fs_row<NC> hp = fs_load_row<NC, VEC>(h, g, min(t0 + 1, g.zc1), gx);
     ring[((t0 + 1) & (FS_RING - 1)) * 64] = hp;
     int t = t0;
     const int slot = (int)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  /* HW_ID.WAVE_ID */
 #define NZ_FS_STEP(NA, C, T, HP, HN)                                                                              \
     do {                                                                                                          \
         if (NZ_FS_PRIO) fs_prio((T) - t0, slot);                                                                      \
-        fs_step<NST, NA, C, XEDGE, VEC>(st, T, HP, HN, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, dst, \
+        fs_step<NST, NC, NA, C, XEDGE, VEC>(st, T, HP, HN, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, dst, \
                                         store_lane);                                                              \
     } while (0)
 #define NZ_FS_PHASE(K)                                                            \
     if (NST > K) {                                                                \
         for (int q = 0; q < 4 && t < t1; q++, t++) {                              \
-            const float2 hn = fs_load_row<VEC>(h, g, min(t + 2, g.zc1), gx);      \
+            const fs_row<NC> hn = fs_load_row<NC, VEC>(h, g, min(t + 2, g.zc1), gx);  \
             NZ_FS_STEP((K < NST ? K : NST), false, t, hp, hn);                    \
             hp = hn;                                                              \
         }                                                                         \
@@ -313,7 +348,7 @@ __device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__re
         // z-neighbours: the last stage's row zc0 + 1, the first whose z-neighbours are both real, is reached at t = zc0 + H - 1
         const int tfill = min(t1, max(s0, g.zc0 + 1) + H - 1);
         for (; t < tfill; t++) {
-            const float2 hn = fs_load_row<VEC>(h, g, min(t + 2, g.zc1), gx);
+            const fs_row<NC> hn = fs_load_row<NC, VEC>(h, g, min(t + 2, g.zc1), gx);
             NZ_FS_STEP(NST, true, t, hp, hn);
             hp = hn;
         }
@@ -326,17 +361,17 @@ __device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__re
     // the windows rotate by renaming, not by moves.
     const int tsteady = min(t1, g.zc1);
     for (; t + 2 < tsteady; t += 3) {
-        const float2 hn = fs_load_row<VEC>(h, g, t + 2, gx);
+        const fs_row<NC> hn = fs_load_row<NC, VEC>(h, g, t + 2, gx);
         NZ_FS_STEP(NST, false, t, hp, hn);
-        const float2 hn2 = fs_load_row<VEC>(h, g, min(t + 3, g.zc1), gx);
+        const fs_row<NC> hn2 = fs_load_row<NC, VEC>(h, g, min(t + 3, g.zc1), gx);
         NZ_FS_STEP(NST, false, t + 1, hn, hn2);
-        const float2 hn3 = fs_load_row<VEC>(h, g, min(t + 4, g.zc1), gx);
+        const fs_row<NC> hn3 = fs_load_row<NC, VEC>(h, g, min(t + 4, g.zc1), gx);
         NZ_FS_STEP(NST, false, t + 2, hn2, hn3);
         hp = hn3;
     }
     // the last one or two steps of an inner segment; the drain of a segment that ends on the grid's last row
     for (; t < t1; t++) {
-        const float2 hn = fs_load_row<VEC>(h, g, min(t + 2, g.zc1), gx);
+        const fs_row<NC> hn = fs_load_row<NC, VEC>(h, g, min(t + 2, g.zc1), gx);
         NZ_FS_STEP(NST, true, t, hp, hn);
         hp = hn;
     }
@@ -344,12 +379,15 @@ __device__ __forceinline__ void flow_stream_body(float2 *ring, const float *__re
 #undef NZ_FS_STEP
 }
 
-template <int NST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NST >= 4 ? NZ_FS_WPE : 4))) void flow_stream_kernel(
-    const float *__restrict__ h, float *__restrict__ dst, nz_geom g, int S, int nstrips, int Se, int nseg_edge, float nmin,
-    float nrange, int aligned) {
-    __shared__ float2 s_ring[FS_RING * 64];
-    constexpr int H = 2 * NST, OW = FS_TW - 2 * H;
+#ifndef NZ_FS_WPE1
+#define NZ_FS_WPE1 5  // waves per SIMD the one-column form is register-allocated for
+#endif
+template <int NST, int NC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 1 ? (NST >= 4 ? NZ_FS_WPE1 : 8) : (NST >= 4 ? NZ_FS_WPE : 4))))
+void flow_stream_kernel(const float *__restrict__ h, float *__restrict__ dst, nz_geom g, int S, int nstrips, int Se,
+                        int nseg_edge, float nmin, float nrange, int aligned) {
+    __shared__ fs_row<NC> s_ring[FS_RING * 64];
+    constexpr int FS_TW = 64 * NC, H = 2 * NST, OW = FS_TW - 2 * H;
     // The first blocks are the two border strips (one when the grid is a single strip wide), whose steps carry the border
     // selects and clamped accesses.  A launch on an idle chip places its blocks breadth first (block b is the (b / number
     // of SIMDs)-th wave of its SIMD, tools/probe_flow_stream.py) and a SIMD serves its waves oldest first: as the first
@@ -371,13 +409,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NST >= 4 ? N
     const int lx0 = strip * OW - H;
     const size_t off = blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
     const bool inner = aligned && lx0 > 0 && lx0 + FS_TW < g.cols;
-    float2 *ring = s_ring + threadIdx.x;
+    fs_row<NC> *ring = s_ring + threadIdx.x;
     NZ_FPROBE(0, __builtin_amdgcn_s_memrealtime());
     NZ_FPROBE(1, __builtin_amdgcn_s_memtime());
     NZ_FPROBE(6, (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)));   // HW_ID
     NZ_FPROBE(7, (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) | ((unsigned long long)inner << 32));  // XCC_ID
-    if (inner) flow_stream_body<NST, false>(ring, h + off, dst + off, g, lx0, s0, s1, nmin, nrange);
-    else flow_stream_body<NST, true>(ring, h + off, dst + off, g, lx0, s0, s1, nmin, nrange);
+    if (inner) flow_stream_body<NST, NC, false>(ring, h + off, dst + off, g, lx0, s0, s1, nmin, nrange);
+    else flow_stream_body<NST, NC, true>(ring, h + off, dst + off, g, lx0, s0, s1, nmin, nrange);
     NZ_FPROBE(4, __builtin_amdgcn_s_memrealtime());
     NZ_FPROBE(5, __builtin_amdgcn_s_memtime());
 }
@@ -397,9 +435,13 @@ bool nz_flow_stream_wanted(const nz_geom &g, int n) {
 
 int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const nz_geom &g, int n, float nmin,
                                      float nrange) {
-    static const int waves = getenv("NZ_FLOW_STREAM_WAVES") ? atoi(getenv("NZ_FLOW_STREAM_WAVES")) : 3072;
+    // NZ_FLOW_STREAM_COLS: columns per lane (2: 128-column strips, three waves per SIMD; 1: 64-column strips, five)
+    static const int ncols = getenv("NZ_FLOW_STREAM_COLS") ? atoi(getenv("NZ_FLOW_STREAM_COLS")) : 2;
+    const int NC = ncols == 1 ? 1 : 2;
+    static const int waves_env = getenv("NZ_FLOW_STREAM_WAVES") ? atoi(getenv("NZ_FLOW_STREAM_WAVES")) : 0;
+    const int waves = waves_env > 0 ? waves_env : (NC == 1 ? 1024 * NZ_FS_WPE1 : 3072);
     static const int s_env = getenv("NZ_FLOW_STREAM_S") ? atoi(getenv("NZ_FLOW_STREAM_S")) : 0;
-    const int H = 2 * n, OW = FS_TW - 2 * H;
+    const int H = 2 * n, OW = 64 * NC - 2 * H;
     const int nstrips = (g.cols + OW - 1) / OW, rows = g.or1 - g.or0;
     // chip_div: the launch shares the chip with launches on other streams (nz_terrain_pipeline's second stripe), mostly of
     // other kernels: 3/4 of a round measured best for two (0.646 against 0.667 ms per 4096^2 step with 1/2)
@@ -417,9 +459,13 @@ int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const n
     const int nblocks = (nstrips > 2 ? nstrips - 2 : 0) * nseg + (nstrips < 2 ? nstrips : 2) * nseg_e;
     uintptr_t bits = reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4) |
                      (uintptr_t)(g.bstride * 4);
-    const int aligned = (bits & 7) == 0;
+    const int aligned = NC == 1 ? 1 : (bits & 7) == 0;
     const dim3 grid((unsigned)nblocks, g.count);
-#define NZ_FS(N) hipLaunchKernelGGL((flow_stream_kernel<N>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned)
+#define NZ_FS(N)                                                                                                                        \
+    do {                                                                                                                                \
+        if (NC == 1) hipLaunchKernelGGL((flow_stream_kernel<N, 1>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned); \
+        else hipLaunchKernelGGL((flow_stream_kernel<N, 2>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned);         \
+    } while (0)
     switch (n) {
         case 1: NZ_FS(1); break;
         case 2: NZ_FS(2); break;

@@ -65,7 +65,13 @@ struct nz_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *pipe_work = nullptr;
     size_t pipe_work_floats = 0;
+    // pool automaton, sparse form (nz_pool_job in nz_stages.cpp): {entries, done, -} in device memory, and in mapped host
+    // memory what the last job that ran reported: job number << 32 | non-empty mask words it found
+    int *pool_ctl = nullptr;
+    unsigned long long *pool_hint = nullptr, *pool_hint_dev = nullptr;
+    unsigned long long pool_seq = 0;
 };
+int32_t nz_ctx_pool_state(nz_ctx *ctx);  // allocates the three on first use
 
 #define NZ_TRY_(expr)             \
     do {                          \
@@ -239,11 +245,15 @@ int32_t nz_launch_normalize_args(hipStream_t s, float *data, size_t n, const flo
 int32_t nz_launch_range_split(hipStream_t s, const float *triples, int n, float *mins, float *maxs);
 int32_t nz_launch_range_compose(hipStream_t s, const float *lo, const float *hi, float *res);
 size_t nz_pool_automata_mask_words(int res);
-int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res, unsigned *mask);
-int32_t nz_launch_pool_automata_clean(hipStream_t s, const float *pool, int res, unsigned *mask);
+int32_t nz_launch_pool_automata_masks(hipStream_t s, const float *pool, int res, unsigned *mask, int *ctl, int with_list);
+int32_t nz_launch_pool_automata_clean(hipStream_t s, const float *pool, int res, unsigned *mask, int *ctl);
 int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *height, int res, int xoff, int zoff,
                                      int32_t *drain_hdr = nullptr, nz_particle *drain_data = nullptr,
-                                     unsigned *mask = nullptr);
+                                     unsigned *mask = nullptr, int *ctl = nullptr);
+// the whole job as one launch of one workgroup, from the list of non-empty mask words (nz_elementwise.hip)
+int32_t nz_launch_pool_automata_sparse(hipStream_t s, float *pool, const float *height, int res, int iterations, int limit,
+                                       int dense_follows, int32_t *drain_hdr, nz_particle *drain_data, unsigned *mask, int *ctl,
+                                       unsigned long long *hint_dev, unsigned long long seq);
 int32_t *nz_particle_queue_hdr(nz_particle_queue *q);
 nz_particle *nz_particle_queue_data(nz_particle_queue *q);
 int32_t nz_launch_crop(hipStream_t s, const float *in, int in_res, float *out, int out_res);

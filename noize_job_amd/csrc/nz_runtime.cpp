@@ -233,6 +233,8 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->pipe_work) (void)hipFree(ctx->pipe_work);
+    if (ctx->pool_ctl) (void)hipFree(ctx->pool_ctl);
+    if (ctx->pool_hint) (void)hipHostFree(ctx->pool_hint);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return NZ_OK;
@@ -352,6 +354,19 @@ int32_t nz_ctx_pipe_state(nz_ctx *ctx, size_t floats, float **work) {
         ctx->pipe_work_floats = floats;
     }
     *work = ctx->pipe_work;
+    return NZ_OK;
+}
+
+int32_t nz_ctx_pool_state(nz_ctx *ctx) {
+    if (!ctx->pool_ctl) {
+        NZ_HIP(hipMalloc((void **)&ctx->pool_ctl, 64));
+        NZ_HIP(hipMemsetAsync(ctx->pool_ctl, 0, 64, ctx->stream));
+    }
+    if (!ctx->pool_hint) {
+        NZ_HIP(hipHostMalloc((void **)&ctx->pool_hint, 64, hipHostMallocMapped));
+        *ctx->pool_hint = 0;  // job 0: nothing known yet
+        NZ_HIP(hipHostGetDevicePointer((void **)&ctx->pool_hint_dev, ctx->pool_hint, 0));
+    }
     return NZ_OK;
 }
 

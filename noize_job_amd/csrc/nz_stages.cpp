@@ -1025,15 +1025,53 @@ extern "C" int32_t nz_update_flow_from_track(nz_ctx *ctx, float *pool, float *fl
     return nz_ctx_finish(ctx, out);
 }
 
-// Scratch for the acting-step bits of the job's passes, filled from the plane as the job finds it; NZ_POOL_RUNS=0 selects the one-lane-per-row walk (mask = NULL)
-static int32_t pool_mask(nz_ctx *ctx, const float *pool, int res, unsigned **mask) {
+// PoolAutomataJob (MultiThreadErosionJob.cs:264-327): `iterations` x four colour passes of WorldTile.SpreadPool.
+//   NZ_POOL_RUNS=0   one lane per row, as the reference walks it (no mask);
+//   otherwise        parallel runs of acting steps (nz_elementwise.hip): a masks launch, then
+//       * the sparse form -- ONE launch of one workgroup that runs the whole job from the list of non-empty mask words --
+//         when the last job that reported (at most 8 jobs ago) found few of them: 2 launches instead of ~50;
+//       * the dense form otherwise: the sparse launch first (it still takes a job with few words and then turns the dense
+//         launches into no-ops; and it reports), then 4 launches per iteration and a clean between iterations.
+//   NZ_POOL_SPARSE=0: never the sparse launch; =2: always, and nothing follows it (the test matrix).
+static int32_t pool_job(nz_ctx *ctx, float *pool, const float *height, int res, int iterations, int32_t *hdr, nz_particle *data) {
     static const int runs = [] { const char *e = getenv("NZ_POOL_RUNS"); return e ? atoi(e) : 1; }();
-    *mask = nullptr;
-    if (!runs) return NZ_OK;
+    static const int sparse = [] { const char *e = getenv("NZ_POOL_SPARSE"); return e ? atoi(e) : 1; }();
+    if (!runs) {
+        for (int i = 0; i < iterations; i++)
+            for (int xoff = 0; xoff < 2; xoff++)
+                for (int zoff = 0; zoff < 2; zoff++)
+                    NZ_TRY(nz_launch_pool_automata_pass(ctx->stream, pool, height, res, xoff, zoff, hdr, data, nullptr, nullptr));
+        return NZ_OK;
+    }
+    if (iterations == 0) return NZ_OK;
     float *p = nullptr;
     NZ_TRY(nz_ctx_scratch(ctx, nz_pool_automata_mask_words(res), &p));
-    *mask = reinterpret_cast<unsigned *>(p);
-    return nz_launch_pool_automata_masks(ctx->stream, pool, res, *mask);
+    unsigned *mask = reinterpret_cast<unsigned *>(p);
+    int *ctl = nullptr;
+    bool dense = true;
+    if (sparse) {
+        NZ_TRY(nz_ctx_pool_state(ctx));
+        ctl = ctx->pool_ctl;
+        constexpr int LIMIT = 1024;  // non-empty words the one workgroup takes on: one per thread and pass
+        const unsigned long long seq = ++ctx->pool_seq;
+        const unsigned long long hint = *reinterpret_cast<volatile unsigned long long *>(ctx->pool_hint);
+        const unsigned long long hint_seq = hint >> 32;
+        const bool fresh = hint_seq != 0 && seq - hint_seq <= 8 && seq > hint_seq;
+        dense = sparse == 2 ? false : !(fresh && (unsigned)hint <= LIMIT / 2);
+        NZ_TRY(nz_launch_pool_automata_masks(ctx->stream, pool, res, mask, ctl, 1));
+        NZ_TRY(nz_launch_pool_automata_sparse(ctx->stream, pool, height, res, iterations, LIMIT, dense ? 1 : 0, hdr, data, mask, ctl,
+                                              ctx->pool_hint_dev, seq & 0xffffffffull));
+    } else {
+        NZ_TRY(nz_launch_pool_automata_masks(ctx->stream, pool, res, mask, nullptr, 0));
+    }
+    if (!dense) return NZ_OK;
+    for (int i = 0; i < iterations; i++) {
+        if (i > 0) NZ_TRY(nz_launch_pool_automata_clean(ctx->stream, pool, res, mask, ctl));
+        for (int xoff = 0; xoff < 2; xoff++)
+            for (int zoff = 0; zoff < 2; zoff++)
+                NZ_TRY(nz_launch_pool_automata_pass(ctx->stream, pool, height, res, xoff, zoff, hdr, data, mask, ctl));
+    }
+    return NZ_OK;
 }
 
 // PoolAutomataJob.Schedule, MultiThreadErosionJob.cs:289-325, with drainParticles == false (the other setting feeds
@@ -1044,15 +1082,7 @@ extern "C" int32_t nz_pool_automata(nz_ctx *ctx, float *pool, const float *heigh
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(pool && height && pool != height, "pool/height must be two distinct planes");
     NZ_REQUIRE(resolution >= 2 && iterations >= 0, "resolution < 2 or iterations < 0");
-    unsigned *mask = nullptr;
-    NZ_TRY(pool_mask(ctx, pool, resolution, &mask));
-    for (int i = 0; i < iterations; i++) {
-        if (i > 0 && mask) NZ_TRY(nz_launch_pool_automata_clean(ctx->stream, pool, resolution, mask));
-        for (int xoff = 0; xoff < 2; xoff++)
-            for (int zoff = 0; zoff < 2; zoff++)
-                NZ_TRY(nz_launch_pool_automata_pass(ctx->stream, pool, height, resolution, xoff, zoff, nullptr, nullptr,
-                                                    mask));
-    }
+    NZ_TRY(pool_job(ctx, pool, height, resolution, iterations, nullptr, nullptr));
     return nz_ctx_finish(ctx, out);
 }
 
@@ -1069,14 +1099,7 @@ extern "C" int32_t nz_pool_automata_job(nz_ctx *ctx, float *pool, const float *h
     NZ_REQUIRE(!drainParticles || particleQueue, "drainParticles needs a particle queue");
     int32_t *hdr = drainParticles ? nz_particle_queue_hdr(particleQueue) : nullptr;
     nz_particle *data = drainParticles ? nz_particle_queue_data(particleQueue) : nullptr;
-    unsigned *mask = nullptr;
-    NZ_TRY(pool_mask(ctx, pool, res, &mask));
-    for (int i = 0; i < iterations; i++) {
-        if (i > 0 && mask) NZ_TRY(nz_launch_pool_automata_clean(ctx->stream, pool, res, mask));
-        for (int xoff = 0; xoff < 2; xoff++)
-            for (int zoff = 0; zoff < 2; zoff++)
-                NZ_TRY(nz_launch_pool_automata_pass(ctx->stream, pool, height, res, xoff, zoff, hdr, data, mask));
-    }
+    NZ_TRY(pool_job(ctx, pool, height, res, iterations, hdr, data));
     return nz_ctx_finish(ctx, out);
 }
 
