@@ -128,7 +128,7 @@ namespace xshazwar.noize.hip {
                     // CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all behind the event reduction
                     // (:408-412): the flow job runs on a stream of its own (a second context), beside the sediment job
                     if (parallelBranch) {
-                        if (branchCtx == null) branchCtx = new GpuContext();
+                        if (branchCtx == null) branchCtx = new GpuContext(ctx.Device);   // the main context's device
                         Native.Check(Native.nz_update_flow_from_track(branchCtx.Handle, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
                                                                       ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out ulong flow), "nz_update_flow_from_track");
                         h = particleQueue.Clear(ctx.Wrap(h)).id;

@@ -207,9 +207,23 @@ namespace xshazwar.noize.hip {
             }
         }
 
+        // pipelineHandle.Complete().  NZ_ERR_RETRY -- a chained kernel-filter launch timed out, the planes computed since are
+        // invalid and the context has switched to separate launches -- is answered once by scheduling the work item again,
+        // when the pipeline regenerates its tile from scratch (its first stage is the NoiseStage); any other pipeline's
+        // input is gone with the stage that failed, and the error goes to the caller.
+        void CompleteActive() {
+            try {
+                pipelineHandle.Complete();
+            } catch (NoizeException e) when (e.status == Native.NZ_ERR_RETRY && stage_instances[0].GetType() == typeof(NoiseStage)) {
+                pipelineRunning = false;
+                Schedule(activeItem);
+                pipelineHandle.Complete();
+            }
+        }
+
         public bool LateUpdate() {                                                                  // :160-181
             if (pipelineRunning && pipelineHandle.IsCompleted) {
-                pipelineHandle.Complete();
+                CompleteActive();
                 foreach (PipelineStage stage in stage_instances) stage.OnStageComplete();
                 activeItem.completeAction?.Invoke(activeItem.data);
                 pipelineRunning = false;

@@ -62,9 +62,15 @@ namespace xshazwar.noize.hip {
         public int MARGIN;
     }
 
+    public class NoizeException : Exception {       // negative nz_status -> exception (SURVEY.md 8b, error convention)
+        public readonly int status;
+        public NoizeException(int status, string message) : base(message) { this.status = status; }
+    }
+
     public static partial class Native {
+        public const int NZ_ERR_RETRY = -7;      // a chained kernel-filter launch timed out: schedule the work item again
         public static void Check(int status, string where) {
-            if (status != 0) throw new Exception($"{where} failed ({status}): {Marshal.PtrToStringAnsi(nz_last_error())}");
+            if (status != 0) throw new NoizeException(status, $"{where} failed ({status}): {Marshal.PtrToStringAnsi(nz_last_error())}");
         }
     }
 
@@ -92,6 +98,7 @@ namespace xshazwar.noize.hip {
     // (the reference schedules everything from the Unity main thread, Pipeline/Executable/Pipeline.cs:29-30).
     public sealed class GpuContext : IDisposable {
         public IntPtr Handle { get; private set; }
+        public int Device => Native.nz_ctx_device(Handle);
         public GpuContext(int device = 0) {
             Native.Check(Native.nz_ctx_create(device, out IntPtr h), "nz_ctx_create");
             Handle = h;

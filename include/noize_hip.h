@@ -37,7 +37,10 @@ enum nz_status {
     NZ_ERR_HIP = -3,         /* HIP runtime error */
     NZ_ERR_NOMEM = -4,
     NZ_ERR_NO_DEVICE = -5,   /* no gfx950 device / HIP runtime unavailable */
-    NZ_ERR_COMM = -6         /* RCCL error, or librccl.so.1 could not be opened */
+    NZ_ERR_COMM = -6,        /* RCCL error, or librccl.so.1 could not be opened */
+    NZ_ERR_RETRY = -7        /* a chained kernel-filter launch timed out (nz_handle_wait / nz_ctx_synchronize report it): the
+                                planes computed since are invalid, the context has switched to separate launches -- schedule
+                                the work item again (the hosts' BasePipeline does, once) */
 };
 
 /* NoiseStage.FractalNoise, Noise/NoiseStage.cs:15-24 */
@@ -100,6 +103,7 @@ int32_t nz_ctx_create_on_stream(int32_t device, void *hip_stream, nz_ctx **out);
 int32_t nz_ctx_destroy(nz_ctx *ctx);
 int32_t nz_ctx_synchronize(nz_ctx *ctx);
 void *nz_ctx_stream(nz_ctx *ctx);
+int32_t nz_ctx_device(nz_ctx *ctx); /* the HIP device the context was created on (-1 for NULL) */
 
 /* NativeArray<float>(n, Allocator.Persistent, UninitializedMemory) / Dispose() */
 int32_t nz_tile_alloc(nz_ctx *ctx, size_t n_floats, float **out_dev);
@@ -441,6 +445,9 @@ int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, float increment
  * the chain, launch 0's tiles first) sleeps `sleeps` x ~3.4 us before it loads its tile -- a straggler that reads a plane
  * later launches overwrite.  Results must not change.  item < 0: off. */
 int32_t nz_debug_chain_delay(int32_t item, int32_t sleeps);
+/* Test hook: polls (~2 us each) after which a tile of a chained launch gives up waiting for a producer; <= 0 restores the
+ * default (2^21: seconds).  With a small limit and a long nz_debug_chain_delay the time-out path can be exercised. */
+int32_t nz_debug_chain_poll_limit(int32_t polls);
 
 /* ---- a whole BasePipeline of the stock stages as one call -------------------------------------------------------
  * BasePipeline.Schedule hands a work item from stage to stage (Pipeline/Executable/Pipeline.cs:91-152,

@@ -74,7 +74,7 @@ class ShardedDesc(C.Structure):
 ep_p, tm_p, tp_p = C.POINTER(ErosionParameters), C.POINTER(TileSetMeta), C.POINTER(TerrainParams)
 sd_p = C.POINTER(ShardedDesc)
 
-NZ_OK, NZ_ERR_INVALID, NZ_ERR_UNSUPPORTED, NZ_ERR_HIP, NZ_ERR_NOMEM, NZ_ERR_NO_DEVICE, NZ_ERR_COMM = 0, -1, -2, -3, -4, -5, -6
+NZ_OK, NZ_ERR_INVALID, NZ_ERR_UNSUPPORTED, NZ_ERR_HIP, NZ_ERR_NOMEM, NZ_ERR_NO_DEVICE, NZ_ERR_COMM, NZ_ERR_RETRY = 0, -1, -2, -3, -4, -5, -6, -7
 NZ_COMM_ID_BYTES = 128
 NZ_HALO_RECOMPUTE, NZ_HALO_EXCHANGE, NZ_HALO_EXCHANGE_ONCE = 0, 1, 2
 
@@ -91,6 +91,7 @@ SIGNATURES = {
     "nz_ctx_destroy": (_i, [ctx_p]),
     "nz_ctx_synchronize": (_i, [ctx_p]),
     "nz_ctx_stream": (C.c_void_p, [ctx_p]),
+    "nz_ctx_device": (_i, [ctx_p]),
     "nz_tile_alloc": (_i, [ctx_p, _sz, C.POINTER(dev_ptr)]),
     "nz_tile_free": (_i, [ctx_p, dev_ptr]),
     "nz_tile_upload": (_i, [ctx_p, dev_ptr, C.c_void_p, _sz] + _tail),
@@ -180,6 +181,7 @@ SIGNATURES = {
     "nz_heightmap_mesh16": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _i, _i, _i, _f, _f, dev_ptr] + _tail),
     "nz_square_grid_mesh": (_i, [ctx_p, dev_ptr, dev_ptr, _i] + _tail),
     "nz_heightmap_mesh_batch": (_i, [ctx_p, _i, dev_ptr, dev_ptr, _i, _i, _i, _f, _f, dev_ptr, _i] + _tail),
+    "nz_debug_chain_poll_limit": (_i, [_i]),
     # one grid over the GPUs of a node (nz_comm.cpp)
     "nz_comm_unique_id": (_i, [C.c_void_p]),
     "nz_comm_init": (_i, [ctx_p, C.c_void_p, _i, _i, C.POINTER(C.c_void_p)]),

@@ -494,37 +494,34 @@ __global__ __launch_bounds__(PST) void pool_sparse_kernel(float *pool, const flo
                                                         int iterations, int limit, int dense_follows, int32_t *drain_hdr,
                                                         nz_particle *drain_data, unsigned long long *hint,
                                                         unsigned long long seq) {
-    __shared__ int s_n, s_scan;
+    // the entry count lives in LDS while the kernel runs (this workgroup is the only one that adds entries): a pass
+    // that finds nothing to do costs one workgroup barrier, not a round trip to the L2
+    __shared__ int s_count;
     const int tid = threadIdx.x;
+    int *const gctl = pm.ctl;
     if (tid == 0) {
-        const int n = __hip_atomic_load(pm.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_n = n;
+        const int n = __hip_atomic_load(gctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_count = n;
         // (job number, entries) in one 8-byte store to mapped host memory
         if (hint) __hip_atomic_store(hint, (seq << 32) | (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
-    const int n0 = s_n;
+    const int n0 = s_count;
     if (n0 > limit && dense_follows) {
         if (tid == 0) {
-            pm.ctl[1] = 0;
-            pm.ctl[0] = 0;  // the next job's masks kernel counts from zero
+            gctl[1] = 0;
+            gctl[0] = 0;  // the next job's masks kernel counts from zero
         }
         return;
     }
-    bool scan_all = n0 > limit || n0 > pm.cap;
+    pm.ctl = &s_count;  // pool_list_add counts here from now on
+    const bool scan_from_start = n0 > limit || n0 > pm.cap;
     const int total = pm.words * pm.walks;
     for (int it = 0; it < iterations; it++) {
         if (it > 0) {  // pool_masks_clean_kernel
             __syncthreads();  // the last pass of the previous iteration is complete
-            if (tid == 0) {
-                const int n = __hip_atomic_load(pm.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_n = n;
-                s_scan = n > pm.cap;
-            }
-            __syncthreads();
-            scan_all = scan_all || s_scan != 0;
-            if (!scan_all) {
-                const int n = min(s_n, pm.cap);
+            const int n = s_count;
+            if (!(scan_from_start || n > pm.cap)) {
                 for (int i = tid; i < n; i += PST) {
                     const unsigned e = pm.list[i];
                     const int c = e & 3, w = (e >> 2) & 1023, k = e >> 12;
@@ -539,16 +536,10 @@ __global__ __launch_bounds__(PST) void pool_sparse_kernel(float *pool, const flo
         for (int xoff = 0; xoff < 2; xoff++)
             for (int zoff = 0; zoff < 2; zoff++) {
                 __syncthreads();  // the previous pass (or the clean) is complete, its stores visible to the workgroup
-                if (tid == 0) {
-                    const int n = __hip_atomic_load(pm.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_n = n;
-                    s_scan = n > pm.cap;
-                }
-                __syncthreads();
-                scan_all = scan_all || s_scan != 0;
+                // entries added while this pass runs belong to other classes: whichever of them a thread already sees, it skips
+                const int n = s_count;
                 const int cls = 2 * xoff + zoff;
-                if (!scan_all) {
-                    const int n = s_n;  // entries added during this pass belong to other classes
+                if (!(scan_from_start || n > pm.cap)) {
                     for (int i = tid; i < n; i += PST) {
                         const unsigned e = pm.list[i];
                         if ((int)(e & 3) != cls) continue;
@@ -563,8 +554,8 @@ __global__ __launch_bounds__(PST) void pool_sparse_kernel(float *pool, const flo
     }
     __syncthreads();
     if (tid == 0) {
-        pm.ctl[1] = 1;
-        pm.ctl[0] = 0;  // the next job's masks kernel counts from zero
+        gctl[1] = 1;
+        gctl[0] = 0;  // the next job's masks kernel counts from zero
     }
 }
 

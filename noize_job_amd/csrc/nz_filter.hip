@@ -330,14 +330,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
 //     ever timed out runs separate launches from then on (nz_runtime.cpp, ctx_chain_check);
 //   * hand-off: producer = sc1 stores, every wave s_waitcnt vmcnt(0), workgroup barrier, ONE lane stores the tile's
 //     flag (agent scope); consumer = up to nine lanes poll one flag each (sc1 loads), workgroup barrier, sc1 loads;
-//   * the poll is bounded: a workgroup that gives up raises ctl[NZ_CHAIN_ERR] and carries on, so the grid always
+//   * the poll is bounded: a workgroup that gives up raises the context's error word (mapped host memory) and carries on, so the grid always
 //     drains and the host reports the failure at its next synchronisation instead of hanging;
 //   * flags carry the launch's epoch, and the last workgroup out zeroes the tickets: nothing is cleared between stages.
 // (A persistent form -- resident workgroups that claim item after item and let a tile's stores drain behind the next
 // tile's loads -- was built and measured: 0.555 ms for Gauss5 x17 against 0.197 ms, the loop-carried state costs the
 // 80-register budget 39 spills.  One item per workgroup it stays.)
 constexpr int NZ_CHAIN_MAXL = 8;
-constexpr int NZ_CHAIN_DONE = 8, NZ_CHAIN_ERR = 9;  // ctl[0..7] = tickets per class
+constexpr int NZ_CHAIN_DONE = 8;  // ctl[0..7] = tickets per class, ctl[8] = workgroups that have finished
 struct nz_chain {
     int L, total;
     int T[NZ_CHAIN_MAXL], first[NZ_CHAIN_MAXL + 1], tiles_x[NZ_CHAIN_MAXL];
@@ -349,6 +349,10 @@ struct nz_chain {
     // between its dependency wait and its loads -- a straggler among the readers of a plane that later launches
     // overwrite; -1: nobody
     int delay_item, delay_sleeps;
+    // a consumer gives up after `spin_limit` polls (~2 us each) and raises *err_host, a word in mapped host memory the
+    // host reads -- with a plain load -- wherever it waits for the context
+    int spin_limit;
+    unsigned *err_host;
 };
 
 __host__ __device__ __forceinline__ int chain_class_count(int n, int c) { return n > c ? (n - c + 7) >> 3 : 0; }  // #{vb < n : vb % 8 == c}
@@ -403,8 +407,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
             int spins = 0;
             while ((unsigned)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ch.epoch) {
                 __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1 << 21)) {  // seconds: the producer is never coming
-                    __hip_atomic_store(&ch.ctl[NZ_CHAIN_ERR], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > ch.spin_limit) {  // seconds: the producer is never coming
+                    __hip_atomic_store(ch.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
             }
@@ -737,10 +741,11 @@ int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom 
 }
 
 int g_chain_delay_item = -1, g_chain_delay_sleeps = 0;  // nz_debug_chain_delay
+int g_chain_spin_limit = 1 << 21;                         // nz_debug_chain_poll_limit
 
 template <int KS>
 int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
-                     int L, int *flags, unsigned *ctl, unsigned epoch) {
+                     int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host) {
     constexpr int O = (KS - 1) / 2;
     constexpr int NT = KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT, RTH = NT / 32 * RB;
     nz_chain ch{};
@@ -761,6 +766,8 @@ int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom 
     ch.plane[1] = plane1;
     ch.delay_item = g_chain_delay_item;
     ch.delay_sleeps = g_chain_delay_sleeps;
+    ch.spin_limit = g_chain_spin_limit;
+    ch.err_host = err_host;
     int aligned = ((reinterpret_cast<uintptr_t>(plane0) | reinterpret_cast<uintptr_t>(plane1) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
     if (k.factor == 1.0f)
         hipLaunchKernelGGL((conv_chain_kernel<KS, true, NT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned);
@@ -788,7 +795,7 @@ int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L) {
 // writes the other one, so the result is in plane0 when L is even.  One grid of the geometry (g.count == 1), planes
 // below 4 GiB.  flags: nz_conv_chain_items() ints, never cleared; ctl: 16 words, zero before the first use.
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
-                             const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch) {
+                             const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host) {
     if (L < 1 || L > NZ_CHAIN_MAXL || g.count != 1 || (size_t)g.rows * g.pitch * 4 >= ((size_t)1 << 32)) {
         nz_set_error("conv_chain: %d launches / %d grids / plane of %zu bytes unsupported", L, g.count, (size_t)g.rows * g.pitch * 4);
         return NZ_ERR_INVALID;
@@ -800,10 +807,10 @@ int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const 
         }
     if (g.or1 <= g.or0) return NZ_OK;
     switch (k.ksize) {
-        case 3: return launch_chain<3>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch);
-        case 5: return launch_chain<5>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch);
-        case 7: return launch_chain<7>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch);
-        case 9: return launch_chain<9>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch);
+        case 3: return launch_chain<3>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
+        case 5: return launch_chain<5>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
+        case 7: return launch_chain<7>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
+        case 9: return launch_chain<9>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
     }
     return NZ_ERR_INVALID;
 }
@@ -912,5 +919,12 @@ extern "C" int32_t nz_debug_set_conv_probe(void *buf) {
 extern "C" int32_t nz_debug_chain_delay(int32_t item, int32_t sleeps) {
     g_chain_delay_item = item;
     g_chain_delay_sleeps = sleeps < 0 ? 0 : sleeps;
+    return NZ_OK;
+}
+
+// Test hook: polls (~2 us each) after which a tile of a chained launch stops waiting for a producer; <= 0: the default
+// (2^21, seconds)
+extern "C" int32_t nz_debug_chain_poll_limit(int32_t polls) {
+    g_chain_spin_limit = polls > 0 ? polls : 1 << 21;
     return NZ_OK;
 }

@@ -57,6 +57,7 @@ struct nz_ctx {
     int *chain_flags = nullptr;
     size_t chain_flags_n = 0;
     unsigned *chain_ctl = nullptr;
+    unsigned *chain_err = nullptr, *chain_err_dev = nullptr;  // the error word in mapped host memory, and its device address
     unsigned chain_epoch = 0;
     bool chain_off = false;  // a chained launch once timed out on this context: separate launches from then on
     // striped pipeline (nz_terrain_pipeline): a second stream with its fork / join markers and the stripes' planes, all
@@ -191,8 +192,8 @@ int32_t nz_launch_conv_stream(hipStream_t s, const float *src, float *dst, const
 // L launches as one grid with tile-level dependencies; see nz_filter.hip
 int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L);
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
-                             const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch);
-int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch);
+                             const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host);
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch, unsigned **err_host);
 // one whole application of a wide odd kernel (11..25 taps), src -> dst
 bool nz_conv_has_wide(int ksize);
 int32_t nz_launch_conv_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k);

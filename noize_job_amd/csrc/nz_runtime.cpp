@@ -44,6 +44,7 @@ static constexpr size_t NZ_EVENT_RING = 4096;
 static int32_t ctx_sync_all(nz_ctx *ctx);
 static void registry_add(nz_ctx *ctx);
 static void registry_remove(nz_ctx *ctx);
+static bool registry_full();
 static int32_t ctx_chain_check(nz_ctx *ctx);
 
 
@@ -182,6 +183,7 @@ static int32_t ctx_create(int32_t device, hipStream_t stream, bool own, nz_ctx *
         return NZ_ERR_NO_DEVICE;
     }
     NZ_REQUIRE(device >= 0 && device < n, "device %d out of range [0,%d)", device, n);
+    NZ_REQUIRE(!registry_full(), "this process has created 2^24 contexts: a handle cannot name another one");
     NZ_HIP(hipSetDevice(device));
     nz_ctx *ctx = new nz_ctx();
     ctx->device = device;
@@ -196,6 +198,10 @@ static int32_t ctx_create(int32_t device, hipStream_t stream, bool own, nz_ctx *
     } else {
         ctx->stream = stream;
     }
+    // The chained filter launches rest on workgroups being started in index order, round-robin over the XCDs; a CU mask
+    // takes that away (a bounded wait would time out and cost a tile): such a process runs separate launches from the start
+    for (const char *v : {"HSA_CU_MASK", "ROC_GLOBAL_CU_MASK", "HSA_CU_MASK_SKIP_INIT"})
+        if (getenv(v) && *getenv(v)) ctx->chain_off = true;
     int32_t rc = build_rgrad_table(ctx);
     if (rc == NZ_OK) rc = build_simplex_tables(ctx);
     if (rc != NZ_OK) {
@@ -226,6 +232,7 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->chain_flags) (void)hipFree(ctx->chain_flags);
     if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
+    if (ctx->chain_err) (void)hipHostFree(ctx->chain_err);
     if (ctx->aux) {
         (void)hipStreamSynchronize(ctx->aux);
         (void)hipStreamDestroy(ctx->aux);
@@ -248,6 +255,7 @@ extern "C" int32_t nz_ctx_synchronize(nz_ctx *ctx) {
 }
 
 extern "C" void *nz_ctx_stream(nz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int32_t nz_ctx_device(nz_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 static int32_t ctx_sync_all(nz_ctx *ctx) {
     NZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -266,6 +274,11 @@ static void registry_add(nz_ctx *ctx) {
     // naming that context, whose slot stays empty, and so reads as completed -- it can never alias a later context's marker
     g_reg.push_back(ctx);
     ctx->id = (uint32_t)g_reg.size();
+}
+static_assert(NZ_HANDLE_SEQ_BITS == 40, "a handle holds 24 bits of context id above 40 bits of sequence number");
+static bool registry_full() {
+    std::lock_guard<std::mutex> lk(g_reg_mx);
+    return g_reg.size() >= ((size_t)1 << (64 - NZ_HANDLE_SEQ_BITS)) - 1;
 }
 
 static void registry_remove(nz_ctx *ctx) {
@@ -391,11 +404,17 @@ int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out) {
 
 // The flags / control block of the chained launches.  Flags are compared with an epoch that grows by one per launch, so
 // stale contents never match; a (re)allocated array is zeroed and the epoch restarts above zero.
-int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch) {
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch, unsigned **err_host) {
     if (!ctx->chain_ctl) {
         NZ_HIP(hipMalloc((void **)&ctx->chain_ctl, 64));
         NZ_HIP(hipMemsetAsync(ctx->chain_ctl, 0, 64, ctx->stream));
     }
+    if (!ctx->chain_err) {  // mapped host memory: a tile that gives up stores here (system scope), the host reads it with a load
+        NZ_HIP(hipHostMalloc((void **)&ctx->chain_err, 64, hipHostMallocMapped));
+        *ctx->chain_err = 0;
+        NZ_HIP(hipHostGetDevicePointer((void **)&ctx->chain_err_dev, ctx->chain_err, 0));
+    }
+    *err_host = ctx->chain_err_dev;
     if (items > ctx->chain_flags_n) {
         if (ctx->chain_flags) {
             NZ_TRY_(ctx_sync_all(ctx));
@@ -415,24 +434,22 @@ int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ct
     return NZ_OK;
 }
 
-// a chained launch that gave up waiting for a producer tile has raised ctl[9]: reported wherever the host waits
+// A chained launch that gave up waiting for a producer tile has raised the context's error word (mapped host memory: no
+// device-to-host copy on the host's wait path): reported wherever the host waits.
 static int32_t ctx_chain_check(nz_ctx *ctx) {
-    if (!ctx->chain_ctl) return NZ_OK;
-    int err = 0;
-    NZ_HIP(hipMemcpy(&err, ctx->chain_ctl + 9, sizeof err, hipMemcpyDeviceToHost));
-    if (err) {
-        (void)hipMemset(ctx->chain_ctl, 0, 64);
-        // The wait of a chained launch terminates whatever happens (bounded poll), but it only makes PROGRESS while the
-        // hardware starts the grid's workgroups in index order, round-robin over the XCDs -- a consumer's producers belong
-        // to other ticket classes (blockIdx.x & 7), and those are claimed by workgroups that must get dispatched.  That
-        // is observed behaviour, not a contract (CU masking or a partitioned mode could break it): after one timeout the
-        // context falls back to separate launches for good.
-        ctx->chain_off = true;
-        nz_set_error("a chained kernel-filter launch timed out waiting for a producer tile: its results are invalid; this "
-                     "context now runs filter stages as separate launches");
-        return NZ_ERR_HIP;
-    }
-    return NZ_OK;
+    if (!ctx->chain_err) return NZ_OK;
+    if (*reinterpret_cast<volatile unsigned *>(ctx->chain_err) == 0) return NZ_OK;
+    *reinterpret_cast<volatile unsigned *>(ctx->chain_err) = 0;
+    // The wait of a chained launch terminates whatever happens (bounded poll), but it only makes PROGRESS while the
+    // hardware starts the grid's workgroups in index order, round-robin over the XCDs -- a consumer's producers belong
+    // to other ticket classes (blockIdx.x & 7), and those are claimed by workgroups that must get dispatched.  That
+    // is observed behaviour, not a contract (CU masking or a partitioned mode could break it): after one timeout the
+    // context falls back to separate launches for good.
+    ctx->chain_off = true;
+    nz_set_error("a chained kernel-filter launch timed out waiting for a producer tile: the plane that stage left (and whatever was "
+                 "computed from it) is invalid; this context now runs filter stages as separate launches -- schedule the work item "
+                 "again (NZ_ERR_RETRY)");
+    return NZ_ERR_RETRY;
 }
 
 extern "C" int32_t nz_handle_record(nz_ctx *ctx, nz_handle *out) {

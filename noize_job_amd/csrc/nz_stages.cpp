@@ -253,9 +253,9 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         int Ts[8];
         for (int i = 0; i < L; i++) Ts[i] = base + (i >= L - rem ? 1 : 0);
         int *flags = nullptr;
-        unsigned *ctl = nullptr, epoch = 0;
-        NZ_TRY_(nz_ctx_chain_state(ctx, (size_t)nz_conv_chain_items(t.ksize, g, Ts, L), &flags, &ctl, &epoch));
-        NZ_TRY_(nz_launch_conv_chain(ctx->stream, src, tmp, g, t, Ts, L, flags, ctl, epoch));
+        unsigned *ctl = nullptr, epoch = 0, *err_host = nullptr;
+        NZ_TRY_(nz_ctx_chain_state(ctx, (size_t)nz_conv_chain_items(t.ksize, g, Ts, L), &flags, &ctl, &epoch, &err_host));
+        NZ_TRY_(nz_launch_conv_chain(ctx->stream, src, tmp, g, t, Ts, L, flags, ctl, epoch, err_host));
         if (swapped) *swapped = (L & 1) != 0;
         return NZ_OK;
     }
@@ -1227,6 +1227,9 @@ extern "C" int32_t nz_terrain_pipeline(nz_ctx *ctx, float *data, int32_t resolut
         sp[s].B = work; work += n;
         sp[s].st = s == 0 ? ctx->stream : ctx->aux;
     }
+    // everything that can be refused is refused before the second stream is involved
+    NZ_REQUIRE(p.noiseType >= 0 && p.noiseType <= NZ_NOISE_DOMAIN_ROTATED_SIMPLEX, "unknown noise type %d", p.noiseType);
+    NZ_REQUIRE(p.octaves >= 0 && p.noiseSize != 0, "octaves < 0 or noiseSize == 0");
     // fork: the second stream starts behind everything this call is ordered after
     NZ_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     NZ_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
@@ -1240,40 +1243,45 @@ extern "C" int32_t nz_terrain_pipeline(nz_ctx *ctx, float *data, int32_t resolut
         g.chip_div = P;
         return g;
     };
-    NZ_TRY(mark(0));
-    for (int s = 0; s < P; s++) {
-        const nz_geom g = geom(sp[s], need_up, need_down);
-        NZ_TRY(fractal_impl(ctx, sp[s].st, p.noiseType, sp[s].A + (size_t)g.or0 * R, g.or1 - g.or0, R, R, p.hurst,
-                            p.startingAmplitude, p.stepdown, p.detuneRate, p.octaves, xpos, zpos + sp[s].b0 + g.or0,
-                            p.noiseSize));
-    }
-    int up_left = need_up, down_left = need_down, kind = 0;
-    bool in_A[2] = {true, true};
-    for (size_t i = 0; i < plan.size(); i++) {
-        const tp_launch &l = plan[i];
-        while (kind < l.kind) NZ_TRY(mark(++kind));  // a stage left out: an empty interval
-        up_left -= l.up;
-        down_left -= l.down;
-        const bool last = i + 1 == plan.size();
+    int kind = 0;
+    const int32_t rc = [&]() -> int32_t {  // whatever happens in here, the join below still orders the second stream
+        NZ_TRY(mark(0));
         for (int s = 0; s < P; s++) {
-            const stripe &q = sp[s];
-            const nz_geom g = geom(q, up_left, down_left);
-            const float *cur = in_A[s] ? q.A : q.B;
-            // the last launch stores its rows -- the stripe's own -- straight into the caller's plane: buffer row 0 is
-            // global row b0
-            float *nxt = last ? data + (size_t)q.b0 * R : (in_A[s] ? q.B : q.A);
-            if (l.kind == 1) NZ_TRY(nz_launch_conv_fused(q.st, cur, nxt, g, taps, l.n));
-            else if (l.kind == 2)
-                NZ_TRY(nz_launch_flow_fused(q.st, cur, nullptr, nullptr, nxt, nullptr, g, l.n, 1, 1, p.normMin,
-                                            p.normMax - p.normMin));
-            else NZ_TRY(nz_launch_erosion_fused(q.st, cur, nxt, g, l.n));
-            in_A[s] = !in_A[s];
+            const nz_geom g = geom(sp[s], need_up, need_down);
+            NZ_TRY(fractal_impl(ctx, sp[s].st, p.noiseType, sp[s].A + (size_t)g.or0 * R, g.or1 - g.or0, R, R, p.hurst,
+                                p.startingAmplitude, p.stepdown, p.detuneRate, p.octaves, xpos, zpos + sp[s].b0 + g.or0,
+                                p.noiseSize));
         }
-    }
-    for (int k = kind + 1; k <= 3; k++) NZ_TRY(mark(k));  // stages left out: empty intervals
-    // join: whatever follows on the context's stream follows both stripes
+        int up_left = need_up, down_left = need_down;
+        bool in_A[2] = {true, true};
+        for (size_t i = 0; i < plan.size(); i++) {
+            const tp_launch &l = plan[i];
+            while (kind < l.kind) NZ_TRY(mark(++kind));  // a stage left out: an empty interval
+            up_left -= l.up;
+            down_left -= l.down;
+            const bool last = i + 1 == plan.size();
+            for (int s = 0; s < P; s++) {
+                const stripe &q = sp[s];
+                const nz_geom g = geom(q, up_left, down_left);
+                const float *cur = in_A[s] ? q.A : q.B;
+                // the last launch stores its rows -- the stripe's own -- straight into the caller's plane: buffer row 0 is
+                // global row b0
+                float *nxt = last ? data + (size_t)q.b0 * R : (in_A[s] ? q.B : q.A);
+                if (l.kind == 1) NZ_TRY(nz_launch_conv_fused(q.st, cur, nxt, g, taps, l.n));
+                else if (l.kind == 2)
+                    NZ_TRY(nz_launch_flow_fused(q.st, cur, nullptr, nullptr, nxt, nullptr, g, l.n, 1, 1, p.normMin,
+                                                p.normMax - p.normMin));
+                else NZ_TRY(nz_launch_erosion_fused(q.st, cur, nxt, g, l.n));
+                in_A[s] = !in_A[s];
+            }
+        }
+        return NZ_OK;
+    }();
+    // join: whatever follows on the context's stream follows both stripes -- also when a launch above was refused
     NZ_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
     NZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (rc) return rc;
+    for (int k = kind + 1; k <= 3; k++) NZ_TRY(mark(k));  // stages left out: empty intervals
     NZ_TRY(mark(4));
     return nz_ctx_finish(ctx, out);
 }

@@ -656,9 +656,23 @@ class BasePipeline {
             if (GetNextJob(wi)) Schedule(wi);
         }
     }
+    // pipelineHandle.Complete().  NZ_ERR_RETRY -- a chained kernel-filter launch timed out, the planes computed since are
+    // invalid and the context has switched to separate launches -- is answered once by scheduling the work item again,
+    // when the pipeline regenerates its tile from scratch (its first stage is the NoiseStage); any other pipeline's input
+    // is gone with the stage that failed, and the error goes to the caller.
+    void CompleteActive() {
+        try {
+            pipelineHandle.Complete();
+        } catch (const NoizeError &e) {
+            if (e.status != NZ_ERR_RETRY || !RegeneratesItsTile()) throw;
+            pipelineRunning = false;
+            Schedule(activeItem);
+            pipelineHandle.Complete();
+        }
+    }
     bool LateUpdate() {
         if (pipelineRunning && pipelineHandle.IsCompleted()) {
-            pipelineHandle.Complete();
+            CompleteActive();
             for (auto *s : stage_instances) s->OnStageComplete();
             if (activeItem.completeAction) activeItem.completeAction(activeItem.data);
             pipelineRunning = false;
@@ -670,7 +684,7 @@ class BasePipeline {
         while (!queue.empty() || !dependencyHell.empty() || pipelineRunning) {
             Update();
             if (pipelineRunning) {
-                pipelineHandle.Complete();
+                CompleteActive();
                 LateUpdate();
             } else if (queue.empty()) {
                 break;  // everything left is parked on a dependency another pipeline has to satisfy
@@ -682,6 +696,7 @@ class BasePipeline {
     }
 
   protected:
+    bool RegeneratesItsTile() const;  // the first stage is the NoiseStage
     // the stock list as one call; false: this list / work item / tile keeps the stage-by-stage hand-over
     bool ScheduleStockList();
     std::vector<size_t> chainLink;  // per stage: index of the hand-over to the next stage in its OnStageScheduledAction
@@ -872,7 +887,7 @@ class LiveErosion {
                 // CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all behind the event reduction
                 // (:408-412): the flow job runs on a stream of its own (a second context), beside the sediment job
                 if (parallelBranch) {
-                    if (!branchCtx) check(nz_ctx_create(0, &branchCtx), "nz_ctx_create");
+                    if (!branchCtx) check(nz_ctx_create(nz_ctx_device(ctx), &branchCtx), "nz_ctx_create");  // the main context's device
                     nz_handle flow = 0, both[2];
                     check(nz_update_flow_from_track(branchCtx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
                                                     ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, h, &flow), "nz_update_flow_from_track");
@@ -939,6 +954,10 @@ inline bool stockListParams(const std::vector<PipelineStage *> &stages, nz_terra
     tp->erosionIterations = e ? e->iterations : 0;
     if (noise) *noise = n;
     return true;
+}
+
+inline bool BasePipeline::RegeneratesItsTile() const {
+    return !stage_instances.empty() && typeid(*stage_instances[0]) == typeid(NoiseStage);
 }
 
 inline bool BasePipeline::ScheduleStockList() {

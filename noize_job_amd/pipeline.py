@@ -729,9 +729,23 @@ class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
             if job is not None:
                 self.Schedule(job)
 
+    def _complete(self):
+        """pipelineHandle.Complete().  NZ_ERR_RETRY -- a chained kernel-filter launch timed out, the planes computed since
+        are invalid and the context has switched to separate launches -- is answered once by scheduling the work item
+        again, when the pipeline regenerates its tile from scratch (its first stage is the NoiseStage); any other
+        pipeline's input is gone with the stage that failed, and the error goes to the caller."""
+        try:
+            self.pipelineHandle.Complete()
+        except N.NoizeError as e:
+            if e.status != N.NZ_ERR_RETRY or not isinstance(self.stage_instances[0], NoiseStage):
+                raise
+            self.pipelineRunning = False
+            self.Schedule(self.activeItem)
+            self.pipelineHandle.Complete()
+
     def LateUpdate(self):  # :160-181
         if self.pipelineRunning and self.pipelineHandle.IsCompleted:
-            self.pipelineHandle.Complete()
+            self._complete()
             self.CleanUp()
             if self.activeItem.completeAction:
                 self.activeItem.completeAction(self.activeItem.data)
@@ -748,7 +762,7 @@ class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
         while self.queue or self.dependencyHell or self.pipelineRunning:
             self.Update()
             if self.pipelineRunning:
-                self.pipelineHandle.Complete()
+                self._complete()
                 self.LateUpdate()
 
     def GetDependencies(self):  # :63-65

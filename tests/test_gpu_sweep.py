@@ -3,6 +3,7 @@ and (for the stripe entry points) random stripe geometry with a row pitch wider 
 comparisons are bit-exact.  Sizes straddle the kernels' tile shapes (64 x 128 / 48 x 128 / 32 x 128
 workgroup tiles, 4-cell vectors) so interior, edge and unaligned paths are all taken."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -272,3 +273,60 @@ def test_chained_filter_launches_tolerate_a_straggling_tile(nj, ctx, oracle):
     finally:
         lib.nz_debug_chain_delay(-1, 0)
     stage.OnDestroy()
+
+
+def test_a_chained_launch_that_times_out_is_reported_and_the_pipeline_runs_again(nj, oracle):
+    # The chained form's wait is bounded: a tile whose producer does not come raises the context's error word (mapped
+    # host memory: no device-to-host copy on the wait path).  The host's wait reports NZ_ERR_RETRY, the context switches
+    # to separate launches for good, and a BasePipeline that regenerates its tile (NoiseStage first) schedules the work
+    # item again on its own -- its result is the oracle's.  Forced here with a poll limit of 8 (~16 us) and one
+    # launch-0 tile held up for ~1.7 ms.
+    lib = nj._native.lib
+    res = 1024
+    want = oracle.pipeline(res, res, octaves=6, noise_size=300, gauss_iterations=17, flow_iterations=0, erosion_iterations=0)
+    if os.environ.get("NZ_CONV_CHAIN", "1") == "0":
+        pytest.skip("the chained form is switched off")
+    with nj.Context(0) as c:
+        data, write = c.alloc(res * res), c.alloc(res * res)
+        stages = [nj.NoiseStage(c, nj.FractalNoise.Simplex, 0.4, 1.0, 6, 2.0, 0.0, 300),
+                  nj.KernelFilterStage(c, nj.KernelFilterType.Gauss5_S1, 17)]
+        try:
+            assert lib.nz_debug_chain_poll_limit(8) == 0 and lib.nz_debug_chain_delay(3, 500) == 0
+            # the delegate-level call: the error reaches the caller
+            gd = nj.GeneratorData("t", data, res, 0, 0, write=write)
+            h = nj.JobHandle()
+            for st in stages:
+                st.Schedule(nj.PipelineWorkItem(gd), h)
+                h = st.jobHandle
+            with pytest.raises(nj.NoizeError) as e:
+                h.Complete()
+            assert e.value.status == nj._native.NZ_ERR_RETRY
+            # ... and from now on the context runs the stage as separate launches: no time-out, the right plane
+            gd = nj.GeneratorData("t", data, res, 0, 0, write=write)
+            h = nj.JobHandle()
+            for st in stages:
+                st.Schedule(nj.PipelineWorkItem(gd), h)
+                h = st.jobHandle
+            h.Complete()
+            assert np.array_equal(gd.data.ToArray((res, res)), want)
+        finally:
+            lib.nz_debug_chain_poll_limit(0)
+            lib.nz_debug_chain_delay(-1, 0)
+        for st in stages:
+            st.OnDestroy()
+    # a fresh context (chained form on again), the same time-out, through BasePipeline: the retry is the pipeline's
+    with nj.Context(0) as c:
+        data, write = c.alloc(res * res), c.alloc(res * res)
+        pipe = nj.BasePipeline([nj.NoiseStage(c, nj.FractalNoise.Simplex, 0.4, 1.0, 6, 2.0, 0.0, 300),
+                                nj.KernelFilterStage(c, nj.KernelFilterType.Gauss5_S1, 17)])
+        try:
+            assert lib.nz_debug_chain_poll_limit(8) == 0 and lib.nz_debug_chain_delay(3, 500) == 0
+            gd = nj.GeneratorData("t", data, res, 0, 0, write=write)
+            done = []
+            pipe.Enqueue(gd, completeAction=lambda d: done.append(d))
+            pipe.RunToCompletion()
+            assert len(done) == 1 and np.array_equal(gd.data.ToArray((res, res)), want)
+        finally:
+            lib.nz_debug_chain_poll_limit(0)
+            lib.nz_debug_chain_delay(-1, 0)
+        pipe.Destroy()

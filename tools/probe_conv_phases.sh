@@ -6,5 +6,5 @@ cd "$ROOT/noize_job_amd/csrc"
 BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -fno-slp-vectorize"
 mkdir -p build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE -DNZ_CONV_PROBE $EXTRA -c nz_filter.hip -o build/nz_filter.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libnoize_hip.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -ldl -o ../libnoize_hip.so
 python3 "$ROOT/tools/probe_conv_phases.py" "$@"

@@ -8,7 +8,7 @@ BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function
 mkdir -p build
 for extra in "" "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE $extra -c nz_flow.hip -o build/nz_flow.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libnoize_hip.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -ldl -o ../libnoize_hip.so
   echo "== flags: [$extra]"
   python3 "$ROOT/tools/bench_stage.py" flow --reps 40 2>/dev/null | tail -1
 done
