@@ -573,6 +573,12 @@ int32_t nz_sharded_stripe(const nz_sharded *sh, int32_t i, nz_stripe *st, float 
  *   op 7 stage marker    n = 0 noise, 1 filter, 2 flow, 3 erosion, 4 end
  * `records` may be NULL to query the count. */
 int32_t nz_sharded_plan(const nz_sharded *sh, int32_t *records, int32_t max_records, int32_t *count);
+/* The transfers of the plan's exchanges in the order this rank posts them, as records of 4 int32 {exchange, source rank,
+ * destination rank, floats}: a rank posts ncclSend for the records it is the source of and ncclRecv for those it is the
+ * destination of, in this order inside one group per exchange.  On a plan-only object (ctx == NULL at creation, asRank of
+ * asWorld) these are the lists of that rank of the real job: laid side by side for all ranks, the k-th send of rank a to
+ * rank b must be the k-th receive rank b posts from rank a, with the same size (tests/test_sharded_native.py). */
+int32_t nz_sharded_transfers(const nz_sharded *sh, int32_t *records, int32_t max_records, int32_t *count);
 /* one pass of the pipeline on every local stripe (enqueue only); `marks` (nullable, 5 handles) as nz_terrain_pipeline */
 int32_t nz_sharded_pipeline(nz_ctx *ctx, nz_sharded *sh, nz_handle *marks, nz_handle dep, nz_handle *out);
 /* exchanges and payload bytes this rank sends per pass */

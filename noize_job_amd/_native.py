@@ -198,6 +198,7 @@ SIGNATURES = {
     "nz_sharded_local_stripes": (_i, [C.c_void_p]),
     "nz_sharded_stripe": (_i, [C.c_void_p, _i, stripe_p, C.POINTER(dev_ptr), C.POINTER(dev_ptr)]),
     "nz_sharded_plan": (_i, [C.c_void_p, C.POINTER(_i), _i, C.POINTER(_i)]),
+    "nz_sharded_transfers": (_i, [C.c_void_p, C.POINTER(_i), _i, C.POINTER(_i)]),
     "nz_sharded_pipeline": (_i, [ctx_p, C.c_void_p, handle_p] + _tail),
     "nz_sharded_traffic": (_i, [C.c_void_p, C.POINTER(_i), C.POINTER(_sz)]),
     "nz_sharded_set_timing": (_i, [C.c_void_p, _i]),

@@ -438,29 +438,28 @@ win rows_window(win w, int a, int b) { return win{std::max(a, w.own0), std::min(
 // `down` ghost rows below from the stripe below.  Walks the edges between adjacent stripes top to bottom.
 int add_batch(nz_sharded &sh, const std::vector<int> &planes, int up, int down) {
     std::vector<xfer> x;
-    if (sh.dry) {
-        sh.batches.push_back(std::move(x));
-        return (int)sh.batches.size() - 1;
-    }
     const size_t W = (size_t)sh.d.cols;
-    const int me = sh.comm ? sh.comm->rank : 0;
-    const bool rehearsal = sh.d.asWorld > 0;
+    // plan only (no context): the lists of the REAL rank asRank of asWorld, without addresses -- what nz_sharded_transfers
+    // hands out, so that a test can lay the lists of all ranks side by side
+    const int me = sh.dry ? sh.rank : (sh.comm ? sh.comm->rank : 0);
+    const bool rehearsal = sh.d.asWorld > 0 && !sh.dry;
     auto local = [&](int v) { return v >= sh.rank * sh.S && v < (sh.rank + 1) * sh.S; };
     auto owner = [&](int v) { return rehearsal ? me : v / sh.S; };
+    auto at = [&](int j, int id, size_t row) -> float * { return sh.dry ? nullptr : sh.plane(j, id) + row * W; };
     auto edge = [&](int ju, int jl, bool lu, bool ll, int ru, int rl) {
         // upper stripe (local index ju if lu) above lower stripe (jl if ll)
         for (int id : planes) {
             if (up > 0) {  // the lower stripe's top ghost rows <- the upper stripe's last owned rows
                 xfer t{nullptr, nullptr, up * W, ru, rl};
-                if (lu) t.send = sh.plane(ju, id) + (size_t)(sh.st[ju].own1 - up) * W;
-                if (ll) t.recv = sh.plane(jl, id) + (size_t)(sh.st[jl].own0 - up) * W;
+                if (lu) t.send = at(ju, id, (size_t)(sh.st[ju].own1 - up));
+                if (ll) t.recv = at(jl, id, (size_t)(sh.st[jl].own0 - up));
                 x.push_back(t);
                 if (lu) sh.bytes_sent += t.floats * sizeof(float);
             }
             if (down > 0) {  // the upper stripe's bottom ghost rows <- the lower stripe's first owned rows
                 xfer t{nullptr, nullptr, down * W, rl, ru};
-                if (ll) t.send = sh.plane(jl, id) + (size_t)sh.st[jl].own0 * W;
-                if (lu) t.recv = sh.plane(ju, id) + (size_t)sh.st[ju].own1 * W;
+                if (ll) t.send = at(jl, id, (size_t)sh.st[jl].own0);
+                if (lu) t.recv = at(ju, id, (size_t)sh.st[ju].own1);
                 x.push_back(t);
                 if (ll) sh.bytes_sent += t.floats * sizeof(float);
             }
@@ -877,6 +876,22 @@ extern "C" int32_t nz_sharded_pipeline(nz_ctx *ctx, nz_sharded *sh, nz_handle *m
     NZ_REQUIRE(sh->ctx == ctx, "the sharded grid belongs to another context");
     for (const sh_op &o : sh->prog) NZ_TRY(run_op(*sh, o, marks));
     return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_sharded_transfers(const nz_sharded *sh, int32_t *records, int32_t max_records, int32_t *count) {
+    NZ_REQUIRE(sh && count, "sharded/count is NULL");
+    int n = 0;
+    for (const std::vector<xfer> &b : sh->batches) n += (int)b.size();
+    *count = n;
+    if (!records) return NZ_OK;
+    NZ_REQUIRE(max_records >= n, "room for %d records, the plan holds %d", max_records, n);
+    int i = 0;
+    for (size_t b = 0; b < sh->batches.size(); b++)
+        for (const xfer &t : sh->batches[b]) {
+            int32_t *r = records + 4 * i++;
+            r[0] = (int32_t)b; r[1] = t.src; r[2] = t.dst; r[3] = (int32_t)t.floats;
+        }
+    return NZ_OK;
 }
 
 extern "C" int32_t nz_sharded_traffic(const nz_sharded *sh, int32_t *exchanges, size_t *bytes_sent) {

@@ -540,6 +540,15 @@ class ShardedGrid:
         N.check(N.lib.nz_sharded_plan(self._h, rec, n.value, C.byref(n)), "nz_sharded_plan")
         return [tuple(rec[8 * i:8 * i + 8]) for i in range(n.value)]
 
+    def transfers(self):
+        """The exchanges' transfers in the order this rank posts them: tuples (exchange, source rank, destination rank,
+        floats).  On a plan-only object: the lists of rank as_rank[0] of the real as_rank[1]-rank job."""
+        n = C.c_int32(0)
+        N.check(N.lib.nz_sharded_transfers(self._h, None, 0, C.byref(n)), "nz_sharded_transfers")
+        rec = (C.c_int32 * (4 * max(1, n.value)))()
+        N.check(N.lib.nz_sharded_transfers(self._h, rec, n.value, C.byref(n)), "nz_sharded_transfers")
+        return [tuple(rec[4 * i:4 * i + 4]) for i in range(n.value)]
+
     def run(self, marks=False, dep=0):
         """One pass (enqueue only).  marks: also return the five stage-boundary handles."""
         from .runtime import JobHandle

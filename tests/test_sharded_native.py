@@ -107,6 +107,36 @@ def test_border_first_plan_covers_every_row_once(nj):
         assert ops.count(sh.OP_XFINISH) >= ops.count(sh.OP_XBEGIN)
 
 
+@pytest.mark.parametrize("mode", ["exchange", "exchange_once"])
+def test_every_send_meets_its_receive_on_every_pair_of_ranks(nj, mode):
+    # No box offers two GPUs, so the lists are checked where they can be: the plans of ALL ranks of a job side by side.
+    # RCCL matches the k-th send of rank a to rank b with the k-th receive rank b posts from rank a (inside one group per
+    # exchange): the two sequences must have the same length and the same sizes, for every pair, in every exchange; a
+    # rank never talks to anyone but its two neighbours; a transfer between two stripes of one rank posts both ends.
+    from noize_job_amd import sharded as sh
+    for kw, (world, per_rank), overlap in itertools.product(PARAM_SETS, [(2, 1), (3, 1), (4, 2), (8, 1), (8, 2)], (0, 1, 2)):
+        p = sh.PipelineParams(haloMode=mode, **kw)
+        grows = 4096
+        lists = []
+        for rank in range(world):
+            g = sh.ShardedGrid(None, None, grows, 640, p, stripes=world * per_rank, overlap=overlap, as_rank=(rank, world))
+            lists.append(g.transfers())
+            exchanges = g.traffic()[0]
+            g.close()
+        assert all(len({t[0] for t in l}) <= exchanges for l in lists)
+        for x in range(exchanges):
+            for a in range(world):
+                mine = [t for t in lists[a] if t[0] == x]
+                assert all(abs(t[1] - t[2]) <= 1 and a in (t[1], t[2]) for t in mine), (kw, world, a)
+                for b in range(world):
+                    sends = [t[3] for t in mine if t[1] == a and t[2] == b]
+                    recvs = [t[3] for t in lists[b] if t[0] == x and t[1] == a and t[2] == b]
+                    assert sends == recvs, (kw, world, overlap, x, a, b)
+        # and something does travel between every pair of neighbours
+        for a in range(world - 1):
+            assert sum(t[3] for t in lists[a] if t[1] == a and t[2] == a + 1) > 0, (kw, world, a)
+
+
 def test_sharded_create_rejects_what_cannot_run(nj):
     from noize_job_amd import sharded as sh
     with pytest.raises(nj.NoizeError):   # stripes thinner than the ghost rows an exchange hands over
