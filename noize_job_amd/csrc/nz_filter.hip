@@ -65,10 +65,15 @@ constexpr int RB = 8;  // rows per thread
 
 // bound_ctrl: the lane without a source reads 0 -- the value update_dpp(0, ...) left there, without the v_mov 0 that
 // initialised its destination (a VALU slot per shifted value: 4 of ~85 per row of the 5-tap X pass)
+#ifndef NZ_DPP_OLD
+#define NZ_DPP_OLD 0
+#endif
 __device__ __forceinline__ float dpp_prev(float v) {  // lane i <- lane i-1
+    if (NZ_DPP_OLD) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float dpp_next(float v) {  // lane i <- lane i+1
+    if (NZ_DPP_OLD) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
