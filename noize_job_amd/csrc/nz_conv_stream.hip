@@ -265,11 +265,15 @@ int nz_conv_stream_max(int ksize) { return ksize == 3 || ksize == 5 ? 6 : 0; }
 // launches of ~3000 long waves each end in a tail of lone waves.  Kept as the barrier-free reference form; buffer offsets
 // are 32 bits with room for the out-of-range marker, so planes must stay below 2 GiB.
 bool nz_conv_stream_wanted(const nz_geom &g, int ksize, int T) {
-    static const int mode = getenv("NZ_CONV_STREAM") ? atoi(getenv("NZ_CONV_STREAM")) : 0;
+    static const int mode = getenv("NZ_CONV_STREAM") ? atoi(getenv("NZ_CONV_STREAM")) : 1;
     if (mode == 0 || T < 1 || T > nz_conv_stream_max(ksize)) return false;
     if ((size_t)g.rows * g.pitch * 4 >= ((size_t)1 << 31)) return false;
     if (mode == 2) return true;
-    return (long long)g.cols * (g.or1 - g.or0) * g.count >= 40ll * 1024 * 1024;
+    // Where it has measured faster than the (chained) tile kernel, Gauss5 x17: 6656^2 0.514 against 0.531 ms, 8192^2 0.741
+    // against 0.759, 11000^2 1.27 against 1.36 (round 4).  Below ~40 M cells a segment is mostly pipeline fill, at 16384^2 it
+    // loses (2.90 against 2.52 ms), and a wide, short stripe (2048 x 16384: 0.432 against 0.391) has too few rows per wave.
+    const long long cells = (long long)g.cols * (g.or1 - g.or0) * g.count;
+    return cells >= 40ll * 1024 * 1024 && cells < 200ll * 1024 * 1024 && g.cols <= 2 * (g.or1 - g.or0);
 }
 
 int32_t nz_launch_conv_stream(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T) {

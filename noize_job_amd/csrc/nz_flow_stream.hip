@@ -43,7 +43,7 @@ __device__ unsigned long long *nz_flow_probe_buf = nullptr;  // [wave][8]
 #define NZ_FPROBE(slot, val)
 #endif
 #ifndef NZ_FS_WPE
-#define NZ_FS_WPE 3  // waves per SIMD the four- and five-iteration kernels are register-allocated for (2: 176 VGPRs, no spill, same time)
+#define NZ_FS_WPE 2  // waves per SIMD the four- and five-iteration kernels are register-allocated for: 176 VGPRs, nothing spilled (3: 168 VGPRs and a 25-dword spill; 0.147 against 0.149 ms at 4096^2, round 4)
 #endif
 #ifndef NZ_FS_PRIO
 #define NZ_FS_PRIO 0
@@ -439,7 +439,7 @@ int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const n
     static const int ncols = getenv("NZ_FLOW_STREAM_COLS") ? atoi(getenv("NZ_FLOW_STREAM_COLS")) : 2;
     const int NC = ncols == 1 ? 1 : 2;
     static const int waves_env = getenv("NZ_FLOW_STREAM_WAVES") ? atoi(getenv("NZ_FLOW_STREAM_WAVES")) : 0;
-    const int waves = waves_env > 0 ? waves_env : (NC == 1 ? 1024 * NZ_FS_WPE1 : 3072);
+    const int waves = waves_env > 0 ? waves_env : 1024 * (NC == 1 ? NZ_FS_WPE1 : NZ_FS_WPE);  // one round of resident waves
     static const int s_env = getenv("NZ_FLOW_STREAM_S") ? atoi(getenv("NZ_FLOW_STREAM_S")) : 0;
     const int H = 2 * n, OW = 64 * NC - 2 * H;
     const int nstrips = (g.cols + OW - 1) / OW, rows = g.or1 - g.or0;
