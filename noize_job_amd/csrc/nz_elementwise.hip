@@ -319,6 +319,12 @@ __global__ __launch_bounds__(NZ_POOL_MASKS_NT) void pool_masks_kernel(const floa
             if (pool_step_acts(vb[e])) m1[e] |= 1u << b;
         }
     }
+    if (LIST) {  // steps that act, over the whole plane: what the host's choice between runs and row walks rests on
+        int bits = __builtin_popcount(m0[0]) + __builtin_popcount(m0[1]) + __builtin_popcount(m1[0]) + __builtin_popcount(m1[1]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bits += __shfl_down(bits, off);
+        if ((threadIdx.x & 63) == 0 && bits) (void)__hip_atomic_fetch_add(pm.ctl + 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int zoff = 0; zoff < 2; zoff++) {
         const size_t i0 = ((size_t)(0 + zoff) * pm.words + w) * pm.walks + k, i1 = ((size_t)(2 + zoff) * pm.words + w) * pm.walks + k;
@@ -379,7 +385,7 @@ constexpr int PCW = 8;  // mask words per thread of the clean kernel
 __global__ __launch_bounds__(256) void pool_masks_clean_kernel(const float *__restrict__ pool, pool_masks pm, int res) {
     const int k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.z;
     if (k >= pm.walks) return;
-    if (pm.ctl && pm.ctl[1]) return;  // the sparse kernel has already run the whole job
+    if (pm.ctl && (pm.ctl[1] || pm.ctl[3])) return;  // the sparse kernel has run the whole job, or the passes walk whole rows
     const int w0 = blockIdx.y * PCW;
     unsigned m[PCW];
 #pragma unroll
@@ -394,6 +400,54 @@ constexpr int PRT = 256;  // threads per workgroup: a pass is 50 tiny launches, 
 #define NZ_POOL_PR 8
 #endif
 constexpr int PR = NZ_POOL_PR;  // steps of a run whose loads are in flight together (all-wet 8192^2: 305 ms one step at a time, 212 with 8, 222 with 16: what is left is the ~1 us instruction stream of a step)
+// The one-lane-per-row form of the same pass (NZ_POOL_RUNS=0): the loads of PU consecutive steps are issued together,
+// ahead of the arithmetic, and the one carried cell travels in a register, so the walk pays one memory round trip per
+// PU steps.  Faster than the run form only where standing water covers most of the plane.
+constexpr int PU = 8;
+
+template <bool DRAIN>
+__device__ __forceinline__ void pool_row_walk(float *pool, const float *__restrict__ height, int res, int xoff, int zoff, int k,
+                                              int32_t *drain_hdr, nz_particle *drain_data) {
+    if (k >= res / 2) return;
+    const int z = 2 * k + zoff;
+    const int zu = min(z + 1, res - 1), zd = max(z - 1, 0);  // SafeIdx clamps (:585-589)
+    float carry = 0.0f;
+    bool have_carry = false;
+    for (int x0 = xoff + ((k & 1) ? 1 : 0); x0 < res; x0 += 2 * PU) {
+        float sw[PU], sh[PU], nh[PU][4], nw[PU][4];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            int x = min(x0 + 2 * u, res - 1);  // steps past the end of the row load a valid cell and are skipped below
+            int xr = min(x + 1, res - 1), xl = max(x - 1, 0);
+            size_t c = (size_t)x * res;
+            sw[u] = pool[c + z];
+            sh[u] = height[c + z];
+            nh[u][0] = height[c + zu];                 nw[u][0] = pool[c + zu];                  // up
+            nh[u][1] = height[(size_t)xr * res + z];   nw[u][1] = pool[(size_t)xr * res + z];    // right
+            nh[u][2] = height[c + zd];                 nw[u][2] = pool[c + zd];                  // down
+            nh[u][3] = height[(size_t)xl * res + z];   nw[u][3] = pool[(size_t)xl * res + z];    // left
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const int x = x0 + 2 * u;
+            if (x >= res) break;
+            if (have_carry) nw[u][3] = carry;
+            carry = nw[u][1];
+            have_carry = true;
+            if (!(sw[u] > 0.0f)) continue;
+            spread_pool_step<DRAIN, false>(pool, res, x, z, zu, zd, sw[u], sh[u], nh[u], nw[u], carry, drain_hdr, drain_data,
+                                           pool_masks{nullptr, 0, 0});
+        }
+    }
+}
+
+template <bool DRAIN>
+__global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *pool, const float *__restrict__ height, int res,
+                                                               int xoff, int zoff, int32_t *drain_hdr,
+                                                               nz_particle *drain_data) {
+    pool_row_walk<DRAIN>(pool, height, res, xoff, zoff, blockIdx.x * 64 + threadIdx.x, drain_hdr, drain_data);
+}
+
 // thread (walk k, mask word w) of a pass: every run that STARTS among the word's 32 steps, walked to its end
 template <bool DRAIN, bool COH>
 __device__ __forceinline__ void pool_walk_word(float *pool, const float *__restrict__ height, const pool_masks &pm, int res,
@@ -472,6 +526,10 @@ __global__ __launch_bounds__(PRT) void pool_runs_kernel(float *pool, const float
     const int k = blockIdx.x * PRT + threadIdx.x, w = blockIdx.y;
     if (k >= pm.walks) return;
     if (pm.ctl && pm.ctl[1]) return;  // the sparse kernel has already run the whole job
+    if (pm.ctl && pm.ctl[3]) {        // a plane under water: whole rows, one lane each (the first word's thread takes the row)
+        if (w == 0) pool_row_walk<DRAIN>(pool, height, res, xoff, zoff, k, drain_hdr, drain_data);
+        return;
+    }
     pool_walk_word<DRAIN, false>(pool, height, pm, res, xoff, zoff, k, w, drain_hdr, drain_data);
 }
 
@@ -504,6 +562,12 @@ __global__ __launch_bounds__(PST) void pool_sparse_kernel(float *pool, const flo
         s_count = n;
         // (job number, entries) in one 8-byte store to mapped host memory
         if (hint) __hip_atomic_store(hint, (seq << 32) | (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // A plane under water (nearly) everywhere is one run per row: the one-lane-per-row walk, its loads eight steps
+        // ahead, is then the faster form (165 against 212 ms all-wet at 8192^2).  Decided here, from THIS job's plane, for
+        // the dense launches that follow: ctl[3] != 0 = more than half of all steps act, the runs kernel walks rows.
+        const unsigned acting = (unsigned)__hip_atomic_load(gctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gctl[3] = (unsigned long long)acting * 2 > (unsigned long long)res * res ? 1 : 0;
+        gctl[2] = 0;
     }
     __syncthreads();
     const int n0 = s_count;
@@ -556,49 +620,6 @@ __global__ __launch_bounds__(PST) void pool_sparse_kernel(float *pool, const flo
     if (tid == 0) {
         gctl[1] = 1;
         gctl[0] = 0;  // the next job's masks kernel counts from zero
-    }
-}
-
-// The one-lane-per-row form of the same pass (NZ_POOL_RUNS=0): the loads of PU consecutive steps are issued together,
-// ahead of the arithmetic, and the one carried cell travels in a register, so the walk pays one memory round trip per
-// PU steps.  Faster than the run form only where standing water covers most of the plane.
-constexpr int PU = 8;
-
-template <bool DRAIN>
-__global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *pool, const float *__restrict__ height, int res,
-                                                               int xoff, int zoff, int32_t *drain_hdr,
-                                                               nz_particle *drain_data) {
-    int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= res / 2) return;
-    const int z = 2 * k + zoff;
-    const int zu = min(z + 1, res - 1), zd = max(z - 1, 0);  // SafeIdx clamps (:585-589)
-    float carry = 0.0f;
-    bool have_carry = false;
-    for (int x0 = xoff + ((k & 1) ? 1 : 0); x0 < res; x0 += 2 * PU) {
-        float sw[PU], sh[PU], nh[PU][4], nw[PU][4];
-#pragma unroll
-        for (int u = 0; u < PU; u++) {
-            int x = min(x0 + 2 * u, res - 1);  // steps past the end of the row load a valid cell and are skipped below
-            int xr = min(x + 1, res - 1), xl = max(x - 1, 0);
-            size_t c = (size_t)x * res;
-            sw[u] = pool[c + z];
-            sh[u] = height[c + z];
-            nh[u][0] = height[c + zu];                 nw[u][0] = pool[c + zu];                  // up
-            nh[u][1] = height[(size_t)xr * res + z];   nw[u][1] = pool[(size_t)xr * res + z];    // right
-            nh[u][2] = height[c + zd];                 nw[u][2] = pool[c + zd];                  // down
-            nh[u][3] = height[(size_t)xl * res + z];   nw[u][3] = pool[(size_t)xl * res + z];    // left
-        }
-#pragma unroll
-        for (int u = 0; u < PU; u++) {
-            const int x = x0 + 2 * u;
-            if (x >= res) break;
-            if (have_carry) nw[u][3] = carry;
-            carry = nw[u][1];
-            have_carry = true;
-            if (!(sw[u] > 0.0f)) continue;
-            spread_pool_step<DRAIN, false>(pool, res, x, z, zu, zd, sw[u], sh[u], nh[u], nw[u], carry, drain_hdr, drain_data,
-                                           pool_masks{nullptr, 0, 0});
-        }
     }
 }
 

@@ -352,7 +352,8 @@ int32_t nz_ctx_pipe_state(nz_ctx *ctx, size_t floats, float **work) {
     if (!ctx->aux) NZ_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
     if (!ctx->ev_fork) NZ_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     if (!ctx->ev_join) NZ_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    if (floats > ctx->pipe_work_floats) {
+    // grown on demand; given back when a much smaller tile follows (the planes of a 16384^2 tile are 2 GB)
+    if (floats > ctx->pipe_work_floats || floats < ctx->pipe_work_floats / 4) {
         if (ctx->pipe_work) {
             NZ_TRY_(ctx_sync_all(ctx));
             NZ_HIP(hipFree(ctx->pipe_work));
@@ -377,7 +378,7 @@ int32_t nz_ctx_pool_state(nz_ctx *ctx) {
     }
     if (!ctx->pool_hint) {
         NZ_HIP(hipHostMalloc((void **)&ctx->pool_hint, 64, hipHostMallocMapped));
-        *ctx->pool_hint = 0;  // job 0: nothing known yet
+        ctx->pool_hint[0] = ctx->pool_hint[1] = 0;  // job 0: nothing known yet
         NZ_HIP(hipHostGetDevicePointer((void **)&ctx->pool_hint_dev, ctx->pool_hint, 0));
     }
     return NZ_OK;

@@ -91,3 +91,13 @@ def test_reduce_pipeline_joins_two_contexts_on_the_device(nj, ctx, oracle):
             y = oracle.fractal(oracle.CELLULAR, res, res, 0.5, 1.0, 2.0, 0.0, 13, 37 * i, 11, 90)
             want = oracle.curve(oracle.reduce(x, y, 1), lut)
             assert np.array_equal(results[0][i], want) and np.array_equal(results[1][i], want), i
+
+
+def test_contexts_report_their_device(nj):
+    # nz_ctx_device: what a host needs to put a second context (LiveErosion.parallelBranch) on the main context's device
+    n = nj.Context.device_count()
+    for dev in range(min(n, 2)):
+        with nj.Context(dev) as c:
+            assert nj._native.lib.nz_ctx_device(c._h) == dev
+    if n < 2:
+        pytest.skip("one device visible: the second-device half needs two")

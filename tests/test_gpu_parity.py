@@ -642,6 +642,24 @@ def test_pool_automata_runs_match_the_row_walk(nj, ctx, oracle, res, cover):
     assert np.array_equal(d_pool.ToArray((res, res)), oracle.pool_automata(pool, height, 2))
 
 
+@pytest.mark.parametrize("res,wet", [(512, 1.0), (640, 0.7), (512, 0.45)])
+def test_pool_automata_on_a_plane_under_water(nj, ctx, oracle, res, wet):
+    # More than half of all steps acting: the job's launches walk whole rows, one lane each (the sparse launch decides
+    # that on the device, from this job's own plane: ctl[3]); just under half: parallel runs.  Twice on the same context,
+    # so that the second job also meets the first one's report.  All equal to the oracle's row walk.
+    rng = np.random.default_rng(res + int(wet * 10))
+    height = (rng.random((res, res), dtype=f32) * f32(0.2)).astype(f32)
+    pool = np.where(rng.random((res, res)) < wet, f32(0.002) + rng.random((res, res), dtype=f32) * f32(0.3), 0).astype(f32)
+    want = oracle.pool_automata(pool, height, 3)
+    d_h = ctx.from_host(height)
+    for _ in range(2):
+        d_pool = ctx.from_host(pool)
+        ctx.call("nz_pool_automata", d_pool.ptr, d_h.ptr, 3, res).Complete()
+        assert np.array_equal(d_pool.ToArray((res, res)), want)
+        d_pool.Dispose()
+    d_h.Dispose()
+
+
 @pytest.mark.parametrize("n", [1, 3, 255, 1024, 4099, 300 * 300, 2048 * 2048 + 5])
 def test_get_map_range_and_device_args_normalise(nj, ctx, oracle, n):
     # GetMapRangeJob (Filter/NormalizeJob.cs:17-55) -> {min, max, range} in device memory -> NormalizeMap reading them
