@@ -141,11 +141,12 @@ constexpr int FT_TH = 48, FT_TW = 128, FT_NT = NZ_FT_NT, FT_LP = FT_TW + 4;
 constexpr int FT_G = FT_TH * FT_TW / 4 / FT_NT;  // groups per thread = 3
 // FT_MAX_N = 5 (nz_flow_common.hpp): 2n halo rows, n = 5 leaves a 28 x 104 interior
 
+// (bound_ctrl: the lane without a source reads 0, and no v_mov 0 has to initialise the destination first)
 __device__ __forceinline__ float wave_from_prev_lane(float v) {  // lane i <- lane i-1
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float wave_from_next_lane(float v) {  // lane i <- lane i+1
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 struct f4 {
