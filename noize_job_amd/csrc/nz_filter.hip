@@ -101,7 +101,7 @@ __device__ unsigned long long *nz_probe_buf = nullptr;  // [workgroup][16]
 #ifndef NZ_CONV5_WAVES
 #define NZ_CONV5_WAVES 6
 #endif
-constexpr int conv_waves(int ks, int nt) { return ks == 5 ? NZ_CONV5_WAVES : nt >= 512 ? 4 : 6; }
+constexpr int conv_waves(int ks, int nt) { return ks == 5 ? NZ_CONV5_WAVES : (nt >= 512 || ks >= 7) ? 4 : 6; }
 
 // 16-byte accesses that other XCDs can see / that see other XCDs' stores while the kernel runs: `sc1` buffer loads and
 // stores (they bypass the CU's L1; the stores write through and leave the XCD's L2), 4-byte ones as agent-scope relaxed
@@ -727,32 +727,55 @@ int32_t launch_wide(hipStream_t s, const float *src, float *dst, const nz_geom &
 #define NZ_CONV_NT_WIDE 512  // threads per workgroup for the 5-, 7- and 9-tap kernels: 128-row tiles (rows = NT / 4)
 #endif
 
-template <int KS>
-int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T) {
-    constexpr int O = (KS - 1) / 2;
+// Threads per workgroup = rows of the register tile / 4.  The 5-, 7- and 9-tap kernels use 128-row tiles (512 threads)
+// where throughput counts; a SMALL grid -- a tile of the reference's own sizes (256 ... 1024^2), a stripe's ghost-row
+// window -- cannot fill the chip whatever the tile, and what it waits for is the latency of one workgroup's dependent
+// applications: 64-row tiles (256 threads: one wave per SIMD instead of two) run an application in half the time.
+// Such a grid also runs its fused launches one after the other, not as a chained grid: with a few dozen tiles per launch
+// the polls and the sc1 accesses of the chain cost more than the launch boundaries it saves.  Gauss5 x17, one tile at a
+// time, 128-row tiles chained -> 64-row tiles in four launches: 256^2 80 -> 52 us, 512^2 81 -> 52, 1024^2 89 -> 54, 1536^2
+// 98 -> 74, 2048^2 110 -> 97, 2560^2 126 -> 117; 2816^2 127 against 131 and 3072^2 134 against 151: from 7 M cells on the
+// big tiles and the chain stay.
+#ifndef NZ_CONV_SMALL_CELLS
+#define NZ_CONV_SMALL_CELLS (7 * 1024 * 1024)
+#endif
+static inline bool conv_small_grid(int ksize, const nz_geom &g) {
+    if (ksize < 5 || NZ_CONV_NT_WIDE <= 256) return false;
+    static const int env = getenv("NZ_CONV_SMALL") ? atoi(getenv("NZ_CONV_SMALL")) : 1;  // 0: never; 2: always (test matrix)
+    if (env == 0) return false;
+    if (env == 2) return true;
+    return (long long)g.cols * (g.or1 - g.or0) * g.count < (long long)NZ_CONV_SMALL_CELLS;
+}
+
+template <int KS, int NT>
+int32_t launch_fused_nt(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T) {
+    constexpr int O = (KS - 1) / 2, RTH = NT / 32 * RB;  // register tile: RTH rows x 128 columns
     int H = T * O, HX = (H + 3) & ~3;
-    {
-        constexpr int NT = KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT, RTH = NT / 32 * RB;  // register tile: RTH rows x 128 columns
-        int OW = TW - 2 * HX, OH = RTH - 2 * H;
-        long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
-        int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
-        if (k.factor == 1.0f)
-            hipLaunchKernelGGL((conv_reg_kernel<KS, true, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
-        else
-            hipLaunchKernelGGL((conv_reg_kernel<KS, false, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
-    }
+    int OW = TW - 2 * HX, OH = RTH - 2 * H;
+    long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
+    int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
+    if (k.factor == 1.0f)
+        hipLaunchKernelGGL((conv_reg_kernel<KS, true, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
+    else
+        hipLaunchKernelGGL((conv_reg_kernel<KS, false, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
+}
+
+template <int KS>
+int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T) {
+    if (KS >= 5 && conv_small_grid(KS, g)) return launch_fused_nt<KS, 256>(s, src, dst, g, k, T);
+    return launch_fused_nt<KS, (KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT)>(s, src, dst, g, k, T);
 }
 
 int g_chain_delay_item = -1, g_chain_delay_sleeps = 0;  // nz_debug_chain_delay
 int g_chain_spin_limit = 1 << 21;                         // nz_debug_chain_poll_limit
 
-template <int KS>
-int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
-                     int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host) {
+template <int KS, int NT>
+int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
+                        int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host) {
     constexpr int O = (KS - 1) / 2;
-    constexpr int NT = KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT, RTH = NT / 32 * RB;
+    constexpr int RTH = NT / 32 * RB;
     nz_chain ch{};
     ch.L = L;
     ch.first[0] = 0;
@@ -782,11 +805,22 @@ int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom 
     return NZ_OK;
 }
 
+template <int KS>
+int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
+                     int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host) {
+    if (KS >= 5 && conv_small_grid(KS, g)) return launch_chain_nt<KS, 256>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
+    return launch_chain_nt<KS, (KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT)>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
+}
+
 }  // namespace
+
+// a grid the 5-, 7- and 9-tap kernels serve with 64-row tiles and separate launches (see conv_small_grid)
+bool nz_conv_small_grid(int ksize, const nz_geom &g) { return conv_small_grid(ksize, g); }
 
 // work items (= flags) the chained form of L launches needs on this geometry
 int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L) {
-    const int O = (ksize - 1) / 2, RTH = (ksize >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT) / 32 * RB;
+    const int O = (ksize - 1) / 2;
+    const int RTH = (ksize >= 5 ? (conv_small_grid(ksize, g) ? 256 : NZ_CONV_NT_WIDE) : NZ_CONV_NT) / 32 * RB;
     int n = 0;
     for (int l = 0; l < L; l++) {
         int H = Ts[l] * O, HX = (H + 3) & ~3;

@@ -191,6 +191,7 @@ bool nz_conv_stream_wanted(const nz_geom &g, int ksize, int T);
 int32_t nz_launch_conv_stream(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T);
 // L launches as one grid with tile-level dependencies; see nz_filter.hip
 int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L);
+bool nz_conv_small_grid(int ksize, const nz_geom &g);  // 64-row tiles, launches not chained
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
                              const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host);
 int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch, unsigned **err_host);

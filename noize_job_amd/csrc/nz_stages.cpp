@@ -244,7 +244,9 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     static const int chain_mode = getenv("NZ_CONV_CHAIN") ? atoi(getenv("NZ_CONV_CHAIN")) : 1;
     // (where the row-streaming form of a launch applies -- big grids, 3 / 5 taps -- plain launches of it are faster still)
     const bool streamed = nz_conv_stream_wanted(g, t.ksize, base + (rem ? 1 : 0)) && nz_conv_stream_wanted(g, t.ksize, base);
-    const bool chain_on = !streamed && !ctx->chain_off && (chain_mode == 2 ? L >= 2 : (chain_mode == 1 && L >= 3 && t.ksize >= 5));
+    // (a small grid -- fewer than ~7 M cells -- keeps separate launches: nz_filter.hip, conv_small_grid)
+    const bool chain_on = !streamed && !ctx->chain_off &&
+                          (chain_mode == 2 ? L >= 2 : (chain_mode == 1 && L >= 3 && t.ksize >= 5 && !nz_conv_small_grid(t.ksize, g)));
     if (chain_on && L <= 8 && g.count == 1 && (size_t)g.rows * g.pitch * 4 < ((size_t)1 << 32) &&
         (swapped || !(L & 1))) {
         // T must not decrease along the chain: a tile of launch l + 1 waits for the launch-l tiles whose INTERIOR meets

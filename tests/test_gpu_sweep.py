@@ -256,7 +256,7 @@ def test_chained_filter_launches_tolerate_a_straggling_tile(nj, ctx, oracle):
     # launches' worth) must still find its input intact: the tiles of the next launch that store into its window are made
     # to wait for it (write after read), whatever the fusion depths along the chain are.
     lib = nj._native.lib
-    res = 1536
+    res = 2816   # 7.9 M cells: below ~7 M a stage runs 64-row tiles as separate launches and nothing is chained
     h = oracle.fractal(oracle.SIMPLEX, res, res, 0.4, 1.0, 2.0, 0.0, 6, 0, 0, 300)
     want = oracle.kernel_filter(h, int(nj.KernelFilterType.Gauss5_S1), 17)
     tiles0 = -(-res // 112) ** 2   # launch 0 of 17 = 4 + 4 + 4 + 5 applications: 112 x 112 interiors
@@ -282,7 +282,7 @@ def test_a_chained_launch_that_times_out_is_reported_and_the_pipeline_runs_again
     # item again on its own -- its result is the oracle's.  Forced here with a poll limit of 8 (~16 us) and one
     # launch-0 tile held up for ~1.7 ms.
     lib = nj._native.lib
-    res = 1024
+    res = 2816   # big enough for the chained form (7 M cells and more)
     want = oracle.pipeline(res, res, octaves=6, noise_size=300, gauss_iterations=17, flow_iterations=0, erosion_iterations=0)
     if os.environ.get("NZ_CONV_CHAIN", "1") == "0" or os.environ.get("NZ_CONV_STREAM", "1") == "2":
         pytest.skip("the chained form is switched off (or every launch is a streaming one)")
