@@ -181,6 +181,9 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     NZ_REQUIRE(iterations >= 1, "iterations < 1");
     if (swapped) *swapped = false;
     int cap = (t.ksize & 1) ? conv_tcap(t.ksize) : 0;
+    // a small grid is served by one round of workgroups whatever the depth: one launch less beats the deeper halo
+    // (512^2 tiles, READ / WRITE pair, 17 applications as 6 + 6 + 5 instead of 5 + 4 + 4 + 4: 11 100 -> 11 700 tiles/s)
+    if (t.ksize == 5 && cap == 5 && !getenv("NZ_CONV_TCAP") && nz_conv_small_grid(t.ksize, g)) cap = 6;
     if (nz_conv_has_wide(t.ksize)) {  // one launch per application, ping-pong, copy back after an odd count
         float *cur = src, *other = tmp;
         for (int i = 0; i < iterations; i++) {
