@@ -55,9 +55,7 @@ KERNEL_PREFIX = {"noise": ("fractal_simplex_tab_kernel",), "gauss": ("conv_chain
 # octaves x ~85; one 5-tap application = 2 passes x (5 mul + 4 add); one flow iteration ~40 + velocity / normalise ~15; one
 # value-erosion application = 2 min.  useful_valu_frac = this x cells / (SQ_INSTS_VALU x 64): what the halo recompute,
 # selects, moves and address arithmetic leave of the instructions executed
-# (noise, round 4: 80 instead of 85 -- the two per-column products of an octave are shared by the four rows of a row group, so
-# they are no longer part of what every cell needs)
-ALGO_LANE_OPS = {"noise": 13 * 80.0, "gauss": G_IT * 18.0, "flow": F_IT * 40.0 + 15.0, "erosion": E_IT * 2.0}
+ALGO_LANE_OPS = {"noise": 13 * 85.0, "gauss": G_IT * 18.0, "flow": F_IT * 40.0 + 15.0, "erosion": E_IT * 2.0}
 
 CPU_PASSES = 11         # ~10 s of host work on the GPU box's 32 cores (0.9-1.0 s per 4096^2 pass)
 PREHEAT_MIN_STEPS = 50  # untimed passes before the timed region, warm-up included (clock settling)

@@ -429,15 +429,9 @@ constexpr int NZ_T1_N = 292, NZ_T2_N = 580;
 // limit (NaN included) take the direct evaluation, which follows the reference's arithmetic wherever it leads.
 constexpr float NZ_TAB_LIMIT = 1048576.0f;
 
-// (vxCy, vyCy = vx * Cy, vy * Cy: a row group shares the first across its rows, a row the second across its cells)
-__device__ __forceinline__ float snoise2_tab_pre(float vx, float vy, float vxCy, float vyCy, const int *s_t1, const float4 *s_t2);
 __device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1, const float4 *s_t2) {
-    const float Cy = 0.366025403784439f;
-    return snoise2_tab_pre(vx, vy, vx * Cy, vy * Cy, s_t1, s_t2);
-}
-__device__ __forceinline__ float snoise2_tab_pre(float vx, float vy, float vxCy, float vyCy, const int *s_t1, const float4 *s_t2) {
-    const float Cx = 0.211324865405187f, Cz = -0.577350269189626f;
-    float s = vxCy + vyCy;
+    const float Cx = 0.211324865405187f, Cy = 0.366025403784439f, Cz = -0.577350269189626f;
+    float s = vx * Cy + vy * Cy;
     float fx = floorf(vx + s), fy = floorf(vy + s);
     float t = fx * Cx + fy * Cx;
     float x0x = vx - fx + t, x0y = vy - fy + t;
@@ -504,67 +498,7 @@ __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restr
 #pragma unroll
     for (int c = 0; c < VEC; c++) xi[c] = ((float)(x0 + c) + p.posx) / p.noise_size;
     int zend = min(rows, (by + 1) * p.rows_per_wg);
-    int z = by * p.rows_per_wg;
-#ifndef NZ_NOISE_ROWGROUP
-#define NZ_NOISE_ROWGROUP 4  // rows that share the per-column products of an octave (1: off)
-#endif
-    constexpr int RG = NZ_NOISE_ROWGROUP;
-    // Row groups: the octave loop OUTSIDE the rows.  f * xi and (f * xi) * Cy of a column are the same for every row, so
-    // a group of RG rows computes them once per octave (2 of an octave-cell's 83 VALU instructions); every cell's
-    // operations and their order are the ones of the row-by-row loop below.
-    for (; RG > 1 && z + RG <= zend; z += RG) {
-        float zi[RG], reach = 0.0f;
-#pragma unroll
-        for (int r = 0; r < RG; r++) {
-            zi[r] = ((float)(z + r) + p.posz) / p.noise_size;
-            reach = fmaxf(reach, fabsf(zi[r]));
-        }
-#pragma unroll
-        for (int c = 0; c < VEC; c++) reach = fmaxf(reach, fabsf(xi[c]));
-        if (!(p.fmax * reach < NZ_TAB_LIMIT)) break;  // out of the tables' range: these rows one by one
-        const float Cy = 0.366025403784439f;
-        float t[RG][VEC];
-#pragma unroll
-        for (int r = 0; r < RG; r++)
-#pragma unroll
-            for (int c = 0; c < VEC; c++) t[r][c] = 0.0f;
-        float detune = 0.0f, f = 1.0f, a = p.amp;
-        for (int i = 0; i < p.octaves; i++) {
-            float xV[VEC], xVCy[VEC];
-#pragma unroll
-            for (int c = 0; c < VEC; c++) {
-                xV[c] = f * xi[c];
-                xVCy[c] = xV[c] * Cy;
-            }
-#pragma unroll
-            for (int r = 0; r < RG; r++) {
-                const float zV = f * zi[r], zVCy = zV * Cy;
-#pragma unroll
-                for (int c = 0; c < VEC; c++) t[r][c] += a * rectify(snoise2_tab_pre(xV[c], zV, xVCy[c], zVCy, s_t1, s_t2));
-            }
-            detune += p.detune_rate;
-            f *= (p.stepdown - detune);
-            a *= p.G;
-        }
-#pragma unroll
-        for (int r = 0; r < RG; r++) {
-            float *row = dst + (size_t)(z + r) * pitch;
-            float o[VEC];
-#pragma unroll
-            for (int c = 0; c < VEC; c++) o[c] = t[r][c] / p.norm;
-            bool full = x0 + VEC <= cols && ((reinterpret_cast<uintptr_t>(row + x0) & (VEC * 4 - 1)) == 0);
-            if (full && VEC == 4) {
-                *reinterpret_cast<float4 *>(row + x0) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
-            } else if (full && VEC == 2) {
-                *reinterpret_cast<float2 *>(row + x0) = make_float2(o[0], o[VEC - 1]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < VEC; c++)
-                    if (x0 + c < cols) row[x0 + c] = o[c];
-            }
-        }
-    }
-    for (; z < zend; z++) {
+    for (int z = by * p.rows_per_wg; z < zend; z++) {
         float zi = ((float)z + p.posz) / p.noise_size;
         float t[VEC];
 #pragma unroll

@@ -10,5 +10,5 @@ for extra in "" "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $BASE $extra -c nz_fractal.hip -o build/nz_fractal.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -ldl -o ../libnoize_hip.so
   echo "== flags: [$extra]"
-  python3 "$ROOT/tools/bench_stage.py" noise --reps 40 2>/dev/null | tail -1
+  python3 "$ROOT/tools/bench_stage.py" noise --reps 400 2>/dev/null | tail -1
 done
