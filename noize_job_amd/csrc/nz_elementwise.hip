@@ -304,15 +304,15 @@ __global__ __launch_bounds__(NZ_POOL_MASKS_NT) void pool_masks_kernel(const floa
     // a lane owns walk k of both z parities: rows z = 2k and 2k + 1 are neighbours in memory, one 8-byte load per column;
     // a workgroup's waves sit side by side in z, so every row is read in pieces of NT * 8 bytes
     const int k = blockIdx.x * NZ_POOL_MASKS_NT + threadIdx.x, w = blockIdx.y;
-    if (k >= pm.walks) return;
+    const bool valid = k < pm.walks;  // (no early return: the wave's lanes count and number their entries together below)
     const int odd = k & 1, z = 2 * k;
     unsigned m0[2] = {0, 0}, m1[2] = {0, 0};  // xoff = 0: x = 64 w + odd + 2 b; xoff = 1: x = 64 w + 1 + odd + 2 b
 #pragma unroll
     for (int b = 0; b < 32; b++) {
         const int xa = 64 * w + odd + 2 * b, xb = xa + 1;
         float va[2] = {0.0f, 0.0f}, vb[2] = {0.0f, 0.0f};
-        if (xa < res) __builtin_memcpy(va, pool + (size_t)xa * res + z, 8);
-        if (xb < res) __builtin_memcpy(vb, pool + (size_t)xb * res + z, 8);
+        if (valid && xa < res) __builtin_memcpy(va, pool + (size_t)xa * res + z, 8);
+        if (valid && xb < res) __builtin_memcpy(vb, pool + (size_t)xb * res + z, 8);
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             if (pool_step_acts(va[e])) m0[e] |= 1u << b;
@@ -325,21 +325,44 @@ __global__ __launch_bounds__(NZ_POOL_MASKS_NT) void pool_masks_kernel(const floa
         for (int off = 32; off > 0; off >>= 1) bits += __shfl_down(bits, off);
         if ((threadIdx.x & 63) == 0 && bits) (void)__hip_atomic_fetch_add(pm.ctl + 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // The non-empty words as a list, one entry each.  One counter increment per WAVE (the lanes' entries are numbered by a
+    // prefix sum over the wave), and none at all once the list has overflowed -- a plane with water everywhere has half a
+    // million non-empty words, and as many returning atomics on one address cost the job 5 ms.
+    int mine = 0, base = 0;
+    if (LIST) {
+        mine = (m0[0] != 0u) + (m0[1] != 0u) + (m1[0] != 0u) + (m1[1] != 0u);
+        int incl = mine;  // inclusive prefix sum over the wave's lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if ((int)(threadIdx.x & 63) >= off) incl += t;
+        }
+        const int total = __shfl(incl, 63);
+        int wave_base = 0;
+        if ((threadIdx.x & 63) == 63 && total > 0) {
+            // beyond the capacity only the count matters, and only that it is beyond: stop counting there
+            const int seen = __hip_atomic_load(pm.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wave_base = seen > pm.cap ? pm.cap + 1 : __hip_atomic_fetch_add(pm.ctl, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        wave_base = __shfl(wave_base, 63);
+        base = wave_base + incl - mine;
+    }
+    if (!valid) return;
 #pragma unroll
     for (int zoff = 0; zoff < 2; zoff++) {
         const size_t i0 = ((size_t)(0 + zoff) * pm.words + w) * pm.walks + k, i1 = ((size_t)(2 + zoff) * pm.words + w) * pm.walks + k;
         pm.m[i0] = m0[zoff];
         pm.m[i1] = m1[zoff];
-        if (LIST) {  // the non-empty words as a list, one entry each
+        if (LIST) {
             pm.listed[i0] = m0[zoff] != 0u;
             pm.listed[i1] = m1[zoff] != 0u;
             if (m0[zoff]) {
-                const int slot = __hip_atomic_fetch_add(pm.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (slot < pm.cap) pm.list[slot] = pool_list_pack(0 + zoff, w, k);
+                if (base < pm.cap) pm.list[base] = pool_list_pack(0 + zoff, w, k);
+                base++;
             }
             if (m1[zoff]) {
-                const int slot = __hip_atomic_fetch_add(pm.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (slot < pm.cap) pm.list[slot] = pool_list_pack(2 + zoff, w, k);
+                if (base < pm.cap) pm.list[base] = pool_list_pack(2 + zoff, w, k);
+                base++;
             }
         }
     }
@@ -447,6 +470,16 @@ __global__ __launch_bounds__(64) void pool_automata_pass_kernel(float *pool, con
                                                                nz_particle *drain_data) {
     pool_row_walk<DRAIN>(pool, height, res, xoff, zoff, blockIdx.x * 64 + threadIdx.x, drain_hdr, drain_data);
 }
+// The same walk as the second half of a dense pass: it runs only when the sparse launch found the plane under water
+// (ctl[3]); the runs kernel launched before it then does nothing.  (One kernel with both forms needs 176 VGPRs instead of
+// 122 and halves the runs' occupancy: 30 % wet 4096^2 3.2 -> 8.3 ms.)
+template <bool DRAIN>
+__global__ __launch_bounds__(64) void pool_rows_if_wet_kernel(float *pool, const float *__restrict__ height, int res, int xoff,
+                                                             int zoff, int32_t *drain_hdr, nz_particle *drain_data,
+                                                             const int *ctl) {
+    if (ctl[1] || !ctl[3]) return;
+    pool_row_walk<DRAIN>(pool, height, res, xoff, zoff, blockIdx.x * 64 + threadIdx.x, drain_hdr, drain_data);
+}
 
 // thread (walk k, mask word w) of a pass: every run that STARTS among the word's 32 steps, walked to its end
 template <bool DRAIN, bool COH>
@@ -526,10 +559,7 @@ __global__ __launch_bounds__(PRT) void pool_runs_kernel(float *pool, const float
     const int k = blockIdx.x * PRT + threadIdx.x, w = blockIdx.y;
     if (k >= pm.walks) return;
     if (pm.ctl && pm.ctl[1]) return;  // the sparse kernel has already run the whole job
-    if (pm.ctl && pm.ctl[3]) {        // a plane under water: whole rows, one lane each (the first word's thread takes the row)
-        if (w == 0) pool_row_walk<DRAIN>(pool, height, res, xoff, zoff, k, drain_hdr, drain_data);
-        return;
-    }
+    if (pm.ctl && pm.ctl[3]) return;  // a plane under water: pool_rows_if_wet_kernel, launched next, walks whole rows
     pool_walk_word<DRAIN, false>(pool, height, pm, res, xoff, zoff, k, w, drain_hdr, drain_data);
 }
 
@@ -564,9 +594,10 @@ __global__ __launch_bounds__(PST) void pool_sparse_kernel(float *pool, const flo
         if (hint) __hip_atomic_store(hint, (seq << 32) | (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // A plane under water (nearly) everywhere is one run per row: the one-lane-per-row walk, its loads eight steps
         // ahead, is then the faster form (165 against 212 ms all-wet at 8192^2).  Decided here, from THIS job's plane, for
-        // the dense launches that follow: ctl[3] != 0 = more than half of all steps act, the runs kernel walks rows.
+        // the dense launches that follow: ctl[3] != 0 = at least seven steps in eight act, the passes walk whole rows.  (At
+        // half the plane under water the runs are still short enough to win: 3.8 against 8.2 ms at 4096^2.)
         const unsigned acting = (unsigned)__hip_atomic_load(gctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gctl[3] = (unsigned long long)acting * 2 > (unsigned long long)res * res ? 1 : 0;
+        gctl[3] = (unsigned long long)acting * 8 >= (unsigned long long)res * res * 7 ? 1 : 0;
         gctl[2] = 0;
     }
     __syncthreads();
@@ -990,6 +1021,14 @@ int32_t nz_launch_pool_automata_pass(hipStream_t s, float *pool, const float *he
         else
             hipLaunchKernelGGL(pool_runs_kernel<false>, rgrid, dim3(PRT), 0, s, pool, height, pm, res, xoff, zoff, drain_hdr,
                                drain_data);
+        if (ctl) {  // the row-walk half of the pass: does something only on a plane under water
+            if (drain_hdr)
+                hipLaunchKernelGGL(pool_rows_if_wet_kernel<true>, grid, dim3(64), 0, s, pool, height, res, xoff, zoff, drain_hdr,
+                                   drain_data, ctl);
+            else
+                hipLaunchKernelGGL(pool_rows_if_wet_kernel<false>, grid, dim3(64), 0, s, pool, height, res, xoff, zoff, drain_hdr,
+                                   drain_data, ctl);
+        }
     } else if (drain_hdr) {
         hipLaunchKernelGGL(pool_automata_pass_kernel<true>, grid, dim3(64), 0, s, pool, height, res, xoff, zoff, drain_hdr,
                            drain_data);

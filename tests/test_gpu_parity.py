@@ -642,10 +642,10 @@ def test_pool_automata_runs_match_the_row_walk(nj, ctx, oracle, res, cover):
     assert np.array_equal(d_pool.ToArray((res, res)), oracle.pool_automata(pool, height, 2))
 
 
-@pytest.mark.parametrize("res,wet", [(512, 1.0), (640, 0.7), (512, 0.45)])
+@pytest.mark.parametrize("res,wet", [(512, 1.0), (640, 0.93), (512, 0.6)])
 def test_pool_automata_on_a_plane_under_water(nj, ctx, oracle, res, wet):
-    # More than half of all steps acting: the job's launches walk whole rows, one lane each (the sparse launch decides
-    # that on the device, from this job's own plane: ctl[3]); just under half: parallel runs.  Twice on the same context,
+    # At least seven steps in eight acting: the job's launches walk whole rows, one lane each (the sparse launch decides
+    # that on the device, from this job's own plane: ctl[3]); fewer: parallel runs.  Twice on the same context,
     # so that the second job also meets the first one's report.  All equal to the oracle's row walk.
     rng = np.random.default_rng(res + int(wet * 10))
     height = (rng.random((res, res), dtype=f32) * f32(0.2)).astype(f32)
