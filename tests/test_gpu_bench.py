@@ -99,7 +99,9 @@ def test_bench_starts_its_own_ranks_one_rank():
     assert d["n_gpus"] == 1 and d["config"]["cells"] == 384 * 1024 and d["value"] > 0
     c = d["comm"]
     assert c["backend"] == "nccl" and c["world"] == 1 and c["halo"] == "exchange" and c["overlapped"] is False
-    assert c["impl"].startswith("native") and c["exchanges_per_step"] == 6 and c["host_enqueue_ms_idle_queue"] > 0.0
+    # one exchange per stencil launch: 4 filter launches + flow + erosion unless a fusion-depth knob regroups them
+    regrouped = any(os.environ.get(k) for k in ("NZ_CONV_TCAP", "NZ_FLOW_NMAX", "NZ_EROSION_EMAX"))
+    assert c["impl"].startswith("native") and (c["exchanges_per_step"] == 6 or regrouped) and c["host_enqueue_ms_idle_queue"] > 0.0
     assert c["exchange_ms_per_step"] is not None and c["exchange_ms_per_step"] >= 0.0 and c["rccl_version"]
     assert d["grid_1024"]["recompute"]["Mcells/s"] > 0
 

@@ -284,8 +284,11 @@ def test_a_chained_launch_that_times_out_is_reported_and_the_pipeline_runs_again
     lib = nj._native.lib
     res = 2816   # big enough for the chained form (7 M cells and more)
     want = oracle.pipeline(res, res, octaves=6, noise_size=300, gauss_iterations=17, flow_iterations=0, erosion_iterations=0)
-    if os.environ.get("NZ_CONV_CHAIN", "1") == "0" or os.environ.get("NZ_CONV_STREAM", "1") == "2":
-        pytest.skip("the chained form is switched off (or every launch is a streaming one)")
+    env = os.environ.get
+    if (env("NZ_CONV_CHAIN", "1") == "0" or env("NZ_CONV_STREAM", "1") == "2" or env("NZ_CONV_TCAP")
+            or (env("NZ_CONV_SMALL") == "2" and env("NZ_CONV_CHAIN", "1") != "2")):
+        pytest.skip("knob matrix: the chained form is switched off for this grid (every launch a streaming one, every grid "
+                    "on the small-grid tiles, or more launches than a chain holds)")
     with nj.Context(0) as c:
         data, write = c.alloc(res * res), c.alloc(res * res)
         stages = [nj.NoiseStage(c, nj.FractalNoise.Simplex, 0.4, 1.0, 6, 2.0, 0.0, 300),

@@ -12,5 +12,9 @@ first=${1:-0}; last=${2:-$((${#KNOBS[@]} - 1))}
 for ((i = first; i <= last && i < ${#KNOBS[@]}; i++)); do
   kv=${KNOBS[$i]}
   echo "== $kv"
-  env $kv timeout -k 10 300 python3 -m pytest tests -m gpu -q 2>&1 | tail -1
+  log=gpurun_out/knob_$i.log
+  mkdir -p gpurun_out
+  env $kv timeout -k 10 300 python3 -m pytest tests -m gpu -q -rf > $log 2>&1
+  grep -E "^FAILED|^ERROR" $log
+  tail -1 $log
 done
