@@ -526,14 +526,20 @@ def main():
         pipe.pipelineRunning = False
         one_call = pipe.fusedMarks is not None
 
+        prev_end = [None]  # the last marked step's final handle, while nothing else has been enqueued since
+
         def step(record):
             if record and not one_call:
-                hs = [ctx.record()]
+                # the step's first marker IS the previous step's last one (the stage handles are the only events a
+                # marked step records: each costs the stream ~3 us, tools/probe_event_cost.py)
+                hs = [prev_end[0] if prev_end[0] is not None else ctx.record()]
                 for st in stages:  # same chain BasePipeline.Schedule builds, with a marker between stages
                     st.Schedule(nj.PipelineWorkItem(gd), hs[-1])
                     hs.append(st.jobHandle)
                 marks.append(hs)
+                prev_end[0] = hs[-1]
             else:
+                prev_end[0] = None
                 pipe.Schedule(gd)
                 pipe.pipelineRunning = False
 
