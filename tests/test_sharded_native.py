@@ -303,6 +303,41 @@ def test_sharded_grid_without_rccl_uses_device_copies(nj, ctx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(36))
+def test_random_stripe_geometry_equals_the_oracle(nj, ctx, oracle, seed):
+    # seeded sweep over what the plan is built from: ragged grids (rows not a multiple of the stripes, columns not a multiple
+    # of 4), the noise bases, 3...9-tap filters, iteration counts that need several launches, the three halo modes and the
+    # three schedules (no split / interior first / border first) -- one rank, ghost rows by device copies
+    from noize_job_amd import sharded as sh
+    rng = np.random.default_rng(7700 + seed)
+    grows, cols = int(rng.integers(150, 460)), int(rng.integers(33, 420))
+    mode = ("exchange", "exchange_once", "recompute")[seed % 3]
+    overlap = int(rng.integers(0, 3))
+    filt = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8]))
+    taps = {0: 9, 1: 7, 2: 5, 3: 3, 4: 9, 5: 7, 6: 5, 7: 3, 8: 3}[filt]
+    # every basis but Sin (0), which calls the device's sinf and is compared with a tolerance elsewhere (test_gpu_parity.py)
+    kw = dict(noiseType=int(rng.integers(1, 8)), octaves=int(rng.integers(1, 7)), noiseSize=int(rng.integers(50, 900)),
+              xpos=int(rng.integers(-3000, 3000)), zpos=int(rng.integers(-3000, 3000)), filter=filt,
+              gaussIterations=int(rng.integers(0, 9)), flowIterations=int(rng.integers(0, 8)),
+              erosionIterations=int(rng.integers(0, 8)))
+    halo = kw["gaussIterations"] * (taps // 2) + 2 * kw["flowIterations"] + kw["erosionIterations"]
+    stripes = int(rng.integers(2, 7))
+    while stripes > 1 and mode != "recompute" and grows // stripes < halo:
+        stripes -= 1  # an exchange takes ghost rows from the adjacent stripe only
+    want = oracle.pipeline(grows, cols, noise_type=kw["noiseType"], octaves=kw["octaves"], noise_size=kw["noiseSize"],
+                           xpos=kw["xpos"], zpos=kw["zpos"], filter_type=filt, gauss_iterations=kw["gaussIterations"],
+                           flow_iterations=kw["flowIterations"], erosion_iterations=kw["erosionIterations"])
+    g = sh.ShardedGrid(ctx, None, grows, cols, sh.PipelineParams(haloMode=mode, **kw), stripes=stripes, overlap=overlap)
+    try:
+        for _ in range(2):  # the second step runs on the planes the first one left behind
+            g.run().Complete()
+        got = np.concatenate([g.owned_rows(i)[1] for i in range(stripes)], axis=0)
+    finally:
+        g.close()
+    assert np.array_equal(got, want, equal_nan=True), (grows, cols, stripes, mode, overlap, kw)
+
+
+@pytest.mark.gpu
 def test_external_source_plane_is_exchanged_not_recomputed(nj, ctx, oracle):
     # an uploaded height map: no noise stage, the ghost rows of the source travel (exchange / exchange_once)
     from noize_job_amd import sharded as sh
