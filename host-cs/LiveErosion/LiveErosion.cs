@@ -49,7 +49,11 @@ namespace xshazwar.noize.hip {
             Handle = h;
         }
         public int Count { get { Native.Check(Native.nz_particle_queue_count(ctx.Handle, Handle, out int n), "nz_particle_queue_count"); return n; } }
-        public GpuJobHandle Clear(GpuJobHandle dependency) {                                         // ClearQueueJob
+        public GpuJobHandle Clear(GpuJobHandle dependency, bool handle = true) {                     // ClearQueueJob
+            if (!handle) {  // ordered by the context's stream only: no event is recorded
+                Native.Check(Native.nz_clear_particle_queue(ctx.Handle, Handle, dependency.id, IntPtr.Zero), "nz_clear_particle_queue");
+                return ctx.Wrap(0);
+            }
             Native.Check(Native.nz_clear_particle_queue(ctx.Handle, Handle, dependency.id, out ulong h), "nz_clear_particle_queue");
             return ctx.Wrap(h);
         }
@@ -102,6 +106,7 @@ namespace xshazwar.noize.hip {
         }
 
         public bool parallelBranch = false;      // true: ErodeHeightMaps || UpdateFlowFromTrackJob on two streams, as in the reference's job graph (measured slower)
+        public bool fewHandles = true;           // false: a handle out of every job, as the reference schedules them (one event record each)
         GpuContext branchCtx;                    // created on first use
 
         // TriggerQueuedBeyerMT :378-436.  seeds: one per cycle.
@@ -111,46 +116,85 @@ namespace xshazwar.noize.hip {
             NzTileSetMeta tm = tileMeta;
             ulong h = 0;
             IntPtr c = ctx.Handle;
+            // The jobs of an Update are links of ONE chain on the context's stream: with fewHandles only the handles somebody
+            // waits for are asked of the library (the IntPtr overloads of Native.cs, IntPtr.Zero) -- a handle is an event
+            // record, ~3 us of the stream.  all: a handle out of every job, as the reference schedules them.
+            bool all = !fewHandles;
             if (performErosion) {
                 if (seeds.Length < es.CYCLES) throw new Exception("one seed per cycle");
                 for (int i = 0; i < es.CYCLES; i++) {
+                    bool last = i + 1 == es.CYCLES && waterControl == null;  // the chain's last handle is the component's jobHandle
                     // `TILE_SIZE.x / HEIGHT` divides two ints in the reference (:386)
-                    if (es.ENABLE_THERMAL && es.BEHAVIOR != ErosionMode.ONLY_FLOW_WATER)
-                        Native.Check(Native.nz_thermal_erosion(c, heightMap.Ptr, es.TALUS, es.THERMAL_STEP, (float) (tm.TILE_SIZE_x / tm.HEIGHT),
-                                                               es.THERMAL_CYCLES, res, h, out h), "nz_thermal_erosion");
-                    if (es.BEHAVIOR != ErosionMode.ONLY_FLOW_WATER)
-                        Native.Check(Native.nz_fill_beyer_queue(c, particleQueue.Handle, ref ep, ref tm, particleGenerationID % 4, res, QUEUE_SIZE, seeds[i],
-                                                                Math.Min(10, QUEUE_SIZE), h, out h), "nz_fill_beyer_queue");
-                    Native.Check(Native.nz_queued_beyer_cycle(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, particleQueue.Handle,
-                                                              events.Handle, ref ep, ref tm, EVENT_LIMIT, res, h, out h), "nz_queued_beyer_cycle");
-                    Native.Check(Native.nz_process_beyer_erosive_events(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, events.Handle,
-                                                                        ref ep, ref tm, res, h, out h), "nz_process_beyer_erosive_events");
+                    if (es.ENABLE_THERMAL && es.BEHAVIOR != ErosionMode.ONLY_FLOW_WATER) {
+                        if (all) Native.Check(Native.nz_thermal_erosion(c, heightMap.Ptr, es.TALUS, es.THERMAL_STEP, (float) (tm.TILE_SIZE_x / tm.HEIGHT),
+                                                                        es.THERMAL_CYCLES, res, h, out h), "nz_thermal_erosion");
+                        else { Native.Check(Native.nz_thermal_erosion(c, heightMap.Ptr, es.TALUS, es.THERMAL_STEP, (float) (tm.TILE_SIZE_x / tm.HEIGHT),
+                                                                      es.THERMAL_CYCLES, res, h, IntPtr.Zero), "nz_thermal_erosion"); h = 0; }
+                    }
+                    if (es.BEHAVIOR != ErosionMode.ONLY_FLOW_WATER) {
+                        if (all) Native.Check(Native.nz_fill_beyer_queue(c, particleQueue.Handle, ref ep, ref tm, particleGenerationID % 4, res, QUEUE_SIZE, seeds[i],
+                                                                         Math.Min(10, QUEUE_SIZE), h, out h), "nz_fill_beyer_queue");
+                        else { Native.Check(Native.nz_fill_beyer_queue(c, particleQueue.Handle, ref ep, ref tm, particleGenerationID % 4, res, QUEUE_SIZE, seeds[i],
+                                                                       Math.Min(10, QUEUE_SIZE), h, IntPtr.Zero), "nz_fill_beyer_queue"); h = 0; }
+                    }
+                    if (all) Native.Check(Native.nz_queued_beyer_cycle(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, particleQueue.Handle,
+                                                                       events.Handle, ref ep, ref tm, EVENT_LIMIT, res, h, out h), "nz_queued_beyer_cycle");
+                    else { Native.Check(Native.nz_queued_beyer_cycle(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, particleQueue.Handle,
+                                                                     events.Handle, ref ep, ref tm, EVENT_LIMIT, res, h, IntPtr.Zero), "nz_queued_beyer_cycle"); h = 0; }
+                    if (all || parallelBranch)  // the branch's stream waits for the event reduction
+                        Native.Check(Native.nz_process_beyer_erosive_events(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, events.Handle,
+                                                                            ref ep, ref tm, res, h, out h), "nz_process_beyer_erosive_events");
+                    else { Native.Check(Native.nz_process_beyer_erosive_events(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, events.Handle,
+                                                                               ref ep, ref tm, res, h, IntPtr.Zero), "nz_process_beyer_erosive_events"); h = 0; }
                     // CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all behind the event reduction
                     // (:408-412): the flow job runs on a stream of its own (a second context), beside the sediment job
                     if (parallelBranch) {
                         if (branchCtx == null) branchCtx = new GpuContext(ctx.Device);   // the main context's device
                         Native.Check(Native.nz_update_flow_from_track(branchCtx.Handle, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
                                                                       ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out ulong flow), "nz_update_flow_from_track");
-                        h = particleQueue.Clear(ctx.Wrap(h)).id;
-                        Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
-                        Native.Check(Native.nz_handle_combine(c, new ulong[] { h, flow }, 2, out h), "nz_handle_combine");
+                        h = particleQueue.Clear(ctx.Wrap(h), all).id;
+                        if (all) {
+                            Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
+                            Native.Check(Native.nz_handle_combine(c, new ulong[] { h, flow }, 2, out h), "nz_handle_combine");
+                        } else {
+                            Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, IntPtr.Zero), "nz_erode_height_maps");
+                            h = flow;  // the automaton follows ErodeHeightMaps on this stream and waits for the branch
+                        }
                     } else {
-                        h = particleQueue.Clear(ctx.Wrap(h)).id;
-                        Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
-                        Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
-                                                                      ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out h), "nz_update_flow_from_track");
+                        h = particleQueue.Clear(ctx.Wrap(h), all).id;
+                        if (all) {
+                            Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
+                            Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
+                                                                          ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out h), "nz_update_flow_from_track");
+                        } else {
+                            Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, IntPtr.Zero), "nz_erode_height_maps");
+                            Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
+                                                                          ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, 0, IntPtr.Zero), "nz_update_flow_from_track");
+                            h = 0;
+                        }
                     }
-                    Native.Check(Native.nz_pool_automata_job(c, poolMap.Ptr, heightMap.Ptr, particleQueue.Handle, ref ep, ref tm, es.WATER_STEPS, res,
-                                                             performErosion ? 1 : 0, h, out h), "nz_pool_automata_job");
+                    if (all || last) Native.Check(Native.nz_pool_automata_job(c, poolMap.Ptr, heightMap.Ptr, particleQueue.Handle, ref ep, ref tm, es.WATER_STEPS, res,
+                                                                              performErosion ? 1 : 0, h, out h), "nz_pool_automata_job");
+                    else { Native.Check(Native.nz_pool_automata_job(c, poolMap.Ptr, heightMap.Ptr, particleQueue.Handle, ref ep, ref tm, es.WATER_STEPS, res,
+                                                                    performErosion ? 1 : 0, h, IntPtr.Zero), "nz_pool_automata_job"); h = 0; }
                 }
             }
             if (waterControl != null) {                                                              // :418-430
                 int mres = tm.TILE_RES_x;
-                Native.Check(Native.nz_set_rgba32(c, poolMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.R, res, mres, 1000f, h, out h), "nz_set_rgba32");
-                Native.Check(Native.nz_set_rgba32(c, poolMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.G, res, mres, 1000f, h, out h), "nz_set_rgba32");
-                Native.Check(Native.nz_set_rgba32(c, streamMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.B, res, mres, 2f, h, out h), "nz_set_rgba32");
-                Native.Check(Native.nz_set_rgba32(c, streamMap.Ptr, textureControl.Ptr, (int) ColorChannelByte.G, res, mres, 3f, h, out h), "nz_set_rgba32");
-                Native.Check(Native.nz_curviture_map(c, textureControl.Ptr, heightMap.Ptr, ref tm, (int) ColorChannelByte.G, res, mres, h, out h), "nz_curviture_map");
+                if (all) {
+                    Native.Check(Native.nz_set_rgba32(c, poolMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.R, res, mres, 1000f, h, out h), "nz_set_rgba32");
+                    Native.Check(Native.nz_set_rgba32(c, poolMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.G, res, mres, 1000f, h, out h), "nz_set_rgba32");
+                    Native.Check(Native.nz_set_rgba32(c, streamMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.B, res, mres, 2f, h, out h), "nz_set_rgba32");
+                    Native.Check(Native.nz_set_rgba32(c, streamMap.Ptr, textureControl.Ptr, (int) ColorChannelByte.G, res, mres, 3f, h, out h), "nz_set_rgba32");
+                    Native.Check(Native.nz_curviture_map(c, textureControl.Ptr, heightMap.Ptr, ref tm, (int) ColorChannelByte.G, res, mres, h, out h), "nz_curviture_map");
+                } else {
+                    Native.Check(Native.nz_set_rgba32(c, poolMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.R, res, mres, 1000f, h, IntPtr.Zero), "nz_set_rgba32");
+                    Native.Check(Native.nz_set_rgba32(c, poolMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.G, res, mres, 1000f, 0, IntPtr.Zero), "nz_set_rgba32");
+                    Native.Check(Native.nz_set_rgba32(c, streamMap.Ptr, waterControl.Ptr, (int) ColorChannelByte.B, res, mres, 2f, 0, IntPtr.Zero), "nz_set_rgba32");
+                    Native.Check(Native.nz_set_rgba32(c, streamMap.Ptr, textureControl.Ptr, (int) ColorChannelByte.G, res, mres, 3f, 0, IntPtr.Zero), "nz_set_rgba32");
+                    Native.Check(Native.nz_curviture_map(c, textureControl.Ptr, heightMap.Ptr, ref tm, (int) ColorChannelByte.G, res, mres, 0, IntPtr.Zero), "nz_curviture_map");
+                    h = 0;
+                }
                 Native.Check(Native.nz_set_rgba32(c, streamMap.Ptr, textureControl.Ptr, (int) ColorChannelByte.A, res, mres, 1f, h, out h), "nz_set_rgba32");
             }
             jobHandle = ctx.Wrap(h);

@@ -195,6 +195,7 @@ bool nz_conv_small_grid(int ksize, const nz_geom &g);  // 64-row tiles, launches
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
                              const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host);
 int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch, unsigned **err_host);
+int32_t nz_ctx_error_word(nz_ctx *ctx, unsigned **err_host);  // mapped host memory, device address
 // one whole application of a wide odd kernel (11..25 taps), src -> dst
 bool nz_conv_has_wide(int ksize);
 int32_t nz_launch_conv_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k);

@@ -41,7 +41,9 @@ struct nz_erosive_events {
     int cur = 0;
     void *pile_scratch = nullptr;       // the ManhattanVertex offsets of the current PILING_RADIUS
     size_t pile_scratch_bytes = 0;
-    int32_t *pile_blocks = nullptr;     // [nb][nb]: which PileSolver blocks hold a pile this cycle
+    // [nb][nb] which PileSolver blocks hold a pile this cycle (1; 2 once the ticket kernel has done it), then PILE_CTL
+    // control words {busy blocks of colour 0..3, ticket}, then the busy blocks listed per colour ((nb + 1)^2 / 4 each)
+    int32_t *pile_blocks = nullptr;
     size_t pile_blocks_n = 0;
 };
 
@@ -661,31 +663,60 @@ __global__ __launch_bounds__(CT) void disperse_frame_kernel(float *__restrict__ 
 // Per pile the wave loads the vertex values side by side (SetPile), walks DepositSediment -- sequential by nature: a
 // running remainder -- over the vertices that qualify (found 64 at a time), and commits the modified vertices in vertex order (the ManhattanVertex list
 // names the centre four times and many ring cells twice, each copy with a value of its own: the LAST copy wins).
-__global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__restrict__ sediment,
-                                                 const int32_t *__restrict__ pile_blocks,
-                                                 const short2 *__restrict__ ofs, int nverts, int res, int maxDistance,
-                                                 int B, int nb, int cx, int cz, float pileThreshold, float increment) {
-    extern __shared__ unsigned char s_raw[];
-    float *s_val = reinterpret_cast<float *>(s_raw);
-    int *s_idx = reinterpret_cast<int *>(s_raw + (size_t)nverts * 4);
-    unsigned char *s_flag = s_raw + (size_t)nverts * 8;  // bit 0 valid, bit 1 modified
-    const int per_row = (nb - cx + 1) / 2;
-    const int bx = cx + 2 * (int)(blockIdx.x % per_row), bz = cz + 2 * (int)(blockIdx.x / per_row);
-    const int lane = threadIdx.x;
-    const int x0 = bx * B, z0 = bz * B, x1 = min(x0 + B, res), z1 = min(z0 + B, res);
-    if (!pile_blocks[bx * nb + bz]) return;  // no pile event in this block (disperse_list_kernel flags them)
-    // the block's sediment events into LDS first, lanes along z (the planes' fast index), all loads in flight together:
-    // walking the block row by row straight from memory cost one dependent round trip per row (32 of them)
-    float *s_sed = reinterpret_cast<float *>(s_raw + (((size_t)nverts * 9 + 15) & ~(size_t)15));
-    short2 *s_ofs = reinterpret_cast<short2 *>(s_sed + B * B);  // the vertex offsets: every pile of the block walks them
+// Heights as the ticket kernel reads and writes them: blocks of different colours run side by side on other CUs (other
+// XCDs), ordered by flags only -- loads that pass the CU's cache, stores that go through (agent scope: `sc1`).
+template <bool COH>
+__device__ __forceinline__ float pile_ld(const float *p) {
+    if (COH) return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void pile_st(float *p, float v) {
+    if (COH) __hip_atomic_store(reinterpret_cast<int *>(p), __builtin_bit_cast(int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+struct pile_lds {
+    float *val;           // per vertex: value
+    int *idx;             // cell
+    unsigned char *flag;  // bit 0 valid, bit 1 modified
+    float *sed;           // the block's sediment events, [B][B]
+    short2 *ofs;          // the vertex offsets: every pile walks them
+};
+__device__ __forceinline__ pile_lds pile_carve(unsigned char *s_raw, int nverts, int B) {
+    pile_lds L;
+    L.val = reinterpret_cast<float *>(s_raw);
+    L.idx = reinterpret_cast<int *>(s_raw + (size_t)nverts * 4);
+    L.flag = s_raw + (size_t)nverts * 8;
+    L.sed = reinterpret_cast<float *>(s_raw + (((size_t)nverts * 9 + 15) & ~(size_t)15));
+    L.ofs = reinterpret_cast<short2 *>(L.sed + B * B);
+    return L;
+}
+__device__ __forceinline__ void pile_load_offsets(const pile_lds &L, const short2 *__restrict__ ofs, int nverts, int lane) {
     for (int i0 = lane; i0 < nverts; i0 += 64 * 16) {  // sixteen loads in flight per lane: a loop of single loads waits for each
         short2 t[16];
 #pragma unroll
         for (int u = 0; u < 16; u++) t[u] = ofs[min(i0 + 64 * u, nverts - 1)];
 #pragma unroll
         for (int u = 0; u < 16; u++)
-            if (i0 + 64 * u < nverts) s_ofs[i0 + 64 * u] = t[u];
+            if (i0 + 64 * u < nverts) L.ofs[i0 + 64 * u] = t[u];
     }
+}
+
+// The piles of block (bx, bz), one wave; the vertex offsets are in LDS already.
+template <bool COH>
+__device__ __forceinline__ void pile_block(const pile_lds &L, float *height, const float *__restrict__ sediment, int nverts,
+                                           int res, int maxDistance, int B, int bx, int bz, float pileThreshold,
+                                           float increment) {
+    float *s_val = L.val;
+    int *s_idx = L.idx;
+    unsigned char *s_flag = L.flag;
+    float *s_sed = L.sed;
+    short2 *s_ofs = L.ofs;
+    const int lane = threadIdx.x;
+    const int x0 = bx * B, z0 = bz * B, x1 = min(x0 + B, res), z1 = min(z0 + B, res);
+    // the block's sediment events into LDS first, lanes along z (the planes' fast index), all loads in flight together:
+    // walking the block row by row straight from memory cost one dependent round trip per row (32 of them)
     const int bw = x1 - x0, bh = z1 - z0;  // <= B each
     for (int i0 = lane; i0 < bw * bh; i0 += 64 * 8) {
         float t[8];
@@ -713,7 +744,7 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
             for (int u = 0; u < 8; u++) {
                 const int vx = px + o[u].x, vz = pz + o[u].y;
                 const bool ok = i0 + 64 * u < v1 && vx >= 0 && vz >= 0 && vx < res && vz < res;
-                hv[u] = height[ok ? (size_t)vx * res + vz : 0];  // cell 0 for a vertex off the grid: never looked at
+                hv[u] = pile_ld<COH>(height + (ok ? (size_t)vx * res + vz : 0));  // cell 0 for a vertex off the grid: never looked at
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -748,7 +779,7 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
                     const int vx = px + o.x, vz = pz + o.y;
                     const bool ok = vx >= 0 && vz >= 0 && vx < res && vz < res;
                     const int cell = ok ? vx * res + vz : 0;
-                    const float hv = height[cell];  // cell 0 for a vertex off the grid: never looked at
+                    const float hv = pile_ld<COH>(height + cell);  // cell 0 for a vertex off the grid: never looked at
                     s_flag[lane] = ok ? 1 : 0;
                     s_idx[lane] = cell;
                     s_val[lane] = ok ? hv : 0.0f;
@@ -821,7 +852,7 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
                             mod &= mod - 1;
                             const int cell = __builtin_amdgcn_readlane(mycell, l);
                             const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), l));
-                            if (lane == 0) height[cell] = v;
+                            if (lane == 0) pile_st<COH>(height + cell, v);
                         }
                     }
                     __threadfence_block();
@@ -829,6 +860,107 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
                 __syncthreads();  // the next pile of this block reads the committed heights
             }
         }
+    }
+}
+
+// One launch per colour, one wave per block of that colour.
+__global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__restrict__ sediment,
+                                                 const int32_t *__restrict__ pile_blocks,
+                                                 const short2 *__restrict__ ofs, int nverts, int res, int maxDistance,
+                                                 int B, int nb, int cx, int cz, float pileThreshold, float increment) {
+    extern __shared__ unsigned char s_raw[];
+    const int per_row = (nb - cx + 1) / 2;
+    const int bx = cx + 2 * (int)(blockIdx.x % per_row), bz = cz + 2 * (int)(blockIdx.x / per_row);
+    if (!pile_blocks[bx * nb + bz]) return;  // no pile event in this block (disperse_list_kernel flags them)
+    const pile_lds L = pile_carve(s_raw, nverts, B);
+    pile_load_offsets(L, ofs, nverts, threadIdx.x);
+    pile_block<false>(L, height, sediment, nverts, res, maxDistance, B, bx, bz, pileThreshold, increment);
+}
+
+// ALL colours in one launch (round 4).  A colour's launch lasts as long as its fullest block (30...40 piles, ~2 us each, at
+// 8192^2 / 10 000 droplets: tools/probe_piles.py) while a busy block holds 3...5 on average -- four launches are four such
+// tails.  Here the busy blocks (disperse_list_kernel lists them per colour) are work items in colour-major order, handed
+// out by an atomic ticket; a block waits only for the busy ones among its eight neighbours that have a LOWER colour --
+// the blocks whose piles the canonical order puts before its own -- i.e. for items with a lower ticket, which a resident
+// workgroup holds or has finished: progress does not depend on how the hardware dispatches workgroups.  blocks[b]: 1 = busy,
+// 2 = done.  Heights travel between CUs with agent-scope accesses, a block's stores have left (vmcnt 0) before its flag is
+// raised.  ctl: {items of colour 0..3, ticket}.  A wait is bounded all the same (err_host, mapped host memory: the context
+// reports an internal error at its next synchronisation instead of hanging).
+constexpr int PILE_CTL = 8;
+// the blocks disperse_list_kernel flagged, listed under their colour (a colour's blocks are independent: any order).  A
+// thread per flag; a wave numbers its blocks with a ballot per colour, the workgroup's waves share LDS counters, and ONE
+// increment per colour and workgroup reaches memory (7 000 returning atomics on four words took 75 us).
+__global__ __launch_bounds__(1024) void pile_list_kernel(const int32_t *__restrict__ blocks, int32_t *ctl, int32_t *list, int cap,
+                                                        int nb) {
+    __shared__ int s_n[4], s_base[4];
+    if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = nb * nb, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 1024 + (int)threadIdx.x;
+    const bool busy = b < n && blocks[b] != 0;
+    const int bx = b / nb, bz = b - bx * nb;
+    const int c = (bx & 1) | ((bz & 1) << 1);
+    int mine = 0;  // my number among the workgroup's blocks of my colour
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long m = __ballot(busy && c == k);
+        if (!m) continue;  // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_n[k], __popcll(m));
+        base = __shfl(base, 0);
+        if (busy && c == k) mine = base + __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) s_base[threadIdx.x] = s_n[threadIdx.x] ? atomicAdd(&ctl[threadIdx.x], s_n[threadIdx.x]) : 0;
+    __syncthreads();
+    if (busy) list[(size_t)c * cap + s_base[c] + mine] = b;
+}
+
+__global__ __launch_bounds__(64) void pile_ticket_kernel(float *height, const float *__restrict__ sediment, int32_t *blocks,
+                                                        const int32_t *__restrict__ list, int32_t *ctl, int cap,
+                                                        const short2 *__restrict__ ofs, int nverts, int res,
+                                                        int maxDistance, int B, int nb, float pileThreshold, float increment,
+                                                        unsigned *err_host) {
+    extern __shared__ unsigned char s_raw[];
+    const pile_lds L = pile_carve(s_raw, nverts, B);
+    const int lane = threadIdx.x;
+    const int n0 = ctl[0], n1 = ctl[1], n2 = ctl[2], n3 = ctl[3];
+    const int total = n0 + n1 + n2 + n3;
+    bool have_ofs = false;
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(&ctl[4], 1);
+        t = __shfl(t, 0);
+        if (t >= total) break;
+        if (!have_ofs) {
+            pile_load_offsets(L, ofs, nverts, lane);
+            have_ofs = true;
+        }
+        const int c = t < n0 ? 0 : (t < n0 + n1 ? 1 : (t < n0 + n1 + n2 ? 2 : 3));
+        const int i = t - (c > 0 ? n0 : 0) - (c > 1 ? n1 : 0) - (c > 2 ? n2 : 0);
+        const int b = list[(size_t)c * cap + i];
+        const int bx = b / nb, bz = b - bx * nb;
+        if (c > 0 && lane < 8) {
+            const int k = lane < 4 ? lane : lane + 1;  // the eight neighbours of the 3 x 3
+            const int qx = bx + k % 3 - 1, qz = bz + k / 3 - 1;
+            const int qc = (qx & 1) | ((qz & 1) << 1);
+            if (qx >= 0 && qz >= 0 && qx < nb && qz < nb && qc < c) {
+                const int32_t *f = blocks + (size_t)qx * nb + qz;
+                int spins = 0;
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > (1 << 22)) {  // seconds: never, unless the protocol is broken
+                        __hip_atomic_store(err_host, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        pile_block<true>(L, height, sediment, nverts, res, maxDistance, B, bx, bz, pileThreshold, increment);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the block's stores have left
+        __syncthreads();
+        if (lane == 0) __hip_atomic_store(blocks + b, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1090,17 +1222,20 @@ extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_e
     const int slot = events->cur ^ 1;
     const int D = ep->PILING_RADIUS;
     const int B = 2 * (D + 1), nb = (res + B - 1) / B;
+    const int pile_cap = ((nb + 1) / 2) * ((nb + 1) / 2);  // blocks of one colour, at most
     if (D >= 1) {
         if ((size_t)nb * nb != events->pile_blocks_n) {  // another radius: rare
             NZ_HIP(hipStreamSynchronize(ctx->stream));
             if (events->pile_blocks) (void)hipFree(events->pile_blocks);
             events->pile_blocks = nullptr;
             events->pile_blocks_n = 0;
-            NZ_HIP(hipMalloc((void **)&events->pile_blocks, (size_t)nb * nb * 4));
+            NZ_HIP(hipMalloc((void **)&events->pile_blocks, ((size_t)nb * nb + PILE_CTL + 4 * (size_t)pile_cap) * 4));
             events->pile_blocks_n = (size_t)nb * nb;
         }
-        NZ_HIP(hipMemsetAsync(events->pile_blocks, 0, (size_t)nb * nb * 4, ctx->stream));
+        NZ_HIP(hipMemsetAsync(events->pile_blocks, 0, ((size_t)nb * nb + PILE_CTL) * 4, ctx->stream));
     }
+    int32_t *pile_ctl = D >= 1 ? events->pile_blocks + (size_t)nb * nb : nullptr;
+    int32_t *pile_list = D >= 1 ? pile_ctl + PILE_CTL : nullptr;
     hipLaunchKernelGGL(disperse_list_kernel, dim3(2048), dim3(CT), 0, ctx->stream, height, events->sediment, events->list[slot],
                        events->counters, slot, res, thr, D >= 1 ? events->pile_blocks : nullptr, B, nb);
     {
@@ -1132,7 +1267,26 @@ extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_e
         const size_t lds = (((size_t)nverts * 9 + 15) & ~(size_t)15) + (size_t)B * B * 4 + (size_t)nverts * 4;
         if (lds > 64 * 1024)
             NZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        for (int colour = 0; colour < 4; colour++) {
+        // NZ_PILE_TICKET (1): all colours in one launch, the busy blocks handed out by ticket (pile_ticket_kernel); 0: one
+        // launch per colour over every block of it
+        static const bool ticket = [] { const char *e = getenv("NZ_PILE_TICKET"); return !e || atoi(e) != 0; }();
+        if (ticket) {
+            unsigned *err_host = nullptr;
+            NZ_TRY_(nz_ctx_error_word(ctx, &err_host));
+            if (lds > 64 * 1024)
+                NZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pile_ticket_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(pile_list_kernel, dim3((unsigned)(((size_t)nb * nb + 1023) / 1024)), dim3(1024), 0, ctx->stream,
+                               events->pile_blocks, pile_ctl, pile_list, pile_cap, nb);
+            // 2048 resident waves: 1024 leave blocks waiting for a wave (248 us), 3584 / 7168 fill the CUs with waves that
+            // poll (239 / 279 us against 211)
+            const unsigned grid = (unsigned)std::min<long long>((long long)nb * nb, 2048);
+            hipLaunchKernelGGL(pile_ticket_kernel, dim3(grid), dim3(64), lds, ctx->stream, height, events->sediment,
+                               events->pile_blocks, pile_list, pile_ctl, pile_cap, (const short2 *)events->pile_scratch, nverts,
+                               res, D, B, nb, thr, ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT, err_host);
+            NZ_HIP(hipGetLastError());
+        }
+        for (int colour = 0; colour < 4 && !ticket; colour++) {
             const int cx = colour & 1, cz = colour >> 1;
             const int bxn = (nb - cx + 1) / 2, bzn = (nb - cz + 1) / 2;
             if (bxn <= 0 || bzn <= 0) continue;

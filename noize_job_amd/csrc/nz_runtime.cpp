@@ -405,17 +405,25 @@ int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out) {
 
 // The flags / control block of the chained launches.  Flags are compared with an epoch that grows by one per launch, so
 // stale contents never match; a (re)allocated array is zeroed and the epoch restarts above zero.
-int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch, unsigned **err_host) {
-    if (!ctx->chain_ctl) {
-        NZ_HIP(hipMalloc((void **)&ctx->chain_ctl, 64));
-        NZ_HIP(hipMemsetAsync(ctx->chain_ctl, 0, 64, ctx->stream));
-    }
-    if (!ctx->chain_err) {  // mapped host memory: a tile that gives up stores here (system scope), the host reads it with a load
+// The context's error word: mapped host memory a kernel whose bounded wait gives up stores to (system scope) and the host
+// reads with a load at its next synchronisation.  1 = a chained filter launch (NZ_ERR_RETRY), 2 = the pile solver's ticket
+// kernel (an internal error: its wait cannot time out unless the protocol is broken).
+int32_t nz_ctx_error_word(nz_ctx *ctx, unsigned **err_host) {
+    if (!ctx->chain_err) {
         NZ_HIP(hipHostMalloc((void **)&ctx->chain_err, 64, hipHostMallocMapped));
         *ctx->chain_err = 0;
         NZ_HIP(hipHostGetDevicePointer((void **)&ctx->chain_err_dev, ctx->chain_err, 0));
     }
     *err_host = ctx->chain_err_dev;
+    return NZ_OK;
+}
+
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch, unsigned **err_host) {
+    if (!ctx->chain_ctl) {
+        NZ_HIP(hipMalloc((void **)&ctx->chain_ctl, 64));
+        NZ_HIP(hipMemsetAsync(ctx->chain_ctl, 0, 64, ctx->stream));
+    }
+    NZ_TRY_(nz_ctx_error_word(ctx, err_host));
     if (items > ctx->chain_flags_n) {
         if (ctx->chain_flags) {
             NZ_TRY_(ctx_sync_all(ctx));
@@ -439,8 +447,14 @@ int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ct
 // device-to-host copy on the host's wait path): reported wherever the host waits.
 static int32_t ctx_chain_check(nz_ctx *ctx) {
     if (!ctx->chain_err) return NZ_OK;
-    if (*reinterpret_cast<volatile unsigned *>(ctx->chain_err) == 0) return NZ_OK;
+    const unsigned word = *reinterpret_cast<volatile unsigned *>(ctx->chain_err);
+    if (word == 0) return NZ_OK;
     *reinterpret_cast<volatile unsigned *>(ctx->chain_err) = 0;
+    if (word == 2) {
+        nz_set_error("internal: a block of the pile solver gave up waiting for a neighbouring block (nz_erode_height_maps); the "
+                     "height plane is invalid.  NZ_PILE_TICKET=0 runs the four colour launches instead");
+        return NZ_ERR_HIP;
+    }
     // The wait of a chained launch terminates whatever happens (bounded poll), but it only makes PROGRESS while the
     // hardware starts the grid's workgroups in index order, round-robin over the XCDs -- a consumer's producers belong
     // to other ticket classes (blockIdx.x & 7), and those are claimed by workgroups that must get dispatched.  That

@@ -871,19 +871,30 @@ class LiveErosion {
         const nz_erosion_params ep = es.AsParameters();
         const nz_tile_set_meta &tm = tileMeta;
         nz_handle h = 0;
+        // The jobs of a cycle are links of ONE chain on the context's stream: with fewHandles only the handles somebody waits
+        // for are asked of the library (out = NULL otherwise) -- a handle is an event record, ~3 us of the stream
+        const bool all = !fewHandles;
+        auto link = [&](bool wanted) -> nz_handle * { return wanted || all ? &h : (h = 0, (nz_handle *)nullptr); };
         if (performErosion) {
             if ((int)seeds.size() < es.CYCLES) throw std::runtime_error("one seed per cycle");
             for (int i = 0; i < es.CYCLES; i++) {
-                if (es.ENABLE_THERMAL && es.BEHAVIOR != ErosionMode::ONLY_FLOW_WATER)  // `TILE_SIZE.x / HEIGHT`: int / int (:386)
+                const bool last = i + 1 == es.CYCLES;  // the chain's last handle is the component's jobHandle
+                nz_handle dep = h;
+                if (es.ENABLE_THERMAL && es.BEHAVIOR != ErosionMode::ONLY_FLOW_WATER) {  // `TILE_SIZE.x / HEIGHT`: int / int (:386)
                     check(nz_thermal_erosion(ctx, heightMap->ptr, es.TALUS, es.THERMAL_STEP, (float)(tm.TILE_SIZE[0] / tm.HEIGHT),
-                                             es.THERMAL_CYCLES, res, h, &h), "nz_thermal_erosion");
-                if (es.BEHAVIOR != ErosionMode::ONLY_FLOW_WATER)
+                                             es.THERMAL_CYCLES, res, dep, link(false)), "nz_thermal_erosion");
+                    dep = h;
+                }
+                if (es.BEHAVIOR != ErosionMode::ONLY_FLOW_WATER) {
                     check(nz_fill_beyer_queue(ctx, particleQueue, &ep, &tm, particleGenerationID % 4, res, QUEUE_SIZE, seeds[i],
-                                              std::min(10, QUEUE_SIZE), h, &h), "nz_fill_beyer_queue");
+                                              std::min(10, QUEUE_SIZE), dep, link(false)), "nz_fill_beyer_queue");
+                    dep = h;
+                }
                 check(nz_queued_beyer_cycle(ctx, heightMap->ptr, poolMap.ptr, streamMap.ptr, particleTrack.ptr, particleQueue, events,
-                                            &ep, &tm, EVENT_LIMIT, res, h, &h), "nz_queued_beyer_cycle");
+                                            &ep, &tm, EVENT_LIMIT, res, dep, link(false)), "nz_queued_beyer_cycle");
+                dep = h;
                 check(nz_process_beyer_erosive_events(ctx, heightMap->ptr, poolMap.ptr, streamMap.ptr, particleTrack.ptr, events, &ep,
-                                                      &tm, res, h, &h), "nz_process_beyer_erosive_events");
+                                                      &tm, res, dep, link(parallelBranch)), "nz_process_beyer_erosive_events");
                 // CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all behind the event reduction
                 // (:408-412): the flow job runs on a stream of its own (a second context), beside the sediment job
                 if (parallelBranch) {
@@ -891,19 +902,29 @@ class LiveErosion {
                     nz_handle flow = 0, both[2];
                     check(nz_update_flow_from_track(branchCtx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
                                                     ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, h, &flow), "nz_update_flow_from_track");
-                    check(nz_clear_particle_queue(ctx, particleQueue, h, &h), "nz_clear_particle_queue");
-                    check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, h, &h), "nz_erode_height_maps");
-                    both[0] = h;
-                    both[1] = flow;
-                    check(nz_handle_combine(ctx, both, 2, &h), "nz_handle_combine");
+                    dep = h;
+                    check(nz_clear_particle_queue(ctx, particleQueue, dep, link(false)), "nz_clear_particle_queue");
+                    dep = h;
+                    check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, dep, link(false)), "nz_erode_height_maps");
+                    if (all) {
+                        both[0] = h;
+                        both[1] = flow;
+                        check(nz_handle_combine(ctx, both, 2, &h), "nz_handle_combine");
+                    } else {
+                        h = flow;  // the automaton follows ErodeHeightMaps on this stream and waits for the branch
+                    }
                 } else {
-                    check(nz_clear_particle_queue(ctx, particleQueue, h, &h), "nz_clear_particle_queue");
-                    check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, h, &h), "nz_erode_height_maps");
+                    dep = h;
+                    check(nz_clear_particle_queue(ctx, particleQueue, dep, link(false)), "nz_clear_particle_queue");
+                    dep = h;
+                    check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, dep, link(false)), "nz_erode_height_maps");
+                    dep = h;
                     check(nz_update_flow_from_track(ctx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
-                                                    ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, h, &h), "nz_update_flow_from_track");
+                                                    ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, dep, link(false)), "nz_update_flow_from_track");
                 }
+                dep = h;
                 check(nz_pool_automata_job(ctx, poolMap.ptr, heightMap->ptr, particleQueue, &ep, &tm, es.WATER_STEPS, res,
-                                           performErosion ? 1 : 0, h, &h), "nz_pool_automata_job");
+                                           performErosion ? 1 : 0, dep, link(last)), "nz_pool_automata_job");
             }
         }
         jobHandle = JobHandle{ctx, h};
@@ -913,6 +934,7 @@ class LiveErosion {
 
     nz_ctx *ctx;
     bool parallelBranch = false;    // true: ErodeHeightMaps || UpdateFlowFromTrackJob on two streams, as in the reference's job graph (measured slower)
+    bool fewHandles = true;         // false: a handle out of every job, as the reference schedules them (one event record each)
     nz_ctx *branchCtx = nullptr;    // (created on first use; destroyed with the component)
     DeviceTile *heightMap;
     nz_tile_set_meta tileMeta;

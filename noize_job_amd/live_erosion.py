@@ -117,8 +117,8 @@ class ParticleQueue:
         p = np.ascontiguousarray(particles, self.DTYPE)
         N.check(N.lib.nz_particle_queue_upload(self.ctx._h, self._h, p.ctypes.data, len(p)), "nz_particle_queue_upload")
 
-    def Clear(self, dep=None):
-        return self.ctx.call("nz_clear_particle_queue", self._h, dep=dep)
+    def Clear(self, dep=None, handle=True):
+        return self.ctx.call("nz_clear_particle_queue", self._h, dep=dep, handle=handle)
 
     def Dispose(self):
         if self._h:
@@ -180,9 +180,14 @@ class LiveErosion:
         # cost more than the overlap saves (2.71 against 2.54 ms per driver cycle)
         self.parallelBranch = False
         self._branchCtx = None
+        # The jobs of a cycle are links of ONE chain on this context's stream: only the handles somebody waits for are
+        # asked of the library (the event reduction's when the branch runs beside it, the branch's, the cycle chain's
+        # last) -- a handle is an event record, ~3 us of the stream.  False: one per job, as the reference
+        # schedules them.
+        self.fewHandles = True
 
-    def _call(self, name, *args, dep=None):
-        return self.ctx.call(name, *args, dep=dep)
+    def _call(self, name, *args, dep=None, handle=True):
+        return self.ctx.call(name, *args, dep=dep, handle=handle or not self.fewHandles)
 
     def TriggerQueuedBeyerMT(self, seeds):
         """:378-436.  `seeds`: one int per cycle (stands for UnityEngine.Random.Range in FillBeyerQueueJob)."""
@@ -193,21 +198,25 @@ class LiveErosion:
         if self.performErosion:
             assert len(seeds) >= es.CYCLES, "one seed per cycle"
             for i in range(es.CYCLES):
+                # the only handle of a cycle anybody outside this stream looks at is its last one -- and that only when
+                # nothing follows on the stream
+                last = i + 1 == es.CYCLES and self.waterControl is None
                 if es.ENABLE_THERMAL and es.BEHAVIOR != ErosionMode.ONLY_FLOW_WATER:
                     handle = self._call("nz_thermal_erosion", self.heightMap.ptr, float(es.TALUS), float(es.THERMAL_STEP),
                                         float(tm.TILE_SIZE[0] // tm.HEIGHT),  # `TILE_SIZE.x / HEIGHT`: both int in C# (:386)
                                         es.THERMAL_CYCLES, res,
-                                        dep=handle)
+                                        dep=handle, handle=False)
                 if es.BEHAVIOR != ErosionMode.ONLY_FLOW_WATER:
                     handle = self._call("nz_fill_beyer_queue", self.particleQueue._h, epp, tmp_, self.particleGenerationID % 4,
-                                        res, self.QUEUE_SIZE, int(seeds[i]), min(10, self.QUEUE_SIZE), dep=handle)
+                                        res, self.QUEUE_SIZE, int(seeds[i]), min(10, self.QUEUE_SIZE), dep=handle, handle=False)
                 # ClearQueueJob<ErosiveEvent> / ClearMultiDict: the event planes clear themselves when they are processed
                 # CopyBeyerQueueJob: the queue's device array is the list
                 handle = self._call("nz_queued_beyer_cycle", self.heightMap.ptr, self.poolMap.ptr, self.streamMap.ptr,
                                     self.particleTrack.ptr, self.particleQueue._h, self.events._h, epp, tmp_, self.EVENT_LIMIT,
-                                    res, dep=handle)
+                                    res, dep=handle, handle=False)
                 handle = self._call("nz_process_beyer_erosive_events", self.heightMap.ptr, self.poolMap.ptr, self.streamMap.ptr,
-                                    self.particleTrack.ptr, self.events._h, epp, tmp_, res, dep=handle)
+                                    self.particleTrack.ptr, self.events._h, epp, tmp_, res, dep=handle,
+                                    handle=self.parallelBranch)  # the branch's stream waits for this one
                 # handle = CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all three behind the
                 # event reduction (:408-412)
                 reduced = handle
@@ -218,25 +227,31 @@ class LiveErosion:
                     flow = self._branchCtx.call("nz_update_flow_from_track", self.poolMap.ptr, self.streamMap.ptr,
                                                 self.particleTrack.ptr, ep.FLOW_LOSS_RATE, ep.SURFACE_EVAPORATION_RATE,
                                                 float(tm.HEIGHT), res, dep=reduced)
-                    handle = self.particleQueue.Clear(dep=reduced)
-                    handle = self._call("nz_erode_height_maps", self.heightMap.ptr, self.events._h, epp, tmp_, res, dep=handle)
-                    handle = JobHandle.CombineDependencies(self.ctx, handle, flow)
+                    handle = self.particleQueue.Clear(dep=reduced, handle=not self.fewHandles)
+                    handle = self._call("nz_erode_height_maps", self.heightMap.ptr, self.events._h, epp, tmp_, res, dep=handle,
+                                        handle=False)
+                    if self.fewHandles:
+                        handle = flow  # the automaton follows ErodeHeightMaps on this stream and waits for the branch
+                    else:
+                        handle = JobHandle.CombineDependencies(self.ctx, handle, flow)
                 else:
-                    handle = self.particleQueue.Clear(dep=reduced)
-                    handle = self._call("nz_erode_height_maps", self.heightMap.ptr, self.events._h, epp, tmp_, res, dep=handle)
+                    handle = self.particleQueue.Clear(dep=reduced, handle=not self.fewHandles)
+                    handle = self._call("nz_erode_height_maps", self.heightMap.ptr, self.events._h, epp, tmp_, res, dep=handle,
+                                        handle=False)
                     handle = self._call("nz_update_flow_from_track", self.poolMap.ptr, self.streamMap.ptr, self.particleTrack.ptr,
-                                        ep.FLOW_LOSS_RATE, ep.SURFACE_EVAPORATION_RATE, float(tm.HEIGHT), res, dep=handle)
+                                        ep.FLOW_LOSS_RATE, ep.SURFACE_EVAPORATION_RATE, float(tm.HEIGHT), res, dep=handle,
+                                        handle=False)
                 handle = self._call("nz_pool_automata_job", self.poolMap.ptr, self.heightMap.ptr, self.particleQueue._h, epp,
-                                    tmp_, es.WATER_STEPS, res, int(self.performErosion), dep=handle)
+                                    tmp_, es.WATER_STEPS, res, int(self.performErosion), dep=handle, handle=last)
         if self.waterControl is not None:  # the RGBA32 control textures (:418-430)
             mres = self.tileMeta.TILE_RES[0]
             for src, tex, ch, scale in ((self.poolMap, self.waterControl, ColorChannelByte.R, 1000.0),
                                         (self.poolMap, self.waterControl, ColorChannelByte.G, 1000.0),
                                         (self.streamMap, self.waterControl, ColorChannelByte.B, 2.0),
                                         (self.streamMap, self.textureControl, ColorChannelByte.G, 3.0)):
-                handle = self._call("nz_set_rgba32", src.ptr, tex.ptr, int(ch), res, mres, scale, dep=handle)
+                handle = self._call("nz_set_rgba32", src.ptr, tex.ptr, int(ch), res, mres, scale, dep=handle, handle=False)
             handle = self._call("nz_curviture_map", self.textureControl.ptr, self.heightMap.ptr, tmp_, int(ColorChannelByte.G),
-                                res, mres, dep=handle)
+                                res, mres, dep=handle, handle=False)
             handle = self._call("nz_set_rgba32", self.streamMap.ptr, self.textureControl.ptr, int(ColorChannelByte.A), res, mres,
                                 1.0, dep=handle)
         self.jobHandle = handle

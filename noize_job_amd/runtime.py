@@ -153,7 +153,13 @@ class Context:
         return ms.value
 
     # generic call helper: appends (dep, &out) and wraps the returned handle
-    def call(self, name, *args, dep=None):
+    def call(self, name, *args, dep=None, handle=True):
+        """handle=False: `out` is NULL -- no event is recorded (one costs the stream ~3 us); the work is ordered by this
+        context's stream only and the JobHandle returned is the empty one.  For links of a chain that stays on this
+        context; never hand such a handle to ANOTHER context as a dependency."""
+        if not handle:
+            N.check(getattr(N.lib, name)(self._h, *args, _dep(dep), None), name)
+            return JobHandle()
         out = N.handle_t(0)
         N.check(getattr(N.lib, name)(self._h, *args, _dep(dep), C.byref(out)), name)
         return JobHandle(self, out.value)

@@ -40,6 +40,13 @@ def test_every_prototype_has_its_dllimport_with_the_same_shape():
         # the reference's delegates end in (JobHandle dependency) and return a JobHandle: (dep, out) close the list
         if params and params[-1] == ("nz_handle*", "out") and len(params) >= 2 and params[-2][0] == "nz_handle":
             assert cs_params[-2:] == ["ulong", "out ulong"], name
+    # ... and every entry that ends in `nz_handle *out` has ONE overload taking the pointer itself (IntPtr.Zero = no handle,
+    # no event record): the same parameters up to it
+    over = gen.parse_cs_overloads()
+    with_out = {n for n, _, ps in header if ps and ps[-1] == ("nz_handle*", "out")}
+    assert set(over) == with_out and len(with_out) >= 60
+    for name in with_out:
+        assert over[name] == cs[name][1][:-1] + ["IntPtr"], name
     # scalar order of three delegates, spelled out against the C# reference signatures
     f = dict((n, [p for _, p in ps]) for n, _, ps in header)
     assert f["nz_fractal"] == ["ctx", "noiseType", "src", "resolution", "hurst", "startingAmplitude", "stepdown", "detuneRate",
@@ -69,6 +76,7 @@ def _split_args(s):
 
 def test_hand_written_files_call_declared_entries_with_the_right_arity():
     cs = gen.parse_cs()
+    over = gen.parse_cs_overloads()
     calls = 0
     for path, text in _cs_sources().items():
         if path == "Native.cs":
@@ -82,9 +90,11 @@ def test_hand_written_files_call_declared_entries_with_the_right_arity():
                 i += 1
             args = _split_args(text[m.end():i - 1])
             assert len(args) == len(cs[name][1]), "%s: %s takes %d arguments, called with %d" % (path, name, len(cs[name][1]), len(args))
-            for a, t in zip(args, cs[name][1]):   # out / ref at the call site where the declaration has them
+            for k, (a, t) in enumerate(zip(args, cs[name][1])):   # out / ref at the call site where the declaration has them
                 if t.startswith("out "):
-                    assert a.startswith("out "), (path, name, a)
+                    # the last argument may pick the overload that leaves the handle out
+                    null_handle = k == len(args) - 1 and t == "out ulong" and a == "IntPtr.Zero" and name in over
+                    assert a.startswith("out ") or null_handle, (path, name, a)
                 if t.startswith("ref "):
                     assert a.startswith("ref "), (path, name, a)
             calls += 1

@@ -26,8 +26,10 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--at", default="", help="comma-separated cycle counts of one long run at which the per-job times are taken")
     ap.add_argument("--skip-fresh", action="store_true", help="only the --at run")
-    ap.add_argument("--serial-branch", action="store_true",
-                    help="driver figures with ErodeHeightMaps and UpdateFlowFromTrackJob one after the other on one stream")
+    ap.add_argument("--parallel-branch", action="store_true",
+                    help="driver figures with UpdateFlowFromTrackJob on a second context beside ErodeHeightMaps "
+                         "(LiveErosion.parallelBranch; off by default: the two cross-stream hand-overs cost more than the "
+                         "overlap saves, 1.64 against 1.55 ms per cycle)")
     a = ap.parse_args()
     res = a.res
     out = {"config": "%dx%d cellular-13oct base + live particle erosion, %d particles per cycle, WATER_STEPS %d" %
@@ -46,7 +48,7 @@ def main():
         es = nj.ErosionSettings(PARTICLES_PER_CYCLE=a.particles, CYCLES=1, WATER_STEPS=a.water_steps)
         tm = nj.tile_set_meta(res, height=1000, tile_size=res, tile_res=res - 16, margin=8)
         G = nj.LiveErosion(ctx, h, tm, es)
-        G.parallelBranch = not a.serial_branch
+        G.parallelBranch = a.parallel_branch
         ep = es.AsParameters()
         epp, tmp_ = C.byref(ep), C.byref(tm)
         jobs = [
@@ -145,13 +147,19 @@ def main():
         out["pool_runs"] = os.environ.get("NZ_POOL_RUNS", "1")
         # whole Updates through the host driver, wall clock
         es.CYCLES = 3
-        G.TriggerQueuedBeyerMT([1, 2, 3]).Complete()
-        t0 = time.perf_counter()
         n_up = max(30, a.cycles // 3)
-        for u in range(n_up):
-            G.TriggerQueuedBeyerMT([10 * u + 1, 10 * u + 2, 10 * u + 3])
-        G.jobHandle.Complete()
-        dt = time.perf_counter() - t0
+
+        def updates():
+            G.TriggerQueuedBeyerMT([1, 2, 3]).Complete()
+            t0 = time.perf_counter()
+            for u in range(n_up):
+                G.TriggerQueuedBeyerMT([10 * u + 1, 10 * u + 2, 10 * u + 3])
+            G.jobHandle.Complete()
+            return time.perf_counter() - t0
+        G.fewHandles = False   # a JobHandle out of every job, as the reference schedules them
+        out["driver_cycle_ms_one_handle_per_job"] = round(updates() / (3 * n_up) * 1e3, 4)
+        G.fewHandles = True    # the default: only the handles somebody waits for
+        dt = updates()
         out["driver_cycles_per_s"] = round(3 * n_up / dt, 2)
         out["driver_cycle_ms"] = round(dt / (3 * n_up) * 1e3, 4)
         out["driver_parallel_branch"] = bool(G.parallelBranch)
