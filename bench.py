@@ -810,13 +810,17 @@ def main():
         rcells = cells // world  # rank 0's own cells: the stage figures are per GPU
         if striped is not None:
             rcells = striped.parts[0][1].nown * res  # stripe 0's own cells
-        acc = {n: 0.0 for n in STAGES}
+        per_step = {n: [] for n in STAGES}
         for hs in marks:
             for i, n in enumerate(STAGES):
-                acc[n] += mctx.elapsed_ms(hs[i], hs[i + 1])
-        stage_ms = {n: acc[n] / len(marks) for n in STAGES}
+                per_step[n].append(mctx.elapsed_ms(hs[i], hs[i + 1]))
+        stage_ms = {n: sum(per_step[n]) / len(marks) for n in STAGES}
         kernel_ms = dict(stage_ms)
-        stages_out = {n: {"ms": round(stage_ms[n], 4), "launches": launches[n]} for n in STAGES}
+        # `ms` is the mean over the marked steps (what the roofline is priced with); the spread says whether a mean is a
+        # few slow steps or all of them
+        stages_out = {n: {"ms": round(stage_ms[n], 4), "launches": launches[n],
+                          "ms_min_median_max": [round(x, 4) for x in (min(per_step[n]), sorted(per_step[n])[len(marks) // 2],
+                                                                     max(per_step[n]))]} for n in STAGES}
         for n, note in stage_note.items():
             stages_out[n]["note"] = note
         # The in-place tile API's one-launch flow stage ends with a plane copy back into the caller's buffer (and the
