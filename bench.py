@@ -27,6 +27,7 @@ Rank 0 prints ONE JSON line:
                 scaling quantity the >= 6x target is defined on -- with ghost rows recomputed and, at N > 1, exchanged.
 """
 import argparse
+import gc
 import glob
 import hashlib
 import json
@@ -344,6 +345,7 @@ def strong_grid(nj, sh, torch, dist, ctx, grid, rank, world, impl="native", ncom
     else:
         modes = ("recompute", "exchange", "exchange_blocking", "exchange_once")
     for label in modes:
+        gc.collect()  # (main() holds the collector off; a pass by hand before every warm-up)
         mode = "exchange" if label.startswith("exchange_") and label != "exchange_once" else label
         p = sh.PipelineParams(gaussIterations=G_IT, flowIterations=F_IT, erosionIterations=E_IT, haloMode=mode)
 
@@ -666,6 +668,14 @@ def main():
     # The chip's clocks need some tens of ms of continuous work to settle (see --steps above).  A caller that asks
     # for a short run still gets the steady-state rate: the GPU is kept busy with untimed passes first, so that
     # warm-up + preheat cover at least PREHEAT_MIN_STEPS passes.  The K timed steps are exactly the K asked for.
+    # The host of this bench is CPython: its cyclic collector starts a full pass at a fixed allocation count -- with the
+    # default steps, inside the 60th marked step's filter stage -- and that pass takes 34-67 ms with torch's heap loaded.  The
+    # host enqueues ~25 us per step and is 38 ms of GPU work ahead at that point: on a slow host the GPU ran dry for up to
+    # 30 ms, one step in 200 (tools/trace_outliers.sh, NZ_BENCH_HOST_TIMES=1).  A host's pauses are not
+    # the library's throughput: the collector is held off while steps are timed (from before the warm-up: a collection is
+    # 35 ms of idle GPU, and the clocks it lets fall take a few steps to come back).
+    gc.collect()
+    gc.disable()
     preheat = max(0, PREHEAT_MIN_STEPS - args.warmup)
     for _ in range(preheat):
         step(False)
@@ -678,6 +688,7 @@ def main():
         host_s[0] = 0.0
     timed_exchanges = sharded and args.halo != "recompute" and (grid is not None or isinstance(comm, TimedComm))
     t0 = time.perf_counter()
+    host_t = [t0]  # when the host had enqueued each timed step
     ex_steps = min(args.steps, 64)  # exchanges are bracketed with markers in the last steps only
     for i in range(args.steps):
         if timed_exchanges and args.steps - i == ex_steps:
@@ -688,8 +699,16 @@ def main():
         elif timed_exchanges and i == 0 and grid is None:
             comm.enabled = False
         step(args.steps - i <= (MAX_MARKED_STEPS if not sharded else min(MAX_MARKED_STEPS, args.marked_steps)))
+        host_t.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
+    # (the collector stays off for the informational measurements below, which collect by hand before their own warm-ups)
+    if os.environ.get("NZ_BENCH_HOST_TIMES"):
+        iv = [(host_t[k + 1] - host_t[k]) * 1e3 for k in range(len(host_t) - 1)]
+        top = sorted(range(len(iv)), key=lambda k: -iv[k])[:4]
+        print("host enqueue per timed step: median %.3f ms; longest %s; all %d steps enqueued after %.2f ms of the %.2f ms they took"
+              % (sorted(iv)[len(iv) // 2], [(k, round(iv[k], 3)) for k in top], len(iv), (host_t[-1] - t0) * 1e3, dt * 1e3),
+              file=sys.stderr)
     exchange_ms = host_enqueue_ms = host_idle_ms = None
     if sharded:
         # the host's own cost of enqueueing a step, measured where the queue cannot push back: eight steps on an idle
@@ -820,7 +839,8 @@ def main():
         # few slow steps or all of them
         stages_out = {n: {"ms": round(stage_ms[n], 4), "launches": launches[n],
                           "ms_min_median_max": [round(x, 4) for x in (min(per_step[n]), sorted(per_step[n])[len(marks) // 2],
-                                                                     max(per_step[n]))]} for n in STAGES}
+                                                                     max(per_step[n]))],
+                          "slowest_marked_step": max(range(len(marks)), key=lambda k, n=n: per_step[n][k])} for n in STAGES}
         for n, note in stage_note.items():
             stages_out[n]["note"] = note
         # The in-place tile API's one-launch flow stage ends with a plane copy back into the caller's buffer (and the
@@ -945,6 +965,7 @@ def main():
                         ("two_tiles_in_flight", lambda: two_tiles(nj, ctx, stages, gd, res, p, swap)),
                         ("tile_as_two_stripes", lambda: two_stripes(nj, sh, torch, local_rank, data, res, p))):
             try:
+                gc.collect()
                 r = fn()
             except Exception as e:  # noqa: BLE001
                 r = {"error": "%s: %s" % (type(e).__name__, e)}
