@@ -10,11 +10,14 @@ import argparse
 import ctypes as C
 import json
 import os
+import gc
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import noize_job_amd as nj  # noqa: E402
+
+gc.disable()  # a full collection pass of the host (tens of ms with a big heap) must not land in a timed loop
 
 
 def main():

@@ -6,10 +6,13 @@ usage: bench_next.py [--res 4096] [--reps 10] [--json out.json]"""
 import argparse
 import json
 import os
+import gc
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import noize_job_amd as nj  # noqa: E402
+
+gc.disable()  # a full collection pass of the host (tens of ms with a big heap) must not land in a timed loop
 
 HBM = 8000.0  # GB/s
 

@@ -5,11 +5,14 @@ With --batch B the tiles go through the batched stage bodies instead (nz_*_batch
 usage: bench_tiles.py [--res 512] [--streams 1 2 4] [--tiles 256] [--batch 4 16 64]"""
 import argparse
 import os
+import gc
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import noize_job_amd as nj  # noqa: E402
+
+gc.disable()  # a full collection pass of the host (tens of ms with a big heap) must not land in a timed loop
 
 
 def make(ctx, res):

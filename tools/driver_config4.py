@@ -2,11 +2,14 @@
 `--updates` Updates of three cycles each through LiveErosion.TriggerQueuedBeyerMT."""
 import argparse
 import os
+import gc
 import sys
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import noize_job_amd as nj  # noqa: E402
+
+gc.disable()  # a full collection pass of the host (tens of ms with a big heap) must not land in a timed loop
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--res", type=int, default=8192)

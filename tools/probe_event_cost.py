@@ -3,12 +3,15 @@ the 4096^2 metric pipeline on one stream, with a handle out of every call (what 
 same calls with out = NULL (stream order only), alternating on one box.  GPU only: python tools/probe_event_cost.py"""
 import ctypes as C
 import os
+import gc
 import sys
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import noize_job_amd as nj  # noqa: E402
 from noize_job_amd import _native as N  # noqa: E402
+
+gc.disable()  # a full collection pass of the host (tens of ms with a big heap) must not land in a timed loop
 
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cells = res * res

@@ -3,12 +3,15 @@ a ~60 us kernel (nz_constant_job on a 4096^2 plane) back to back, each call time
 handle out of every call.  GPU only."""
 import ctypes as C
 import os
+import gc
 import sys
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import noize_job_amd as nj  # noqa: E402
 from noize_job_amd import _native as N  # noqa: E402
+
+gc.disable()  # a full collection pass of the host (tens of ms with a big heap) must not land in a timed loop
 
 res = 4096
 ctx = nj.Context(0)
