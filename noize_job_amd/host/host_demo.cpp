@@ -22,6 +22,13 @@
 
 using namespace noize;
 
+// a pipeline whose driver does not wait for a work item before it schedules the next one (the `tiles` mode: the tile's
+// planes are the pipeline's own, and the stream orders the work items)
+struct FreeRunningPipeline : BasePipeline {
+    using BasePipeline::BasePipeline;
+    void Release() { pipelineRunning = pipelineBeingScheduled = false; }
+};
+
 int main(int argc, char **argv) {
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s <resolution> <out.f32> [G F E]\n", argv[0]);
@@ -38,6 +45,7 @@ int main(int argc, char **argv) {
     const bool sharded_rank = argc > 6 && std::strcmp(argv[3], "sharded-rank") == 0;
     // `onecall`: BasePipeline.fuseStages -- the stock stage list as one nz_terrain_pipeline call (tiles of 2048^2 and more)
     const bool onecall = argc > 3 && std::strcmp(argv[3], "onecall") == 0;
+    const bool tiles = argc > 5 && std::strcmp(argv[3], "tiles") == 0;  // <res> <out> tiles <pipelines> <tiles>
     if (rw || onecall) argc = 3;
     int G = argc > 3 ? std::atoi(argv[3]) : 17, F = argc > 4 ? std::atoi(argv[4]) : 5, E = argc > 5 ? std::atoi(argv[5]) : 5;
     try {
@@ -213,6 +221,77 @@ int main(int argc, char **argv) {
             std::fwrite(host.data(), sizeof(float), host.size(), f);
             std::fclose(f);
             pipe.Destroy();
+        } else if (tiles) {
+            // What a COMPILED host gets out of small tiles (tools/bench_tiles.py is the same loop in Python, where the
+            // interpreter's ~30 us per tile is the limit from two pipelines on): S pipelines, each on a context (stream) of
+            // its own with a READ / WRITE pair, take the tiles of a row of the world in turn; nobody waits until the end.
+            const int S = std::atoi(argv[4]), T = std::atoi(argv[5]);
+            struct lane {
+                nz_ctx *c = nullptr;
+                std::unique_ptr<DeviceTile> a, b;
+                std::unique_ptr<NoiseStage> noise;
+                std::unique_ptr<KernelFilterStage> gauss;
+                std::unique_ptr<FlowMapStage> flow;
+                std::unique_ptr<ErosionStage> erosion;
+                std::unique_ptr<FreeRunningPipeline> pipe;
+                GeneratorData gd;
+            };
+            std::vector<lane> lanes(S);
+            for (lane &l : lanes) {
+                check(nz_ctx_create(0, &l.c), "nz_ctx_create");
+                l.a.reset(new DeviceTile(l.c, (size_t)res * res));
+                l.b.reset(new DeviceTile(l.c, (size_t)res * res));
+                l.noise.reset(new NoiseStage(l.c));
+                l.noise->noiseType = FractalNoise::Simplex;
+                l.noise->hurst = 0.4f;
+                l.noise->octaves = 13;
+                l.noise->noiseSize = 1700;
+                l.gauss.reset(new KernelFilterStage(l.c));
+                l.gauss->filter = NZ_GAUSS5_S1;
+                l.gauss->iterations = 17;
+                l.flow.reset(new FlowMapStage(l.c));
+                l.flow->iterations = 5;
+                l.flow->normMin = 0.0f;
+                l.flow->normMax = 0.005f;
+                l.erosion.reset(new ErosionStage(l.c));
+                l.erosion->iterations = 5;
+                l.pipe.reset(new FreeRunningPipeline({l.noise.get(), l.gauss.get(), l.flow.get(), l.erosion.get()}));
+                l.gd.uuid = "tile";
+                l.gd.data = l.a.get();
+                l.gd.write = l.b.get();
+                l.gd.resolution = res;
+            }
+            auto pass = [&](int n, int x0) {
+                for (int k = 0; k < n; k++) {
+                    lane &l = lanes[k % S];
+                    l.gd.xpos = x0 + res * k;  // a different tile of the world each time
+                    l.pipe->Schedule(PipelineWorkItem{&l.gd, nullptr, nullptr, JobHandle(), nullptr});
+                    l.pipe->Release();
+                }
+            };
+            pass(3 * S, 7);
+            for (lane &l : lanes) check(nz_ctx_synchronize(l.c), "nz_ctx_synchronize");
+            const auto t0 = std::chrono::steady_clock::now();
+            pass(T, 0);
+            const auto t1 = std::chrono::steady_clock::now();
+            for (lane &l : lanes) check(nz_ctx_synchronize(l.c), "nz_ctx_synchronize");
+            const auto t2 = std::chrono::steady_clock::now();
+            const double dt = std::chrono::duration<double>(t2 - t0).count(), host = std::chrono::duration<double>(t1 - t0).count();
+            std::printf("res %5d  pipelines %2d: %9.1f tiles/s  %9.0f Mcells/s  (%.3f ms per tile, host enqueue %.4f ms per tile)\n", res, S,
+                        T / dt, (double)T * res * res / dt / 1e6, dt / T * 1e3, host / T * 1e3);
+            // the last tile of pipeline 0, for the caller to check
+            std::vector<float> host_plane((size_t)res * res);
+            lanes[0].gd.data->CopyTo(host_plane.data());
+            FILE *f = std::fopen(argv[2], "wb");
+            if (!f) throw std::runtime_error("cannot open output");
+            std::fwrite(host_plane.data(), sizeof(float), host_plane.size(), f);
+            std::fclose(f);
+            for (lane &l : lanes) {
+                l.pipe->Destroy();
+                l.a.reset();
+                l.b.reset();
+                nz_ctx_destroy(l.c);
+            }
         } else if (reduce) {
             DeviceTile tile(ctx, (size_t)res * res);
             NoiseStage nl(ctx), nr(ctx);

@@ -404,6 +404,10 @@ def test_cpp_host_mirror_runs_the_metric_pipeline(oracle, tmp_path):
     for c in range(cycles):
         L.cycle(0, particles, 11 * c + 3, water_steps=5, thermal=(st.TALUS, st.THERMAL_STEP, 2.0, st.THERMAL_CYCLES))
     assert np.array_equal(got[0], L.height) and np.array_equal(got[1], L.pool) and np.array_equal(got[2], L.flow)
+    # free-running pipelines of the C++ mirror (what tools/bench_tiles.py does in Python): 3 pipelines on 3 contexts take 11
+    # tiles of 160^2 in turn, nobody waits until the end; the file holds pipeline 0's last tile (tile 9, xpos 160 * 9)
+    subprocess.check_call([exe, "160", out, "tiles", "3", "11"], stdout=subprocess.DEVNULL)
+    assert np.array_equal(np.fromfile(out, dtype=np.float32).reshape(160, 160), oracle.pipeline(160, 160, xpos=160 * 9))
     # batched stage bodies from the C++ mirror: 3 tiles of 96^2 at (k * 96, -3 k)
     subprocess.check_call([exe, "96", out, "batch", "3"])
     got = np.fromfile(out, dtype=np.float32).reshape(3, 96, 96)
