@@ -406,7 +406,10 @@ int32_t nz_process_beyer_erosive_events(nz_ctx *ctx, float *height, float *pool,
                                         nz_erosive_events *events, const nz_erosion_params *ep,
                                         const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out);
 /* ErodeHeightMaps.ScheduleRun(height, erosions, ep, tm, res, deps), :459-479: applies the events of the LAST
- * nz_process_beyer_erosive_events on `events` (in place on `height`) */
+ * nz_process_beyer_erosive_events on `events` (in place on `height`).  The PileSolver events of all four block colours run as
+ * ONE launch whose busy blocks wait for their lower-coloured busy neighbours (NZ_PILE_TICKET=0: a launch per colour); that
+ * wait is bounded -- a block that gives up makes the context's next wait / synchronisation return NZ_ERR_HIP, the height
+ * plane is then invalid */
 int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *events, const nz_erosion_params *ep,
                              const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out);
 /* PoolAutomataJob.Schedule(pool, height, particleQueue, ep, tm, iterations, res, drainParticles, deps), :289-325:
