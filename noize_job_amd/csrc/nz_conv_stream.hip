@@ -245,9 +245,9 @@ int32_t launch_stream(hipStream_t s, const float *src, float *dst, const nz_geom
     const int aligned = (bits & 7) == 0;
     const dim3 grid((unsigned)(nstrips * nseg), g.count);
     if (k.factor == 1.0f)
-        hipLaunchKernelGGL((conv_stream_kernel<KS, T, true>), grid, dim3(64), 0, s, src, dst, g, k, S, nstrips, aligned);
+        NZ_LAUNCH((conv_stream_kernel<KS, T, true>), grid, dim3(64), 0, s, src, dst, g, k, S, nstrips, aligned);
     else
-        hipLaunchKernelGGL((conv_stream_kernel<KS, T, false>), grid, dim3(64), 0, s, src, dst, g, k, S, nstrips, aligned);
+        NZ_LAUNCH((conv_stream_kernel<KS, T, false>), grid, dim3(64), 0, s, src, dst, g, k, S, nstrips, aligned);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

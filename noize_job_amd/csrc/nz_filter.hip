@@ -702,10 +702,10 @@ int32_t launch_wide_nt(hipStream_t s, const float *src, float *dst, const nz_geo
     long long blocks = (long long)((g.cols + WD_W - 1) / WD_W) * ((g.or1 - g.or0 + WD_H - 1) / WD_H);
     int aligned = (g.pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     if (k.factor == 1.0f)
-        hipLaunchKernelGGL((conv_wide_kernel<O, true, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k,
+        NZ_LAUNCH((conv_wide_kernel<O, true, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k,
                            aligned);
     else
-        hipLaunchKernelGGL((conv_wide_kernel<O, false, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k,
+        NZ_LAUNCH((conv_wide_kernel<O, false, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k,
                            aligned);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
@@ -755,9 +755,9 @@ int32_t launch_fused_nt(hipStream_t s, const float *src, float *dst, const nz_ge
     long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
     int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
     if (k.factor == 1.0f)
-        hipLaunchKernelGGL((conv_reg_kernel<KS, true, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
+        NZ_LAUNCH((conv_reg_kernel<KS, true, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
     else
-        hipLaunchKernelGGL((conv_reg_kernel<KS, false, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
+        NZ_LAUNCH((conv_reg_kernel<KS, false, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -798,9 +798,9 @@ int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_ge
     ch.err_host = err_host;
     int aligned = ((reinterpret_cast<uintptr_t>(plane0) | reinterpret_cast<uintptr_t>(plane1) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
     if (k.factor == 1.0f)
-        hipLaunchKernelGGL((conv_chain_kernel<KS, true, NT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned);
+        NZ_LAUNCH((conv_chain_kernel<KS, true, NT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned);
     else
-        hipLaunchKernelGGL((conv_chain_kernel<KS, false, NT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned);
+        NZ_LAUNCH((conv_chain_kernel<KS, false, NT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -934,14 +934,14 @@ int32_t nz_launch_erosion_fused(hipStream_t s, const float *src, float *dst, con
     long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
     int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
     switch (E) {
-        case 1: hipLaunchKernelGGL((erosion_reg_kernel<1>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
-        case 2: hipLaunchKernelGGL((erosion_reg_kernel<2>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
-        case 3: hipLaunchKernelGGL((erosion_reg_kernel<3>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
-        case 4: hipLaunchKernelGGL((erosion_reg_kernel<4>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
-        case 5: hipLaunchKernelGGL((erosion_reg_kernel<5>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
-        case 6: hipLaunchKernelGGL((erosion_reg_kernel<6>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
-        case 7: hipLaunchKernelGGL((erosion_reg_kernel<7>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
-        default: hipLaunchKernelGGL((erosion_reg_kernel<8>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 1: NZ_LAUNCH((erosion_reg_kernel<1>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 2: NZ_LAUNCH((erosion_reg_kernel<2>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 3: NZ_LAUNCH((erosion_reg_kernel<3>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 4: NZ_LAUNCH((erosion_reg_kernel<4>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 5: NZ_LAUNCH((erosion_reg_kernel<5>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 6: NZ_LAUNCH((erosion_reg_kernel<6>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        case 7: NZ_LAUNCH((erosion_reg_kernel<7>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
+        default: NZ_LAUNCH((erosion_reg_kernel<8>), dim3((unsigned)blocks, g.count), dim3(CT), 0, s, src, dst, g, aligned); break;
     }
     NZ_HIP(hipGetLastError());
     return NZ_OK;

@@ -433,11 +433,11 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
 #define NZ_FF(F, L)                                                                                                  \
     do {                                                                                                             \
         if (occ >= 4)                                                                                                \
-            hipLaunchKernelGGL((flow_fused_kernel<F, L, NZ_FT_OCC>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, \
+            NZ_LAUNCH((flow_fused_kernel<F, L, NZ_FT_OCC>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, \
                                fN_in, fS_in, fE_in, fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n,   \
                                nmin, nrange, aligned);                                                                     \
         else                                                                                                         \
-            hipLaunchKernelGGL((flow_fused_kernel<F, L, 2>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, \
+            NZ_LAUNCH((flow_fused_kernel<F, L, 2>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, \
                                fN_in, fS_in, fE_in, fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n,   \
                                nmin, nrange, aligned);                                                                     \
     } while (0)

@@ -463,8 +463,8 @@ int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const n
     const dim3 grid((unsigned)nblocks, g.count);
 #define NZ_FS(N)                                                                                                                        \
     do {                                                                                                                                \
-        if (NC == 1) hipLaunchKernelGGL((flow_stream_kernel<N, 1>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned); \
-        else hipLaunchKernelGGL((flow_stream_kernel<N, 2>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned);         \
+        if (NC == 1) NZ_LAUNCH((flow_stream_kernel<N, 1>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned); \
+        else NZ_LAUNCH((flow_stream_kernel<N, 2>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned);         \
     } while (0)
     switch (n) {
         case 1: NZ_FS(1); break;

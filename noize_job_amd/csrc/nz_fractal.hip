@@ -923,7 +923,7 @@ int32_t launch_basis(hipStream_t s, float *dst, int rows, int cols, int pitch, c
         nz_set_error("fractal grid too large");
         return NZ_ERR_INVALID;
     }
-    hipLaunchKernelGGL((fractal_kernel<BASIS, VEC>), dim3((unsigned)blocks, count), dim3(FR_THREADS), 0, s, dst, rows,
+    NZ_LAUNCH((fractal_kernel<BASIS, VEC>), dim3((unsigned)blocks, count), dim3(FR_THREADS), 0, s, dst, rows,
                        cols, pitch, bpr, p, reinterpret_cast<const float2 *>(d_rgrad));
     NZ_HIP(hipGetLastError());
     return NZ_OK;
@@ -957,7 +957,7 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         long long blocks = (long long)bpr * ((rows + p.rows_per_wg - 1) / p.rows_per_wg);
         const int *t1 = reinterpret_cast<const int *>(d_simplex);
         const float4 *t2 = reinterpret_cast<const float4 *>(t1 + NZ_T1_N);
-        hipLaunchKernelGGL((fractal_simplex_tab_kernel<VEC>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows, cols,
+        NZ_LAUNCH((fractal_simplex_tab_kernel<VEC>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows, cols,
                            pitch, bpr, p, t1, t2);
         NZ_HIP(hipGetLastError());
         return NZ_OK;
@@ -978,13 +978,13 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
             constexpr int V = NZ_TAB2_VEC_PERLIN;
             int bpr = (cols + 256 * V - 1) / (256 * V);
             long long blocks = (long long)bpr * ((rows + p.rows_per_wg - 1) / p.rows_per_wg);
-            hipLaunchKernelGGL((fractal_tab2_kernel<NZ_NOISE_PERLIN, V>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows,
+            NZ_LAUNCH((fractal_tab2_kernel<NZ_NOISE_PERLIN, V>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows,
                                cols, pitch, bpr, p, t1, t2);
         } else {
             constexpr int V = NZ_TAB2_VEC_CELLULAR;
             int bpr = (cols + 256 * V - 1) / (256 * V);
             long long blocks = (long long)bpr * ((rows + p.rows_per_wg - 1) / p.rows_per_wg);
-            hipLaunchKernelGGL((fractal_tab2_kernel<NZ_NOISE_CELLULAR, V>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst,
+            NZ_LAUNCH((fractal_tab2_kernel<NZ_NOISE_CELLULAR, V>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst,
                                rows, cols, pitch, bpr, p, t1, t2);
         }
         NZ_HIP(hipGetLastError());
@@ -1003,10 +1003,10 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         int bpr = (cols + 256 * V3 - 1) / (256 * V3);
         long long blocks = (long long)bpr * ((rows + p.rows_per_wg - 1) / p.rows_per_wg);
         if (noiseType == NZ_NOISE_DOMAIN_ROTATED_PERLIN)
-            hipLaunchKernelGGL((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_PERLIN, V3>), dim3((unsigned)blocks, count), dim3(256), 0,
+            NZ_LAUNCH((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_PERLIN, V3>), dim3((unsigned)blocks, count), dim3(256), 0,
                                s, dst, rows, cols, pitch, bpr, p, p3, g3);
         else
-            hipLaunchKernelGGL((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_SIMPLEX, V3>), dim3((unsigned)blocks, count), dim3(256), 0,
+            NZ_LAUNCH((fractal_tab3_kernel<NZ_NOISE_DOMAIN_ROTATED_SIMPLEX, V3>), dim3((unsigned)blocks, count), dim3(256), 0,
                                s, dst, rows, cols, pitch, bpr, p, p3, g3 + NZ_G3_N);
         NZ_HIP(hipGetLastError());
         return NZ_OK;

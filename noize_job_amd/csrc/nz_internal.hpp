@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -60,6 +61,8 @@ struct nz_ctx {
     unsigned *chain_err = nullptr, *chain_err_dev = nullptr;  // the error word in mapped host memory, and its device address
     unsigned chain_epoch = 0;
     bool chain_off = false;  // a chained launch once timed out on this context: separate launches from then on
+    bool handle_rides = false;    // this entry's handle may ride on its last kernel launch (nz_ctx_handle_rides)
+    uint64_t armed_seq = 0;       // ... and this is the sequence number reserved for it (nz_ctx_arm_last_launch)
     // striped pipeline (nz_terrain_pipeline): a second stream with its fork / join markers and the stripes' planes, all
     // created on first use
     hipStream_t aux = nullptr;
@@ -160,6 +163,28 @@ inline nz_geom nz_geom_from_stripe(const nz_stripe &s) {
 }
 
 inline nz_geom nz_geom_tile(int res) { return nz_geom{res, res, res, 0, res - 1, 0, res}; }
+
+// ---- handles that ride on a launch --------------------------------------------------------------------------------------
+// A JobHandle used to be a hipEventRecord behind the entry's work: a barrier packet of its own, ~2.8 us of the stream.  A
+// kernel launch can carry the event instead (hipExtLaunchKernelGGL's stop event: the dispatch's own completion signal,
+// tools/probe_write_value.hip measures no cost at all).  An entry whose LAST enqueued operation is the last launch of a
+// helper says so (nz_ctx_handle_rides); the helper arms the launch it knows to be its last (nz_ctx_arm_last_launch); that
+// launch -- NZ_LAUNCH instead of hipLaunchKernelGGL -- takes the event; nz_ctx_finish hands out the handle, or records an
+// event the old way when nothing took it.  nz_ctx_begin disarms whatever an entry that failed left behind.
+// NZ_HANDLE_ON_LAUNCH=0: always the old way.
+extern thread_local hipEvent_t nz_tls_stop_event;
+#define NZ_LAUNCH(kernel, grid, block, lds, stream, ...)                                                  \
+    do {                                                                                                   \
+        if (nz_tls_stop_event) {                                                                           \
+            hipEvent_t nz_stop_ = nz_tls_stop_event;                                                       \
+            nz_tls_stop_event = nullptr;                                                                   \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, nz_stop_, 0, __VA_ARGS__);    \
+        } else {                                                                                           \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                             \
+        }                                                                                                  \
+    } while (0)
+void nz_ctx_handle_rides(nz_ctx *ctx, bool wanted);
+void nz_ctx_arm_last_launch(nz_ctx *ctx);
 
 // every stage launch goes through here: one place that knows which stream a context's work runs on
 template <class F>

@@ -313,8 +313,33 @@ static hipEvent_t event_for(nz_ctx *owner, uint64_t q) {
     return owner->last_seq ? owner->events[owner->last_seq % NZ_EVENT_RING] : nullptr;
 }
 
+thread_local hipEvent_t nz_tls_stop_event = nullptr;
+
+void nz_ctx_handle_rides(nz_ctx *ctx, bool wanted) {
+    static const bool enabled = [] { const char *e = getenv("NZ_HANDLE_ON_LAUNCH"); return !e || atoi(e) != 0; }();
+    ctx->handle_rides = wanted && enabled;
+}
+
+void nz_ctx_arm_last_launch(nz_ctx *ctx) {
+    if (!ctx->handle_rides) return;
+    std::lock_guard<std::mutex> lk(ctx->hmx);
+    if (ctx->events.empty()) ctx->events.assign(NZ_EVENT_RING, nullptr);
+    const uint64_t q = ctx->last_seq + 1;
+    if (q >= NZ_HANDLE_SEQ_MASK) return;  // nz_ctx_finish reports it
+    hipEvent_t *ev = &ctx->events[q % NZ_EVENT_RING];
+    if (!*ev && hipEventCreate(ev) != hipSuccess) {
+        *ev = nullptr;
+        return;  // nz_ctx_finish records the old way and reports what fails
+    }
+    nz_tls_stop_event = *ev;
+    ctx->armed_seq = q;
+}
+
 int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep) {
     NZ_REQUIRE(ctx, "ctx is NULL");
+    nz_tls_stop_event = nullptr;  // (an entry that failed between arming and finishing)
+    ctx->armed_seq = 0;
+    ctx->handle_rides = false;
     NZ_HIP(hipSetDevice(ctx->device));
     if (dep == 0) return NZ_OK;  // default(JobHandle)
     if (handle_ctx_id(dep) == ctx->id) {
@@ -335,8 +360,19 @@ int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep) {
 }
 
 int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out) {
+    // the entry's last launch took the event with it: the handle is that launch's completion
+    const uint64_t armed = ctx->armed_seq;
+    const bool rode = armed != 0 && nz_tls_stop_event == nullptr;
+    nz_tls_stop_event = nullptr;
+    ctx->armed_seq = 0;
+    ctx->handle_rides = false;
     if (!out) return NZ_OK;
     std::lock_guard<std::mutex> lk(ctx->hmx);
+    if (rode && armed == ctx->last_seq + 1) {
+        ctx->last_seq = armed;
+        *out = ((uint64_t)ctx->id << NZ_HANDLE_SEQ_BITS) | armed;
+        return NZ_OK;
+    }
     if (ctx->events.empty()) ctx->events.assign(NZ_EVENT_RING, nullptr);
     uint64_t q = ctx->last_seq + 1;
     NZ_REQUIRE(q < NZ_HANDLE_SEQ_MASK, "handle sequence exhausted");

@@ -187,6 +187,8 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     if (nz_conv_has_wide(t.ksize)) {  // one launch per application, ping-pong, copy back after an odd count
         float *cur = src, *other = tmp;
         for (int i = 0; i < iterations; i++) {
+            // (a READ / WRITE pair ends with this launch -- odd count or not, nothing is copied back: see below)
+            if (swapped && i == iterations - 1) nz_ctx_arm_last_launch(ctx);
             NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
                 return nz_launch_conv_wide(st, cur, other, gb, t);
             }));
@@ -203,6 +205,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         return NZ_OK;
     }
     if (cap > 0 && iterations == 1) {  // the delegate's single application: one launch into tmp, copy back
+        if (swapped) nz_ctx_arm_last_launch(ctx);
         NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_conv_fused(st, src, tmp, gb, t, 1);
         }));
@@ -260,6 +263,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         int *flags = nullptr;
         unsigned *ctl = nullptr, epoch = 0, *err_host = nullptr;
         NZ_TRY_(nz_ctx_chain_state(ctx, (size_t)nz_conv_chain_items(t.ksize, g, Ts, L), &flags, &ctl, &epoch, &err_host));
+        nz_ctx_arm_last_launch(ctx);  // (one launch; no copy follows in either form: an even count or a pair)
         NZ_TRY_(nz_launch_conv_chain(ctx->stream, src, tmp, g, t, Ts, L, flags, ctl, epoch, err_host));
         if (swapped) *swapped = (L & 1) != 0;
         return NZ_OK;
@@ -267,6 +271,8 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
         int T = base + (i < rem ? 1 : 0);
+        // the last launch is the stage's last operation unless a copy back follows (single plane, odd count)
+        if (i == L - 1 && (swapped || !(L & 1))) nz_ctx_arm_last_launch(ctx);
         int32_t rc = launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_conv_fused(st, cur, other, gb, t, T);
         });
@@ -314,6 +320,7 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
     float *cur = src, *other = tmp;
     for (int i = 0; i < L; i++) {
         int E = base + (i < rem ? 1 : 0);
+        if (i == L - 1 && (swapped || !(L & 1))) nz_ctx_arm_last_launch(ctx);  // no copy back follows
         int32_t rc = launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_erosion_fused(st, cur, other, gb, E);
         });
@@ -361,6 +368,8 @@ extern "C" int32_t nz_fractal(nz_ctx *ctx, int32_t noiseType, float *src, int32_
                               int32_t xpos, int32_t zpos, int32_t noiseSize, nz_handle dep, nz_handle *out) {
     NZ_BEGIN(ctx, dep);
     NZ_TRY(check_res(resolution));
+    nz_ctx_handle_rides(ctx, out != nullptr);  // one launch, and nothing behind it: the handle rides on it
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(fractal_impl(ctx, ctx->stream, noiseType, src, resolution, resolution, resolution, hurst, startingAmplitude,
                         stepdown, detuneRate, octaves, xpos, zpos, noiseSize));
     return nz_ctx_finish(ctx, out);
@@ -419,6 +428,7 @@ extern "C" int32_t nz_kernel_filter_stage(nz_ctx *ctx, float *src, float *tmp, i
     }
     nz_kernel_taps t;
     NZ_TRY(filter_taps(filter, &t));
+    nz_ctx_handle_rides(ctx, out != nullptr);  // (conv_iterations arms its last launch unless a copy back follows it)
     NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_tile(resolution), t, iterations));
     return nz_ctx_finish(ctx, out);
 }
@@ -455,6 +465,7 @@ extern "C" int32_t nz_gauss_blur_stage(nz_ctx *ctx, float *src, float *tmp, int3
     NZ_TRY(check_res(resolution));
     nz_kernel_taps t;
     NZ_TRY(gauss_taps(width, sigma, &t));
+    nz_ctx_handle_rides(ctx, out != nullptr);  // (conv_iterations arms its last launch unless a copy back follows it)
     NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_tile(resolution), t, iterations));
     return nz_ctx_finish(ctx, out);
 }
@@ -470,6 +481,7 @@ extern "C" int32_t nz_smooth_blur_stage(nz_ctx *ctx, float *src, float *tmp, int
     NZ_TRY(check_res(resolution));
     nz_kernel_taps t;
     NZ_TRY(smooth_taps(width, &t));
+    nz_ctx_handle_rides(ctx, out != nullptr);  // (conv_iterations arms its last launch unless a copy back follows it)
     NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_tile(resolution), t, iterations));
     return nz_ctx_finish(ctx, out);
 }
@@ -501,6 +513,7 @@ extern "C" int32_t nz_erosion_stage(nz_ctx *ctx, float *src, float *tmp, int32_t
                                     nz_handle dep, nz_handle *out) {
     NZ_BEGIN(ctx, dep);
     NZ_TRY(check_res(resolution));
+    nz_ctx_handle_rides(ctx, out != nullptr);  // (as conv_iterations)
     NZ_TRY(erosion_iterations(ctx, src, tmp, nz_geom_tile(resolution), iterations));
     return nz_ctx_finish(ctx, out);
 }
@@ -732,6 +745,8 @@ extern "C" int32_t nz_fractal_batch(nz_ctx *ctx, int32_t noiseType, float *data,
     NZ_BEGIN(ctx, dep);
     NZ_TRY(check_batch(resolution, count));
     NZ_REQUIRE(positions, "positions is NULL");
+    nz_ctx_handle_rides(ctx, out != nullptr);
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(fractal_impl(ctx, ctx->stream, noiseType, data, resolution, resolution, resolution, hurst, startingAmplitude,
                         stepdown, detuneRate, octaves, 0, 0, noiseSize, count, (size_t)resolution * resolution, positions));
     return nz_ctx_finish(ctx, out);
@@ -743,6 +758,7 @@ extern "C" int32_t nz_kernel_filter_stage_batch(nz_ctx *ctx, float *src, float *
     NZ_TRY(check_batch(resolution, count));
     nz_kernel_taps t;
     NZ_TRY(filter_taps(filter, &t));
+    nz_ctx_handle_rides(ctx, out != nullptr);  // (conv_iterations arms its last launch unless a copy back follows it)
     NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_batch(resolution, count), t, iterations));
     return nz_ctx_finish(ctx, out);
 }
@@ -754,6 +770,7 @@ extern "C" int32_t nz_gauss_blur_stage_batch(nz_ctx *ctx, float *src, float *tmp
     NZ_TRY(check_batch(resolution, count));
     nz_kernel_taps t;
     NZ_TRY(gauss_taps(width, sigma, &t));
+    nz_ctx_handle_rides(ctx, out != nullptr);  // (conv_iterations arms its last launch unless a copy back follows it)
     NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_batch(resolution, count), t, iterations));
     return nz_ctx_finish(ctx, out);
 }
@@ -764,6 +781,7 @@ extern "C" int32_t nz_smooth_blur_stage_batch(nz_ctx *ctx, float *src, float *tm
     NZ_TRY(check_batch(resolution, count));
     nz_kernel_taps t;
     NZ_TRY(smooth_taps(width, &t));
+    nz_ctx_handle_rides(ctx, out != nullptr);  // (conv_iterations arms its last launch unless a copy back follows it)
     NZ_TRY(conv_iterations(ctx, src, tmp, nz_geom_batch(resolution, count), t, iterations));
     return nz_ctx_finish(ctx, out);
 }
@@ -772,6 +790,7 @@ extern "C" int32_t nz_erosion_stage_batch(nz_ctx *ctx, float *src, float *tmp, i
                                           int32_t count, nz_handle dep, nz_handle *out) {
     NZ_BEGIN(ctx, dep);
     NZ_TRY(check_batch(resolution, count));
+    nz_ctx_handle_rides(ctx, out != nullptr);  // (as conv_iterations)
     NZ_TRY(erosion_iterations(ctx, src, tmp, nz_geom_batch(resolution, count), iterations));
     return nz_ctx_finish(ctx, out);
 }
@@ -805,6 +824,7 @@ static void rw_swap(nz_rw_tile *t, bool swapped) {
 
 static int32_t conv_rw(nz_ctx *ctx, nz_rw_tile *tile, const nz_kernel_taps &t, int32_t iterations, nz_handle *out) {
     bool swapped = false;
+    nz_ctx_handle_rides(ctx, out != nullptr);  // conv_iterations' last launch is this entry's last operation
     NZ_TRY(conv_iterations(ctx, tile->read, tile->write, rw_geom(tile), t, iterations, &swapped));
     rw_swap(tile, swapped);
     return nz_ctx_finish(ctx, out);
@@ -843,6 +863,7 @@ extern "C" int32_t nz_erosion_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, int32_t it
     NZ_BEGIN(ctx, dep);
     NZ_TRY(check_rw(tile));
     bool swapped = false;
+    nz_ctx_handle_rides(ctx, out != nullptr);  // erosion_iterations' last launch is this entry's last operation
     NZ_TRY(erosion_iterations(ctx, tile->read, tile->write, rw_geom(tile), iterations, &swapped));
     rw_swap(tile, swapped);
     return nz_ctx_finish(ctx, out);
@@ -873,6 +894,10 @@ extern "C" int32_t nz_flowmap_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, float *wor
     for (int i = 0; i < launches; i++) {
         int nit = base + (i < rem ? 1 : 0);
         int first = i == 0, last = i == launches - 1;
+        if (last) {  // the stage's last operation: its handle rides on this launch
+            nz_ctx_handle_rides(ctx, out != nullptr);
+            nz_ctx_arm_last_launch(ctx);
+        }
         NZ_TRY(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_flow_fused(st, tile->read, first ? nullptr : cur, last ? nullptr : nxt,
                                         last ? tile->write : nullptr, nullptr, gb, nit, first, last, normMin,

@@ -50,6 +50,41 @@ def test_dependency_on_another_contexts_handle_orders_the_streams(nj, ctx, oracl
         plane.Dispose()
 
 
+def test_handles_that_ride_on_a_launch_complete_with_it(nj, oracle):
+    # The stage entries of the metric pipeline hand out handles that ride on their last kernel launch (no event record of
+    # their own).  Producer (context A): noise -> Gauss5 x17 -> flow x5 -> erosion x5 on a READ / WRITE pair, ~0.2 ms of GPU
+    # work at 2048^2; consumer (context B): a copy of the result plane, enqueued at once with the LAST stage's handle as
+    # its dependency and no host wait in between -- a handle that completed before its kernel would copy a half-made plane.
+    # Then the same with the filter stage's handle and a copy of what the filter left.
+    res = 2048
+    want = oracle.pipeline(res, res, octaves=6, noise_size=500, xpos=11, zpos=-7)
+    want_f = oracle.kernel_filter(oracle.fractal(oracle.SIMPLEX, res, res, 0.4, 1.0, 2.0, 0.0, 6, 11, -7, 500), 2, 17)
+    with nj.Context(0) as a, nj.Context(0) as b:
+        p0, p1, snap = a.alloc(res * res), a.alloc(res * res), b.alloc(res * res)
+        stages = [nj.NoiseStage(a, nj.FractalNoise.Simplex, 0.4, 1.0, 6, 2.0, 0.0, 500),
+                  nj.KernelFilterStage(a, nj.KernelFilterType.Gauss5_S1, 17), nj.FlowMapStage(a, 5, 0.0, 0.005),
+                  nj.ErosionStage(a, 5)]
+        for upto, expect in ((4, want), (2, want_f)):
+            for rep in range(4):  # repeated: a race would not lose every time
+                b.call("nz_fill_array", snap.ptr, res, float("nan"))
+                b.synchronize()
+                d = nj.GeneratorData("x", p0, res, 11, -7, write=p1)
+                h = nj.JobHandle()
+                for st in stages[:upto]:
+                    st.Schedule(nj.PipelineWorkItem(d), h)
+                    h = st.jobHandle
+                assert h.id != 0
+                done = b.call("nz_flush_write_slice", snap.ptr, d.data.ptr, res * res, dep=h)
+                done.Complete()
+                assert h.IsCompleted
+                assert np.array_equal(snap.ToArray((res, res)), expect), (upto, rep)
+                assert a.elapsed_ms(stages[0].jobHandle, h) > 0.0  # the riding events carry time stamps like recorded ones
+        for st in stages:
+            st.OnDestroy()
+        for t in (p0, p1, snap):
+            t.Dispose()
+
+
 def test_reduce_pipeline_joins_two_contexts_on_the_device(nj, ctx, oracle):
     # ReducePipeline.cs:82-148 with the two upstream pipelines on their own contexts (streams) and the reduce stages
     # on a third: deviceJoin schedules the reduce stages behind CombineDependencies(left, right) -- no host wait
