@@ -899,8 +899,8 @@ unsigned blocks_for(size_t n) { return (unsigned)((n + (size_t)CT * 4 - 1) / ((s
 int32_t nz_launch_constant(hipStream_t s, int op, float *data, size_t n, float c) {
     if (n == 0) return NZ_OK;
     int aligned = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
-    if (op == 0) hipLaunchKernelGGL(constant_kernel<0>, dim3(blocks_for(n)), dim3(CT), 0, s, data, n, c, aligned);
-    else if (op == 1) hipLaunchKernelGGL(constant_kernel<1>, dim3(blocks_for(n)), dim3(CT), 0, s, data, n, c, aligned);
+    if (op == 0) NZ_LAUNCH(constant_kernel<0>, dim3(blocks_for(n)), dim3(CT), 0, s, data, n, c, aligned);
+    else if (op == 1) NZ_LAUNCH(constant_kernel<1>, dim3(blocks_for(n)), dim3(CT), 0, s, data, n, c, aligned);
     else {
         nz_set_error("unknown ConstantOperationType %d", op);
         return NZ_ERR_INVALID;
@@ -914,11 +914,11 @@ int32_t nz_launch_reduce(hipStream_t s, int op, float *l, const float *r, size_t
     int aligned = ((reinterpret_cast<uintptr_t>(l) | reinterpret_cast<uintptr_t>(r)) & 15) == 0;
     dim3 grid(blocks_for(n)), block(CT);
     switch (op) {
-        case 0: hipLaunchKernelGGL(reduce_kernel<0>, grid, block, 0, s, l, r, n, aligned); break;
-        case 1: hipLaunchKernelGGL(reduce_kernel<1>, grid, block, 0, s, l, r, n, aligned); break;
-        case 2: hipLaunchKernelGGL(reduce_kernel<2>, grid, block, 0, s, l, r, n, aligned); break;
-        case 3: hipLaunchKernelGGL(reduce_kernel<3>, grid, block, 0, s, l, r, n, aligned); break;
-        case 4: hipLaunchKernelGGL(reduce_kernel<4>, grid, block, 0, s, l, r, n, aligned); break;
+        case 0: NZ_LAUNCH(reduce_kernel<0>, grid, block, 0, s, l, r, n, aligned); break;
+        case 1: NZ_LAUNCH(reduce_kernel<1>, grid, block, 0, s, l, r, n, aligned); break;
+        case 2: NZ_LAUNCH(reduce_kernel<2>, grid, block, 0, s, l, r, n, aligned); break;
+        case 3: NZ_LAUNCH(reduce_kernel<3>, grid, block, 0, s, l, r, n, aligned); break;
+        case 4: NZ_LAUNCH(reduce_kernel<4>, grid, block, 0, s, l, r, n, aligned); break;
         default: nz_set_error("unknown ReductionType %d", op); return NZ_ERR_INVALID;
     }
     NZ_HIP(hipGetLastError());
@@ -928,7 +928,7 @@ int32_t nz_launch_reduce(hipStream_t s, int op, float *l, const float *r, size_t
 int32_t nz_launch_curve(hipStream_t s, float *data, size_t n, const float *curve, int curveSize) {
     if (n == 0) return NZ_OK;
     int aligned = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
-    hipLaunchKernelGGL(curve_kernel, dim3(blocks_for(n)), dim3(CT), (size_t)curveSize * sizeof(float), s, data, n, curve,
+    NZ_LAUNCH(curve_kernel, dim3(blocks_for(n)), dim3(CT), (size_t)curveSize * sizeof(float), s, data, n, curve,
                        curveSize, aligned);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
@@ -1057,7 +1057,7 @@ int32_t nz_launch_map_range(hipStream_t s, const float *map, size_t n, float lim
 int32_t nz_launch_normalize_args(hipStream_t s, float *data, size_t n, const float *args) {
     if (n == 0) return NZ_OK;
     const int vec = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
-    hipLaunchKernelGGL(normalize_args_kernel, dim3((unsigned)(((n + 3) / 4 + CT - 1) / CT)), dim3(CT), 0, s, data, n, vec, args);
+    NZ_LAUNCH(normalize_args_kernel, dim3((unsigned)(((n + 3) / 4 + CT - 1) / CT)), dim3(CT), 0, s, data, n, vec, args);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -1078,7 +1078,7 @@ int32_t nz_launch_range_compose(hipStream_t s, const float *lo, const float *hi,
 int32_t nz_launch_crop(hipStream_t s, const float *in, int in_res, float *out, int out_res) {
     if (out_res <= 0) return NZ_OK;
     dim3 grid((out_res + CT - 1) / CT, out_res);
-    hipLaunchKernelGGL(crop_kernel, grid, dim3(CT), 0, s, in, in_res, out, out_res, 0);
+    NZ_LAUNCH(crop_kernel, grid, dim3(CT), 0, s, in, in_res, out, out_res, 0);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -1094,7 +1094,7 @@ int32_t nz_launch_thermal_pair(hipStream_t s, float *data, int resolution, int z
         NZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(thermal_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // a row pair of 2 x resolution cells per workgroup: enough threads to keep the loads of a 64 KB pair in flight
     const int nt = resolution >= 8192 ? 1024 : (resolution >= 2048 ? 512 : 256);
-    hipLaunchKernelGGL(thermal_pair_kernel, dim3((unsigned)jobs), dim3(nt), lds, s, data, resolution, zodd, maxDiff, increment, vec);
+    NZ_LAUNCH(thermal_pair_kernel, dim3((unsigned)jobs), dim3(nt), lds, s, data, resolution, zodd, maxDiff, increment, vec);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -1105,7 +1105,7 @@ int32_t nz_launch_thermal_phase(hipStream_t s, float *data, int resolution, int 
     int per_row = (resolution - 1) / 2;  // upper bound on the blocks of a row
     if (per_row <= 0) return NZ_OK;
     dim3 grid((per_row + CT - 1) / CT, jobs);
-    hipLaunchKernelGGL(thermal_phase_kernel, grid, dim3(CT), 0, s, data, resolution, flip, maxDiff, increment);
+    NZ_LAUNCH(thermal_phase_kernel, grid, dim3(CT), 0, s, data, resolution, flip, maxDiff, increment);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

@@ -453,7 +453,7 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
 int32_t nz_launch_fill(hipStream_t s, float *data, size_t n, float value) {
     if (n == 0) return NZ_OK;
     size_t blocks = (n + (size_t)CT * 4 - 1) / ((size_t)CT * 4);
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(CT), 0, s, data, n, value);
+    NZ_LAUNCH(fill_kernel, dim3((unsigned)blocks), dim3(CT), 0, s, data, n, value);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -461,7 +461,7 @@ int32_t nz_launch_fill(hipStream_t s, float *data, size_t n, float value) {
 int32_t nz_launch_copy(hipStream_t s, float *dst, const float *src, size_t n) {
     if (n == 0) return NZ_OK;
     size_t blocks = (n + (size_t)CT * 4 - 1) / ((size_t)CT * 4);
-    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(CT), 0, s, dst, src, n);
+    NZ_LAUNCH(copy_kernel, dim3((unsigned)blocks), dim3(CT), 0, s, dst, src, n);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -497,7 +497,7 @@ int32_t nz_launch_velocity(hipStream_t s, float *dst, const float *fN, const flo
 int32_t nz_launch_normalize(hipStream_t s, const float *src, float *dst, size_t n, float nmin, float nrange) {
     if (n == 0) return NZ_OK;
     size_t blocks = (n + CT - 1) / CT;
-    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, n, nmin, nrange);
+    NZ_LAUNCH(normalize_kernel, dim3((unsigned)blocks), dim3(CT), 0, s, src, dst, n, nmin, nrange);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

@@ -223,10 +223,10 @@ int32_t nz_launch_mesh(hipStream_t s, int meshType, void *vertices, uint32_t *in
     NZ_HIP(hipGetLastError());
     size_t nthreads = (ni + 3) / 4;
     if (index16)
-        hipLaunchKernelGGL(mesh_index16_kernel, dim3((unsigned)((nthreads + CT - 1) / CT), count), dim3(CT), 0, s,
+        NZ_LAUNCH(mesh_index16_kernel, dim3((unsigned)((nthreads + CT - 1) / CT), count), dim3(CT), 0, s,
                            reinterpret_cast<uint16_t *>(indices), (uint32_t)res, ni, ni);
     else
-        hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT), count), dim3(CT), 0, s, indices,
+        NZ_LAUNCH(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT), count), dim3(CT), 0, s, indices,
                            (uint32_t)res, mesh_rinv(res), ni, ni);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
@@ -247,7 +247,7 @@ int32_t nz_launch_mesh_planar(hipStream_t s, void *vertices, uint32_t *indices, 
                        reinterpret_cast<float4 *>(vertices), res);
     NZ_HIP(hipGetLastError());
     size_t nthreads = (ni + 3) / 4;
-    hipLaunchKernelGGL(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT)), dim3(CT), 0, s, indices,
+    NZ_LAUNCH(mesh_index_kernel, dim3((unsigned)((nthreads + CT - 1) / CT)), dim3(CT), 0, s, indices,
                        (uint32_t)res, mesh_rinv(res), ni, (size_t)0);
     NZ_HIP(hipGetLastError());
     return NZ_OK;

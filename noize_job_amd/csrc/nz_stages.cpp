@@ -197,6 +197,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         if (cur != src && swapped) {
             *swapped = true;
         } else if (cur != src) {
+            nz_ctx_arm_last_launch(ctx);  // the copy back is the last operation
             NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
                 size_t off = (size_t)gb.or0 * gb.pitch;
                 return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
@@ -213,6 +214,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
             *swapped = true;
             return NZ_OK;
         }
+        nz_ctx_arm_last_launch(ctx);  // the copy back is the last operation
         return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
             return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
@@ -284,6 +286,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         return NZ_OK;
     }
     if (cur != src) {  // odd count (only when cap == 1): copy back
+        nz_ctx_arm_last_launch(ctx);
         return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
             return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
@@ -303,6 +306,7 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
         NZ_TRY_(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_erosion_fused(st, src, tmp, gb, 1);
         }));
+        nz_ctx_arm_last_launch(ctx);  // the copy back is the last operation
         return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
             return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
@@ -331,11 +335,13 @@ static int32_t erosion_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_
         *swapped = true;
         return NZ_OK;
     }
-    if (cur != src)
+    if (cur != src) {
+        nz_ctx_arm_last_launch(ctx);  // the copy back is the last operation
         return launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
             return nz_launch_copy(st, src + off, tmp + off, nz_geom_span(gb));
         });
+    }
     return NZ_OK;
 }
 
@@ -524,6 +530,7 @@ extern "C" int32_t nz_erosion_kernel(nz_ctx *ctx, float *src, int32_t resolution
     // the reference allocates its own TempJob plane (KernelJob.cs:327); here it is ctx scratch
     float *tmp = nullptr;
     NZ_TRY(nz_ctx_scratch(ctx, (size_t)resolution * resolution, &tmp));
+    nz_ctx_handle_rides(ctx, out != nullptr);
     NZ_TRY(erosion_iterations(ctx, src, tmp, nz_geom_tile(resolution), 1));
     return nz_ctx_finish(ctx, out);
 }
@@ -574,6 +581,8 @@ extern "C" int32_t nz_flush_write_slice(nz_ctx *ctx, float *write_, const float 
     NZ_BEGIN(ctx, dep);
     NZ_REQUIRE(write_ && read_, "write/read is NULL");
     NZ_REQUIRE(write_ != read_, "write and read are the same slice");
+    nz_ctx_handle_rides(ctx, out != nullptr);
+    nz_ctx_arm_last_launch(ctx);
     if (n_floats) NZ_TRY(nz_launch_copy(ctx->stream, write_, read_, n_floats));
     return nz_ctx_finish(ctx, out);
 }
@@ -583,6 +592,8 @@ extern "C" int32_t nz_fill_array(nz_ctx *ctx, float *data, int32_t resolution, f
     NZ_BEGIN(ctx, dep);
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(data, "data is NULL");
+    nz_ctx_handle_rides(ctx, out != nullptr);
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(nz_launch_fill(ctx->stream, data, (size_t)resolution * resolution, value));
     return nz_ctx_finish(ctx, out);
 }
@@ -633,6 +644,8 @@ extern "C" int32_t nz_map_normalize_values(nz_ctx *ctx, float *src, float *tmp, 
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(src && args, "src/args is NULL");
     (void)tmp;  // element-wise: done in place, no flush copy
+    nz_ctx_handle_rides(ctx, out != nullptr);  // one launch, nothing behind it
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(nz_launch_normalize(ctx->stream, src, src, (size_t)resolution * resolution, args[0], args[2]));
     return nz_ctx_finish(ctx, out);
 }
@@ -656,6 +669,8 @@ extern "C" int32_t nz_map_normalize_values_dev(nz_ctx *ctx, float *src, float *t
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(src && args, "src/args is NULL");
     (void)tmp;  // element-wise: done in place, no flush copy
+    nz_ctx_handle_rides(ctx, out != nullptr);  // one launch, nothing behind it
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(nz_launch_normalize_args(ctx->stream, src, (size_t)resolution * resolution, args));
     return nz_ctx_finish(ctx, out);
 }
@@ -665,6 +680,8 @@ extern "C" int32_t nz_normalize_cells_dev(nz_ctx *ctx, float *data, size_t n_flo
                                           nz_handle *out) {
     NZ_BEGIN(ctx, dep);
     NZ_REQUIRE(data && args, "data/args is NULL");
+    nz_ctx_handle_rides(ctx, out != nullptr);  // one launch, nothing behind it
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(nz_launch_normalize_args(ctx->stream, data, n_floats, args));
     return nz_ctx_finish(ctx, out);
 }
@@ -704,6 +721,10 @@ static int32_t flowmap_stage_impl(nz_ctx *ctx, float *src, float *work, int32_t 
         int first = i == 0, last = i == launches - 1;
         const float *hsrc = first ? src : hcopy;
         float *dst = !last ? nullptr : (launches == 1 ? hcopy : src);
+        if (last && launches > 1) {  // the stage's last operation (a single launch is followed by the copy back below)
+            nz_ctx_handle_rides(ctx, out != nullptr);
+            nz_ctx_arm_last_launch(ctx);
+        }
         NZ_TRY(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             return nz_launch_flow_fused(st, hsrc, first ? nullptr : cur, last ? nullptr : nxt, dst,
                                         (first && !last) ? hcopy : nullptr, gb, nit, first, last, normMin,
@@ -712,6 +733,8 @@ static int32_t flowmap_stage_impl(nz_ctx *ctx, float *src, float *work, int32_t 
         float **s = cur; cur = nxt; nxt = s;
     }
     if (launches == 1) {
+        nz_ctx_handle_rides(ctx, out != nullptr);
+        nz_ctx_arm_last_launch(ctx);
         NZ_TRY(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
             size_t off = (size_t)gb.or0 * gb.pitch;
             return nz_launch_copy(st, src + off, hcopy + off, nz_geom_span(gb));
@@ -963,6 +986,8 @@ static int32_t heightmap_mesh_impl(nz_ctx *ctx, int32_t meshType, void *vertices
         nz_set_error("unknown MeshType %d", meshType);
         return NZ_ERR_INVALID;
     }
+    nz_ctx_handle_rides(ctx, out != nullptr);  // vertex launch, then the index launch: the handle rides on that one
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(nz_launch_mesh(ctx->stream, meshType, vertices, indices, resolution, inputResolution, tileHeight, tileSize,
                           heights, count, index16));
     return nz_ctx_finish(ctx, out);
@@ -993,6 +1018,8 @@ extern "C" int32_t nz_square_grid_mesh(nz_ctx *ctx, void *vertices, uint32_t *in
     NZ_BEGIN(ctx, dep);
     NZ_REQUIRE(vertices && indices, "buffer is NULL");
     NZ_REQUIRE(resolution >= 1 && resolution <= 26754, "resolution %d out of range", resolution);
+    nz_ctx_handle_rides(ctx, out != nullptr);  // vertex launch, then the index launch: the handle rides on that one
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(nz_launch_mesh_planar(ctx->stream, vertices, indices, resolution));
     return nz_ctx_finish(ctx, out);
 }
@@ -1017,6 +1044,8 @@ extern "C" int32_t nz_constant_job(nz_ctx *ctx, int32_t operation, float *srcL, 
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(srcL, "srcL is NULL");
     (void)tmp;  // element-wise: updated in place, no flush copy
+    nz_ctx_handle_rides(ctx, out != nullptr);  // one launch, nothing behind it
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(nz_launch_constant(ctx->stream, operation, srcL, (size_t)resolution * resolution, constantValue));
     return nz_ctx_finish(ctx, out);
 }
@@ -1027,6 +1056,8 @@ extern "C" int32_t nz_reduction_job(nz_ctx *ctx, int32_t operation, float *srcL,
     NZ_TRY(check_res(resolution));
     NZ_REQUIRE(srcL && srcR, "srcL/srcR is NULL");
     (void)tmp;
+    nz_ctx_handle_rides(ctx, out != nullptr);  // one launch, nothing behind it
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(nz_launch_reduce(ctx->stream, operation, srcL, srcR, (size_t)resolution * resolution));
     return nz_ctx_finish(ctx, out);
 }
@@ -1038,6 +1069,8 @@ extern "C" int32_t nz_curve_job(nz_ctx *ctx, float *src, float *tmp, const float
     NZ_REQUIRE(src && curve, "src/curve is NULL");
     NZ_REQUIRE(curveSize >= 2 && curveSize <= 16384, "curve length %d out of range [2,16384]", curveSize);
     (void)tmp;
+    nz_ctx_handle_rides(ctx, out != nullptr);  // one launch, nothing behind it
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(nz_launch_curve(ctx->stream, src, (size_t)resolution * resolution, curve, curveSize));
     return nz_ctx_finish(ctx, out);
 }
@@ -1140,6 +1173,8 @@ extern "C" int32_t nz_crop_job(nz_ctx *ctx, const float *input, int32_t inputRes
     NZ_TRY(check_res(inputResolution));
     NZ_TRY(check_res(outputResolution));
     NZ_REQUIRE(input && output && input != output, "input/output must be two distinct planes");
+    nz_ctx_handle_rides(ctx, out != nullptr);  // one launch, nothing behind it
+    nz_ctx_arm_last_launch(ctx);
     NZ_TRY(nz_launch_crop(ctx->stream, input, inputResolution, output, outputResolution));
     return nz_ctx_finish(ctx, out);
 }
@@ -1155,13 +1190,18 @@ extern "C" int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, floa
     float t = (talus / 90.0f) * 3.14159f / 2.0f;                             // :131
     float maxDiff = (tanf(t) * meshHeightWidthRatio) / (float)resolution;   // :132
     static const int pairs = [] { const char *e = getenv("NZ_THERMAL_PAIRS"); return e ? atoi(e) : 1; }();
+    nz_ctx_handle_rides(ctx, out != nullptr);  // the handle rides on the last phase's launch
     for (int i = 0; i < iterations; i++) {
+        const bool last = i == iterations - 1;
         if (pairs && nz_thermal_pair_fits(resolution)) {  // two phases per pass over the plane
             NZ_TRY(nz_launch_thermal_pair(ctx->stream, src, resolution, 0, maxDiff, incrementRatio));
+            if (last) nz_ctx_arm_last_launch(ctx);
             NZ_TRY(nz_launch_thermal_pair(ctx->stream, src, resolution, 1, maxDiff, incrementRatio));
         } else {
-            for (int flip = 0; flip < 4; flip++)
+            for (int flip = 0; flip < 4; flip++) {
+                if (last && flip == 3) nz_ctx_arm_last_launch(ctx);
                 NZ_TRY(nz_launch_thermal_phase(ctx->stream, src, resolution, flip, maxDiff, incrementRatio));
+            }
         }
     }
     return nz_ctx_finish(ctx, out);
