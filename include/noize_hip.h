@@ -107,6 +107,28 @@ int32_t nz_ctx_synchronize(nz_ctx *ctx);
 void *nz_ctx_stream(nz_ctx *ctx);
 int32_t nz_ctx_device(nz_ctx *ctx); /* the HIP device the context was created on (-1 for NULL) */
 
+/* Floating-point mode of a context's kernels.  The reference compiles every hot job with
+ * [BurstCompile(FloatPrecision.Standard/High, FloatMode.Fast)] (Noise/Fractal/Fractal.cs:19, Filter/Kernel/KernelJob.cs:17,
+ * Geologic/FlowMap/FlowMapJob.cs:16): Burst may contract and re-associate, so the reference's own results are only defined to
+ * a tolerance (1e-5 relative, 1e-6 absolute is the contract of this path).
+ *   NZ_FLOAT_STRICT (default): every kernel reproduces the operation sequence of the C# source, IEEE binary32, no
+ *     contraction -- results are a pure function of the inputs, equal across every launch shape;
+ *   NZ_FLOAT_FAST: the smooth tail of the simplex fBm octave (corner falloffs, gradient dots, octave accumulation) and the
+ *     convolution tap sums are FMA-contracted; every discrete decision and every cancellation (skew / unskew, floors, lattice
+ *     hashes, selects, clamps, the min filter) stays exact.  Every stage stays within 1e-5 relative / 1e-6 absolute of the strict
+ *     result for the same input plane (measured at 4096^2: fBm 9e-7, Gauss5 x17 4.5e-7);
+ *   NZ_FLOAT_RELAXED: FAST, and the flow map's iterations use a reciprocal (v_rcp_f32) for the outflow scale's division, an FMA
+ *     in the water update, v_sqrt_f32 and a reciprocal multiply in the velocity / normalise epilogue.  The flow map itself
+ *     amplifies a change of one ulp: total = water + height rounds the water (~1e-4) to the height's ulp (6e-8), so a 1e-11
+ *     change of a cell's water moves its outflows by 6e-8 wherever it crosses a rounding boundary -- ~1e-4 of the cells of the
+ *     metric tile leave the 1e-5 band (largest deviation 2e-5 of the normalised range), with ANY arithmetic that is not
+ *     bit-identical, Burst's own FloatMode.Fast builds included.
+ * Within a mode sharded == monolithic and all launch shapes of a stage still agree bit for bit.  Kernels without a tolerance
+ * form run their strict one.  Applies to work enqueued after the call. */
+enum nz_float_mode { NZ_FLOAT_STRICT = 0, NZ_FLOAT_FAST = 1, NZ_FLOAT_RELAXED = 2 };
+int32_t nz_ctx_set_float_mode(nz_ctx *ctx, int32_t mode);
+int32_t nz_ctx_float_mode(nz_ctx *ctx); /* -1 for NULL */
+
 /* NativeArray<float>(n, Allocator.Persistent, UninitializedMemory) / Dispose() */
 int32_t nz_tile_alloc(nz_ctx *ctx, size_t n_floats, float **out_dev);
 int32_t nz_tile_free(nz_ctx *ctx, float *dev);

@@ -77,6 +77,7 @@ sd_p = C.POINTER(ShardedDesc)
 NZ_OK, NZ_ERR_INVALID, NZ_ERR_UNSUPPORTED, NZ_ERR_HIP, NZ_ERR_NOMEM, NZ_ERR_NO_DEVICE, NZ_ERR_COMM, NZ_ERR_RETRY = 0, -1, -2, -3, -4, -5, -6, -7
 NZ_COMM_ID_BYTES = 128
 NZ_HALO_RECOMPUTE, NZ_HALO_EXCHANGE, NZ_HALO_EXCHANGE_ONCE = 0, 1, 2
+NZ_FLOAT_STRICT, NZ_FLOAT_FAST, NZ_FLOAT_RELAXED = 0, 1, 2
 
 _i, _f, _sz = C.c_int32, C.c_float, C.c_size_t
 _tail = [handle_t, handle_p]  # (dep, out)
@@ -92,6 +93,8 @@ SIGNATURES = {
     "nz_ctx_synchronize": (_i, [ctx_p]),
     "nz_ctx_stream": (C.c_void_p, [ctx_p]),
     "nz_ctx_device": (_i, [ctx_p]),
+    "nz_ctx_set_float_mode": (_i, [ctx_p, _i]),
+    "nz_ctx_float_mode": (_i, [ctx_p]),
     "nz_tile_alloc": (_i, [ctx_p, _sz, C.POINTER(dev_ptr)]),
     "nz_tile_free": (_i, [ctx_p, dev_ptr]),
     "nz_tile_upload": (_i, [ctx_p, dev_ptr, C.c_void_p, _sz] + _tail),

@@ -53,7 +53,14 @@ struct cs_bounds {
 //   COND : stages outside their row range are skipped and the grid's first / last rows get their clamped windows
 //          (pipeline fill and drain); the steps in between run without tests;
 //   XEDGE: the strip touches the grid's first / last column.
-template <int KS, int T, bool UNIT, bool COND, bool XEDGE>
+// FAST (NZ_FLOAT_FAST): the tap sums as FMAs, same tap order -- the very sums of conv_tile's tolerance form (nz_filter.hip),
+// so both forms still agree bit for bit within the mode
+template <bool FAST>
+__device__ __forceinline__ float cs_acc(float total, float v, float k) {
+    return FAST ? __builtin_fmaf(v, k, total) : total + v * k;
+}
+
+template <int KS, int T, bool UNIT, bool COND, bool XEDGE, bool FAST>
 __device__ __forceinline__ void cs_step(float (&X)[T][KS - 1][2], const int t, const float2 vin, const cs_bounds<T> &b,
                                         const nz_kernel_taps &taps, const nz_geom &g, __amdgpu_buffer_rsrc_t rdst,
                                         const unsigned vo_st0, const unsigned vo_st1, const bool lane_x0,
@@ -93,7 +100,7 @@ __device__ __forceinline__ void cs_step(float (&X)[T][KS - 1][2], const int t, c
                 for (int e = 0; e < 2; e++) {
                     float total = w[e] * taps.kx[0];  // 0 + a*b == a*b
 #pragma unroll
-                    for (int kk = 1; kk < KS; kk++) total += w[e + kk] * taps.kx[kk];
+                    for (int kk = 1; kk < KS; kk++) total = cs_acc<FAST>(total, w[e + kk], taps.kx[kk]);
                     xn[e] = UNIT ? total : total * taps.factor;
                 }
             } else {  // below the grid's last row: the clamped tap repeats that row's X-pass result
@@ -115,7 +122,7 @@ __device__ __forceinline__ void cs_step(float (&X)[T][KS - 1][2], const int t, c
                 for (int e = 0; e < 2; e++) {
                     float total = xn[e] * taps.kz[0];
 #pragma unroll
-                    for (int kk = 1; kk < KS; kk++) total += X[j][HW - kk][e] * taps.kz[kk];
+                    for (int kk = 1; kk < KS; kk++) total = cs_acc<FAST>(total, X[j][HW - kk][e], taps.kz[kk]);
                     out[e] = UNIT ? total : total * taps.factor;
                 }
             }
@@ -157,7 +164,7 @@ __device__ __forceinline__ float2 cs_load_row(__amdgpu_buffer_rsrc_t rsrc, const
                        __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)vo1, (int)so, 0)));
 }
 
-template <int KS, int T, bool UNIT, bool XEDGE>
+template <int KS, int T, bool UNIT, bool XEDGE, bool FAST>
 __device__ __forceinline__ void conv_stream_body(const float *__restrict__ src, float *__restrict__ dst, const nz_geom &g,
                                                  const nz_kernel_taps &taps, const int lx0, const int s0, const int s1,
                                                  const unsigned plane_bytes) {
@@ -197,7 +204,7 @@ __device__ __forceinline__ void conv_stream_body(const float *__restrict__ src, 
 #define NZ_CS_TRIP(C)                                                                                                 \
     _Pragma("unroll") for (int u = 0; u < U; u++) {                                                                   \
         const float2 vin = P[u];                                                                                      \
-        cs_step<KS, T, UNIT, C, XEDGE>(X, t + u, vin, b, taps, g, rdst, vo_st0, vo_st1, lane_x0, lane_x1, lane_x1o);  \
+        cs_step<KS, T, UNIT, C, XEDGE, FAST>(X, t + u, vin, b, taps, g, rdst, vo_st0, vo_st1, lane_x0, lane_x1, lane_x1o);  \
         /* the row U steps ahead, asked for once this step's row is dead: it lands in the same registers */           \
         P[u] = cs_load_row<XEDGE>(rsrc, g, min(t + u + U, g.zc1), vo_ld0, vo_ld1);                                    \
         /* nothing moves across steps: left alone, the scheduler gathers the trip's loads at its end and their uses  */ \
@@ -215,7 +222,7 @@ __device__ __forceinline__ void conv_stream_body(const float *__restrict__ src, 
 #undef NZ_CS_TRIP
 }
 
-template <int KS, int T, bool UNIT>
+template <int KS, int T, bool UNIT, bool FAST>
 __global__ __launch_bounds__(64) void conv_stream_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
                                                         nz_kernel_taps taps, int S, int nstrips, int aligned) {
     constexpr int O = (KS - 1) / 2, HX = (O * T + 1) & ~1, OW = CS_TW - 2 * HX;
@@ -225,8 +232,8 @@ __global__ __launch_bounds__(64) void conv_stream_kernel(const float *__restrict
     const size_t off = blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
     const unsigned plane_bytes = (unsigned)g.rows * (unsigned)g.pitch * 4u;
     const bool inner = aligned && lx0 > 0 && lx0 + CS_TW < g.cols;
-    if (inner) conv_stream_body<KS, T, UNIT, false>(src + off, dst + off, g, taps, lx0, s0, s1, plane_bytes);
-    else conv_stream_body<KS, T, UNIT, true>(src + off, dst + off, g, taps, lx0, s0, s1, plane_bytes);
+    if (inner) conv_stream_body<KS, T, UNIT, false, FAST>(src + off, dst + off, g, taps, lx0, s0, s1, plane_bytes);
+    else conv_stream_body<KS, T, UNIT, true, FAST>(src + off, dst + off, g, taps, lx0, s0, s1, plane_bytes);
 }
 
 template <int KS, int T>
@@ -244,10 +251,14 @@ int32_t launch_stream(hipStream_t s, const float *src, float *dst, const nz_geom
                            (uintptr_t)(g.bstride * 4);
     const int aligned = (bits & 7) == 0;
     const dim3 grid((unsigned)(nstrips * nseg), g.count);
-    if (k.factor == 1.0f)
-        NZ_LAUNCH((conv_stream_kernel<KS, T, true>), grid, dim3(64), 0, s, src, dst, g, k, S, nstrips, aligned);
-    else
-        NZ_LAUNCH((conv_stream_kernel<KS, T, false>), grid, dim3(64), 0, s, src, dst, g, k, S, nstrips, aligned);
+    const bool fast = nz_tls_float_mode >= NZ_FLOAT_FAST;
+#define NZ_CSL(U, F) NZ_LAUNCH((conv_stream_kernel<KS, T, U, F>), grid, dim3(64), 0, s, src, dst, g, k, S, nstrips, aligned)
+    if (k.factor == 1.0f) {
+        if (fast) NZ_CSL(true, true); else NZ_CSL(true, false);
+    } else {
+        if (fast) NZ_CSL(false, true); else NZ_CSL(false, false);
+    }
+#undef NZ_CSL
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

@@ -80,13 +80,21 @@ __device__ __forceinline__ float dpp_next(float v) {  // lane i <- lane i+1
 // -DNZ_CONV_PROBE: thread 0 of every workgroup stamps s_memrealtime (100 MHz) at the start, after each application and
 // at the end, plus its HW_ID / XCC_ID, into a caller-supplied buffer (tools/probe_conv_phases.py).  Never built by the Makefile.
 #ifdef NZ_CONV_PROBE
-__device__ unsigned long long *nz_probe_buf = nullptr;  // [workgroup][16]
-#define NZ_PROBE(slot, val)                                                                                   \
-    do {                                                                                                      \
-        if (threadIdx.x == 0 && nz_probe_buf) nz_probe_buf[(size_t)blockIdx.x * 16 + (slot)] = (val);        \
+__device__ unsigned long long *nz_probe_buf = nullptr;  // [workgroup][24]
+// the buffer's address is read ONCE per workgroup (a __device__ variable re-read at every stamp would put a ~1 us load in front
+// of each of them); conv_tile receives it as an extra argument
+#define NZ_PB_PARAM , unsigned long long *nz_pb
+#define NZ_PB_ARG , nz_pb
+#define NZ_PB_INIT unsigned long long *nz_pb = threadIdx.x == 0 ? nz_probe_buf : nullptr
+#define NZ_PROBE(slot, val)                                              \
+    do {                                                                 \
+        if (nz_pb) nz_pb[(size_t)blockIdx.x * 24 + (slot)] = (val);      \
     } while (0)
 #define NZ_PROBE_T(slot) NZ_PROBE(slot, __builtin_amdgcn_s_memrealtime())
 #else
+#define NZ_PB_PARAM
+#define NZ_PB_ARG
+#define NZ_PB_INIT
 #define NZ_PROBE(slot, val)
 #define NZ_PROBE_T(slot)
 #endif
@@ -133,10 +141,17 @@ __device__ __forceinline__ void store4_sc1(float *base, size_t float_off, float 
 
 // One workgroup's tile: T applications on the (NT/4) x 128 register tile whose interior starts at (ox0, oz0).
 // SC1: every global access is an sc1 access (see above); the plane must then be smaller than 4 GiB (32-bit offsets).
-template <int KS, bool UNIT, int NT, bool SC1>
+// FAST (NZ_FLOAT_FAST): the tap sums as one multiply and KS - 1 FMAs, same tap order (the reference compiles its kernel jobs
+// with FloatMode.Fast, Filter/Kernel/KernelJob.cs:17: Burst is free to contract exactly these sums)
+template <bool FAST>
+__device__ __forceinline__ float tap_acc(float total, float v, float k) {
+    return FAST ? __builtin_fmaf(v, k, total) : total + v * k;
+}
+
+template <int KS, bool UNIT, int NT, bool SC1, bool FAST>
 __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *__restrict__ dst, const nz_geom &g,
                                           const nz_kernel_taps &taps, int T, int aligned, int ox0, int oz0,
-                                          float4 *s_edge_raw) {
+                                          float4 *s_edge_raw NZ_PB_PARAM) {
     constexpr int O = (KS - 1) / 2;
     constexpr int WN = 4 + 2 * O;   // X window
     constexpr int ZN = RB + 2 * O;  // Z window
@@ -179,6 +194,10 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
             }
         }
     }
+#ifdef NZ_CONV_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NZ_PROBE_T(9);  // wave 0's tile rows have landed (the wait exists in this build only)
+#endif
     // window indices of the last grid column / first and last grid rows, for the clamps of edge tiles
     const int icx = g.cols - 1 - gx0 + O;
     const int iz0 = g.zc0 - gzb + O, iz1 = g.zc1 - gzb + O;
@@ -212,7 +231,7 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
             for (int e = 0; e < 4; e++) {
                 float total = w[e] * taps.kx[0];  // 0 + a*b == a*b
 #pragma unroll
-                for (int kk = 1; kk < KS; kk++) total += w[e + kk] * taps.kx[kk];
+                for (int kk = 1; kk < KS; kk++) total = tap_acc<FAST>(total, w[e + kk], taps.kx[kk]);
                 v[r][e] = UNIT ? total : total * taps.factor;
             }
         }
@@ -223,7 +242,9 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
             s_edge[par][rb][0][o][cg] = make_float4(v[o][0], v[o][1], v[o][2], v[o][3]);
             s_edge[par][rb][1][o][cg] = make_float4(v[RB - O + o][0], v[RB - O + o][1], v[RB - O + o][2], v[RB - O + o][3]);
         }
+        if (t == 0) NZ_PROBE_T(16);  // application 1: X pass done, edge rows written
         __syncthreads();
+        if (t == 0) NZ_PROBE_T(17);  // ... and everybody has arrived
         float z[ZN][4];
 #pragma unroll
         for (int o = 0; o < O; o++) {
@@ -268,7 +289,7 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
             for (int e = 0; e < 4; e++) {
                 float total = z[r + 2 * O][e] * taps.kz[0];
 #pragma unroll
-                for (int kk = 1; kk < KS; kk++) total += z[r + 2 * O - kk][e] * taps.kz[kk];
+                for (int kk = 1; kk < KS; kk++) total = tap_acc<FAST>(total, z[r + 2 * O - kk][e], taps.kz[kk]);
                 v[r][e] = UNIT ? total : total * taps.factor;
             }
         }
@@ -305,7 +326,7 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
     NZ_PROBE_T(12);
 }
 
-template <int KS, bool UNIT, int NT>
+template <int KS, bool UNIT, int NT, bool FAST>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(KS, NT)))) void conv_reg_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
                                                      nz_kernel_taps taps, int T, int aligned) {
     constexpr int O = (KS - 1) / 2;
@@ -317,7 +338,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
     dst += blockIdx.y * g.bstride;
     int ox0, oz0;
     tile_origin(g, TW - 2 * HX, TH - 2 * H, ox0, oz0);
-    conv_tile<KS, UNIT, NT, false>(src, dst, g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0]);
+    NZ_PB_INIT;
+    conv_tile<KS, UNIT, NT, false, FAST>(src, dst, g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0] NZ_PB_ARG);
 }
 
 // ---- the launches of a stage as ONE grid with tile-level dependencies -------------------------------------------------
@@ -328,27 +350,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
 // are dealt so that a class works through a contiguous eighth of every launch's tiles, in launch order), waits until
 // the <= 9 tiles of the previous launch that its input window touches have been stored, and runs the same tile code
 // with sc1 accesses.  Loads of launch l + 1 overlap arithmetic of launch l, and nothing drains in between.
-//   * work items are claimed with an atomic ticket per class, so within a class a workgroup only ever waits for items
-//     claimed before its own.  Across classes the producers of an item are claimed by workgroups of OTHER classes, which
-//     must get dispatched: progress rests on the hardware starting workgroups in index order, round-robin over the XCDs
-//     (observed, not promised).  Termination does not: the poll is bounded, see below, and a context whose chained launch
-//     ever timed out runs separate launches from then on (nz_runtime.cpp, ctx_chain_check);
+//   * a workgroup's work item is its position in the grid (class = blockIdx.x & 7, k = blockIdx.x >> 3; no ticket since round
+//     5): the producers of an item are earlier items of its own or of other classes, which must get dispatched: progress rests on
+//     the hardware starting a grid's workgroups in index order, round-robin over the XCDs (observed, not promised).
+//     Termination does not: the poll is bounded, see below, and a context whose chained launch ever timed out runs separate
+//     launches from then on (nz_runtime.cpp, ctx_chain_check);
 //   * hand-off: producer = sc1 stores, every wave s_waitcnt vmcnt(0), workgroup barrier, ONE lane stores the tile's
 //     flag (agent scope); consumer = up to nine lanes poll one flag each (sc1 loads), workgroup barrier, sc1 loads;
 //   * the poll is bounded: a workgroup that gives up raises the context's error word (mapped host memory) and carries on, so the grid always
 //     drains and the host reports the failure at its next synchronisation instead of hanging;
-//   * flags carry the launch's epoch, and the last workgroup out zeroes the tickets: nothing is cleared between stages.
+//   * flags carry the launch's epoch: nothing is cleared between stages.
 // (A persistent form -- resident workgroups that claim item after item and let a tile's stores drain behind the next
 // tile's loads -- was built and measured: 0.555 ms for Gauss5 x17 against 0.197 ms, the loop-carried state costs the
 // 80-register budget 39 spills.  One item per workgroup it stays.)
 constexpr int NZ_CHAIN_MAXL = 8;
-constexpr int NZ_CHAIN_DONE = 8;  // ctl[0..7] = tickets per class, ctl[8] = workgroups that have finished
 struct nz_chain {
     int L, total;
     int T[NZ_CHAIN_MAXL], first[NZ_CHAIN_MAXL + 1], tiles_x[NZ_CHAIN_MAXL];
     unsigned epoch;
     int *flags;       // one per work item, indexed first[l] + tile
-    unsigned *ctl;
     float *plane[2];  // launch l reads plane[l & 1] and writes plane[(l + 1) & 1]
     // test hook (nz_debug_chain_delay): the workgroup that claims work item `delay_item` sleeps `delay_sleeps` x ~1 us
     // between its dependency wait and its loads -- a straggler among the readers of a plane that later launches
@@ -362,19 +382,25 @@ struct nz_chain {
 
 __host__ __device__ __forceinline__ int chain_class_count(int n, int c) { return n > c ? (n - c + 7) >> 3 : 0; }  // #{vb < n : vb % 8 == c}
 
-template <int KS, bool UNIT, int NT>
+template <int KS, bool UNIT, int NT, bool FAST>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(KS, NT)))) void conv_chain_kernel(nz_geom g, nz_kernel_taps taps,
                                                                                                                   nz_chain ch, int aligned) {
     constexpr int O = (KS - 1) / 2;
     constexpr int TH = NT / 32 * RB;
     constexpr int NBUF = (O == 2 && NZ_CONV5_NBUF == 2) ? 2 : (O >= 2 ? 1 : 2);
     __shared__ float4 s_edge[NBUF][TH / RB][2][O][TW / 4];
-    __shared__ int s_item[2];
-    if (threadIdx.x == 0) {
-        const int cls = blockIdx.x & 7;
-        const int k = (int)atomicAdd(&ch.ctl[cls], 1u);
-        const int vb = 8 * k + cls;  // < total: the grid holds exactly as many workgroups of this class
-        int l = 0;
+    NZ_PB_INIT;
+    NZ_PROBE_T(18);  // the workgroup's first instruction (after the kernel arguments' scalar loads)
+    int l = 0, tile = 0;
+    {
+        // Work item = position in the grid: vb = blockIdx.x, class = vb & 7 (the XCD that receives the workgroup), k = vb >> 3.
+        // (Rounds 2 .. 4 drew k from an atomic ticket per class, which made the order within a class the order in which
+        // workgroups actually start -- and put a returning atomic, a write to LDS and a barrier in front of every tile: ~2 us of
+        // a tile's ~22, Gauss5 x17 0.203 -> 0.189 ms without it.  The dispatcher starts a grid's workgroups in index order, so
+        // within a class a lower k has started whenever a higher one runs; the hand-off already rested on that order ACROSS
+        // classes, and the wait is bounded either way.)
+        const int vb = blockIdx.x;
+        const int cls = vb & 7;
         while (l + 1 < ch.L && vb >= ch.first[l + 1]) l++;
         // the class's share of launch l is a contiguous run of tiles: classes before it, then its own earlier items
         int start = 0;
@@ -385,11 +411,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
         // other, neighbouring classes finish a launch on the rows they share and start the next one at the far ends.
         const int mine = chain_class_count(ch.first[l + 1], cls) - chain_class_count(ch.first[l], cls);
         const int j = chain_class_count(vb, cls) - chain_class_count(ch.first[l], cls);
-        s_item[0] = l;
-        s_item[1] = start + ((cls & 1) ? mine - 1 - j : j);
+        tile = start + ((cls & 1) ? mine - 1 - j : j);
     }
-    __syncthreads();
-    const int l = s_item[0], tile = s_item[1];
+    NZ_PROBE_T(7);  // the ticket is back
+    NZ_PROBE(13, ((unsigned long long)l << 32) | (unsigned)tile);
     const int T = ch.T[l], H = T * O, HX = (H + 3) & ~3;
     const int OW = TW - 2 * HX, OH = TH - 2 * H;
     const int by = tile / ch.tiles_x[l], bx = tile - by * ch.tiles_x[l];
@@ -420,17 +445,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
         }
         __syncthreads();
     }
+    NZ_PROBE_T(8);  // the producers' flags are up
     if (ch.first[l] + tile == ch.delay_item)
         for (int i = 0; i < ch.delay_sleeps; i++) __builtin_amdgcn_s_sleep(127);  // 127 x 64 clocks ~ 3.4 us
-    conv_tile<KS, UNIT, NT, true>(ch.plane[l & 1], ch.plane[(l + 1) & 1], g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0]);
+    conv_tile<KS, UNIT, NT, true, FAST>(ch.plane[l & 1], ch.plane[(l + 1) & 1], g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0] NZ_PB_ARG);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
+    NZ_PROBE_T(10);  // wave 0's stores are acknowledged
     __syncthreads();
+    NZ_PROBE_T(11);  // everybody's are
     if (threadIdx.x == 0) {
         __hip_atomic_store(&ch.flags[ch.first[l] + tile], (int)ch.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)atomicAdd(&ch.ctl[NZ_CHAIN_DONE], 1u) == ch.total - 1) {  // the last one out resets the tickets for the next stage
-#pragma unroll
-            for (int c = 0; c <= NZ_CHAIN_DONE; c++) __hip_atomic_store(&ch.ctl[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -558,6 +582,7 @@ __global__ __launch_bounds__(CT) void erosion_reg_kernel(const float *__restrict
 
 // generic single passes straight from global memory (any odd/even kernelSize <= 25); neighbour
 // reuse is served by L1/L2.  One thread per cell.
+template <bool FAST>
 __global__ __launch_bounds__(CT) void conv_pass_x_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                         nz_geom g, nz_kernel_taps taps) {
     int x = blockIdx.x * CT + threadIdx.x;
@@ -566,10 +591,11 @@ __global__ __launch_bounds__(CT) void conv_pass_x_kernel(const float *__restrict
     const int k_off = (taps.ksize - 1) / 2;
     const float *row = src + (size_t)z * g.pitch;
     float total = 0.0f;
-    for (int k = -k_off; k <= k_off; k++) total += row[clampi(x + k, 0, g.cols - 1)] * taps.kx[k_off + k];
+    for (int k = -k_off; k <= k_off; k++) total = tap_acc<FAST>(total, row[clampi(x + k, 0, g.cols - 1)], taps.kx[k_off + k]);
     dst[(size_t)z * g.pitch + x] = total * taps.factor;
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(CT) void conv_pass_z_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                         nz_geom g, nz_kernel_taps taps) {
     int x = blockIdx.x * CT + threadIdx.x;
@@ -578,7 +604,7 @@ __global__ __launch_bounds__(CT) void conv_pass_z_kernel(const float *__restrict
     const int k_off = (taps.ksize - 1) / 2;
     float total = 0.0f;
     for (int k = k_off; k >= -k_off; k--)
-        total += src[(size_t)clampi(z + k, g.zc0, g.zc1) * g.pitch + x] * taps.kz[k_off - k];
+        total = tap_acc<FAST>(total, src[(size_t)clampi(z + k, g.zc0, g.zc1) * g.pitch + x], taps.kz[k_off - k]);
     dst[(size_t)z * g.pitch + x] = total * taps.factor;
 }
 
@@ -592,7 +618,7 @@ __global__ __launch_bounds__(CT) void conv_pass_z_kernel(const float *__restrict
 // rows give the X-pass value of the clamped row, which is what the reference's Z pass reads after the flush.
 constexpr int WD_W = 128, WD_XH = 16, WD_AP = WD_W + 2 * WD_XH;
 
-template <int O, bool UNIT, int WD_NT>
+template <int O, bool UNIT, int WD_NT, bool FAST>
 __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
                                                       nz_kernel_taps taps, int aligned) {
     constexpr int KS = 2 * O + 1;
@@ -650,7 +676,7 @@ __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restric
             for (int e = 0; e < 8; e++) {
                 float total = w[SH + e] * taps.kx[0];  // 0 + a*b == a*b
 #pragma unroll
-                for (int kk = 1; kk < KS; kk++) total += w[SH + e + kk] * taps.kx[kk];
+                for (int kk = 1; kk < KS; kk++) total = tap_acc<FAST>(total, w[SH + e + kk], taps.kx[kk]);
                 o[e] = UNIT ? total : total * taps.factor;
             }
             float4 *b = s_a + (r * WD_AP + WD_XH + 8 * tx) / 4;
@@ -677,7 +703,7 @@ __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restric
             for (int e = 0; e < 4; e++) {
                 float total = v[j + 2 * O][e] * taps.kz[0];
 #pragma unroll
-                for (int kk = 1; kk < KS; kk++) total += v[j + 2 * O - kk][e] * taps.kz[kk];
+                for (int kk = 1; kk < KS; kk++) total = tap_acc<FAST>(total, v[j + 2 * O - kk][e], taps.kz[kk]);
                 o[e] = UNIT ? total : total * taps.factor;
             }
             int gz = z0 + rg * 4 + j;
@@ -701,12 +727,14 @@ int32_t launch_wide_nt(hipStream_t s, const float *src, float *dst, const nz_geo
     constexpr int WD_H = NT / 8;
     long long blocks = (long long)((g.cols + WD_W - 1) / WD_W) * ((g.or1 - g.or0 + WD_H - 1) / WD_H);
     int aligned = (g.pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
-    if (k.factor == 1.0f)
-        NZ_LAUNCH((conv_wide_kernel<O, true, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k,
-                           aligned);
-    else
-        NZ_LAUNCH((conv_wide_kernel<O, false, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k,
-                           aligned);
+    const bool fast = nz_tls_float_mode >= NZ_FLOAT_FAST;
+#define NZ_WD(U, F) NZ_LAUNCH((conv_wide_kernel<O, U, NT, F>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, aligned)
+    if (k.factor == 1.0f) {
+        if (fast) NZ_WD(true, true); else NZ_WD(true, false);
+    } else {
+        if (fast) NZ_WD(false, true); else NZ_WD(false, false);
+    }
+#undef NZ_WD
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -754,10 +782,14 @@ int32_t launch_fused_nt(hipStream_t s, const float *src, float *dst, const nz_ge
     int OW = TW - 2 * HX, OH = RTH - 2 * H;
     long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
     int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
-    if (k.factor == 1.0f)
-        NZ_LAUNCH((conv_reg_kernel<KS, true, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
-    else
-        NZ_LAUNCH((conv_reg_kernel<KS, false, NT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned);
+    const bool fast = nz_tls_float_mode >= NZ_FLOAT_FAST;
+#define NZ_CR(U, F) NZ_LAUNCH((conv_reg_kernel<KS, U, NT, F>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned)
+    if (k.factor == 1.0f) {
+        if (fast) NZ_CR(true, true); else NZ_CR(true, false);
+    } else {
+        if (fast) NZ_CR(false, true); else NZ_CR(false, false);
+    }
+#undef NZ_CR
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -773,7 +805,7 @@ int g_chain_spin_limit = 1 << 21;                         // nz_debug_chain_poll
 
 template <int KS, int NT>
 int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
-                        int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host) {
+                        int L, int *flags, unsigned epoch, unsigned *err_host) {
     constexpr int O = (KS - 1) / 2;
     constexpr int RTH = NT / 32 * RB;
     nz_chain ch{};
@@ -789,7 +821,6 @@ int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_ge
     ch.total = ch.first[L];
     ch.epoch = epoch;
     ch.flags = flags;
-    ch.ctl = ctl;
     ch.plane[0] = plane0;
     ch.plane[1] = plane1;
     ch.delay_item = g_chain_delay_item;
@@ -797,19 +828,23 @@ int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_ge
     ch.spin_limit = g_chain_spin_limit;
     ch.err_host = err_host;
     int aligned = ((reinterpret_cast<uintptr_t>(plane0) | reinterpret_cast<uintptr_t>(plane1) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
-    if (k.factor == 1.0f)
-        NZ_LAUNCH((conv_chain_kernel<KS, true, NT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned);
-    else
-        NZ_LAUNCH((conv_chain_kernel<KS, false, NT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned);
+    const bool fast = nz_tls_float_mode >= NZ_FLOAT_FAST;
+#define NZ_CC(U, F) NZ_LAUNCH((conv_chain_kernel<KS, U, NT, F>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned)
+    if (k.factor == 1.0f) {
+        if (fast) NZ_CC(true, true); else NZ_CC(true, false);
+    } else {
+        if (fast) NZ_CC(false, true); else NZ_CC(false, false);
+    }
+#undef NZ_CC
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
 
 template <int KS>
 int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
-                     int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host) {
-    if (KS >= 5 && conv_small_grid(KS, g)) return launch_chain_nt<KS, 256>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
-    return launch_chain_nt<KS, (KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT)>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
+                     int L, int *flags, unsigned epoch, unsigned *err_host) {
+    if (KS >= 5 && conv_small_grid(KS, g)) return launch_chain_nt<KS, 256>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
+    return launch_chain_nt<KS, (KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT)>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
 }
 
 }  // namespace
@@ -832,9 +867,9 @@ int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L) {
 
 // L <= 8 fused launches as ONE grid with tile-level dependencies (conv_chain_kernel): launch l reads plane (l & 1) and
 // writes the other one, so the result is in plane0 when L is even.  One grid of the geometry (g.count == 1), planes
-// below 4 GiB.  flags: nz_conv_chain_items() ints, never cleared; ctl: 16 words, zero before the first use.
+// below 4 GiB.  flags: nz_conv_chain_items() ints, never cleared (they carry an epoch).
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
-                             const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host) {
+                             const int *Ts, int L, int *flags, unsigned epoch, unsigned *err_host) {
     if (L < 1 || L > NZ_CHAIN_MAXL || g.count != 1 || (size_t)g.rows * g.pitch * 4 >= ((size_t)1 << 32)) {
         nz_set_error("conv_chain: %d launches / %d grids / plane of %zu bytes unsupported", L, g.count, (size_t)g.rows * g.pitch * 4);
         return NZ_ERR_INVALID;
@@ -846,10 +881,10 @@ int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const 
         }
     if (g.or1 <= g.or0) return NZ_OK;
     switch (k.ksize) {
-        case 3: return launch_chain<3>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
-        case 5: return launch_chain<5>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
-        case 7: return launch_chain<7>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
-        case 9: return launch_chain<9>(s, plane0, plane1, g, k, Ts, L, flags, ctl, epoch, err_host);
+        case 3: return launch_chain<3>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
+        case 5: return launch_chain<5>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
+        case 7: return launch_chain<7>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
+        case 9: return launch_chain<9>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
     }
     return NZ_ERR_INVALID;
 }
@@ -905,7 +940,8 @@ int32_t nz_launch_conv_pass_x(hipStream_t s, const float *src, float *dst, const
                               const nz_kernel_taps &k) {
     if (g.or1 <= g.or0) return NZ_OK;
     dim3 grid((g.cols + CT - 1) / CT, g.or1 - g.or0);
-    hipLaunchKernelGGL(conv_pass_x_kernel, grid, dim3(CT), 0, s, src, dst, g, k);
+    if (nz_tls_float_mode >= NZ_FLOAT_FAST) hipLaunchKernelGGL(conv_pass_x_kernel<true>, grid, dim3(CT), 0, s, src, dst, g, k);
+    else hipLaunchKernelGGL(conv_pass_x_kernel<false>, grid, dim3(CT), 0, s, src, dst, g, k);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }
@@ -914,7 +950,8 @@ int32_t nz_launch_conv_pass_z(hipStream_t s, const float *src, float *dst, const
                               const nz_kernel_taps &k) {
     if (g.or1 <= g.or0) return NZ_OK;
     dim3 grid((g.cols + CT - 1) / CT, g.or1 - g.or0);
-    hipLaunchKernelGGL(conv_pass_z_kernel, grid, dim3(CT), 0, s, src, dst, g, k);
+    if (nz_tls_float_mode >= NZ_FLOAT_FAST) hipLaunchKernelGGL(conv_pass_z_kernel<true>, grid, dim3(CT), 0, s, src, dst, g, k);
+    else hipLaunchKernelGGL(conv_pass_z_kernel<false>, grid, dim3(CT), 0, s, src, dst, g, k);
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

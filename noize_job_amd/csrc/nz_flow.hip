@@ -187,7 +187,7 @@ __device__ __forceinline__ void store_group(float *__restrict__ p, const nz_geom
     }
 }
 
-template <bool FIRST, bool LAST, bool EDGE>
+template <bool FIRST, bool LAST, bool EDGE, bool FAST>
 __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float *s_fs, int tile, const float *__restrict__ h, const float *__restrict__ w_in,
                                                           const float *__restrict__ fN_in, const float *__restrict__ fS_in,
                                                           const float *__restrict__ fE_in, const float *__restrict__ fW_in,
@@ -269,7 +269,7 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
                     if (gz <= g.zc0) ts = self;
                     if (gz >= g.zc1) tn = self;
                 }
-                flux4 f = compute_flow(self, ww[j][e], tW, tE, ts, tn, flux4{fW[j][e], fE[j][e], fS[j][e], fN[j][e]});
+                flux4 f = compute_flow_m<FAST>(self, ww[j][e], tW, tE, ts, tn, flux4{fW[j][e], fE[j][e], fS[j][e], fN[j][e]}, false);
                 fW[j][e] = f.w; fE[j][e] = f.e; fS[j][e] = f.s; fN[j][e] = f.n;
             }
             lds_store4(&s_fn[r * FT_LP + gcol[j]], fN[j]);
@@ -297,12 +297,13 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
                     if (gz <= g.zc0) inN = fN[j][e];
                     if (gz >= g.zc1) inS = fS[j][e];
                 }
-                ww[j][e] = update_water(ww[j][e], flux4{fW[j][e], fE[j][e], fS[j][e], fN[j][e]}, inE, inW, inN, inS);
+                ww[j][e] = update_water_m<FAST>(ww[j][e], flux4{fW[j][e], fE[j][e], fS[j][e], fN[j][e]}, inE, inW, inN, inS);
             }
         }
     }
 
     // ---- epilogue: interior groups only
+    const float inv_range = FAST && LAST ? 1.0f / nrange : 0.0f;
 #pragma unroll
     for (int j = 0; j < FT_G; j++) {
         int r = grow[j];
@@ -329,11 +330,7 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
                 float dr = fE[j][e] - fW_e;
                 float dt = fS_n - fN[j][e];
                 float db = fS[j][e] - fN_s;
-                float vx = (dl + dr) * 0.5f;
-                float vy = (dt + db) * 0.5f;
-                float v = sqrtf(vx * vx + vy * vy);
-                if (nrange < 1e-12f) v = 0.0f;
-                out[e] = (v - nmin) / nrange;
+                out[e] = velocity_norm_m<FAST>(dl, dr, dt, db, nmin, nrange, inv_range);
             }
         }
         if (interior) {
@@ -354,7 +351,7 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
 
 // The interior instantiation (tile strictly inside the grid) carries no border selects; the choice is
 // uniform per workgroup.
-template <bool FIRST, bool LAST, int OCC>
+template <bool FIRST, bool LAST, int OCC, bool FAST>
 __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__restrict__ h, const float *__restrict__ w_in,
                                                                const float *__restrict__ fN_in, const float *__restrict__ fS_in,
                                                                const float *__restrict__ fE_in, const float *__restrict__ fW_in,
@@ -383,12 +380,12 @@ __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__r
     const size_t off = blockIdx.y * g.bstride;
 #define NZ_SH(p) ((p) ? (p) + off : (p))
     if (inner)
-        flow_fused_body<FIRST, LAST, false>(s_tot, s_fn, s_fs, tile, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
+        flow_fused_body<FIRST, LAST, false, FAST>(s_tot, s_fn, s_fs, tile, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
                                             NZ_SH(fE_in), NZ_SH(fW_in), NZ_SH(w_out), NZ_SH(fN_out), NZ_SH(fS_out),
                                             NZ_SH(fE_out), NZ_SH(fW_out), NZ_SH(dst), NZ_SH(h_out), g, n, nmin, nrange,
                                             aligned);
     else
-        flow_fused_body<FIRST, LAST, true>(s_tot, s_fn, s_fs, tile, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
+        flow_fused_body<FIRST, LAST, true, FAST>(s_tot, s_fn, s_fs, tile, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
                                            NZ_SH(fE_in), NZ_SH(fW_in), NZ_SH(w_out), NZ_SH(fN_out), NZ_SH(fS_out),
                                            NZ_SH(fE_out), NZ_SH(fW_out), NZ_SH(dst), NZ_SH(h_out), g, n, nmin, nrange,
                                            aligned);
@@ -430,22 +427,23 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
     float *fE_out = last ? nullptr : out[3], *fW_out = last ? nullptr : out[4];
     // OCC = waves per SIMD the register allocator must leave room for: 4 -> two 512-thread workgroups per CU
     static const int occ = getenv("NZ_FLOW_OCC") ? atoi(getenv("NZ_FLOW_OCC")) : 4;
-#define NZ_FF(F, L)                                                                                                  \
-    do {                                                                                                             \
-        if (occ >= 4)                                                                                                \
-            NZ_LAUNCH((flow_fused_kernel<F, L, NZ_FT_OCC>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, \
-                               fN_in, fS_in, fE_in, fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n,   \
-                               nmin, nrange, aligned);                                                                     \
-        else                                                                                                         \
-            NZ_LAUNCH((flow_fused_kernel<F, L, 2>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, \
-                               fN_in, fS_in, fE_in, fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n,   \
-                               nmin, nrange, aligned);                                                                     \
+    const bool fast = nz_tls_float_mode >= NZ_FLOAT_RELAXED;
+#define NZ_FFL(F, L, O, M)                                                                                                    \
+    NZ_LAUNCH((flow_fused_kernel<F, L, O, M>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, fN_in, fS_in, fE_in, \
+              fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n, nmin, nrange, aligned)
+#define NZ_FF(F, L)                                        \
+    do {                                                   \
+        if (occ >= 4 && fast) NZ_FFL(F, L, NZ_FT_OCC, true);  \
+        else if (occ >= 4) NZ_FFL(F, L, NZ_FT_OCC, false);    \
+        else if (fast) NZ_FFL(F, L, 2, true);                 \
+        else NZ_FFL(F, L, 2, false);                          \
     } while (0)
     if (first && last) NZ_FF(true, true);
     else if (first) NZ_FF(true, false);
     else if (last) NZ_FF(false, true);
     else NZ_FF(false, false);
 #undef NZ_FF
+#undef NZ_FFL
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

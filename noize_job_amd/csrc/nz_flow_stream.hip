@@ -81,11 +81,12 @@ struct fs_bounds {
 //   XEDGE: the strip touches the grid's first / last column: the lane that holds it takes its own value for the clamped
 //          x-neighbour (column 0 is the first of its lane's two columns; the last column the second, or the first when the row length is odd).
 // Cells outside the grid are computed like any other and never read by a cell inside it.
-template <int NST, int NC, int NACT, bool COND, bool XEDGE, bool VEC>
+template <int NST, int NC, int NACT, bool COND, bool XEDGE, bool VEC, bool FAST>
 __device__ __forceinline__ void fs_step(fs_state<NST, NC> &st, const int t, const fs_row<NC> hp, const fs_row<NC> hn,
                                         fs_row<NC> *ring, const fs_bounds &b, const int gx, const bool lane_x0,
                                         const bool lane_x1, const bool lane_x1o, const nz_geom &g, const float nmin,
-                                        const float nrange, float *__restrict__ dst, const bool store_lane) {
+                                        const float nrange, const float inv_range, float *__restrict__ dst,
+                                        const bool store_lane) {
     float Tp[NC], Wp[NC], FCprev[NC][4];
 #pragma unroll
     for (int e = 0; e < NC; e++) {
@@ -138,7 +139,7 @@ __device__ __forceinline__ void fs_step(fs_state<NST, NC> &st, const int t, cons
                 if (i == 0) old = flux4{0.0f, 0.0f, 0.0f, 0.0f};
                 else old = flux4{st.FA[i > 0 ? i - 1 : 0][e][0], st.FA[i > 0 ? i - 1 : 0][e][1],
                                  st.FA[i > 0 ? i - 1 : 0][e][2], st.FA[i > 0 ? i - 1 : 0][e][3]};
-                const flux4 f = compute_flow_nb(self, st.W0[i][e], tW, tE, tS, tN, old);
+                const flux4 f = compute_flow_m<FAST>(self, st.W0[i][e], tW, tE, tS, tN, old, true);
                 FC[e][0] = f.w; FC[e][1] = f.e; FC[e][2] = f.s; FC[e][3] = f.n;
             }
         } else {
@@ -186,7 +187,7 @@ __device__ __forceinline__ void fs_step(fs_state<NST, NC> &st, const int t, cons
                     const float inE = e == 0 ? eW : st.FB[i][e > 0 ? e - 1 : 0][1];
                     float inW = e == NC - 1 ? wE : st.FB[i][e + 1 < NC ? e + 1 : e][0];
                     if (XEDGE && NC == 2 && e == 0 && lane_x1o) inW = st.FB[i][0][0];
-                    Wn[e] = update_water(st.Wm[i][e], flux4{st.FB[i][e][0], st.FB[i][e][1], st.FB[i][e][2], st.FB[i][e][3]},
+                    Wn[e] = update_water_m<FAST>(st.Wm[i][e], flux4{st.FB[i][e][0], st.FB[i][e][1], st.FB[i][e][2], st.FB[i][e][3]},
                                          inE, inW, nS[e], sN[e]);
                     Tn[e] = Wn[e] + hh.c[e];
                 }
@@ -202,11 +203,7 @@ __device__ __forceinline__ void fs_step(fs_state<NST, NC> &st, const int t, cons
                     const float dr = st.FB[i][e][1] - fW_e;
                     const float dt = sN[e] - st.FB[i][e][3];
                     const float db = st.FB[i][e][2] - nS[e];
-                    const float vx = (dl + dr) * 0.5f;
-                    const float vy = (dt + db) * 0.5f;
-                    float v = sqrtf(vx * vx + vy * vy);
-                    if (nrange < 1e-12f) v = 0.0f;
-                    out[e] = (v - nmin) / nrange;
+                    out[e] = velocity_norm_m<FAST>(dl, dr, dt, db, nmin, nrange, inv_range);
                 }
                 if (store_lane && (COND || rw >= b.loW[NST - 1])) {
                     float *p = dst + (size_t)rw * g.pitch + gx;
@@ -277,11 +274,12 @@ __device__ __forceinline__ fs_row<NC> fs_load_row(const float *__restrict__ h, c
     return o;
 }
 
-template <int NST, int NC, bool XEDGE>
+template <int NST, int NC, bool XEDGE, bool FAST>
 __device__ __forceinline__ void flow_stream_body(fs_row<NC> *ring, const float *__restrict__ h, float *__restrict__ dst,
                                                  const nz_geom &g, const int lx0, const int s0, const int s1,
                                                  const float nmin, const float nrange) {
     constexpr bool VEC = !XEDGE;
+    const float inv_range = FAST ? 1.0f / nrange : 0.0f;
     constexpr int H = 2 * NST, FS_TW = 64 * NC;
     const int lane = threadIdx.x;
     const int gx = lx0 + NC * lane;
@@ -326,8 +324,8 @@ __device__ __forceinline__ void flow_stream_body(fs_row<NC> *ring, const float *
 #define NZ_FS_STEP(NA, C, T, HP, HN)                                                                              \
     do {                                                                                                          \
         if (NZ_FS_PRIO) fs_prio((T) - t0, slot);                                                                      \
-        fs_step<NST, NC, NA, C, XEDGE, VEC>(st, T, HP, HN, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, dst, \
-                                        store_lane);                                                              \
+        fs_step<NST, NC, NA, C, XEDGE, VEC, FAST>(st, T, HP, HN, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, \
+                                              inv_range, dst, store_lane);                                        \
     } while (0)
 #define NZ_FS_PHASE(K)                                                            \
     if (NST > K) {                                                                \
@@ -382,7 +380,7 @@ __device__ __forceinline__ void flow_stream_body(fs_row<NC> *ring, const float *
 #ifndef NZ_FS_WPE1
 #define NZ_FS_WPE1 5  // waves per SIMD the one-column form is register-allocated for
 #endif
-template <int NST, int NC>
+template <int NST, int NC, bool FAST>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 1 ? (NST >= 4 ? NZ_FS_WPE1 : 8) : (NST >= 4 ? NZ_FS_WPE : 4))))
 void flow_stream_kernel(const float *__restrict__ h, float *__restrict__ dst, nz_geom g, int S, int nstrips, int Se,
                         int nseg_edge, float nmin, float nrange, int aligned) {
@@ -414,8 +412,8 @@ void flow_stream_kernel(const float *__restrict__ h, float *__restrict__ dst, nz
     NZ_FPROBE(1, __builtin_amdgcn_s_memtime());
     NZ_FPROBE(6, (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)));   // HW_ID
     NZ_FPROBE(7, (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) | ((unsigned long long)inner << 32));  // XCC_ID
-    if (inner) flow_stream_body<NST, NC, false>(ring, h + off, dst + off, g, lx0, s0, s1, nmin, nrange);
-    else flow_stream_body<NST, NC, true>(ring, h + off, dst + off, g, lx0, s0, s1, nmin, nrange);
+    if (inner) flow_stream_body<NST, NC, false, FAST>(ring, h + off, dst + off, g, lx0, s0, s1, nmin, nrange);
+    else flow_stream_body<NST, NC, true, FAST>(ring, h + off, dst + off, g, lx0, s0, s1, nmin, nrange);
     NZ_FPROBE(4, __builtin_amdgcn_s_memrealtime());
     NZ_FPROBE(5, __builtin_amdgcn_s_memtime());
 }
@@ -461,10 +459,14 @@ int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const n
                      (uintptr_t)(g.bstride * 4);
     const int aligned = NC == 1 ? 1 : (bits & 7) == 0;
     const dim3 grid((unsigned)nblocks, g.count);
-#define NZ_FS(N)                                                                                                                        \
-    do {                                                                                                                                \
-        if (NC == 1) NZ_LAUNCH((flow_stream_kernel<N, 1>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned); \
-        else NZ_LAUNCH((flow_stream_kernel<N, 2>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned);         \
+    const bool fast = nz_tls_float_mode >= NZ_FLOAT_RELAXED;
+#define NZ_FSL(N, C, F) NZ_LAUNCH((flow_stream_kernel<N, C, F>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned)
+#define NZ_FS(N)                                \
+    do {                                        \
+        if (NC == 1 && fast) NZ_FSL(N, 1, true);  \
+        else if (NC == 1) NZ_FSL(N, 1, false);    \
+        else if (fast) NZ_FSL(N, 2, true);        \
+        else NZ_FSL(N, 2, false);                 \
     } while (0)
     switch (n) {
         case 1: NZ_FS(1); break;
@@ -474,6 +476,7 @@ int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const n
         default: NZ_FS(5); break;
     }
 #undef NZ_FS
+#undef NZ_FSL
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

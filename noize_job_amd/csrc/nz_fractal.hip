@@ -469,6 +469,45 @@ __device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1
     return 130.0f * (m0 * q0 + m1 * q1 + m2 * q2);
 }
 
+// ---- tolerance mode (NZ_FLOAT_FAST, nz_ctx_set_float_mode) ---------------------------------------------------------
+// The reference compiles FractalJob with FloatMode.Fast (Noise/Fractal/Fractal.cs:19): its own results move with the
+// compiler's contractions.  This form keeps every operation a DISCRETE decision or a cancellation depends on exactly as
+// above -- the skew, both floors, the unskew (v - i + t cancels ~1e4 down to [0, 1)), the i1 select, mod289 and the table
+// indices -- and contracts only the smooth polynomial tail: the corner falloffs m = 0.5 - x.x as two FMAs, the gradient
+// dots and the corner sum as FMAs, the corner normalisation folded into the staged gradient table (g * norm, one rounding
+// more per component), 130 * n -> rectify -> a * r folded into one FMA per octave-cell (t += (65 a) * n; the 0.5 a terms are
+// wave-uniform and added once per cell).  Per octave-cell 63 VALU instructions instead of 83; every difference from the strict
+// form is a rounding of relative size 2^-24 in a term of the octave, i.e. <= ~2e-7 relative on the fBm sum.
+__device__ __forceinline__ float snoise2_tab_fast(float vx, float vy, const int *s_t1, const float2 *s_t2) {
+    const float Cx = 0.211324865405187f, Cy = 0.366025403784439f, Cz = -0.577350269189626f;
+    float s = vx * Cy + vy * Cy;
+    float fx = floorf(vx + s), fy = floorf(vy + s);
+    float t = fx * Cx + fy * Cx;
+    float x0x = vx - fx + t, x0y = vy - fy + t;
+    bool gt = x0x > x0y;
+    // x12.xy = x0 + C.xx - i1: the constant pair selected instead of subtracted
+    float x12x = x0x + (gt ? Cx - 1.0f : Cx), x12y = x0y + (gt ? Cx : Cx - 1.0f);
+    float x12z = x0x + Cz, x12w = x0y + Cz;
+    int ixi = (int)mod289i(fx), iyi = (int)mod289i(fy);
+    int ix8 = ixi << 3;
+    int k0 = s_t1[iyi], k2 = s_t1[iyi + 1];  // 8 * permute (staged halved)
+    const char *t2 = reinterpret_cast<const char *>(s_t2);
+    int a0 = k0 + ix8, a2 = k2 + ix8;
+    int a1 = gt ? a0 + 8 : a2;
+    float2 g0 = *reinterpret_cast<const float2 *>(t2 + a0);
+    float2 g1 = *reinterpret_cast<const float2 *>(t2 + a1);
+    float2 g2 = *reinterpret_cast<const float2 *>(t2 + (a2 + 8));
+    float m0 = fmaxf(__builtin_fmaf(-x0y, x0y, __builtin_fmaf(-x0x, x0x, 0.5f)), 0.0f);
+    float m1 = fmaxf(__builtin_fmaf(-x12y, x12y, __builtin_fmaf(-x12x, x12x, 0.5f)), 0.0f);
+    float m2 = fmaxf(__builtin_fmaf(-x12w, x12w, __builtin_fmaf(-x12z, x12z, 0.5f)), 0.0f);
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
+    float q0 = __builtin_fmaf(g0.x, x0x, g0.y * x0y);
+    float q1 = __builtin_fmaf(g1.x, x12x, g1.y * x12y);
+    float q2 = __builtin_fmaf(g2.x, x12z, g2.y * x12w);
+    return __builtin_fmaf(m2, q2, __builtin_fmaf(m1, q1, m0 * q0));  // snoise / 130
+}
+
 // batched launch: grid blockIdx.y of the batch has its own world position and output plane
 __device__ __forceinline__ void fractal_batch_enter(nz_fractal_params &p, float *__restrict__ &dst) {
     if (p.positions) {
@@ -479,15 +518,24 @@ __device__ __forceinline__ void fractal_batch_enter(nz_fractal_params &p, float 
 }
 
 
-template <int VEC>
+template <int VEC, bool FAST>
 __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restrict__ dst, int rows, int cols, int pitch,
                                                                  int blocks_per_row, nz_fractal_params p,
                                                                  const int *__restrict__ t1g,
                                                                  const float4 *__restrict__ t2g) {
     __shared__ int s_t1[NZ_T1_N];
-    __shared__ float4 s_t2[NZ_T2_N];
-    for (int i = threadIdx.x; i < NZ_T1_N; i += 256) s_t1[i] = t1g[i];
-    for (int i = threadIdx.x; i < NZ_T2_N; i += 256) s_t2[i] = t2g[i];
+    __shared__ float4 s_t2[FAST ? 1 : NZ_T2_N];
+    __shared__ float2 s_t2f[FAST ? NZ_T2_N : 1];  // tolerance mode: {a0, h} * norm, 8-byte entries (T1 staged as 8 * permute)
+    if constexpr (FAST) {
+        for (int i = threadIdx.x; i < NZ_T1_N; i += 256) s_t1[i] = t1g[i] >> 1;
+        for (int i = threadIdx.x; i < NZ_T2_N; i += 256) {
+            const float4 g = t2g[i];
+            s_t2f[i] = make_float2(g.x * g.z, g.y * g.z);
+        }
+    } else {
+        for (int i = threadIdx.x; i < NZ_T1_N; i += 256) s_t1[i] = t1g[i];
+        for (int i = threadIdx.x; i < NZ_T2_N; i += 256) s_t2[i] = t2g[i];
+    }
     __syncthreads();
     fractal_batch_enter(p, dst);
     int by = blockIdx.x / blocks_per_row;
@@ -507,7 +555,20 @@ __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restr
         float reach = fabsf(zi);
 #pragma unroll
         for (int c = 0; c < VEC; c++) reach = fmaxf(reach, fabsf(xi[c]));
-        if (p.fmax * reach < NZ_TAB_LIMIT) {  // every octave of this row stays inside the tables' range
+        if (FAST && p.fmax * reach < NZ_TAB_LIMIT) {
+            float bias = 0.0f;  // the octaves' 0.5 a (wave-uniform)
+            for (int i = 0; i < p.octaves; i++) {
+                const float zV = f * zi, a65 = 65.0f * a;
+#pragma unroll
+                for (int c = 0; c < VEC; c++) t[c] = __builtin_fmaf(a65, snoise2_tab_fast(f * xi[c], zV, s_t1, s_t2f), t[c]);
+                bias = __builtin_fmaf(0.5f, a, bias);
+                detune += p.detune_rate;
+                f *= (p.stepdown - detune);
+                a *= p.G;
+            }
+#pragma unroll
+            for (int c = 0; c < VEC; c++) t[c] += bias;
+        } else if (p.fmax * reach < NZ_TAB_LIMIT) {  // every octave of this row stays inside the tables' range
             for (int i = 0; i < p.octaves; i++) {
                 float zV = f * zi;
 #pragma unroll
@@ -529,7 +590,7 @@ __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restr
                     xV[c] = f * xi[c];
                     big = fmaxf(big, fabsf(xV[c]));
                 }
-                if (big < NZ_TAB_LIMIT) {
+                if (!FAST && big < NZ_TAB_LIMIT) {  // (tolerance mode: beyond the tables' range the strict direct form)
 #pragma unroll
                     for (int c = 0; c < VEC; c++) t[c] += a * rectify(snoise2_tab(xV[c], zV, s_t1, s_t2));
                 } else {
@@ -957,8 +1018,12 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         long long blocks = (long long)bpr * ((rows + p.rows_per_wg - 1) / p.rows_per_wg);
         const int *t1 = reinterpret_cast<const int *>(d_simplex);
         const float4 *t2 = reinterpret_cast<const float4 *>(t1 + NZ_T1_N);
-        NZ_LAUNCH((fractal_simplex_tab_kernel<VEC>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows, cols,
-                           pitch, bpr, p, t1, t2);
+        if (nz_tls_float_mode >= NZ_FLOAT_FAST)
+            NZ_LAUNCH((fractal_simplex_tab_kernel<VEC, true>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows, cols,
+                      pitch, bpr, p, t1, t2);
+        else
+            NZ_LAUNCH((fractal_simplex_tab_kernel<VEC, false>), dim3((unsigned)blocks, count), dim3(256), 0, s, dst, rows, cols,
+                      pitch, bpr, p, t1, t2);
         NZ_HIP(hipGetLastError());
         return NZ_OK;
     }

@@ -53,11 +53,9 @@ struct nz_ctx {
     // stage scratch owned by the ctx (grown on demand)
     float *scratch = nullptr;
     size_t scratch_floats = 0;
-    // chained launches (nz_launch_conv_chain): tile flags (grown on demand, never cleared: they carry an epoch) and
-    // the control block {8 tickets, done, error, ...}
+    // chained launches (nz_launch_conv_chain): tile flags (grown on demand, never cleared: they carry an epoch)
     int *chain_flags = nullptr;
     size_t chain_flags_n = 0;
-    unsigned *chain_ctl = nullptr;
     unsigned *chain_err = nullptr, *chain_err_dev = nullptr;  // the error word in mapped host memory, and its device address
     unsigned chain_epoch = 0;
     bool chain_off = false;  // a chained launch once timed out on this context: separate launches from then on
@@ -74,6 +72,7 @@ struct nz_ctx {
     int *pool_ctl = nullptr;
     unsigned long long *pool_hint = nullptr, *pool_hint_dev = nullptr;
     unsigned long long pool_seq = 0;
+    int float_mode = NZ_FLOAT_STRICT;  // nz_ctx_set_float_mode
 };
 int32_t nz_ctx_pool_state(nz_ctx *ctx);  // allocates the three on first use
 
@@ -173,6 +172,8 @@ inline nz_geom nz_geom_tile(int res) { return nz_geom{res, res, res, 0, res - 1,
 // event the old way when nothing took it.  nz_ctx_begin disarms whatever an entry that failed left behind.
 // NZ_HANDLE_ON_LAUNCH=0: always the old way.
 extern thread_local hipEvent_t nz_tls_stop_event;
+// the float mode of the context whose entry this thread is running (set by nz_ctx_begin: every launcher runs behind one)
+extern thread_local int nz_tls_float_mode;
 #define NZ_LAUNCH(kernel, grid, block, lds, stream, ...)                                                  \
     do {                                                                                                   \
         if (nz_tls_stop_event) {                                                                           \
@@ -218,8 +219,8 @@ int32_t nz_launch_conv_stream(hipStream_t s, const float *src, float *dst, const
 int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L);
 bool nz_conv_small_grid(int ksize, const nz_geom &g);  // 64-row tiles, launches not chained
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
-                             const int *Ts, int L, int *flags, unsigned *ctl, unsigned epoch, unsigned *err_host);
-int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch, unsigned **err_host);
+                             const int *Ts, int L, int *flags, unsigned epoch, unsigned *err_host);
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned *epoch, unsigned **err_host);
 int32_t nz_ctx_error_word(nz_ctx *ctx, unsigned **err_host);  // mapped host memory, device address
 // one whole application of a wide odd kernel (11..25 taps), src -> dst
 bool nz_conv_has_wide(int ksize);

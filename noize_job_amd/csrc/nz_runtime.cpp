@@ -231,7 +231,6 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     if (ctx->d_simplex) (void)hipFree(ctx->d_simplex);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->chain_flags) (void)hipFree(ctx->chain_flags);
-    if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
     if (ctx->chain_err) (void)hipHostFree(ctx->chain_err);
     if (ctx->aux) {
         (void)hipStreamSynchronize(ctx->aux);
@@ -314,6 +313,15 @@ static hipEvent_t event_for(nz_ctx *owner, uint64_t q) {
 }
 
 thread_local hipEvent_t nz_tls_stop_event = nullptr;
+thread_local int nz_tls_float_mode = NZ_FLOAT_STRICT;
+
+extern "C" int32_t nz_ctx_set_float_mode(nz_ctx *ctx, int32_t mode) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    NZ_REQUIRE(mode >= NZ_FLOAT_STRICT && mode <= NZ_FLOAT_RELAXED, "unknown float mode %d", mode);
+    ctx->float_mode = mode;
+    return NZ_OK;
+}
+extern "C" int32_t nz_ctx_float_mode(nz_ctx *ctx) { return ctx ? ctx->float_mode : -1; }
 
 void nz_ctx_handle_rides(nz_ctx *ctx, bool wanted) {
     static const bool enabled = [] { const char *e = getenv("NZ_HANDLE_ON_LAUNCH"); return !e || atoi(e) != 0; }();
@@ -340,6 +348,7 @@ int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep) {
     nz_tls_stop_event = nullptr;  // (an entry that failed between arming and finishing)
     ctx->armed_seq = 0;
     ctx->handle_rides = false;
+    nz_tls_float_mode = ctx->float_mode;
     NZ_HIP(hipSetDevice(ctx->device));
     if (dep == 0) return NZ_OK;  // default(JobHandle)
     if (handle_ctx_id(dep) == ctx->id) {
@@ -454,11 +463,7 @@ int32_t nz_ctx_error_word(nz_ctx *ctx, unsigned **err_host) {
     return NZ_OK;
 }
 
-int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ctl, unsigned *epoch, unsigned **err_host) {
-    if (!ctx->chain_ctl) {
-        NZ_HIP(hipMalloc((void **)&ctx->chain_ctl, 64));
-        NZ_HIP(hipMemsetAsync(ctx->chain_ctl, 0, 64, ctx->stream));
-    }
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned *epoch, unsigned **err_host) {
     NZ_TRY_(nz_ctx_error_word(ctx, err_host));
     if (items > ctx->chain_flags_n) {
         if (ctx->chain_flags) {
@@ -474,7 +479,6 @@ int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned **ct
     }
     if (++ctx->chain_epoch == 0) ctx->chain_epoch = 1;  // 0 is what a fresh flag holds
     *flags = ctx->chain_flags;
-    *ctl = ctx->chain_ctl;
     *epoch = ctx->chain_epoch;
     return NZ_OK;
 }

@@ -132,6 +132,16 @@ class Context:
     def synchronize(self):
         N.check(N.lib.nz_ctx_synchronize(self._h), "nz_ctx_synchronize")
 
+    # nz_ctx_set_float_mode: FloatMode.Strict / FloatMode.Fast of the [BurstCompile] attributes (Fractal.cs:19,
+    # KernelJob.cs:17, FlowMapJob.cs:16) as a property of the context the jobs are scheduled on
+    @property
+    def float_mode(self):
+        return N.lib.nz_ctx_float_mode(self._h)
+
+    @float_mode.setter
+    def float_mode(self, mode):
+        N.check(N.lib.nz_ctx_set_float_mode(self._h, int(mode)), "nz_ctx_set_float_mode")
+
     def alloc(self, length, dtype=np.float32):
         return DeviceTile(self, length, dtype=dtype)
 
