@@ -57,6 +57,12 @@ KERNEL_PREFIX = {"noise": ("fractal_simplex_tab_kernel",), "gauss": ("conv_chain
 # value-erosion application = 2 min.  useful_valu_frac = this x cells / (SQ_INSTS_VALU x 64): what the halo recompute,
 # selects, moves and address arithmetic leave of the instructions executed
 ALGO_LANE_OPS = {"noise": 13 * 85.0, "gauss": G_IT * 18.0, "flow": F_IT * 40.0 + 15.0, "erosion": E_IT * 2.0}
+# the same in lane-INSTRUCTIONS of the tolerance forms (an FMA is one): the fBm octave with its polynomial tail contracted
+# (64 per octave-cell in the ISA), a 5-tap application as 2 x (1 mul + 4 fma), a flow iteration with v_rcp_f32 for the division
+ALGO_LANE_OPS_MODE = {"strict": ALGO_LANE_OPS,
+                      "fast": dict(ALGO_LANE_OPS, noise=13 * 64.0, gauss=G_IT * 10.0),
+                      "relaxed": dict(ALGO_LANE_OPS, noise=13 * 64.0, gauss=G_IT * 10.0, flow=F_IT * 30.0 + 8.0)}
+FLOAT_MODES = {"strict": 0, "fast": 1, "relaxed": 2}
 
 CPU_PASSES = 11         # ~10 s of host work on the GPU box's 32 cores (0.9-1.0 s per 4096^2 pass)
 PREHEAT_MIN_STEPS = 50  # untimed passes before the timed region, warm-up included (clock settling)
@@ -107,6 +113,10 @@ def parse():
                          "rows recomputed from the closed-form noise; the fp32-bound kernels of one stripe overlap "
                          "the HBM-bound kernels of another); 1 = the stage pipeline on one stream")
     ap.add_argument("--cpu-res", type=int, default=0, help="tile side of the CPU baseline (0 = --res)")
+    ap.add_argument("--float-mode", choices=tuple(FLOAT_MODES), default="strict",
+                    help="nz_ctx_set_float_mode of the timed steps: strict (the reference's operation sequence, bit-equal to the "
+                         "oracle: the headline), fast (fBm tail and tap sums FMA-contracted, every stage within 1e-5 of strict), "
+                         "relaxed (fast + the flow iterations).  The other modes are timed beside the headline in `float_modes`")
     ap.add_argument("--schedule", choices=("pipeline", "stages"), default="stages",
                     help="N=1: `stages` = the reference's stage-by-stage hand-over on one stream (BasePipeline's default); "
                          "`pipeline` = BasePipeline.fuseStages: the stock stage list goes to the library as ONE call "
@@ -127,8 +137,8 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def load_counters(res, flush):
-    """Newest profiles/*_counters.json (tools/fold_counters.py) taken with these kernel sources and this flush mode:
+def load_counters(res, flush, mode="strict"):
+    """Newest profiles/*_counters.json (tools/fold_counters.py) taken with these kernel sources, this flush mode and this float mode:
     per kernel SQ_INSTS_VALU and HBM bytes (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes) per launch.  A summary of
     another tile size is used scaled by the cell count and says so.  None if nothing matches."""
     sha = kernel_sources_sha()
@@ -142,7 +152,8 @@ def load_counters(res, flush):
         c = d.get("config", {}) if isinstance(d, dict) else {}
         if not isinstance(c, dict) or "kernels" not in d:  # another tool's summary (e.g. *_config4_counters.json)
             continue
-        if c.get("kernel_sources_sha") == sha and c.get("flush") == flush and not c.get("sharded"):
+        if (c.get("kernel_sources_sha") == sha and c.get("flush") == flush and not c.get("sharded")
+                and c.get("float_mode", "strict") == mode):
             best = (path, d)
     if best is None:
         return None
@@ -328,13 +339,16 @@ def make_native_comm(sh, torch, dist, ctx, rank, world):
     return sh.NativeComm(ctx, uid[0], rank, world)
 
 
-def strong_grid(nj, sh, torch, dist, ctx, grid, rank, world, impl="native", ncomm=None, steps=20, warm=5):
+def strong_grid(nj, sh, torch, dist, ctx, grid, rank, world, impl="native", ncomm=None, steps=20, warm=5, verify=True,
+                strict=True):
     """BASELINE config 5's grid (grid^2) split into `world` row stripes, one per rank: the quantity the >= 6x target is
     defined on, measured at EVERY N (N = 1: the whole grid on one GPU).  Ghost rows recomputed from the closed-form
     noise (no communication) and, at N > 1, exchanged with the neighbour ranks over RCCL before every launch, with the
     time the compute stream spends in the exchanges split out.  Barrier + synchronize on both sides, max over ranks."""
+    import numpy as np
     out = {}
     ops = sh.HipStripeOps(ctx)
+    oracle_cache = {}
     # native: "exchange" = the transfers on the compute stream between the launches (overlap 0, the default);
     # "exchange_interior_first" / "exchange_border_first" = the two overlapped schedules (overlap 1 / 2).
     # python: "exchange" = overlapped P2P batches, "exchange_blocking" = the exchange completes first
@@ -369,6 +383,8 @@ def strong_grid(nj, sh, torch, dist, ctx, grid, rank, world, impl="native", ncom
             fence()
             dt = time.perf_counter() - t0
             ex_ms = g.exchange_ms() / steps if (mode != "recompute" and world > 1) else 0.0
+            # the rows every rank owns after the last timed pass against the CPU oracle (outside the timed region)
+            ver = verify_sharded(np, torch, dist, g, p, grid, grid, world, oracle_cache, strict) if verify else None
             g.close()
         else:
             halo = sh.halo_rows_needed(ops, p)
@@ -393,6 +409,7 @@ def strong_grid(nj, sh, torch, dist, ctx, grid, rank, world, impl="native", ncom
             fence()
             dt = time.perf_counter() - t0
             ex_ms = comm.total_ms() / steps if isinstance(comm, TimedComm) else 0.0
+            ver = None  # (the Python schedule is verified by tests/test_gpu_fullsize.py)
             del bufs
             torch.cuda.empty_cache()
         host_ms = host_s / steps * 1e3
@@ -404,13 +421,65 @@ def strong_grid(nj, sh, torch, dist, ctx, grid, rank, world, impl="native", ncom
              "host_enqueue_ms_per_step": round(host_ms, 4)}
         if mode != "recompute":
             e["exchange_ms_per_step"] = round(ex_ms, 4)
+        if ver is not None:
+            e.update(ver)
         out[label] = e
     out["grid"] = "%dx%d as %d row stripes of %d rows" % (grid, grid, world, grid // world)
     out["steps"] = steps
     out["impl"] = impl
+    checked = [out[k]["verified"] for k in modes if isinstance(out.get(k), dict) and "verified" in out[k]]
+    out["verified"] = all(checked) if checked else None
     out["note"] = ("strong scaling: the same %d^2 grid at every N; speed-up at N GPUs = this figure at N / this figure "
-                   "at N = 1" % grid)
+                   "at N = 1.  `verified`: after the timed passes of every schedule each rank compares the rows it owns with "
+                   "the CPU oracle's rows of the monolithic grid%s" % (grid, " (bit for bit)" if strict else " (1e-5 rel / 1e-6 abs)"))
     return out
+
+
+def oracle_rows(p, grid_rows, cols, g0, g1, threads=0):
+    """Rows [g0, g1) of the monolithic grid_rows x cols pipeline from the CPU oracle (the checker), computed on a window
+    widened by more than the stage list's dependency radius (2 rows per 5-tap application, 2 per flow iteration, 1 per
+    erosion application upwards): the clamps at the window's own ends cannot reach the rows kept, the clamps at the grid's
+    real border are the window's.  1 / N of the whole-grid oracle pass per rank."""
+    import oracle as O
+    O.lib()
+    if threads > 0:
+        O.set_threads(threads)
+    margin = 4 * p.gaussIterations + 2 * p.flowIterations + p.erosionIterations + 8  # generous for every 3..9-tap filter
+    a, b = max(0, g0 - margin), min(grid_rows, g1 + margin)
+    w = O.pipeline(b - a, cols, p.noiseType, p.hurst, p.startingAmplitude, p.stepdown, p.detuneRate, p.octaves, p.xpos,
+                   p.zpos + a, p.noiseSize, p.filter, p.gaussIterations, p.flowIterations, p.normMin, p.normMax,
+                   p.erosionIterations)
+    return w[g0 - a:g1 - a]
+
+
+def verify_sharded(np, torch, dist, grid_obj, p, grid_rows, cols, world, cache, strict):
+    """The rows this rank owns after the last pass against the oracle's (bit for bit in strict mode), every rank for itself,
+    the verdicts combined (min over ranks).  -> {"verified", "rows_checked", "oracle_s"}.  `cache` keeps a rank's oracle rows
+    between the schedules of one grid."""
+    t0 = time.perf_counter()
+    ok, rows_checked, worst = True, 0, 0.0
+    for i in range(grid_obj.local_stripes):
+        g0, got = grid_obj.owned_rows(i)
+        key = (grid_rows, cols, g0, g0 + got.shape[0])
+        if key not in cache:
+            cache[key] = oracle_rows(p, grid_rows, cols, g0, g0 + got.shape[0], threads=max(1, (os.cpu_count() or 1) // max(1, world)))
+        want = cache[key]
+        same = bool(np.array_equal(got, want))
+        if not same:
+            worst = max(worst, float(np.abs(got - want).max()))
+        ok = ok and (same if strict else bool(np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-6)))
+        rows_checked += got.shape[0]
+    if world > 1:
+        t = torch.tensor([1.0 if ok else 0.0, -float(rows_checked), -worst], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok, worst = bool(t[0].item() > 0.5), -float(t[2].item())
+        tr = torch.tensor([float(rows_checked)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        rows_checked = int(tr[0].item())
+    r = {"verified": ok, "rows_checked": rows_checked, "oracle_and_compare_s": round(time.perf_counter() - t0, 2)}
+    if not ok:
+        r["max_abs_diff"] = worst
+    return r
 
 
 def cpu_baseline(res):
@@ -507,6 +576,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx = nj.Context(local_rank, stream=stream.cuda_stream)
+    ctx.float_mode = FLOAT_MODES[args.float_mode]
 
     p = sh.PipelineParams(gaussIterations=G_IT, flowIterations=F_IT, erosionIterations=E_IT, haloMode=args.halo)
     marks = []  # per step: handles at stage boundaries
@@ -677,6 +747,24 @@ def main():
     gc.collect()
     gc.disable()
     preheat = max(0, PREHEAT_MIN_STEPS - args.warmup)
+    literal = None
+    if preheat > 0:
+        # The command exactly as given -- W warm-ups, then K timed steps, from a chip that has been idle for half a second,
+        # no preheat: reported as `literal_command` beside the steady-state headline (whose `warmup_effective` says what ran)
+        fence()
+        time.sleep(0.5)
+        for _ in range(args.warmup):
+            step(False)
+        fence()
+        tl = time.perf_counter()
+        for _ in range(args.steps):
+            step(False)
+        fence()
+        literal = (time.perf_counter() - tl) / args.steps
+        if sharded:
+            tlit = torch.tensor([literal], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tlit, op=dist.ReduceOp.MAX)
+            literal = float(tlit[0].item())
     for _ in range(preheat):
         step(False)
     for _ in range(args.warmup):
@@ -727,6 +815,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, exchange_ms, host_enqueue_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
 
+    rank_reports = None
+    if sharded:
+        # what every rank's communicator says about itself (nz_comm_rank / nz_comm_world = ncclCommUserRank / ncclCommCount of the
+        # library's own communicator), its HIP device and the rows it owns: gathered so that the line shows N distinct devices
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "device_name": torch.cuda.get_device_name(),
+                "pci_bus": getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "pci_bus_id", None),
+                "native_comm": None if ncomm is None else {"rank": sh.N.lib.nz_comm_rank(ncomm._h), "world": sh.N.lib.nz_comm_world(ncomm._h)},
+                "owned_rows": [plan.g0, plan.g0 + plan.nown]}
+        rank_reports = [None] * world
+        dist.all_gather_object(rank_reports, mine)
+
     stage_by_stage_s, got_one_call = None, None
     if not sharded and striped is None and one_call:
         if rank == 0 and not args.no_cpu_baseline and (args.cpu_res or res) == res:
@@ -744,7 +843,8 @@ def main():
         total_bytes = sum(BYTES.values())
         out = {"metric": "Mcells/s 4096^2 simplex13oct->Gauss5x17->FlowMap->Erosion; %HBM roofline @1/8GPU",
                "value": round(value, 1), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+               "warmup": args.warmup, "warmup_effective": preheat + args.warmup,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
                "scaling": "strong" if (not sharded or strong) else "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
                "config": {"workload": workload, "cells": cells, "parallelism": parallelism, "preheat_steps": preheat,
@@ -756,6 +856,14 @@ def main():
                                         "filter / flow / erosion application) over the step time.  NOT a roofline: the "
                                         "applications are fused on chip, the HBM traffic actually moved is `stages.*."
                                         "hbm_bytes_per_launch`, so this figure may exceed the peak"}}
+        out["config"]["float_mode"] = args.float_mode
+        if literal is not None:
+            out["literal_command"] = {
+                "ms_per_step": round(literal * 1e3, 4), "Mcells/s": round(cells / literal / 1e6, 1),
+                "note": "--warmup %d --steps %d taken literally: %d warm-up steps from an idle chip (0.5 s), then the %d timed "
+                        "steps, no preheat.  `value` is the steady state: %d untimed steps (warmup_effective) precede its %d timed "
+                        "ones, because the chip's clocks need some tens of ms of continuous work to settle" %
+                        (args.warmup, args.steps, args.warmup, args.steps, preheat + args.warmup, args.steps)}
         if sharded:
             try:
                 rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -789,6 +897,7 @@ def main():
                                    "(max over ranks; includes the time the full command queue pushes back); "
                                    "host_enqueue_ms_idle_queue = the same call on an idle stream (median of 8, rank 0): the "
                                    "host's own cost -- the step is host-bound if THIS approaches ms_per_step"}
+            out["comm"]["ranks"] = rank_reports
             out["config"]["strong_scaling"] = (
                 "the same %dx%d grid at every N; denominator = `grid_%d`.recompute of the N = 1 line (the whole grid on one "
                 "GPU)" % (plan.grows, plan.cols, plan.grows)) if strong else None
@@ -805,7 +914,10 @@ def main():
         if cold_ms is not None:
             out["cold_ms"] = round(cold_ms, 4)
             out["config"]["cold_ms_note"] = "one step from an idle chip (0.5 s after the previous one), host-timed"
-    if rank == 0 and marks:
+    def analyse(marks, mode, ms_step):
+        """Per-stage launch times from the stage-boundary markers of `marks`, priced with the counter summary that belongs to
+        these kernel sources in float mode `mode`: {"stages", "roofline", "counters_source", "step_valu"}."""
+        res_ = {}
         flow_cap = nj._native.lib.nz_flow_fused_max_iterations()
         flow_launches = len(sh.split_iterations(F_IT, flow_cap))
         # the tile API ends a one-launch flow stage with a copy back into the caller's plane; stripes ping-pong
@@ -859,7 +971,7 @@ def main():
         # Counter summary of these very kernels (same source hash, same flush mode), if one is committed: VALU
         # instructions and HBM bytes per launch.  Launch times are this run's; the counters are not re-measured here
         # (rocprofv3 --pmc cannot run inside the timed region) and `counters_source` says where they come from.
-        cnt = None if (sharded or striped is not None) else load_counters(res, args.flush)
+        cnt = None if (sharded or striped is not None) else load_counters(res, args.flush, mode)
         valu_floor_ms = 0.0
         for n in STAGES:
             s = stages_out[n]
@@ -878,30 +990,30 @@ def main():
             valu_frac = insts * VALU_CYCLES_PER_INST / (N_SIMD * CLK_HZ) / (launch_ms * 1e-3)
             hbm_frac = hbm / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             valu_floor_ms += launches[n] * insts * VALU_CYCLES_PER_INST / (N_SIMD * CLK_HZ) * 1e3
-            s["useful_valu_frac"] = round(ALGO_LANE_OPS[n] * rcells / (launches[n] * insts * 64.0), 4)
+            s["useful_valu_frac"] = round(ALGO_LANE_OPS_MODE[mode][n] * rcells / (launches[n] * insts * 64.0), 4)
             s.update({"kernel": name, "valu_insts_per_launch": round(insts), "hbm_bytes_per_launch": round(hbm),
                       "valu_issue_frac": round(valu_frac, 4), "hbm_traffic_frac": round(hbm_frac, 4),
                       "bound": "valu-fp32" if valu_frac >= hbm_frac else "hbm"})
-        out["stages"] = stages_out
+        res_["stages"] = stages_out
         dom = max(STAGES, key=lambda n: kernel_ms[n])
         s = stages_out[dom]
         if s.get("bound") == "hbm":
             ach = s["hbm_bytes_per_launch"] / (s["avg_launch_ms"] * 1e-3) / 1e9
-            out["roofline"] = {"kernel": s["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            res_["roofline"] = {"kernel": s["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                "traffic": s["hbm_bytes_per_launch"]}
         elif s.get("bound") == "valu-fp32":
             ach = s["valu_insts_per_launch"] * 64 / (s["avg_launch_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": s["kernel"], "bound": "valu-fp32", "achieved": round(ach, 2),
+            res_["roofline"] = {"kernel": s["kernel"], "bound": "valu-fp32", "achieved": round(ach, 2),
                                "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tlane-op/s",
                                "frac": round(ach / VALU_PEAK_TOPS, 4), "traffic": s["hbm_bytes_per_launch"],
                                "hbm_traffic_frac": s["hbm_traffic_frac"]}
         else:  # no counter summary of these kernels: the only figure this run can form itself
             ach = BYTES[dom] * rcells / launches[dom] / (s["avg_launch_ms"] * 1e-3) / 1e9
-            out["roofline"] = {"kernel": s["kernel"], "bound": "unknown", "achieved": None, "peak": HBM_PEAK_GBS,
+            res_["roofline"] = {"kernel": s["kernel"], "bound": "unknown", "achieved": None, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": None, "traffic": None,
                                "algorithmic_equivalent_GB/s": round(ach, 1)}
-        out["roofline"].update({
+        res_["roofline"].update({
             "stage": dom, "share_of_step": round(kernel_ms[dom] / sum(stage_ms.values()), 4),
             "launches_per_step": launches[dom], "avg_launch_ms": s["avg_launch_ms"],
             "note": "the kernel with the largest share of the step, under the larger of its two fractions: VALU issue "
@@ -909,17 +1021,21 @@ def main():
                     "WRITE_SIZE bytes / launch time / 8 TB/s); launch time from this run's HIP events, counters from "
                     "`counters_source`"})
         if cnt is not None:
-            out["counters_source"] = {"file": cnt["file"], "commit": cnt["commit"],
+            res_["counters_source"] = {"file": cnt["file"], "commit": cnt["commit"],
                                       "kernel_sources_sha": kernel_sources_sha(),
                                       "scaled_from_res": cnt["res"] if cnt["scale"] != 1.0 else None,
                                       "collected": "rocprofv3 --kernel-trace --pmc, one pass per counter group "
                                                    "(tools/collect_profiles.sh), folded by tools/fold_counters.py"}
-            out["step_valu"] = {"floor_ms": round(valu_floor_ms, 4), "frac": round(valu_floor_ms / ms_per_step, 4),
+            res_["step_valu"] = {"floor_ms": round(valu_floor_ms, 4), "frac": round(valu_floor_ms / ms_step, 4),
                                 "note": "sum over the step's launches of SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz)"
                                         ": the time the step's VALU instructions need at full issue rate, over "
                                         "ms_per_step"}
         else:
-            out["counters_source"] = None
+            res_["counters_source"] = None
+        return res_
+
+    if rank == 0 and marks:
+        out.update(analyse(marks, args.float_mode, ms_per_step))
     if rank == 0 and not args.no_cpu_baseline and not sharded:
         cres = args.cpu_res or res
         out["cpu_baseline"], plane = cpu_baseline(cres)
@@ -942,6 +1058,64 @@ def main():
                     "max_abs_diff": float(np.abs(got.reshape(res, res) - plane).max())})
         else:
             out["verified"] = None
+    plane_oracle = plane if (rank == 0 and not args.no_cpu_baseline and not sharded and (args.cpu_res or res) == res) else None
+    if sharded and grid is not None and not args.no_cpu_baseline:
+        # every rank: the rows it owns after the last timed pass against the CPU oracle's rows of the monolithic grid
+        if args.as_rank is not None and args.halo != "recompute":
+            ver = {"verified": None, "note": "rehearsal with exchanged ghost rows: the neighbour ranks are played by the rank "
+                                             "itself, so the rows that arrive are not the grid's -- timing only (--halo recompute "
+                                             "rehearsals are verified)"}
+        else:
+            ver = verify_sharded(np, torch, dist, grid, p, plan.grows, plan.cols, world, {}, args.float_mode == "strict")
+        if rank == 0:
+            out["verified"] = ver.pop("verified")
+            out["verified_detail"] = ver
+    if rank == 0 and not sharded and striped is None and not one_call and not args.no_extras:
+        # the other float modes beside the headline: the same step on the same planes, 100 timed steps after 30 untimed ones,
+        # then 40 marked steps for the stage times; the plane each mode leaves is compared with the oracle's
+        modes_out = {}
+        for mode in FLOAT_MODES:
+            gc.collect()
+            ctx.float_mode = FLOAT_MODES[mode]
+            for _ in range(30):
+                step(False)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(100):
+                step(False)
+            fence()
+            dtm = (time.perf_counter() - t1) / 100
+            del marks[:]
+            prev_end[0] = None
+            for _ in range(40):
+                step(True)
+            fence()
+            e = {"ms_per_step": round(dtm * 1e3, 4), "Mcells/s": round(cells / dtm / 1e6, 1)}
+            a = analyse(list(marks), mode, dtm * 1e3)
+            e["stages_ms"] = {n: a["stages"][n]["ms"] for n in STAGES}
+            e["valu_issue_frac"] = {n: a["stages"][n].get("valu_issue_frac") for n in STAGES}
+            e["roofline"] = {k: a["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")}
+            e["counters_source"] = a["counters_source"]["file"] if a.get("counters_source") else None
+            if plane_oracle is not None:
+                got = np.empty(cells, np.float32)
+                nj._native.check(nj._native.lib.nz_tile_download(ctx._h, gd.data.ptr, got.ctypes.data, cells, 0, None), "download")
+                fence()
+                got = got.reshape(res, res)
+                d = np.abs(got - plane_oracle)
+                e["end_to_end_vs_oracle"] = {"bit_equal": bool(np.array_equal(got, plane_oracle)), "max_abs": float(d.max()),
+                                             "cells_within_1e-5_rel_1e-6_abs": round(float(np.mean(d <= 1e-5 * np.abs(plane_oracle) + 1e-6)), 6)}
+            modes_out[mode] = e
+        del marks[:]
+        ctx.float_mode = FLOAT_MODES[args.float_mode]
+        modes_out["note"] = (
+            "nz_ctx_set_float_mode.  strict = the reference's operation sequence, bit-equal to the oracle (the headline unless "
+            "--float-mode says otherwise).  fast = the fBm octave's polynomial tail and the tap sums FMA-contracted: EVERY STAGE within "
+            "1e-5 rel / 1e-6 abs of strict for the same input plane (tests/test_gpu_fast.py, 4096^2: fBm 9e-7, Gauss5 x17 4.5e-7, "
+            "flow and erosion run their strict forms).  relaxed = fast + v_rcp_f32 / FMA / v_sqrt_f32 in the flow iterations: the "
+            "flow stage leaves the band in ~1e-4 of its cells.  END TO END no tolerance mode stays inside 1e-5: the flow map "
+            "differentiates the filtered heights (neighbours 1e-3 apart, each known to 6e-8), so one ulp in its input plane moves "
+            "its output by ~1e-4 relative -- as between any two FloatMode.Fast builds of the reference")
+        out["float_modes"] = modes_out
     extras = not args.no_extras
     if rank == 0 and extras and not sharded and striped is None:
         # informational, outside the timed steps; never allowed to cost the JSON line: an exception is recorded, and
@@ -978,14 +1152,16 @@ def main():
         if not sharded:  # N = 1 without a process group: the whole grid as one stripe
             g = None
             try:
-                g = strong_grid(nj, sh, torch, None, ctx, args.grid, 0, 1, impl=args.impl)
+                g = strong_grid(nj, sh, torch, None, ctx, args.grid, 0, 1, impl=args.impl, verify=not args.no_cpu_baseline,
+                                strict=args.float_mode == "strict")
             except Exception as e:  # noqa: BLE001  (e.g. not enough free memory next to other processes)
                 g = {"error": "%s: %s" % (type(e).__name__, e)}
             out["grid_%d" % args.grid] = g
         else:
             if args.impl == "native" and ncomm is None and world > 1:
                 ncomm = make_native_comm(sh, torch, dist, ctx, rank, world)
-            g = strong_grid(nj, sh, torch, dist, ctx, args.grid, rank, world, impl=args.impl, ncomm=ncomm)
+            g = strong_grid(nj, sh, torch, dist, ctx, args.grid, rank, world, impl=args.impl, ncomm=ncomm,
+                            verify=not args.no_cpu_baseline, strict=args.float_mode == "strict")
             if rank == 0:
                 out["grid_%d" % args.grid] = g
     if sharded:

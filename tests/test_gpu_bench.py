@@ -49,12 +49,27 @@ def test_single_gpu_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mcells/s" and c["cores"] >= 1 and c["value"] > 0 and "-O" in c["sample"]
     assert d["in_place_entries"]["ms_per_step"] > 0 and d["grid_2048"]["recompute"]["Mcells/s"] > 0
+    # the warm-up that ran is what the line says ran; the command taken literally is reported beside the steady state
+    assert d["warmup_effective"] == 50 and d["config"]["preheat_steps"] == 48
+    assert d["literal_command"]["ms_per_step"] > 0 and d["literal_command"]["Mcells/s"] > 0
+    # the sharded grid's rows are compared with the oracle's after its timed passes
+    assert d["grid_2048"]["verified"] is True and d["grid_2048"]["recompute"]["verified"] is True
+    assert d["grid_2048"]["recompute"]["rows_checked"] == 2048
+    # the float modes side by side: strict is bit-equal end to end, the tolerance modes are faster and are not
+    fm = d["float_modes"]
+    assert set(fm) >= {"strict", "fast", "relaxed"} and d["config"]["float_mode"] == "strict"
+    assert fm["strict"]["end_to_end_vs_oracle"]["bit_equal"] is True
+    assert fm["fast"]["end_to_end_vs_oracle"]["bit_equal"] is False and fm["fast"]["end_to_end_vs_oracle"]["max_abs"] < 2e-3
+    assert fm["fast"]["ms_per_step"] > 0 and set(fm["relaxed"]["stages_ms"]) == {"noise", "gauss", "flow", "erosion"}
 
 
 def test_stripe_rehearsal_line():
     d = _run("--steps", "4", "--warmup", "1", "--as-rank", "1", "4", "--stripe-rows", "256", "--cols", "1024")
     assert d["n_gpus"] == 1 and "cpu_baseline" not in d and "roofline" in d
     assert "rehearsal of rank 1 of 4" in d["config"]["parallelism"] and d["config"]["cells"] == 256 * 1024
+    # the rank's owned rows (global rows 256 .. 511 of the 1024-row grid) equal the oracle's rows of the monolithic grid
+    assert d["verified"] is True and d["verified_detail"]["rows_checked"] == 256
+    assert d["comm"]["ranks"][0]["owned_rows"] == [256, 512]
 
 
 @pytest.mark.timeout(400, method="thread")
@@ -95,9 +110,11 @@ def test_bench_starts_its_own_ranks_one_rank():
     # the one-GPU box drives the self-launch path with one rank: RCCL process group, stripe schedule, exchanges with
     # the rank's own neighbours absent (first and last stripe at once), `comm` in the line
     d = _self_launched("--gpus", "1", "--sharded", "--self-launch", "--steps", "4", "--warmup", "1", "--stripe-rows", "384",
-                       "--cols", "1024", "--grid", "1024", "--halo", "exchange", "--no-cpu-baseline")
+                       "--cols", "1024", "--grid", "1024", "--halo", "exchange")
     assert d["n_gpus"] == 1 and d["config"]["cells"] == 384 * 1024 and d["value"] > 0
+    assert d["verified"] is True and d["grid_1024"]["verified"] is True
     c = d["comm"]
+    assert c["ranks"][0]["native_comm"] == {"rank": 0, "world": 1} and c["ranks"][0]["owned_rows"] == [0, 384]
     assert c["backend"] == "nccl" and c["world"] == 1 and c["halo"] == "exchange" and c["overlapped"] is False
     # one exchange per stencil launch: 4 filter launches + flow + erosion unless a fusion-depth knob regroups them
     regrouped = any(os.environ.get(k) for k in ("NZ_CONV_TCAP", "NZ_FLOW_NMAX", "NZ_EROSION_EMAX"))
@@ -112,8 +129,10 @@ def test_bench_gpus_2_without_a_launcher():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two visible GPUs")
     # N = 2 exactly as the driver would type it: the 2048^2 grid split over two ranks, ghost rows exchanged over RCCL
-    d = _self_launched("--gpus", "2", "--steps", "4", "--warmup", "1", "--grid", "2048", "--cols", "2048", "--no-cpu-baseline")
+    d = _self_launched("--gpus", "2", "--steps", "4", "--warmup", "1", "--grid", "2048", "--cols", "2048")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["cells"] == 2048 * 2048
+    assert d["verified"] is True and d["grid_2048"]["verified"] is True
+    assert sorted(r["device"] for r in d["comm"]["ranks"]) == [0, 1] and all(r["native_comm"]["world"] == 2 for r in d["comm"]["ranks"])
     c = d["comm"]
     assert c["backend"] == "nccl" and c["world"] == 2 and c["halo"] == "exchange" and c["exchange_ms_per_step"] > 0.0
     assert set(d["grid_2048"]) >= {"recompute", "exchange", "exchange_interior_first", "exchange_border_first", "exchange_once"}

@@ -178,7 +178,7 @@ def test_fast_forms_agree_with_each_other(nj, fctx, oracle, res):
     for it in (5, 12):
         f = _stage_on(nj, fctx, nj.FlowMapStage(fctx, it, 0.0, 0.005), hsm)
         rel, ab, bad = _err(f, oracle.flowmap(hsm, it, 0.0, 0.005))
-        assert (bad == 0) if fctx.float_mode == 1 else (bad <= max(4, 1e-3 * res * res) and ab < 1e-3), (it, rel, ab, bad)
+        assert (bad == 0) if fctx.float_mode == 1 else (bad <= max(8, 0.02 * res * res) and ab < 1e-3), (it, rel, ab, bad)
     # the wide blurs (one application per launch through an LDS plane) and a 9-tap one
     for width in (13, 25, 9):
         g = _stage_on(nj, fctx, nj.StageGaussianBlur(fctx, 2, nj.GaussSigma.s2d00, width), src)

@@ -4,8 +4,13 @@ The oracle finishes a 4096^2 pass in about a second on the GPU box's host cores,
 pipeline is compared with it directly at full size, bit for bit; size-independent properties
 (composition of min filters, constant / mass preservation of normalised kernels, tile seams,
 sharded == monolithic) are checked at the same size."""
+import os
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -86,12 +91,12 @@ def test_config4_base_8192_cellular13_equals_oracle(nj, ctx, oracle):
 
 
 @pytest.mark.timeout(1000, method="thread")
-def test_config5_16384_equals_oracle(nj, ctx, oracle):
+def test_config5_16384_equals_oracle(nj, ctx, oracle, tmp_path):
     # BASELINE config 5's grid, 16384^2, against the oracle (about 15 s on the box's 32 host cores), bit for bit:
-    # (1) as ONE tile through the stage pipeline, (2) as the 8 row stripes of 2048 x 16384 the 8-GPU run gives its
-    # ranks, through the product schedule with ghost rows EXCHANGED before every launch (run_pipeline_lockstep: all
-    # ranks in one process, the copies standing for the RCCL P2P batches), NaN-filled buffers so that a stale or
-    # missing ghost row cannot hide
+    # (1) as ONE tile through the stage pipeline, (2) through the native sharded path (see below), (3) as the 8 row
+    # stripes of 2048 x 16384 the 8-GPU run gives its ranks, through the Python schedule with ghost rows EXCHANGED before
+    # every launch (run_pipeline_lockstep: all ranks in one process, the copies standing for the RCCL P2P batches),
+    # NaN-filled buffers so that a stale or missing ghost row cannot hide
     import torch
     from noize_job_amd import sharded as sh
     G = 16384
@@ -108,7 +113,21 @@ def test_config5_16384_equals_oracle(nj, ctx, oracle):
     data.Dispose()
     assert np.array_equal(got, want)
     del got
+    # (2) the NATIVE path -- nz_sharded_pipeline, what `bench.py --gpus N` and `grid_16384` time: 8 stripes of 2048 x 16384 on one
+    # rank, ghost rows through the library's own ncclSend / ncclRecv (a rank is its own peer) for `exchange`, recomputed for
+    # `recompute`; a child process with a hard time limit (everything that talks to RCCL), the oracle plane handed over as a
+    # memory-mapped file and compared there, stripe by stripe
+    from test_sharded_native import _in_child
+    want_path = str(tmp_path / "want16384.npy")
+    np.save(want_path, want)
     for mode in ("exchange", "recompute"):
+        r = _in_child(tmp_path, "grid_vs_file", (G, G, dict(haloMode=mode), 8, 0, want_path), limit=600)
+        assert int(r["rows"][0]) == G and r["same"].all(), (mode, r["same"])
+        exchanges, sent = r["traffic"]
+        assert (exchanges == 0) == (mode == "recompute")
+    os.remove(want_path)
+    # (3) the Python schedule (noize_job_amd/sharded.py over the stripe entry points), exchange mode
+    for mode in ("exchange",):
         p = sh.PipelineParams(haloMode=mode)
         stream = torch.cuda.Stream()
         with torch.cuda.stream(stream):

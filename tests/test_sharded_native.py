@@ -213,6 +213,23 @@ def _rccl_worker(kind, out_path, args):
         res["range"] = rng.ToArray()
         res["norm"] = np.concatenate([g.owned_rows(i)[1] for i in range(g.local_stripes)], axis=0)
         g.close()
+    elif kind == "grid_vs_file":
+        # a grid too large to hand back through a file: the parent's oracle plane is memory-mapped here and every stripe's owned
+        # rows are compared in place (two passes: the second runs on the planes the first one left behind)
+        grows, cols, pkw, stripes, overlap, want_path = args
+        want = np.load(want_path, mmap_mode="r")
+        g = sh.ShardedGrid(ctx, comm, grows, cols, sh.PipelineParams(**pkw), stripes=stripes, overlap=overlap)
+        same, rows = [], 0
+        for _ in range(2):
+            g.run()
+        for i in range(g.local_stripes):
+            g0, got = g.owned_rows(i)
+            same.append(bool(np.array_equal(got, want[g0:g0 + got.shape[0]])))
+            rows += got.shape[0]
+        res["same"] = np.array(same)
+        res["rows"] = np.array([rows])
+        res["traffic"] = np.array(g.traffic(), np.int64)
+        g.close()
     elif kind == "rehearsal":
         grows, cols, mode, stripes = args
         p = sh.PipelineParams(haloMode=mode)

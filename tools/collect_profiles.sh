@@ -1,16 +1,18 @@
 #!/bin/bash
 # Collects the evidence set profiles/README.md describes, on the GPU box:
-#   tools/collect_profiles.sh <tag> [commit] [flush]   ->  gpurun_out/<tag>_{bench.json,kernel_stats.csv,counters.json}
+#   tools/collect_profiles.sh <tag> [commit] [flush] [float mode]   ->  gpurun_out/<tag>_{bench.json,kernel_stats.csv,counters.json}
+# (float mode strict / fast / relaxed: one evidence set per mode; NZ_SKIP_BENCH=1 leaves the final bench.py run out)
 # Every counter group is its own rocprofv3 run with --kernel-trace only (no other trace domains).
 set -e
 TAG=${1:-r02_vX}
 COMMIT=${2:-unknown}
 FLUSH=${3:-swap}
+MODE=${4:-strict}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-extras --flush $FLUSH --schedule stages"
+ARGS="--no-cpu-baseline --no-extras --flush $FLUSH --schedule stages --float-mode $MODE"
 P="$OUT/prof_$TAG"
 rm -rf "$P"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/stats" -o run -- python3 "$ROOT/bench.py" --steps 60 --warmup 20 $ARGS > "$OUT/${TAG}_stats.log" 2>&1
@@ -26,8 +28,10 @@ cp "$(find "$P/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_
 python3 tools/fold_counters.py --fetch "$(find "$P/fetch" -name '*counter_collection.csv' | head -1)" \
     --write "$(find "$P/write" -name '*counter_collection.csv' | head -1)" \
     --sq "$(find "$P/sq" -name '*counter_collection.csv' | head -1)" --stats "$OUT/${TAG}_kernel_stats.csv" \
-    --out "$OUT/${TAG}_counters.json" --res 4096 --flush $FLUSH --commit "$COMMIT" --note "$TAG kernels"
+    --out "$OUT/${TAG}_counters.json" --res 4096 --flush $FLUSH --float-mode $MODE --commit "$COMMIT" --note "$TAG kernels"
 rm -rf "$P"
 # the bench line of these kernels, now that their counter summary exists (bench.py reads profiles/*_counters.json)
 cp "$OUT/${TAG}_counters.json" "$ROOT/profiles/${TAG}_counters.json"
-python3 bench.py --flush $FLUSH > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+if [ -z "$NZ_SKIP_BENCH" ]; then
+  python3 bench.py --flush $FLUSH --float-mode $MODE > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+fi

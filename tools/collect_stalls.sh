@@ -1,16 +1,17 @@
 #!/bin/bash
 # Where do the waves of the metric pipeline's kernels spend their cycles?  SQ counters in separate rocprofv3 passes
 # (kernel trace only), folded into gpurun_out/<tag>_stalls.json (means per launch).
-#   tools/collect_stalls.sh <tag>
+#   tools/collect_stalls.sh <tag> [float mode]
 set -e
 TAG=${1:-stalls}
+MODE=${2:-strict}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 P="$OUT/prof_stalls"
 rm -rf "$P"
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras --schedule stages"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras --schedule stages --float-mode $MODE"
 i=0
 for GROUP in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVES" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT" \

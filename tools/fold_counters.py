@@ -11,7 +11,7 @@ Inputs (each from its own `rocprofv3 --kernel-trace --pmc <group>` run of the sa
 Values are means per launch over the launches sampled.
 
 usage: fold_counters.py --fetch F.csv --write W.csv --sq S.csv --stats K.csv --out OUT.json
-                        --res 4096 --flush swap --commit <sha> [--note "..."]
+                        --res 4096 --flush swap --float-mode strict --commit <sha> [--note "..."]
 """
 import argparse
 import collections
@@ -52,6 +52,7 @@ def main():
     ap = argparse.ArgumentParser()
     for k in ("fetch", "write", "sq", "stats", "out", "commit", "note", "flush"):
         ap.add_argument("--" + k, default=None)
+    ap.add_argument("--float-mode", default="strict")
     ap.add_argument("--res", type=int, default=4096)
     a = ap.parse_args()
     mean = lambda v: sum(v) / len(v)  # noqa: E731
@@ -80,10 +81,10 @@ def main():
             e["avg_ns_in_stats_run"] = stats[k]["avg_ns"]
             e["pct_of_kernel_time"] = stats[k]["pct"]
         kernels[k] = e
-    out = {"config": {"res": a.res, "flush": a.flush, "sharded": False, "commit": a.commit,
+    out = {"config": {"res": a.res, "flush": a.flush, "float_mode": a.float_mode, "sharded": False, "commit": a.commit,
                       "kernel_sources_sha": kernel_sources_sha(),
-                      "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --res %d --flush %s "
-                                 "(counter passes); --steps 60 --warmup 20 (stats pass)" % (a.res, a.flush),
+                      "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --res %d --flush %s --float-mode %s "
+                                 "(counter passes); --steps 60 --warmup 20 (stats pass)" % (a.res, a.flush, a.float_mode),
                       "note": a.note or ""},
            "corrections": "FETCH_SIZE KiB x2 (gfx950 under-report of wide reads), WRITE_SIZE KiB x1; means per launch",
            "kernels": kernels}
