@@ -207,17 +207,31 @@ namespace xshazwar.noize.hip {
             }
         }
 
+        // Nobody outside this pipeline has been handed a handle of the pass that is running: the work item carries no
+        // scheduledAction and no stage has a scheduled-action hook beyond its hand-over to the next stage (a joint, a
+        // downstream pipeline).  Work scheduled on such a handle has consumed the failed pass's planes and cannot be recalled.
+        bool RetryIsLocal() {
+            if (activeItem.scheduledAction != null) return false;
+            foreach (PipelineStage s in stage_instances)
+                if (s.OnStageScheduledAction == null || s.OnStageScheduledAction.GetInvocationList().Length != 1) return false;
+            return true;
+        }
+
         // pipelineHandle.Complete().  NZ_ERR_RETRY -- a chained kernel-filter launch timed out, the planes computed since are
-        // invalid and the context has switched to separate launches -- is answered once by scheduling the work item again,
-        // when the pipeline regenerates its tile from scratch (its first stage is the NoiseStage); any other pipeline's
-        // input is gone with the stage that failed, and the error goes to the caller.
+        // invalid and the context has switched to separate launches -- is answered once by running the work item again, when
+        // the pipeline regenerates its tile from scratch (its first stage is the NoiseStage) and the failed pass is this
+        // pipeline's own business (RetryIsLocal).  The failed pass is wound up first (OnStageComplete, as after any pass); the
+        // item's dependency was satisfied by the first pass and is not applied again.  Otherwise the error goes to the caller.
         void CompleteActive() {
             try {
                 pipelineHandle.Complete();
-            } catch (NoizeException e) when (e.status == Native.NZ_ERR_RETRY && stage_instances[0].GetType() == typeof(NoiseStage)) {
+            } catch (NoizeException e) when (e.status == Native.NZ_ERR_RETRY && stage_instances[0].GetType() == typeof(NoiseStage)
+                                             && RetryIsLocal()) {
+                foreach (PipelineStage stage in stage_instances) stage.OnStageComplete();
                 pipelineRunning = false;
+                activeItem.dependency = default(GpuJobHandle);
                 Schedule(activeItem);
-                pipelineHandle.Complete();
+                pipelineHandle.Complete();  // (a second failure is the caller's)
             }
         }
 

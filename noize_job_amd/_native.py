@@ -227,19 +227,21 @@ def _share_hip_runtime_with_torch():
     if spec is None or not spec.submodule_search_locations:
         return
     libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
-    # RCCL is opened lazily by the library (nz_comm.cpp, first communicator call): the copy that was built against the
-    # HIP runtime in use -- the wheel's -- not /opt/rocm's
+    wheel_hip = "torch" in sys.modules  # torch has mapped its own runtime already
+    if not wheel_hip:
+        cand = os.path.join(libdir, "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                wheel_hip = True
+            except OSError:
+                pass
+    # RCCL is opened lazily by the library (nz_comm.cpp, first communicator call).  Point it at the wheel's copy only when the
+    # wheel's HIP runtime is the one this process runs on -- an RCCL built against another runtime than the one
+    # libnoize_hip.so is bound to must not be mixed in; otherwise the system's librccl.so.1 is found by name
     rccl = os.path.join(libdir, "librccl.so")
-    if os.path.exists(rccl):
+    if wheel_hip and os.path.exists(rccl):
         os.environ.setdefault("NZ_RCCL_LIB", rccl)
-    if "torch" in sys.modules:
-        return
-    cand = os.path.join(libdir, "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
 
 
 def _load():

@@ -42,13 +42,17 @@ int32_t rccl_load(const rccl_api **out) {
         const char *env = getenv("NZ_RCCL_LIB");
         const char *names[] = {env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
         void *so = nullptr;
+        char tried[768] = "";
         for (const char *n : names) {
             if (!n || !*n) continue;
             so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (so) break;
+            const char *why = dlerror();  // every candidate's reason, not only the last one's
+            size_t used = strlen(tried);
+            snprintf(tried + used, sizeof tried - used, "%s%s: %s", used ? "; " : "", n, why ? why : "?");
         }
         if (!so) {
-            nz_set_error("RCCL is not available: dlopen(librccl.so.1) failed: %s (NZ_RCCL_LIB names another path)", dlerror());
+            nz_set_error("RCCL is not available (NZ_RCCL_LIB names another path): %s", tried);
             return NZ_ERR_COMM;
         }
         rccl_api a;
@@ -108,6 +112,7 @@ struct nz_comm {
     nz_ctx *ctx = nullptr;
     const rccl_api *api = nullptr;
     int device = 0, rank = 0, world = 1;
+    int users = 0;  // nz_sharded objects that hold this communicator
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;                 // the exchanges' own stream
     hipEvent_t ev_go = nullptr, ev_done = nullptr;  // ctx stream -> comm stream, comm stream -> ctx stream
@@ -234,7 +239,13 @@ extern "C" int32_t nz_comm_init(nz_ctx *ctx, const uint8_t *id, int32_t rank, in
 
 extern "C" int32_t nz_comm_destroy(nz_comm *c) {
     if (!c) return NZ_OK;
+    // a sharded grid keeps a pointer to its communicator: destroy the grids first
+    NZ_REQUIRE(c->users == 0, "nz_comm_destroy: %d nz_sharded object(s) still use this communicator (nz_sharded_destroy them first)",
+               c->users);
     (void)hipSetDevice(c->device);
+    // with overlap 0 (the default) the transfers and the one collective run on the CONTEXT's stream: both streams drain
+    // before ncclCommDestroy
+    if (c->ctx && c->ctx->stream) (void)hipStreamSynchronize(c->ctx->stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)c->api->CommDestroy(c->comm);
     if (c->ev_go) (void)hipEventDestroy(c->ev_go);
@@ -764,6 +775,7 @@ extern "C" int32_t nz_sharded_create(nz_ctx *ctx, nz_comm *comm, const nz_sharde
     nz_sharded *sh = new nz_sharded();
     sh->ctx = ctx;
     sh->comm = comm;
+    if (comm) comm->users++;
     sh->d = *desc;
     sh->p = *params;
     sh->rank = crank;
@@ -840,6 +852,7 @@ extern "C" int32_t nz_sharded_destroy(nz_sharded *sh) {
         if (s.A) (void)hipFree(s.A);
     if (sh->range_work) (void)hipFree(sh->range_work);
     for (hipEvent_t e : sh->ev_pool) (void)hipEventDestroy(e);
+    if (sh->comm) sh->comm->users--;
     delete sh;
     return NZ_OK;
 }

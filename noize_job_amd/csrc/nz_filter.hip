@@ -378,6 +378,7 @@ struct nz_chain {
     // host reads -- with a plain load -- wherever it waits for the context
     int spin_limit;
     unsigned *err_host;
+    unsigned *err_epoch;  // device memory: the lowest epoch of a launch that gave up (which work the failure belongs to)
 };
 
 __host__ __device__ __forceinline__ int chain_class_count(int n, int c) { return n > c ? (n - c + 7) >> 3 : 0; }  // #{vb < n : vb % 8 == c}
@@ -438,7 +439,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
             while ((unsigned)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ch.epoch) {
                 __builtin_amdgcn_s_sleep(32);
                 if (++spins > ch.spin_limit) {  // seconds: the producer is never coming
-                    __hip_atomic_store(ch.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    atomicMin(ch.err_epoch, ch.epoch);
+                    __threadfence();
+                    __hip_atomic_store(ch.err_host, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
             }
@@ -805,7 +808,7 @@ int g_chain_spin_limit = 1 << 21;                         // nz_debug_chain_poll
 
 template <int KS, int NT>
 int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
-                        int L, int *flags, unsigned epoch, unsigned *err_host) {
+                        int L, int *flags, unsigned epoch, unsigned *err_host, unsigned *err_epoch) {
     constexpr int O = (KS - 1) / 2;
     constexpr int RTH = NT / 32 * RB;
     nz_chain ch{};
@@ -827,6 +830,7 @@ int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_ge
     ch.delay_sleeps = g_chain_delay_sleeps;
     ch.spin_limit = g_chain_spin_limit;
     ch.err_host = err_host;
+    ch.err_epoch = err_epoch;
     int aligned = ((reinterpret_cast<uintptr_t>(plane0) | reinterpret_cast<uintptr_t>(plane1) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
     const bool fast = nz_tls_float_mode >= NZ_FLOAT_FAST;
 #define NZ_CC(U, F) NZ_LAUNCH((conv_chain_kernel<KS, U, NT, F>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned)
@@ -842,9 +846,9 @@ int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_ge
 
 template <int KS>
 int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
-                     int L, int *flags, unsigned epoch, unsigned *err_host) {
-    if (KS >= 5 && conv_small_grid(KS, g)) return launch_chain_nt<KS, 256>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
-    return launch_chain_nt<KS, (KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT)>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
+                     int L, int *flags, unsigned epoch, unsigned *err_host, unsigned *err_epoch) {
+    if (KS >= 5 && conv_small_grid(KS, g)) return launch_chain_nt<KS, 256>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host, err_epoch);
+    return launch_chain_nt<KS, (KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT)>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host, err_epoch);
 }
 
 }  // namespace
@@ -869,7 +873,7 @@ int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L) {
 // writes the other one, so the result is in plane0 when L is even.  One grid of the geometry (g.count == 1), planes
 // below 4 GiB.  flags: nz_conv_chain_items() ints, never cleared (they carry an epoch).
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
-                             const int *Ts, int L, int *flags, unsigned epoch, unsigned *err_host) {
+                             const int *Ts, int L, int *flags, unsigned epoch, unsigned *err_host, unsigned *err_epoch) {
     if (L < 1 || L > NZ_CHAIN_MAXL || g.count != 1 || (size_t)g.rows * g.pitch * 4 >= ((size_t)1 << 32)) {
         nz_set_error("conv_chain: %d launches / %d grids / plane of %zu bytes unsupported", L, g.count, (size_t)g.rows * g.pitch * 4);
         return NZ_ERR_INVALID;
@@ -881,10 +885,10 @@ int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const 
         }
     if (g.or1 <= g.or0) return NZ_OK;
     switch (k.ksize) {
-        case 3: return launch_chain<3>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
-        case 5: return launch_chain<5>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
-        case 7: return launch_chain<7>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
-        case 9: return launch_chain<9>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host);
+        case 3: return launch_chain<3>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host, err_epoch);
+        case 5: return launch_chain<5>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host, err_epoch);
+        case 7: return launch_chain<7>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host, err_epoch);
+        case 9: return launch_chain<9>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host, err_epoch);
     }
     return NZ_ERR_INVALID;
 }

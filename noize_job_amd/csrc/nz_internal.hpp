@@ -56,9 +56,21 @@ struct nz_ctx {
     // chained launches (nz_launch_conv_chain): tile flags (grown on demand, never cleared: they carry an epoch)
     int *chain_flags = nullptr;
     size_t chain_flags_n = 0;
-    unsigned *chain_err = nullptr, *chain_err_dev = nullptr;  // the error word in mapped host memory, and its device address
+    // the error words in mapped host memory ([0]: a chained filter launch gave up waiting, [1]: the pile solver's ticket launch
+    // did -- one word per kind, so neither overwrites the other), and their device address
+    unsigned *chain_err = nullptr, *chain_err_dev = nullptr;
     unsigned chain_epoch = 0;
     bool chain_off = false;  // a chained launch once timed out on this context: separate launches from then on
+    // Which work a chained launch's time-out belongs to: a failing tile lowers *chain_err_epoch (device memory, atomicMin) to
+    // its launch's epoch before it raises the flag; the host remembers the handle sequence number each of its last chained
+    // launches was issued at.  Once seen, the failure is reported (NZ_ERR_RETRY) by every wait on a handle in [retry_lo,
+    // retry_hi] -- issued at or after the failing launch and before the host noticed -- and by the next nz_ctx_synchronize;
+    // a wait on an older handle (another pipeline's, a fence recorded before the stage) completes clean.
+    unsigned *chain_err_epoch = nullptr;
+    struct chain_mark { unsigned epoch; uint64_t seq; };
+    chain_mark chain_marks[64] = {};
+    uint64_t retry_lo = 0, retry_hi = 0;
+    bool retry_sync_pending = false;
     bool handle_rides = false;    // this entry's handle may ride on its last kernel launch (nz_ctx_handle_rides)
     uint64_t armed_seq = 0;       // ... and this is the sequence number reserved for it (nz_ctx_arm_last_launch)
     // striped pipeline (nz_terrain_pipeline): a second stream with its fork / join markers and the stripes' planes, all
@@ -67,6 +79,7 @@ struct nz_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *pipe_work = nullptr;
     size_t pipe_work_floats = 0;
+    int pipe_small_streak = 0;  // consecutive requests of less than a quarter of pipe_work (nz_ctx_pipe_state)
     // pool automaton, sparse form (nz_pool_job in nz_stages.cpp): {entries, done, -} in device memory, and in mapped host
     // memory what the last job that ran reported: job number << 32 | non-empty mask words it found
     int *pool_ctl = nullptr;
@@ -219,9 +232,9 @@ int32_t nz_launch_conv_stream(hipStream_t s, const float *src, float *dst, const
 int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L);
 bool nz_conv_small_grid(int ksize, const nz_geom &g);  // 64-row tiles, launches not chained
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
-                             const int *Ts, int L, int *flags, unsigned epoch, unsigned *err_host);
-int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned *epoch, unsigned **err_host);
-int32_t nz_ctx_error_word(nz_ctx *ctx, unsigned **err_host);  // mapped host memory, device address
+                             const int *Ts, int L, int *flags, unsigned epoch, unsigned *err_host, unsigned *err_epoch);
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned *epoch, unsigned **err_host, unsigned **err_epoch);
+int32_t nz_ctx_error_word(nz_ctx *ctx, unsigned **err_host);  // mapped host memory, device address: [0] chained filter, [1] pile solver
 // one whole application of a wide odd kernel (11..25 taps), src -> dst
 bool nz_conv_has_wide(int ksize);
 int32_t nz_launch_conv_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k);

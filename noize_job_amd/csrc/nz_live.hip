@@ -950,7 +950,7 @@ __global__ __launch_bounds__(64) void pile_ticket_kernel(float *height, const fl
                 while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) {
                     __builtin_amdgcn_s_sleep(16);
                     if (++spins > (1 << 22)) {  // seconds: never, unless the protocol is broken
-                        __hip_atomic_store(err_host, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(err_host + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // word [1]: the pile solver's
                         break;
                     }
                 }

@@ -45,7 +45,8 @@ static int32_t ctx_sync_all(nz_ctx *ctx);
 static void registry_add(nz_ctx *ctx);
 static void registry_remove(nz_ctx *ctx);
 static bool registry_full();
-static int32_t ctx_chain_check(nz_ctx *ctx);
+static int32_t ctx_chain_check(nz_ctx *ctx, uint64_t waited_seq);
+static constexpr uint64_t NZ_WAIT_ALL = ~0ull;  // nz_ctx_synchronize: everything issued so far
 
 
 static float h_mod289(float x);
@@ -232,6 +233,7 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->chain_flags) (void)hipFree(ctx->chain_flags);
     if (ctx->chain_err) (void)hipHostFree(ctx->chain_err);
+    if (ctx->chain_err_epoch) (void)hipFree(ctx->chain_err_epoch);
     if (ctx->aux) {
         (void)hipStreamSynchronize(ctx->aux);
         (void)hipStreamDestroy(ctx->aux);
@@ -250,7 +252,7 @@ extern "C" int32_t nz_ctx_synchronize(nz_ctx *ctx) {
     NZ_REQUIRE(ctx, "ctx is NULL");
     NZ_HIP(hipSetDevice(ctx->device));
     NZ_TRY_(ctx_sync_all(ctx));
-    return ctx_chain_check(ctx);
+    return ctx_chain_check(ctx, NZ_WAIT_ALL);
 }
 
 extern "C" void *nz_ctx_stream(nz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -261,8 +263,6 @@ static int32_t ctx_sync_all(nz_ctx *ctx) {
     if (ctx->aux) NZ_HIP(hipStreamSynchronize(ctx->aux));  // (its work is joined into `stream` before a call returns)
     return NZ_OK;
 }
-static int32_t ctx_chain_check(nz_ctx *ctx);
-
 // ---- context registry: a handle value carries the id of the context that issued it ------------------------------
 static std::mutex g_reg_mx;
 static std::vector<nz_ctx *> g_reg;  // index = ctx id - 1; nullptr once destroyed
@@ -397,8 +397,13 @@ int32_t nz_ctx_pipe_state(nz_ctx *ctx, size_t floats, float **work) {
     if (!ctx->aux) NZ_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
     if (!ctx->ev_fork) NZ_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     if (!ctx->ev_join) NZ_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    // grown on demand; given back when a much smaller tile follows (the planes of a 16384^2 tile are 2 GB)
-    if (floats > ctx->pipe_work_floats || floats < ctx->pipe_work_floats / 4) {
+    // grown on demand; given back only after EIGHT consecutive requests of less than a quarter of it (the planes of a
+    // 16384^2 tile are 2 GB) -- a context that alternates tile sizes must not pay a stream drain and a hipFree / hipMalloc per
+    // call -- and never below 64 MB
+    const bool small = floats < ctx->pipe_work_floats / 4 && ctx->pipe_work_floats > ((size_t)16 << 20);
+    ctx->pipe_small_streak = small ? ctx->pipe_small_streak + 1 : 0;
+    if (floats > ctx->pipe_work_floats || ctx->pipe_small_streak >= 8) {
+        ctx->pipe_small_streak = 0;
         if (ctx->pipe_work) {
             NZ_TRY_(ctx_sync_all(ctx));
             NZ_HIP(hipFree(ctx->pipe_work));
@@ -448,23 +453,27 @@ int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out) {
     return NZ_OK;
 }
 
-// The flags / control block of the chained launches.  Flags are compared with an epoch that grows by one per launch, so
-// stale contents never match; a (re)allocated array is zeroed and the epoch restarts above zero.
-// The context's error word: mapped host memory a kernel whose bounded wait gives up stores to (system scope) and the host
-// reads with a load at its next synchronisation.  1 = a chained filter launch (NZ_ERR_RETRY), 2 = the pile solver's ticket
+// The flags of the chained launches.  Flags are compared with an epoch that grows by one per launch, so stale contents never
+// match; a (re)allocated array is zeroed and the epoch restarts above zero.
+// The context's error words: mapped host memory a kernel whose bounded wait gives up stores to (system scope) and the host
+// reads with a load at its next synchronisation.  [0] = a chained filter launch (NZ_ERR_RETRY), [1] = the pile solver's ticket
 // kernel (an internal error: its wait cannot time out unless the protocol is broken).
 int32_t nz_ctx_error_word(nz_ctx *ctx, unsigned **err_host) {
     if (!ctx->chain_err) {
         NZ_HIP(hipHostMalloc((void **)&ctx->chain_err, 64, hipHostMallocMapped));
-        *ctx->chain_err = 0;
+        ctx->chain_err[0] = ctx->chain_err[1] = 0;
         NZ_HIP(hipHostGetDevicePointer((void **)&ctx->chain_err_dev, ctx->chain_err, 0));
     }
     *err_host = ctx->chain_err_dev;
     return NZ_OK;
 }
 
-int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned *epoch, unsigned **err_host) {
+int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned *epoch, unsigned **err_host, unsigned **err_epoch) {
     NZ_TRY_(nz_ctx_error_word(ctx, err_host));
+    if (!ctx->chain_err_epoch) {
+        NZ_HIP(hipMalloc((void **)&ctx->chain_err_epoch, 4));
+        NZ_HIP(hipMemsetAsync(ctx->chain_err_epoch, 0xff, 4, ctx->stream));
+    }
     if (items > ctx->chain_flags_n) {
         if (ctx->chain_flags) {
             NZ_TRY_(ctx_sync_all(ctx));
@@ -478,29 +487,54 @@ int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned *epo
         ctx->chain_flags_n = n;
     }
     if (++ctx->chain_epoch == 0) ctx->chain_epoch = 1;  // 0 is what a fresh flag holds
+    // the handle sequence number this launch is issued at: the next handle of the context is the launching entry's own or a
+    // later one
+    ctx->chain_marks[ctx->chain_epoch % 64] = {ctx->chain_epoch, ctx->last_seq + 1};
     *flags = ctx->chain_flags;
     *epoch = ctx->chain_epoch;
+    *err_epoch = ctx->chain_err_epoch;
     return NZ_OK;
 }
 
-// A chained launch that gave up waiting for a producer tile has raised the context's error word (mapped host memory: no
-// device-to-host copy on the host's wait path): reported wherever the host waits.
-static int32_t ctx_chain_check(nz_ctx *ctx) {
+// A kernel whose bounded wait gave up has raised one of the context's error words (mapped host memory: no device-to-host
+// copy on the host's wait path): reported wherever the host waits for work the failure can have touched.  `waited_seq`: the
+// sequence number of the handle the host has just waited for (NZ_WAIT_ALL: the whole stream).
+static int32_t ctx_chain_check(nz_ctx *ctx, uint64_t waited_seq) {
     if (!ctx->chain_err) return NZ_OK;
-    const unsigned word = *reinterpret_cast<volatile unsigned *>(ctx->chain_err);
-    if (word == 0) return NZ_OK;
-    *reinterpret_cast<volatile unsigned *>(ctx->chain_err) = 0;
-    if (word == 2) {
+    volatile unsigned *w = reinterpret_cast<volatile unsigned *>(ctx->chain_err);
+    if (w[1]) {
+        w[1] = 0;
         nz_set_error("internal: a block of the pile solver gave up waiting for a neighbouring block (nz_erode_height_maps); the "
                      "height plane is invalid.  NZ_PILE_TICKET=0 runs the four colour launches instead");
         return NZ_ERR_HIP;
     }
-    // The wait of a chained launch terminates whatever happens (bounded poll), but it only makes PROGRESS while the
-    // hardware starts the grid's workgroups in index order, round-robin over the XCDs -- a consumer's producers belong
-    // to other ticket classes (blockIdx.x & 7), and those are claimed by workgroups that must get dispatched.  That
-    // is observed behaviour, not a contract (CU masking or a partitioned mode could break it): after one timeout the
-    // context falls back to separate launches for good.
-    ctx->chain_off = true;
+    if (w[0]) {
+        w[0] = 0;
+        if (!ctx->retry_hi) {
+            // first sight of it.  The wait of a chained launch terminates whatever happens (bounded poll), but it only makes
+            // PROGRESS while the hardware starts the grid's workgroups in index order, round-robin over the XCDs -- observed
+            // behaviour, not a contract (CU masking or a partitioned mode could break it): after one time-out the context
+            // falls back to separate launches for good.
+            ctx->chain_off = true;
+            unsigned e = 0xffffffffu;
+            (void)hipMemcpy(&e, ctx->chain_err_epoch, 4, hipMemcpyDeviceToHost);  // (slow path: once per context at most)
+            uint64_t lo = 1;
+            if (e != 0xffffffffu && ctx->chain_marks[e % 64].epoch == e) lo = ctx->chain_marks[e % 64].seq;
+            ctx->retry_lo = lo;
+            ctx->retry_hi = ctx->last_seq > lo ? ctx->last_seq : lo;
+            ctx->retry_sync_pending = true;
+        }
+    }
+    if (!ctx->retry_hi) return NZ_OK;
+    bool hit;
+    if (waited_seq == NZ_WAIT_ALL) {
+        hit = ctx->retry_sync_pending;
+        ctx->retry_sync_pending = false;
+    } else {
+        hit = waited_seq >= ctx->retry_lo && waited_seq <= ctx->retry_hi;
+        if (hit) ctx->retry_sync_pending = false;
+    }
+    if (!hit) return NZ_OK;
     nz_set_error("a chained kernel-filter launch timed out waiting for a producer tile: the plane that stage left (and whatever was "
                  "computed from it) is invalid; this context now runs filter stages as separate launches -- schedule the work item "
                  "again (NZ_ERR_RETRY)");
@@ -569,7 +603,9 @@ extern "C" int32_t nz_handle_wait(nz_ctx *ctx, nz_handle h) {
     // caller must not run concurrently with a wait on that context's handles.)
     NZ_HIP(hipSetDevice(dev));
     NZ_HIP(hipEventSynchronize(ev));
-    return handle_ctx_id(h) == ctx->id ? ctx_chain_check(ctx) : NZ_OK;
+    // a failure is reported to whoever waits for work at or after the launch that failed -- on the context that ISSUED the
+    // handle, whichever context the caller passed
+    return with_owner(h, [&](nz_ctx *owner, uint64_t q) -> int32_t { return owner ? ctx_chain_check(owner, q) : NZ_OK; });
 }
 
 extern "C" int32_t nz_handle_elapsed_ms(nz_ctx *ctx, nz_handle start, nz_handle stop, float *ms) {

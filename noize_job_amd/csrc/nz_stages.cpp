@@ -263,10 +263,10 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
         int Ts[8];
         for (int i = 0; i < L; i++) Ts[i] = base + (i >= L - rem ? 1 : 0);
         int *flags = nullptr;
-        unsigned epoch = 0, *err_host = nullptr;
-        NZ_TRY_(nz_ctx_chain_state(ctx, (size_t)nz_conv_chain_items(t.ksize, g, Ts, L), &flags, &epoch, &err_host));
+        unsigned epoch = 0, *err_host = nullptr, *err_epoch = nullptr;
+        NZ_TRY_(nz_ctx_chain_state(ctx, (size_t)nz_conv_chain_items(t.ksize, g, Ts, L), &flags, &epoch, &err_host, &err_epoch));
         nz_ctx_arm_last_launch(ctx);  // (one launch; no copy follows in either form: an even count or a pair)
-        NZ_TRY_(nz_launch_conv_chain(ctx->stream, src, tmp, g, t, Ts, L, flags, epoch, err_host));
+        NZ_TRY_(nz_launch_conv_chain(ctx->stream, src, tmp, g, t, Ts, L, flags, epoch, err_host, err_epoch));
         if (swapped) *swapped = (L & 1) != 0;
         return NZ_OK;
     }

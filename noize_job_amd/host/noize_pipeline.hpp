@@ -656,18 +656,30 @@ class BasePipeline {
             if (GetNextJob(wi)) Schedule(wi);
         }
     }
+    // Nobody outside this pipeline has been handed a handle of the pass that is running: the work item carries no
+    // scheduledAction and no stage has a scheduled-action hook beyond its hand-over to the next stage (a joint, a downstream
+    // pipeline).  Work scheduled on such a handle has consumed the failed pass's planes and cannot be recalled from here.
+    bool RetryIsLocal() const {
+        if (activeItem.scheduledAction) return false;
+        for (size_t i = 0; i < stage_instances.size(); i++)
+            if (stage_instances[i]->OnStageScheduledAction.size() != 1) return false;  // (Setup() gave every stage exactly one)
+        return true;
+    }
     // pipelineHandle.Complete().  NZ_ERR_RETRY -- a chained kernel-filter launch timed out, the planes computed since are
-    // invalid and the context has switched to separate launches -- is answered once by scheduling the work item again,
-    // when the pipeline regenerates its tile from scratch (its first stage is the NoiseStage); any other pipeline's input
-    // is gone with the stage that failed, and the error goes to the caller.
+    // invalid and the context has switched to separate launches -- is answered once by running the work item again, when
+    // the pipeline regenerates its tile from scratch (its first stage is the NoiseStage) and the failed pass is this
+    // pipeline's own business (RetryIsLocal).  The failed pass is wound up first (OnStageComplete, as after any pass); the
+    // item's dependency was satisfied by the first pass and is not applied again.  Otherwise the error goes to the caller.
     void CompleteActive() {
         try {
             pipelineHandle.Complete();
         } catch (const NoizeError &e) {
-            if (e.status != NZ_ERR_RETRY || !RegeneratesItsTile()) throw;
+            if (e.status != NZ_ERR_RETRY || !RegeneratesItsTile() || !RetryIsLocal()) throw;
+            for (auto *s : stage_instances) s->OnStageComplete();
             pipelineRunning = false;
+            activeItem.dependency = JobHandle();
             Schedule(activeItem);
-            pipelineHandle.Complete();
+            pipelineHandle.Complete();  // (a second failure is the caller's)
         }
     }
     bool LateUpdate() {

@@ -729,19 +729,34 @@ class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
             if job is not None:
                 self.Schedule(job)
 
+    def _retry_is_local(self):
+        """Nobody outside this pipeline has been handed a handle of the pass that is running: the work item carries no
+        scheduledAction, and no stage has a scheduled-action hook beyond the hand-over to the next stage (a joint, a
+        downstream pipeline's OnScheduledUpstream).  Work scheduled on such a handle has consumed the failed pass's planes
+        and cannot be recalled from here."""
+        own = {s.ReceiveHandledInput for s in self.stage_instances} | {self.OnPipelineFullyScheduled}
+        return self.activeItem.scheduledAction is None and all(a in own for s in self.stage_instances
+                                                               for a in s.OnStageScheduledAction)
+
     def _complete(self):
         """pipelineHandle.Complete().  NZ_ERR_RETRY -- a chained kernel-filter launch timed out, the planes computed since
-        are invalid and the context has switched to separate launches -- is answered once by scheduling the work item
-        again, when the pipeline regenerates its tile from scratch (its first stage is the NoiseStage); any other
-        pipeline's input is gone with the stage that failed, and the error goes to the caller."""
+        are invalid and the context has switched to separate launches -- is answered once by running the work item again,
+        when (a) the pipeline regenerates its tile from scratch (its first stage is the NoiseStage) and (b) the failed pass
+        is this pipeline's own business (_retry_is_local).  The failed pass is wound up first (the stages' OnStageComplete,
+        as after any pass), then the item is scheduled as a retry: its dependency was satisfied by the first pass and is
+        not applied again.  Any other pipeline's input is gone with the stage that failed, or its handles are in other
+        hands: the error goes to the caller."""
         try:
             self.pipelineHandle.Complete()
         except N.NoizeError as e:
-            if e.status != N.NZ_ERR_RETRY or not isinstance(self.stage_instances[0], NoiseStage):
+            if e.status != N.NZ_ERR_RETRY or not isinstance(self.stage_instances[0], NoiseStage) or not self._retry_is_local():
                 raise
+            self.CleanUp()
             self.pipelineRunning = False
-            self.Schedule(self.activeItem)
-            self.pipelineHandle.Complete()
+            item = self.activeItem
+            item.dependency, item.retries = JobHandle(), getattr(item, "retries", 0) + 1
+            self.Schedule(item)
+            self.pipelineHandle.Complete()  # (a second failure is the caller's)
 
     def LateUpdate(self):  # :160-181
         if self.pipelineRunning and self.pipelineHandle.IsCompleted:

@@ -333,3 +333,52 @@ def test_a_chained_launch_that_times_out_is_reported_and_the_pipeline_runs_again
             lib.nz_debug_chain_poll_limit(0)
             lib.nz_debug_chain_delay(-1, 0)
         pipe.Destroy()
+    # The failure belongs to the work that caused it.  (a) A handle recorded on the same context BEFORE the stage that fails
+    # (another job's fence) completes clean, even when it is waited for after the launch has given up; the stage's own handle
+    # and every handle issued after it report NZ_ERR_RETRY, however often they are waited for; handles issued after the host
+    # has noticed are clean again.  (b) A pipeline whose handles are in other hands (a scheduleAction) does not re-run on its
+    # own: the status goes to the caller.
+    import time
+    with nj.Context(0) as c:
+        data, write = c.alloc(res * res), c.alloc(res * res)
+        stages = [nj.NoiseStage(c, nj.FractalNoise.Simplex, 0.4, 1.0, 6, 2.0, 0.0, 300),
+                  nj.KernelFilterStage(c, nj.KernelFilterType.Gauss5_S1, 17)]
+        try:
+            assert lib.nz_debug_chain_poll_limit(8) == 0 and lib.nz_debug_chain_delay(3, 500) == 0
+            before = c.record()
+            gd = nj.GeneratorData("t", data, res, 0, 0, write=write)
+            h = nj.JobHandle()
+            for st in stages:
+                st.Schedule(nj.PipelineWorkItem(gd), h)
+                h = st.jobHandle
+            after = c.record()
+            time.sleep(0.05)     # the launch has given up by now
+            before.Complete()    # an unrelated, older handle: no error
+            for hh in (h, after, h):
+                with pytest.raises(nj.NoizeError) as e:
+                    hh.Complete()
+                assert e.value.status == nj._native.NZ_ERR_RETRY
+            c.synchronize()      # (reported through the handles already)
+            later = c.record()
+            later.Complete()
+        finally:
+            lib.nz_debug_chain_poll_limit(0)
+            lib.nz_debug_chain_delay(-1, 0)
+        for st in stages:
+            st.OnDestroy()
+    with nj.Context(0) as c:
+        data, write = c.alloc(res * res), c.alloc(res * res)
+        pipe = nj.BasePipeline([nj.NoiseStage(c, nj.FractalNoise.Simplex, 0.4, 1.0, 6, 2.0, 0.0, 300),
+                                nj.KernelFilterStage(c, nj.KernelFilterType.Gauss5_S1, 17)])
+        try:
+            assert lib.nz_debug_chain_poll_limit(8) == 0 and lib.nz_debug_chain_delay(3, 500) == 0
+            gd = nj.GeneratorData("t", data, res, 0, 0, write=write)
+            scheduled, done = [], []
+            pipe.Enqueue(gd, scheduleAction=lambda d, hdl: scheduled.append(hdl), completeAction=lambda d: done.append(d))
+            with pytest.raises(nj.NoizeError) as e:
+                pipe.RunToCompletion()
+            assert e.value.status == nj._native.NZ_ERR_RETRY and len(scheduled) == 1 and not done
+        finally:
+            lib.nz_debug_chain_poll_limit(0)
+            lib.nz_debug_chain_delay(-1, 0)
+        pipe.Destroy()
