@@ -23,10 +23,30 @@ namespace xshazwar.noize.hip {
         public DeviceTile write;
     }
 
+    // New-framework payload: `count` independent tiles of resolution^2 cells stored back to back in `data` (tile k at offset
+    // k * resolution^2), world positions in `positions` (device int32 pairs {xpos, zpos} per tile).  The noise / filter / blur /
+    // erosion / flow-map stages run such a batch through ONE launch sequence (nz_*_batch); every tile comes out exactly as it
+    // would alone.  (The reference runs one BasePipeline per tile request, Scripts/MeshTileGenerator.cs:181-211: 512^2 tiles
+    // one at a time cannot fill 256 CUs.)
+    public class GeneratorDataBatch : GeneratorData {
+        public DeviceTile positions;
+        public int count = 1;
+
+        public static GeneratorDataBatch Create(GpuContext ctx, string uuid, int resolution, int[] positionsXZ) {
+            int n = positionsXZ.Length / 2;
+            GeneratorDataBatch b = new GeneratorDataBatch { uuid = uuid, resolution = resolution, count = n,
+                                                            data = ctx.Alloc(n * resolution * resolution), positions = ctx.Alloc(2 * n) };
+            b.positions.CopyFrom(positionsXZ);
+            return b;
+        }
+        public DeviceTile tile(int k) => data.Offset(k * resolution * resolution, resolution * resolution);
+    }
+
     public class MeshStageData : StageIO {       // StageIOTypes/MeshStageData.cs:9-21
         public int resolution, inputResolution, marginPix, xpos, zpos;
         public float tileSize, tileHeight;
         public DeviceTile vertices, indices;     // stand in for UnityEngine.Mesh: 48-byte Stream0 records, uint indices
+        public int count = 1;                    // new: `count` height planes stored back to back -> `count` meshes, one launch
     }
 
     public class ReduceData : StageIO {          // StageIOTypes/ReduceData.cs:9-17
@@ -44,6 +64,7 @@ namespace xshazwar.noize.hip {
         public Action<StageIO> completeAction;
         public Action<StageIO, GpuJobHandle> scheduledAction;
         public GpuJobHandle dependency;
+        public PipelineStateManager stageManager;    // the context buffers this item's stages may read / write (:24)
     }
 
     public abstract class PipelineStage {        // PipelineStage.cs:10-62
@@ -93,8 +114,11 @@ namespace xshazwar.noize.hip {
         public GpuJobHandle pipelineHandle;
         public bool pipelineRunning, pipelineBeingScheduled;
 
-        public BasePipeline(IEnumerable<PipelineStage> stages, string alias = "Unnamed Pipeline") {
+        public PipelineStateManager contextManager;  // handed to every work item (Pipeline.cs:76-104)
+
+        public BasePipeline(IEnumerable<PipelineStage> stages, string alias = "Unnamed Pipeline", PipelineStateManager contextManager = null) {
             this.alias = alias;
+            this.contextManager = contextManager;
             stage_instances = new List<PipelineStage>(stages);
             Setup();
         }
@@ -111,7 +135,7 @@ namespace xshazwar.noize.hip {
         public void Enqueue(StageIO input, Action<StageIO, GpuJobHandle> scheduleAction = null, Action<StageIO> completeAction = null,
                             GpuJobHandle dependency = default) {                                  // :76-90
             queue.Enqueue(new PipelineWorkItem { data = input, completeAction = completeAction, scheduledAction = scheduleAction,
-                                                 dependency = dependency });
+                                                 dependency = dependency, stageManager = contextManager });
         }
 
         // Opt-in: the stock stage list -- NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionStage], README.md:23-32

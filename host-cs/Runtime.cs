@@ -104,6 +104,16 @@ namespace xshazwar.noize.hip {
             Handle = h;
         }
         public DeviceTile Alloc(int length) => new DeviceTile(this, length);
+        // FloatMode of the [BurstCompile] attributes (Fractal.cs:19, KernelJob.cs:17, FlowMapJob.cs:16) as a property of the
+        // context the jobs are scheduled on: 0 strict (default), 1 fast, 2 relaxed (include/noize_hip.h, nz_float_mode)
+        public int FloatMode {
+            get => Native.nz_ctx_float_mode(Handle);
+            set => Native.Check(Native.nz_ctx_set_float_mode(Handle, value), "nz_ctx_set_float_mode");
+        }
+        public GpuJobHandle Record() {            // a marker behind everything enqueued so far
+            Native.Check(Native.nz_handle_record(Handle, out ulong h), "nz_handle_record");
+            return Wrap(h);
+        }
         public void Synchronize() => Native.Check(Native.nz_ctx_synchronize(Handle), "nz_ctx_synchronize");
         public GpuJobHandle Wrap(ulong id) => new GpuJobHandle { ctx = Handle, id = id };
         public void Dispose() {
@@ -130,6 +140,14 @@ namespace xshazwar.noize.hip {
                 Native.Check(Native.nz_handle_wait(ctx.Handle, h), "nz_handle_wait");
             }
         }
+        public unsafe void CopyFrom(int[] host) {         // an int32 plane (a batch's positions): the same four-byte elements
+            fixed (int* p = host) {
+                Native.Check(Native.nz_tile_upload(ctx.Handle, Ptr, (IntPtr)p, (UIntPtr)(uint)host.Length, 0, out ulong h), "nz_tile_upload");
+                Native.Check(Native.nz_handle_wait(ctx.Handle, h), "nz_handle_wait");
+            }
+        }
+        // NativeSlice(array, start, length): a view, not an owner
+        public DeviceTile Offset(int start, int length) => new DeviceTile(ctx, IntPtr.Add(Ptr, start * sizeof(float)), length);
         public unsafe float[] ToArray() {                  // NativeArray.ToArray
             float[] host = new float[Length];
             fixed (float* p = host) {

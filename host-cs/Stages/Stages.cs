@@ -34,6 +34,7 @@ namespace xshazwar.noize.hip {
 
     public abstract class TmpStage : PipelineStage {   // the `tmp` NativeArray the filter stages own (KernelFilterStage.cs:22-29)
         protected DeviceTile tmp;
+        protected static int BatchCount(GeneratorData d) => d is GeneratorDataBatch b ? b.count : 1;
         protected TmpStage(GpuContext ctx) : base(ctx) {}
         public override void ResizeNativeContainers(int size) { tmp?.Dispose(); tmp = ctx.Alloc(size); }
         public override void OnDestroy() { tmp?.Dispose(); tmp = null; }
@@ -47,6 +48,12 @@ namespace xshazwar.noize.hip {
         public override void Schedule(PipelineWorkItem requirements, GpuJobHandle dependency) {     // :55-60
             CheckRequirements<GeneratorData>(requirements);
             GeneratorData d = (GeneratorData) requirements.data;
+            if (d is GeneratorDataBatch b) {      // `count` tiles, one launch
+                Native.Check(Native.nz_fractal_batch(ctx.Handle, (int) noiseType, b.data.Ptr, b.resolution, b.count, b.positions.Ptr, hurst,
+                                                     startingAmplitude, stepdown, detuneRate, octaves, noiseSize, dependency.id, out ulong hb), "nz_fractal_batch");
+                jobHandle = Done(hb);
+                return;
+            }
             // jobs[(int) noiseType](d.data, d.resolution, hurst, startingAmplitude, stepdown, detuneRate, octaves, d.xpos, d.zpos, noiseSize, dependency)
             Native.Check(Native.nz_fractal(ctx.Handle, (int) noiseType, d.data.Ptr, d.resolution, hurst, startingAmplitude, stepdown,
                                            detuneRate, octaves, d.xpos, d.zpos, noiseSize, dependency.id, out ulong h), "nz_fractal");
@@ -63,9 +70,11 @@ namespace xshazwar.noize.hip {
             GeneratorData d = (GeneratorData) requirements.data;
             ulong h;
             if (d.write != null && filter != KernelFilterType.Sobel3_2D) {
-                NzRwTile t = new NzRwTile { read = d.data.Ptr, write = d.write.Ptr, resolution = d.resolution, count = 1 };
+                NzRwTile t = new NzRwTile { read = d.data.Ptr, write = d.write.Ptr, resolution = d.resolution, count = BatchCount(d) };
                 Native.Check(Native.nz_kernel_filter_stage_rw(ctx.Handle, ref t, (int) filter, iterations, dependency.id, out h), "nz_kernel_filter_stage_rw");
                 Adopt(d, t);
+            } else if (d is GeneratorDataBatch b) {
+                Native.Check(Native.nz_kernel_filter_stage_batch(ctx.Handle, b.data.Ptr, tmp.Ptr, (int) filter, iterations, b.resolution, b.count, dependency.id, out h), "nz_kernel_filter_stage_batch");
             } else {
                 // the reference chains `iterations` SeparableKernelFilter.Schedule calls (:35-41); the library fuses the chain
                 Native.Check(Native.nz_kernel_filter_stage(ctx.Handle, d.data.Ptr, tmp.Ptr, (int) filter, iterations, d.resolution, dependency.id, out h), "nz_kernel_filter_stage");
@@ -84,9 +93,11 @@ namespace xshazwar.noize.hip {
             int width_ = BlurHelper.limitWidth(width);
             ulong h;
             if (d.write != null) {
-                NzRwTile t = new NzRwTile { read = d.data.Ptr, write = d.write.Ptr, resolution = d.resolution, count = 1 };
+                NzRwTile t = new NzRwTile { read = d.data.Ptr, write = d.write.Ptr, resolution = d.resolution, count = BatchCount(d) };
                 Native.Check(Native.nz_gauss_blur_stage_rw(ctx.Handle, ref t, width_, (int) sigma, iterations, dependency.id, out h), "nz_gauss_blur_stage_rw");
                 Adopt(d, t);
+            } else if (d is GeneratorDataBatch b) {
+                Native.Check(Native.nz_gauss_blur_stage_batch(ctx.Handle, b.data.Ptr, tmp.Ptr, width_, (int) sigma, iterations, b.resolution, b.count, dependency.id, out h), "nz_gauss_blur_stage_batch");
             } else {
                 Native.Check(Native.nz_gauss_blur_stage(ctx.Handle, d.data.Ptr, tmp.Ptr, width_, (int) sigma, iterations, d.resolution, dependency.id, out h), "nz_gauss_blur_stage");
             }
@@ -103,9 +114,11 @@ namespace xshazwar.noize.hip {
             int width_ = BlurHelper.limitWidth(width);
             ulong h;
             if (d.write != null) {
-                NzRwTile t = new NzRwTile { read = d.data.Ptr, write = d.write.Ptr, resolution = d.resolution, count = 1 };
+                NzRwTile t = new NzRwTile { read = d.data.Ptr, write = d.write.Ptr, resolution = d.resolution, count = BatchCount(d) };
                 Native.Check(Native.nz_smooth_blur_stage_rw(ctx.Handle, ref t, width_, iterations, dependency.id, out h), "nz_smooth_blur_stage_rw");
                 Adopt(d, t);
+            } else if (d is GeneratorDataBatch b) {
+                Native.Check(Native.nz_smooth_blur_stage_batch(ctx.Handle, b.data.Ptr, tmp.Ptr, width_, iterations, b.resolution, b.count, dependency.id, out h), "nz_smooth_blur_stage_batch");
             } else {
                 Native.Check(Native.nz_smooth_blur_stage(ctx.Handle, d.data.Ptr, tmp.Ptr, width_, iterations, d.resolution, dependency.id, out h), "nz_smooth_blur_stage");
             }
@@ -121,9 +134,11 @@ namespace xshazwar.noize.hip {
             GeneratorData d = (GeneratorData) requirements.data;
             ulong h;
             if (d.write != null) {
-                NzRwTile t = new NzRwTile { read = d.data.Ptr, write = d.write.Ptr, resolution = d.resolution, count = 1 };
+                NzRwTile t = new NzRwTile { read = d.data.Ptr, write = d.write.Ptr, resolution = d.resolution, count = BatchCount(d) };
                 Native.Check(Native.nz_erosion_stage_rw(ctx.Handle, ref t, iterations, dependency.id, out h), "nz_erosion_stage_rw");
                 Adopt(d, t);
+            } else if (d is GeneratorDataBatch b) {
+                Native.Check(Native.nz_erosion_stage_batch(ctx.Handle, b.data.Ptr, tmp.Ptr, iterations, b.resolution, b.count, dependency.id, out h), "nz_erosion_stage_batch");
             } else {
                 Native.Check(Native.nz_erosion_stage(ctx.Handle, d.data.Ptr, tmp.Ptr, iterations, d.resolution, dependency.id, out h), "nz_erosion_stage");
             }
@@ -160,17 +175,18 @@ namespace xshazwar.noize.hip {
         public FlowMapStage(GpuContext ctx) : base(ctx) {}
         public override void ResizeNativeContainers(int size) {                                     // :197-205
             work?.Dispose();
-            int res = (int) Math.Sqrt(size);
-            work = ctx.Alloc((int) (ulong) Native.nz_flowmap_stage_work_floats(res));
+            work = ctx.Alloc(11 * size);         // the stage's 11 planes (nz_flowmap_stage_work_floats); a batch stacks its tiles inside every plane
         }
         public override void Schedule(PipelineWorkItem requirements, GpuJobHandle dependency) {     // :207-214 -> ScheduleAll :124-195
             CheckRequirements<GeneratorData>(requirements);
             GeneratorData d = (GeneratorData) requirements.data;
             ulong h;
             if (d.write != null) {
-                NzRwTile t = new NzRwTile { read = d.data.Ptr, write = d.write.Ptr, resolution = d.resolution, count = 1 };
+                NzRwTile t = new NzRwTile { read = d.data.Ptr, write = d.write.Ptr, resolution = d.resolution, count = d is GeneratorDataBatch bb ? bb.count : 1 };
                 Native.Check(Native.nz_flowmap_stage_rw(ctx.Handle, ref t, work.Ptr, iterations, normMin, normMax, dependency.id, out h), "nz_flowmap_stage_rw");
                 Adopt(d, t);
+            } else if (d is GeneratorDataBatch b) {
+                Native.Check(Native.nz_flowmap_stage_batch(ctx.Handle, b.data.Ptr, work.Ptr, iterations, normMin, normMax, b.resolution, b.count, dependency.id, out h), "nz_flowmap_stage_batch");
             } else {
                 Native.Check(Native.nz_flowmap_stage(ctx.Handle, d.data.Ptr, work.Ptr, iterations, normMin, normMax, d.resolution, dependency.id, out h), "nz_flowmap_stage");
             }
@@ -184,14 +200,20 @@ namespace xshazwar.noize.hip {
         public MeshTileStage(GpuContext ctx) : base(ctx) {}
         public override void Schedule(PipelineWorkItem requirements, GpuJobHandle dependency) {     // :40-46
             MeshStageData d = (MeshStageData) requirements.data;
-            int nv = (int) (ulong) Native.nz_mesh_vertex_count(d.resolution), ni = (int) (ulong) Native.nz_mesh_index_count(d.resolution);
+            int count = Math.Max(1, d.count);
+            int nv = (int) (ulong) Native.nz_mesh_vertex_count(d.resolution) * count, ni = (int) (ulong) Native.nz_mesh_index_count(d.resolution) * count;
             if (d.vertices == null || d.vertices.Length != nv * 12) {   // Mesh.AllocateWritableMeshData(1)
                 d.vertices?.Dispose(); d.indices?.Dispose();
                 d.vertices = ctx.Alloc(nv * 12);                         // 48-byte records {pos3, normal3, tangent4, uv2}
                 d.indices = ctx.Alloc(ni);                               // uint32
             }
-            Native.Check(Native.nz_heightmap_mesh(ctx.Handle, (int) meshType, d.vertices.Ptr, d.indices.Ptr, d.resolution, d.inputResolution,
-                                                  d.marginPix, d.tileHeight, d.tileSize, d.data.Ptr, dependency.id, out ulong h), "nz_heightmap_mesh");
+            ulong h;
+            if (count > 1)
+                Native.Check(Native.nz_heightmap_mesh_batch(ctx.Handle, (int) meshType, d.vertices.Ptr, d.indices.Ptr, d.resolution, d.inputResolution,
+                                                            d.marginPix, d.tileHeight, d.tileSize, d.data.Ptr, count, dependency.id, out h), "nz_heightmap_mesh_batch");
+            else
+                Native.Check(Native.nz_heightmap_mesh(ctx.Handle, (int) meshType, d.vertices.Ptr, d.indices.Ptr, d.resolution, d.inputResolution,
+                                                      d.marginPix, d.tileHeight, d.tileSize, d.data.Ptr, dependency.id, out h), "nz_heightmap_mesh");
             jobHandle = Done(h);
         }
         // OnStageComplete (:48-57): Mesh.ApplyAndDisposeWritableMeshData -> copy d.vertices / d.indices into the engine's mesh

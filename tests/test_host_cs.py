@@ -152,3 +152,42 @@ def test_sequential_structs_match_the_c_structs():
         assert [n for _, n in cf] == [n for _, n in sf], cname
         for (ct, n), (st, _) in zip(cf, sf):
             assert st == ("IntPtr" if ct not in kind else kind[ct]), (cname, n)
+
+
+def test_the_cs_host_has_every_class_the_python_host_exports():
+    # host-cs/ is level with the two hosts the test suite drives: every public class / enum of noize_job_amd (the operator
+    # API: payloads, stages, pipelines, the state manager with its context stages, persistence, the live erosion) exists in
+    # the C# sources under the same name -- or under the name the .NET side gives it
+    import ast
+    pkg = os.path.join(ROOT, "noize_job_amd")
+    exported = set()
+    for mod in ("pipeline.py", "pipeline_state.py", "persistence.py", "live_erosion.py", "runtime.py", "sharded.py"):
+        tree = ast.parse(open(os.path.join(pkg, mod)).read())
+        exported |= {n.name for n in tree.body if isinstance(n, ast.ClassDef) and not n.name.startswith("_")}
+    renamed = {"Context": "GpuContext", "JobHandle": "GpuJobHandle", "NativeComm": "GpuComm", "ShardedGrid": "ShardedPipeline"}
+    # Python-side plumbing with no counterpart in a compiled host: the mesh buffers are two members of MeshStageData, the
+    # Python schedule of the sharded path (sharded.py) is nz_sharded_* behind the C ABI for a compiled host
+    python_only = {"MeshBuffers", "StripePlan", "PipelineParams", "PlaneWindow", "StripedTile", "HipStripeOps", "TorchComm", "NoComm"}
+    text = "\n".join(_cs_sources().values())
+    missing = []
+    for name in sorted(exported - python_only):
+        cs_name = renamed.get(name, name)
+        if not re.search(r"\b(class|struct|enum)\s+%s\b" % re.escape(cs_name), text):
+            missing.append(cs_name)
+    assert not missing, missing
+    # the members the context stages and the batch payload rest on
+    state = _cs_sources()["PipelineState/PipelineState.cs"]
+    for member in ("GetBuffer", "GetBufferNoLoad", "SaveBufferToDisk", "BufferExists", "ReleaseBuffer", "IsLocked", "TrySetLock",
+                   "RegisterCallback", "RemoveCallback", "TriggerUpdateCallbacks", "SetSavePath", "OnDestroy"):
+        assert re.search(r"public\s+[\w<>\[\]]+\s+%s\s*\(" % member, state), member
+    serde = _cs_sources()["PipelineState/PipelineSerialization.cs"]
+    for member in ("WriteData", "ReadData", "CachedSize", "GetFQN", "SetCount", "GetCount", "FlushToDisk", "FromFile"):
+        assert re.search(r"\b%s\s*\(" % member, serde), member
+    assert '"NativeArray`1"' in serde and "save__" in serde and "files.json" in serde
+    stages = _cs_sources()["Stages/Stages.cs"]
+    for entry in ("nz_fractal_batch", "nz_kernel_filter_stage_batch", "nz_gauss_blur_stage_batch", "nz_smooth_blur_stage_batch",
+                  "nz_erosion_stage_batch", "nz_flowmap_stage_batch", "nz_heightmap_mesh_batch"):
+        assert "Native.%s(" % entry in stages, entry
+    ctxs = _cs_sources()["Stages/ContextStages.cs"]
+    assert ctxs.count("Native.nz_flush_write_slice(") == 2 and "Native.nz_handle_record(" in ctxs
+    assert "stageManager" in _cs_sources()["Pipeline/Pipeline.cs"] and "nz_ctx_set_float_mode" in _cs_sources()["Runtime.cs"]
