@@ -108,20 +108,11 @@ def parse():
     ap.add_argument("--flush", choices=("swap", "copy"), default="swap",
                     help="N=1: the tile is a READ / WRITE plane pair and TileHelpers.SWAP_RWTILE is a pointer swap "
                          "(nz_*_rw entries), or one plane with the in-place entries and their flush copies")
-    ap.add_argument("--stripes", type=int, default=1,
-                    help="N=1: run the tile as this many independent row stripes, each on its own HIP stream (ghost "
-                         "rows recomputed from the closed-form noise; the fp32-bound kernels of one stripe overlap "
-                         "the HBM-bound kernels of another); 1 = the stage pipeline on one stream")
     ap.add_argument("--cpu-res", type=int, default=0, help="tile side of the CPU baseline (0 = --res)")
     ap.add_argument("--float-mode", choices=tuple(FLOAT_MODES), default="strict",
                     help="nz_ctx_set_float_mode of the timed steps: strict (the reference's operation sequence, bit-equal to the "
                          "oracle: the headline), fast (fBm tail and tap sums FMA-contracted, every stage within 1e-5 of strict), "
                          "relaxed (fast + the flow iterations).  The other modes are timed beside the headline in `float_modes`")
-    ap.add_argument("--schedule", choices=("pipeline", "stages"), default="stages",
-                    help="N=1: `stages` = the reference's stage-by-stage hand-over on one stream (BasePipeline's default); "
-                         "`pipeline` = BasePipeline.fuseStages: the stock stage list goes to the library as ONE call "
-                         "(nz_terrain_pipeline: two independent row stripes on two HIP streams of the context, ghost rows "
-                         "recomputed)")
     return ap.parse_args()
 
 
@@ -213,31 +204,6 @@ def two_tiles(nj, ctx, stages, gd, res, p, swap, steps=100):
             "note": "two independent %d^2 tiles on two HIP streams, not the headline value" % res}
 
 
-def two_stripes(nj, sh, torch, device, data, res, p, steps=100):
-    """Informational, outside the timed steps: the SAME tile as two independent row stripes, each on its own
-    HIP stream (ghost rows recomputed from the closed-form noise, the last launch storing into the tile's plane):
-    what `--stripes 2` times as its headline."""
-    ctxs = [nj.Context(device) for _ in range(2)]
-    try:
-        tile = sh.StripedTile(ctxs, data.data_ptr(), res, res, p,
-                              lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda"))
-        torch.cuda.synchronize()
-        for _ in range(20):
-            tile.run()
-        tile.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            tile.run()
-        tile.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-    finally:
-        for c in ctxs:
-            c.close()
-    return {"streams": 2, "ms_per_tile": round(dt * 1e3, 4), "Mcells/s": round(res * res / dt / 1e6, 1),
-            "note": "one %d^2 tile as two independent row stripes on two HIP streams (bench.py --stripes 2), "
-                    "not the headline value" % res}
-
-
 def in_place_entries(nj, ctx, res, p, steps=60):
     """Informational: the strictly drop-in form -- ONE plane, the in-place stage entries, results land in `data` as in
     the reference (their flush copies stand for TileHelpers.SWAP_RWTILE) -- what `--flush copy` times as its headline."""
@@ -245,7 +211,6 @@ def in_place_entries(nj, ctx, res, p, steps=60):
     stages = make_stages(nj, ctx, p)
     gd = nj.GeneratorData("inplace", ctx.alloc(cells), res, 0, 0)
     pipe = nj.BasePipeline(stages, "in-place")
-    pipe.fuseStages = False
 
     def one():
         pipe.Schedule(gd)
@@ -263,39 +228,6 @@ def in_place_entries(nj, ctx, res, p, steps=60):
     return {"ms_per_step": round(dt * 1e3, 4), "Mcells/s": round(cells / dt / 1e6, 1),
             "note": "one plane, in-place entries with their flush copies (bench.py --flush copy): results land in "
                     "`data` exactly as in the reference"}
-
-
-def one_call_pipeline(nj, ctx, res, p, steps=60):
-    """Informational: BasePipeline.fuseStages -- the stock stage list handed to the library as ONE call
-    (nz_terrain_pipeline: two independent row stripes on two HIP streams of the context, ghost rows recomputed, result in
-    the tile's own plane) -- what `--schedule pipeline` times as its headline."""
-    cells = res * res
-    stages = make_stages(nj, ctx, p)
-    gd = nj.GeneratorData("one-call", ctx.alloc(cells), res, 0, 0)
-    pipe = nj.BasePipeline(stages, "one-call")
-    pipe.fuseStages = True
-
-    def one():
-        pipe.Schedule(gd)
-        pipe.pipelineRunning = False
-    one()
-    if pipe.fusedMarks is None:
-        pipe.Destroy()
-        gd.data.Dispose()
-        return {"applies": False, "note": "nz_terrain_pipeline does not apply to this tile (too small to split)"}
-    for _ in range(20):
-        one()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    ctx.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    pipe.Destroy()
-    gd.data.Dispose()
-    return {"ms_per_step": round(dt * 1e3, 4), "Mcells/s": round(cells / dt / 1e6, 1),
-            "note": "BasePipeline.fuseStages: one nz_terrain_pipeline call per tile, two row stripes on two streams; no "
-                    "WRITE plane, no stage scratch"}
 
 
 class TimedComm:
@@ -593,15 +525,13 @@ def main():
         pipe = nj.BasePipeline(stages, "metric")
         gd = nj.GeneratorData("bench", tile, res, 0, 0, write=ctx.wrap(data_w.data_ptr(), cells) if swap else None)
 
-        pipe.fuseStages = args.schedule == "pipeline"
-        pipe.Schedule(gd)  # one untimed pass: buffers, code objects -- and whether the one-call form applies to this tile
+        pipe.Schedule(gd)  # one untimed pass: buffers, code objects
         pipe.pipelineRunning = False
-        one_call = pipe.fusedMarks is not None
 
         prev_end = [None]  # the last marked step's final handle, while nothing else has been enqueued since
 
         def step(record):
-            if record and not one_call:
+            if record:
                 # the step's first marker IS the previous step's last one (the stage handles are the only events a
                 # marked step records: each costs the stream ~3 us, tools/probe_event_cost.py)
                 hs = [prev_end[0] if prev_end[0] is not None else ctx.record()]
@@ -615,35 +545,11 @@ def main():
                 pipe.Schedule(gd)
                 pipe.pipelineRunning = False
 
-        def stage_pass(steps=100, warm=20):
-            """The same stage list scheduled stage by stage on ONE stream, markers between the stages: every kernel has
-            the chip to itself, which is what a launch time and a roofline fraction mean.  Host-timed like the headline."""
-            def one(rec):
-                hs = [ctx.record()]
-                for st in stages:
-                    st.Schedule(nj.PipelineWorkItem(gd), hs[-1])
-                    hs.append(st.jobHandle)
-                if rec:
-                    marks.append(hs)
-            for _ in range(warm):
-                one(False)
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                one(True)
-            fence()
-            return (time.perf_counter() - t0) / steps
-
         workload = "%dx%d tile: simplex-13oct(h0.4,size1700) -> Gauss5_S1 x%d -> FlowMap x%d (norm 0/0.005) -> " \
                    "ValueErosion x%d" % (res, res, G_IT, F_IT, E_IT)
         parallelism = "single tile"
         flush_note = ("READ/WRITE plane pair, SWAP_RWTILE = pointer swap (nz_*_rw entries)" if swap else
                       "one plane, in-place entries with flush copies")
-        if one_call:
-            parallelism = "single tile; BasePipeline.Schedule = one nz_terrain_pipeline call: two row stripes on two HIP " \
-                          "streams of the context"
-            flush_note = "result lands in the tile's own plane (no WRITE plane, no flush copy); the per-stage figures " \
-                         "come from the stage-by-stage pass (" + flush_note + ")"
     else:
         swap, flush_note = False, "stripe entries (explicit src / dst planes)"
         ops = sh.HipStripeOps(ctx)
@@ -699,29 +605,9 @@ def main():
         if args.as_rank is not None:
             parallelism = "rehearsal of rank %d of %d on one GPU" % (prank, pworld)
 
-    striped = None
-    if not sharded and args.stripes > 1:
-        # the same tile, same kernels, as independent stripes on their own streams; no per-stage markers here
-        sctx = [nj.Context(local_rank) for _ in range(args.stripes)]
-        striped = sh.StripedTile(sctx, data.data_ptr(), res, res, p,
-                                 lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda"))
-        torch.cuda.synchronize()
-
-        def step(record):  # noqa: F811
-            if record:  # stream markers of stripe 0 (its kernels share the chip with the other stripes')
-                hs = {}
-                striped.run(on_stage=lambda name: hs.__setitem__(name, sctx[0].record()))
-                marks.append([hs[n] for n in ("noise", "gauss", "flow", "erosion", "end")])
-            else:
-                striped.run()
-        parallelism = "single tile as %d row stripes on %d HIP streams" % (args.stripes, args.stripes)
-        flush_note = "stripe entries (explicit src / dst planes), last launch stores into the tile's plane"
-
     def fence():
         if sharded:
             dist.barrier()
-        if striped is not None:
-            striped.synchronize()
         torch.cuda.synchronize()
 
     if not sharded:
@@ -826,15 +712,6 @@ def main():
         rank_reports = [None] * world
         dist.all_gather_object(rank_reports, mine)
 
-    stage_by_stage_s, got_one_call = None, None
-    if not sharded and striped is None and one_call:
-        if rank == 0 and not args.no_cpu_baseline and (args.cpu_res or res) == res:
-            # the plane the last timed step (one call, two stripes) left behind, kept for the comparison with the oracle
-            got_one_call = np.empty(cells, np.float32)
-            nj._native.check(nj._native.lib.nz_tile_download(ctx._h, gd.data.ptr, got_one_call.ctypes.data, cells, 0, None),
-                             "download")
-            fence()
-        stage_by_stage_s = stage_pass()
     out = None
     out_lock = threading.Lock()
     if rank == 0:
@@ -905,12 +782,6 @@ def main():
             out["config"]["strong_scaling"] = ("this N = 1 line is the 4096^2 metric tile; the N > 1 lines run the %d^2 grid "
                                                "split over the ranks, whose one-GPU figure is `grid_%d` below" %
                                                (args.grid, args.grid)) if args.grid else None
-        if stage_by_stage_s is not None:
-            out["stage_by_stage"] = {"ms_per_step": round(stage_by_stage_s * 1e3, 4),
-                                     "Mcells/s": round(cells / stage_by_stage_s / 1e6, 1),
-                                     "note": "the same stage list, stage after stage on one stream (bench.py --schedule "
-                                             "stages): `stages` and `roofline` below are measured in this pass, where a "
-                                             "kernel has the chip to itself; `value` is the one-call form"}
         if cold_ms is not None:
             out["cold_ms"] = round(cold_ms, 4)
             out["config"]["cold_ms_note"] = "one step from an idle chip (0.5 s after the previous one), host-timed"
@@ -921,15 +792,15 @@ def main():
         flow_cap = nj._native.lib.nz_flow_fused_max_iterations()
         flow_launches = len(sh.split_iterations(F_IT, flow_cap))
         # the tile API ends a one-launch flow stage with a copy back into the caller's plane; stripes ping-pong
-        pingpong = sharded or swap or striped is not None  # explicit src / dst: no copy back, no even-launch-count rule
-        mctx = sctx[0] if striped is not None else ctx    # the context whose stream carries the markers
+        pingpong = sharded or swap  # explicit src / dst: no copy back, no even-launch-count rule
+        mctx = ctx
         ero_cap = nj._native.lib.nz_erosion_max_fused_iterations()
         n_gauss = len(sh.split_iterations(G_IT, nj._native.lib.nz_kernel_filter_max_fused(2)))
         if n_gauss & 1 and not pingpong:  # the tile API keeps the launch count even (result back in `src`)
             n_gauss += 1
         # the tile entries run these fused launches as ONE grid with tile-level dependencies (conv_chain_kernel) unless
         # NZ_CONV_CHAIN=0; the stripe entries launch them one by one
-        gauss_chained = (not sharded and striped is None and os.environ.get("NZ_CONV_CHAIN", "1") != "0" and 3 <= n_gauss <= 8)
+        gauss_chained = (not sharded and os.environ.get("NZ_CONV_CHAIN", "1") != "0" and 3 <= n_gauss <= 8)
         if gauss_chained:
             stage_note = {"gauss": "%d fused launches (%s applications) as one chained grid" %
                                    (n_gauss, "+".join(str(t) for t in sh.split_iterations(G_IT, nj._native.lib.nz_kernel_filter_max_fused(2))))}
@@ -939,8 +810,6 @@ def main():
         launches = {"noise": 1, "gauss": n_gauss, "flow": flow_launches,
                     "erosion": len(sh.split_iterations(E_IT, ero_cap)) if pingpong else 2}
         rcells = cells // world  # rank 0's own cells: the stage figures are per GPU
-        if striped is not None:
-            rcells = striped.parts[0][1].nown * res  # stripe 0's own cells
         per_step = {n: [] for n in STAGES}
         for hs in marks:
             for i, n in enumerate(STAGES):
@@ -971,7 +840,7 @@ def main():
         # Counter summary of these very kernels (same source hash, same flush mode), if one is committed: VALU
         # instructions and HBM bytes per launch.  Launch times are this run's; the counters are not re-measured here
         # (rocprofv3 --pmc cannot run inside the timed region) and `counters_source` says where they come from.
-        cnt = None if (sharded or striped is not None) else load_counters(res, args.flush, mode)
+        cnt = None if sharded else load_counters(res, args.flush, mode)
         valu_floor_ms = 0.0
         for n in STAGES:
             s = stages_out[n]
@@ -1042,14 +911,10 @@ def main():
         if cres == res:
             # the device plane the last timed step left behind against the oracle's (outside the timed region)
             got = np.empty(cells, np.float32)
-            src = gd.data if striped is None else tile
+            src = gd.data
             nj._native.check(nj._native.lib.nz_tile_download(ctx._h, src.ptr, got.ctypes.data, cells, 0, None), "download")
             fence()
             same = bool(np.array_equal(got.reshape(res, res), plane))
-            if got_one_call is not None:  # both forms: the one call of the timed steps and the stage-by-stage pass
-                same_one = bool(np.array_equal(got_one_call.reshape(res, res), plane))
-                out["verified_detail"] = {"one_call_plane_equals_oracle": same_one, "stage_by_stage_plane_equals_oracle": same}
-                same = same and same_one
             out["verified"] = same
             if not same:
                 bad = ~(np.abs(got.reshape(res, res) - plane) <= 1e-5 * np.abs(plane) + 1e-6)
@@ -1070,7 +935,7 @@ def main():
         if rank == 0:
             out["verified"] = ver.pop("verified")
             out["verified_detail"] = ver
-    if rank == 0 and not sharded and striped is None and not one_call and not args.no_extras:
+    if rank == 0 and not sharded and not args.no_extras:
         # the other float modes beside the headline: the same step on the same planes, 100 timed steps after 30 untimed ones,
         # then 40 marked steps for the stage times; the plane each mode leaves is compared with the oracle's
         modes_out = {}
@@ -1117,7 +982,7 @@ def main():
             "its output by ~1e-4 relative -- as between any two FloatMode.Fast builds of the reference")
         out["float_modes"] = modes_out
     extras = not args.no_extras
-    if rank == 0 and extras and not sharded and striped is None:
+    if rank == 0 and extras and not sharded:
         # informational, outside the timed steps; never allowed to cost the JSON line: an exception is recorded, and
         # should one of them ever block, a watchdog prints the line without them and ends the process
         printed = []
@@ -1134,10 +999,8 @@ def main():
         watchdog = threading.Timer(240.0, bail)
         watchdog.daemon = True
         watchdog.start()
-        for key, fn in (("one_call_pipeline", lambda: one_call_pipeline(nj, ctx, res, p) if not one_call else None),
-                        ("in_place_entries", lambda: in_place_entries(nj, ctx, res, p) if swap else None),
-                        ("two_tiles_in_flight", lambda: two_tiles(nj, ctx, stages, gd, res, p, swap)),
-                        ("tile_as_two_stripes", lambda: two_stripes(nj, sh, torch, local_rank, data, res, p))):
+        for key, fn in (("in_place_entries", lambda: in_place_entries(nj, ctx, res, p) if swap else None),
+                        ("two_tiles_in_flight", lambda: two_tiles(nj, ctx, stages, gd, res, p, swap))):
             try:
                 gc.collect()
                 r = fn()
@@ -1148,7 +1011,7 @@ def main():
                     out[key] = r
         watchdog.cancel()
     # BASELINE config 5's grid at this N (every rank takes part)
-    if extras and args.grid > 0 and args.as_rank is None and striped is None and args.grid % world == 0:
+    if extras and args.grid > 0 and args.as_rank is None and args.grid % world == 0:
         if not sharded:  # N = 1 without a process group: the whole grid as one stripe
             g = None
             try:
@@ -1171,9 +1034,6 @@ def main():
             ncomm.close()
         dist.barrier()
         dist.destroy_process_group()
-    if striped is not None:
-        for c in sctx:
-            c.close()
     ctx.close()
     sys.stdout.flush()
     os.dup2(real_stdout, 1)

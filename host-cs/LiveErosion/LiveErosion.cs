@@ -105,9 +105,7 @@ namespace xshazwar.noize.hip {
             waterControl.CopyFrom(zeros); textureControl.CopyFrom(zeros);
         }
 
-        public bool parallelBranch = false;      // true: ErodeHeightMaps || UpdateFlowFromTrackJob on two streams, as in the reference's job graph (measured slower)
         public bool fewHandles = true;           // false: a handle out of every job, as the reference schedules them (one event record each)
-        GpuContext branchCtx;                    // created on first use
 
         // TriggerQueuedBeyerMT :378-436.  seeds: one per cycle.
         public GpuJobHandle TriggerQueuedBeyerMT(int[] seeds) {
@@ -141,37 +139,23 @@ namespace xshazwar.noize.hip {
                                                                        events.Handle, ref ep, ref tm, EVENT_LIMIT, res, h, out h), "nz_queued_beyer_cycle");
                     else { Native.Check(Native.nz_queued_beyer_cycle(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, particleQueue.Handle,
                                                                      events.Handle, ref ep, ref tm, EVENT_LIMIT, res, h, IntPtr.Zero), "nz_queued_beyer_cycle"); h = 0; }
-                    if (all || parallelBranch)  // the branch's stream waits for the event reduction
+                    if (all)
                         Native.Check(Native.nz_process_beyer_erosive_events(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, events.Handle,
                                                                             ref ep, ref tm, res, h, out h), "nz_process_beyer_erosive_events");
                     else { Native.Check(Native.nz_process_beyer_erosive_events(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, events.Handle,
                                                                                ref ep, ref tm, res, h, IntPtr.Zero), "nz_process_beyer_erosive_events"); h = 0; }
                     // CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all behind the event reduction
-                    // (:408-412): the flow job runs on a stream of its own (a second context), beside the sediment job
-                    if (parallelBranch) {
-                        if (branchCtx == null) branchCtx = new GpuContext(ctx.Device);   // the main context's device
-                        Native.Check(Native.nz_update_flow_from_track(branchCtx.Handle, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
-                                                                      ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out ulong flow), "nz_update_flow_from_track");
-                        h = particleQueue.Clear(ctx.Wrap(h), all).id;
-                        if (all) {
-                            Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
-                            Native.Check(Native.nz_handle_combine(c, new ulong[] { h, flow }, 2, out h), "nz_handle_combine");
-                        } else {
-                            Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, IntPtr.Zero), "nz_erode_height_maps");
-                            h = flow;  // the automaton follows ErodeHeightMaps on this stream and waits for the branch
-                        }
+                    // (:408-412): one after the other on the context's stream
+                    h = particleQueue.Clear(ctx.Wrap(h), all).id;
+                    if (all) {
+                        Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
+                        Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
+                                                                      ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out h), "nz_update_flow_from_track");
                     } else {
-                        h = particleQueue.Clear(ctx.Wrap(h), all).id;
-                        if (all) {
-                            Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
-                            Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
-                                                                          ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out h), "nz_update_flow_from_track");
-                        } else {
-                            Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, IntPtr.Zero), "nz_erode_height_maps");
-                            Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
-                                                                          ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, 0, IntPtr.Zero), "nz_update_flow_from_track");
-                            h = 0;
-                        }
+                        Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, IntPtr.Zero), "nz_erode_height_maps");
+                        Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
+                                                                      ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, 0, IntPtr.Zero), "nz_update_flow_from_track");
+                        h = 0;
                     }
                     if (all || last) Native.Check(Native.nz_pool_automata_job(c, poolMap.Ptr, heightMap.Ptr, particleQueue.Handle, ref ep, ref tm, es.WATER_STEPS, res,
                                                                               performErosion ? 1 : 0, h, out h), "nz_pool_automata_job");
@@ -207,7 +191,6 @@ namespace xshazwar.noize.hip {
             foreach (DeviceTile t in new[] { poolMap, streamMap, particleTrack, waterControl, textureControl }) t?.Dispose();
             particleQueue.Dispose();
             events.Dispose();
-            branchCtx?.Dispose();
         }
     }
 }

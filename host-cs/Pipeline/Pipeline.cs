@@ -138,23 +138,15 @@ namespace xshazwar.noize.hip {
                                                  dependency = dependency, stageManager = contextManager });
         }
 
-        // Opt-in: the stock stage list -- NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionStage], README.md:23-32
-        // -- on a tile big enough to split goes to the library as ONE call (nz_terrain_pipeline: two independent row stripes
-        // on two streams of the context, ghost rows recomputed; same plane, bit for bit).  Every stage still gets its
-        // jobHandle, TransformData and scheduled actions; no WRITE plane and no stage scratch are needed.
-        public bool fuseStages = false;
-        public bool lastScheduleWasOneCall = false;
-
         public void Schedule(PipelineWorkItem item) {                                               // :104-120
             activeItem = item;
             if (stage_instances.Count == 0) throw new Exception("No stages in pipeline");
             pipelineBeingScheduled = true;
-            lastScheduleWasOneCall = fuseStages && ScheduleStockList();
-            if (!lastScheduleWasOneCall) stage_instances[0].ReceiveHandledInput(activeItem, activeItem.dependency);
+            stage_instances[0].ReceiveHandledInput(activeItem, activeItem.dependency);
         }
 
         // The stock stage list NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionStage] (README.md:23-32), all on
-        // one context, as nz_terrain_params; false if the list is anything else.
+        // one context, as nz_terrain_params (what ShardedPipeline hands to nz_sharded_create); false if the list is anything else.
         public static bool StockListParams(IList<PipelineStage> stages, out NzTerrainParams tp, out NoiseStage n) {
             tp = default(NzTerrainParams); n = null;
             if (stages.Count == 0 || stages[0].GetType() != typeof(NoiseStage)) return false;
@@ -176,28 +168,6 @@ namespace xshazwar.noize.hip {
                 filter = f != null ? (int) f.filter : 0, filterIterations = f != null ? f.iterations : 0,
                 flowIterations = w != null ? w.iterations : 0, normMin = w != null ? w.normMin : 0f, normMax = w != null ? w.normMax : 0f,
                 erosionIterations = e != null ? e.iterations : 0 };
-            return true;
-        }
-
-        bool ScheduleStockList() {
-            if (!(activeItem.data is GeneratorData d) || d.GetType() != typeof(GeneratorData) || stage_instances.Count < 2) return false;
-            if (!StockListParams(stage_instances, out NzTerrainParams tp, out NoiseStage n)) return false;
-            if (Native.nz_terrain_pipeline_stripes(ref tp, d.resolution) <= 0) return false;
-            Native.Check(Native.nz_terrain_pipeline(n.Context.Handle, d.data.Ptr, d.resolution, d.xpos, d.zpos, ref tp, null,
-                                                    activeItem.dependency.id, out ulong h), "nz_terrain_pipeline");
-            GpuJobHandle done = n.Context.Wrap(h);
-            for (int i = 0; i < stage_instances.Count; i++) {
-                PipelineStage s = stage_instances[i];
-                s.jobHandle = done;
-                s.TransformData(activeItem);
-                // every scheduled action except the hand-over to the next stage, which happened inside the call
-                if (s.OnStageScheduledAction == null) continue;
-                foreach (Delegate a in s.OnStageScheduledAction.GetInvocationList()) {
-                    bool chain = i + 1 < stage_instances.Count && ReferenceEquals(a.Target, stage_instances[i + 1]) &&
-                                 a.Method.Name == nameof(PipelineStage.ReceiveHandledInput);
-                    if (!chain) ((Action<PipelineWorkItem, GpuJobHandle>) a)(activeItem, done);
-                }
-            }
             return true;
         }
 

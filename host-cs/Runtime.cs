@@ -15,7 +15,7 @@ namespace xshazwar.noize.hip {
     [StructLayout(LayoutKind.Sequential)]
     public struct NzRwTile { public IntPtr read, write; public int resolution, count; }           // nz_rw_tile
 
-    // the stock stage list handed over as one call (nz_terrain_pipeline)
+    // the stock stage list as a parameter block (nz_sharded_create)
     [StructLayout(LayoutKind.Sequential)]
     public struct NzTerrainParams {                                                                  // nz_terrain_params
         public int noiseType;

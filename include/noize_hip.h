@@ -476,20 +476,11 @@ int32_t nz_debug_chain_delay(int32_t item, int32_t sleeps);
  * default (2^21: seconds).  With a small limit and a long nz_debug_chain_delay the time-out path can be exercised. */
 int32_t nz_debug_chain_poll_limit(int32_t polls);
 
-/* ---- a whole BasePipeline of the stock stages as one call -------------------------------------------------------
- * BasePipeline.Schedule hands a work item from stage to stage (Pipeline/Executable/Pipeline.cs:91-152,
- * Pipeline/Stage/PipelineStage.cs:41-48); when the stage list is NoiseStage -> [KernelFilterStage] -> [FlowMapStage] ->
- * [ErosionKernelJob x n] (README.md:23-32, the metric pipeline) the host may hand the whole list over instead.  The
- * source is closed-form noise, so the tile is run as two independent row stripes on two HIP streams of the context --
- * every stripe evaluates the noise on its rows plus the stencil radius of everything downstream and each launch
- * produces a window that shrinks by the radius it consumed -- and the fp32-bound kernels of one stripe overlap the
- * memory-bound ones of the other.  Same kernels, same results as the stage-by-stage calls, bit for bit; the result lands
- * in `data` (the tile's READ plane), no WRITE plane or stage scratch is needed (the context owns the stripes' planes).
- * An iteration count of 0 leaves a stage out.  `marks` (nullable, 5 handles): markers on the context's stream where the
- * noise, filter, flow and erosion launches of the FIRST stripe begin, and at the end.
- * nz_terrain_pipeline_stripes: the number of stripes the call would use on this tile, 0 if it does not apply (tile too
- * small to split, no stencil stage, a filter or iteration count without a fused kernel): the host then schedules stage by
- * stage as the reference does. */
+/* ---- the stock stage list as a parameter block --------------------------------------------------------------------
+ * NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionKernelJob x n] (README.md:23-32, the metric pipeline) as
+ * nz_sharded_create takes it; an iteration count of 0 leaves a stage out.  (Rounds 3 and 4 also offered the list as ONE call
+ * on a single tile, nz_terrain_pipeline: two row stripes on two streams of the context.  With the round-3 kernels the
+ * overlap bought nothing -- 0.6595 against 0.6413 ms per 4096^2 step stage by stage -- and it was removed in round 5.) */
 typedef struct nz_terrain_params {
     int32_t noiseType;            /* NoiseStage.FractalNoise, Noise/NoiseStage.cs:15-24 */
     float hurst, startingAmplitude, stepdown, detuneRate;
@@ -500,9 +491,6 @@ typedef struct nz_terrain_params {
     float normMin, normMax;
     int32_t erosionIterations;    /* ErosionKernelJob applications, 0 = none */
 } nz_terrain_params;
-int32_t nz_terrain_pipeline_stripes(const nz_terrain_params *p, int32_t resolution);
-int32_t nz_terrain_pipeline(nz_ctx *ctx, float *data, int32_t resolution, int32_t xpos, int32_t zpos,
-                            const nz_terrain_params *p, nz_handle *marks, nz_handle dep, nz_handle *out);
 
 /* ---- one large grid over the GPUs of a node: row stripes + RCCL neighbour halo exchange (new-framework feature,
  * SURVEY.md 8e; the reference only has independent clamped tiles, Scripts/MeshTileGenerator.cs:166-192, which a host
@@ -606,7 +594,8 @@ int32_t nz_sharded_plan(const nz_sharded *sh, int32_t *records, int32_t max_reco
  * asWorld) these are the lists of that rank of the real job: laid side by side for all ranks, the k-th send of rank a to
  * rank b must be the k-th receive rank b posts from rank a, with the same size (tests/test_sharded_native.py). */
 int32_t nz_sharded_transfers(const nz_sharded *sh, int32_t *records, int32_t max_records, int32_t *count);
-/* one pass of the pipeline on every local stripe (enqueue only); `marks` (nullable, 5 handles) as nz_terrain_pipeline */
+/* one pass of the pipeline on every local stripe (enqueue only); `marks` (nullable, 5 handles): markers on the context's
+ * stream where the noise, filter, flow and erosion launches begin, and at the end */
 int32_t nz_sharded_pipeline(nz_ctx *ctx, nz_sharded *sh, nz_handle *marks, nz_handle dep, nz_handle *out);
 /* exchanges and payload bytes this rank sends per pass */
 int32_t nz_sharded_traffic(const nz_sharded *sh, int32_t *exchanges, size_t *bytes_sent);

@@ -57,7 +57,7 @@ class Particle(C.Structure):
 
 
 class TerrainParams(C.Structure):
-    """nz_terrain_params (include/noize_hip.h): the stock stage list handed over as one call."""
+    """nz_terrain_params (include/noize_hip.h): the stock stage list as a parameter block (nz_sharded_create)."""
     _fields_ = [("noiseType", C.c_int32), ("hurst", C.c_float), ("startingAmplitude", C.c_float), ("stepdown", C.c_float),
                 ("detuneRate", C.c_float), ("octaves", C.c_int32), ("noiseSize", C.c_int32), ("filter", C.c_int32),
                 ("filterIterations", C.c_int32), ("flowIterations", C.c_int32), ("normMin", C.c_float),
@@ -122,8 +122,6 @@ SIGNATURES = {
     "nz_smooth_blur_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
     "nz_erosion_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
     "nz_debug_chain_delay": (_i, [_i, _i]),
-    "nz_terrain_pipeline_stripes": (_i, [tp_p, _i]),
-    "nz_terrain_pipeline": (_i, [ctx_p, dev_ptr, _i, _i, _i, tp_p, handle_p] + _tail),
     "nz_kernel_filter_halo_rows": (_i, [_i, _i]),
     "nz_kernel_filter_max_fused": (_i, [_i]),
     "nz_erosion_max_fused_iterations": (_i, []),

@@ -239,13 +239,11 @@ __global__ __launch_bounds__(64) void conv_stream_kernel(const float *__restrict
 template <int KS, int T>
 int32_t launch_stream(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int waves) {
     constexpr int O = (KS - 1) / 2, HX = (O * T + 1) & ~1, OW = CS_TW - 2 * HX;
-    static const int s_env = getenv("NZ_CONV_STREAM_S") ? atoi(getenv("NZ_CONV_STREAM_S")) : 0;
     const int nstrips = (g.cols + OW - 1) / OW, rows = g.or1 - g.or0;
-    const long long per = (long long)nstrips * g.count * (g.chip_div > 1 ? g.chip_div : 1);  // chip_div: its share of the chip
+    const long long per = (long long)nstrips * g.count;
     int nseg = (int)(waves / per > 0 ? waves / per : 1);
     int S = (rows + nseg - 1) / nseg;
     if (S < 16) S = 16;
-    if (s_env > 0) S = s_env;
     nseg = (rows + S - 1) / S;
     const uintptr_t bits = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4) |
                            (uintptr_t)(g.bstride * 4);

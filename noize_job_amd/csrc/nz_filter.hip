@@ -893,11 +893,11 @@ int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const 
     return NZ_ERR_INVALID;
 }
 
-// largest T with a useful interior left (OH >= 32, OW >= 96); 0 = this size has no fused kernel
+// largest T with a useful interior left (OH >= 28, OW >= 88); 0 = this size has no fused kernel
 int nz_conv_max_fused(int ksize) {
     switch (ksize) {
         case 3: return 8;
-        case 5: return 8;
+        case 5: return 9;
         case 7: return 5;
         case 9: return 4;
         default: return 0;

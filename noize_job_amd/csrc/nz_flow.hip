@@ -425,18 +425,16 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
     const float *fE_in = first ? nullptr : in[3], *fW_in = first ? nullptr : in[4];
     float *w_out = last ? nullptr : out[0], *fN_out = last ? nullptr : out[1], *fS_out = last ? nullptr : out[2];
     float *fE_out = last ? nullptr : out[3], *fW_out = last ? nullptr : out[4];
-    // OCC = waves per SIMD the register allocator must leave room for: 4 -> two 512-thread workgroups per CU
-    static const int occ = getenv("NZ_FLOW_OCC") ? atoi(getenv("NZ_FLOW_OCC")) : 4;
+    // (the kernel is register-allocated for four waves per SIMD = two 512-thread workgroups per CU: one workgroup per CU with
+    // the whole register file lost twice, 0.342 against 0.241 ms)
     const bool fast = nz_tls_float_mode >= NZ_FLOAT_RELAXED;
-#define NZ_FFL(F, L, O, M)                                                                                                    \
-    NZ_LAUNCH((flow_fused_kernel<F, L, O, M>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, fN_in, fS_in, fE_in, \
+#define NZ_FFL(F, L, M)                                                                                                             \
+    NZ_LAUNCH((flow_fused_kernel<F, L, NZ_FT_OCC, M>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, fN_in, fS_in, fE_in, \
               fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n, nmin, nrange, aligned)
-#define NZ_FF(F, L)                                        \
-    do {                                                   \
-        if (occ >= 4 && fast) NZ_FFL(F, L, NZ_FT_OCC, true);  \
-        else if (occ >= 4) NZ_FFL(F, L, NZ_FT_OCC, false);    \
-        else if (fast) NZ_FFL(F, L, 2, true);                 \
-        else NZ_FFL(F, L, 2, false);                          \
+#define NZ_FF(F, L)                    \
+    do {                               \
+        if (fast) NZ_FFL(F, L, true);  \
+        else NZ_FFL(F, L, false);      \
     } while (0)
     if (first && last) NZ_FF(true, true);
     else if (first) NZ_FF(true, false);

@@ -45,9 +45,6 @@ __device__ unsigned long long *nz_flow_probe_buf = nullptr;  // [wave][8]
 #ifndef NZ_FS_WPE
 #define NZ_FS_WPE 2  // waves per SIMD the four- and five-iteration kernels are register-allocated for: 176 VGPRs, nothing spilled (3: 168 VGPRs and a 25-dword spill; 0.147 against 0.149 ms at 4096^2, round 4)
 #endif
-#ifndef NZ_FS_PRIO
-#define NZ_FS_PRIO 0
-#endif
 constexpr int FS_RING = 16;   // rows of height kept per wave (needs 2n - 1 <= 9)
 // NC = columns per lane: 2 (a 128-column strip per wave, 12 registers of state per column and iteration = 120 at n = 5:
 // three waves per SIMD) or 1 (64-column strips: 1.22x the halo columns, half the state per lane -- five waves per SIMD)
@@ -238,23 +235,6 @@ __device__ __forceinline__ void fs_step(fs_state<NST, NC> &st, const int t, cons
         }
 }
 
-// Waves of a SIMD are served oldest first: left alone, the three waves of a SIMD finish one after the other (after 45 %,
-// 70 % and 100 % of the launch) and the last one runs alone, at most one VALU instruction per four cycles, for the last
-// third.  NZ_FS_PRIO rotates the priority among the SIMD's wave slots (slot id from HW_ID):
-//   1: by the wave's own step count -- the order moves on every 2^NZ_FS_PRIO_SHIFT steps;
-//   2: by the 100 MHz real-time counter, the same for every wave -- every slot is first for a third of the time.
-#ifndef NZ_FS_PRIO_SHIFT
-#define NZ_FS_PRIO_SHIFT 8
-#endif
-__device__ __forceinline__ void fs_prio(int step, int slot) {
-    unsigned phase = (unsigned)step >> NZ_FS_PRIO_SHIFT;
-    if (NZ_FS_PRIO == 2) phase = (unsigned)(__builtin_amdgcn_s_memrealtime() >> NZ_FS_PRIO_SHIFT);
-    const unsigned k = ((unsigned)slot + phase) % 3u;
-    if (k == 0) __builtin_amdgcn_s_setprio(2);
-    else if (k == 1) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-}
-
 template <int NC, bool VEC>
 __device__ __forceinline__ fs_row<NC> fs_load_row(const float *__restrict__ h, const nz_geom &g, int row, int gx) {
     fs_row<NC> o;
@@ -320,10 +300,8 @@ __device__ __forceinline__ void flow_stream_body(fs_row<NC> *ring, const float *
     fs_row<NC> hp = fs_load_row<NC, VEC>(h, g, min(t0 + 1, g.zc1), gx);
     ring[((t0 + 1) & (FS_RING - 1)) * 64] = hp;
     int t = t0;
-    const int slot = (int)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  /* HW_ID.WAVE_ID */
 #define NZ_FS_STEP(NA, C, T, HP, HN)                                                                              \
     do {                                                                                                          \
-        if (NZ_FS_PRIO) fs_prio((T) - t0, slot);                                                                      \
         fs_step<NST, NC, NA, C, XEDGE, VEC, FAST>(st, T, HP, HN, ring, b, gx, lane_x0, lane_x1, lane_x1o, g, nmin, nrange, \
                                               inv_range, dst, store_lane);                                        \
     } while (0)
@@ -377,11 +355,8 @@ __device__ __forceinline__ void flow_stream_body(fs_row<NC> *ring, const float *
 #undef NZ_FS_STEP
 }
 
-#ifndef NZ_FS_WPE1
-#define NZ_FS_WPE1 5  // waves per SIMD the one-column form is register-allocated for
-#endif
 template <int NST, int NC, bool FAST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 1 ? (NST >= 4 ? NZ_FS_WPE1 : 8) : (NST >= 4 ? NZ_FS_WPE : 4))))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NST >= 4 ? NZ_FS_WPE : 4)))
 void flow_stream_kernel(const float *__restrict__ h, float *__restrict__ dst, nz_geom g, int S, int nstrips, int Se,
                         int nseg_edge, float nmin, float nrange, int aligned) {
     __shared__ fs_row<NC> s_ring[FS_RING * 64];
@@ -433,22 +408,17 @@ bool nz_flow_stream_wanted(const nz_geom &g, int n) {
 
 int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const nz_geom &g, int n, float nmin,
                                      float nrange) {
-    // NZ_FLOW_STREAM_COLS: columns per lane (2: 128-column strips, three waves per SIMD; 1: 64-column strips, five)
-    static const int ncols = getenv("NZ_FLOW_STREAM_COLS") ? atoi(getenv("NZ_FLOW_STREAM_COLS")) : 2;
-    const int NC = ncols == 1 ? 1 : 2;
+    // two columns per lane: a 128-column strip per wave (one column per lane -- 64-column strips, five waves per SIMD -- was built
+    // in round 4 and lost: 0.174 against 0.148 ms, 1.22x the halo columns; removed in round 5)
+    constexpr int NC = 2;
     static const int waves_env = getenv("NZ_FLOW_STREAM_WAVES") ? atoi(getenv("NZ_FLOW_STREAM_WAVES")) : 0;
-    const int waves = waves_env > 0 ? waves_env : 1024 * (NC == 1 ? NZ_FS_WPE1 : NZ_FS_WPE);  // one round of resident waves
-    static const int s_env = getenv("NZ_FLOW_STREAM_S") ? atoi(getenv("NZ_FLOW_STREAM_S")) : 0;
+    const int waves = waves_env > 0 ? waves_env : 1024 * NZ_FS_WPE;  // one round of resident waves
     const int H = 2 * n, OW = 64 * NC - 2 * H;
     const int nstrips = (g.cols + OW - 1) / OW, rows = g.or1 - g.or0;
-    // chip_div: the launch shares the chip with launches on other streams (nz_terrain_pipeline's second stripe), mostly of
-    // other kernels: 3/4 of a round measured best for two (0.646 against 0.667 ms per 4096^2 step with 1/2)
-    long long per = (long long)nstrips * g.count;
-    if (g.chip_div > 1) per = (per * (2 * g.chip_div) + 2) / 3;
+    const long long per = (long long)nstrips * g.count;
     int nseg = (int)(waves / per > 0 ? waves / per : 1);
     int S = (rows + nseg - 1) / nseg;
     if (S < 16) S = 16;
-    if (s_env > 0) S = s_env;
     nseg = (rows + S - 1) / S;
     // border strips: ~12 % shorter segments (their steps are that much longer)
     int Se = (S * 7 + 7) / 8;
@@ -457,16 +427,14 @@ int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const n
     const int nblocks = (nstrips > 2 ? nstrips - 2 : 0) * nseg + (nstrips < 2 ? nstrips : 2) * nseg_e;
     uintptr_t bits = reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4) |
                      (uintptr_t)(g.bstride * 4);
-    const int aligned = NC == 1 ? 1 : (bits & 7) == 0;
+    const int aligned = (bits & 7) == 0;
     const dim3 grid((unsigned)nblocks, g.count);
     const bool fast = nz_tls_float_mode >= NZ_FLOAT_RELAXED;
-#define NZ_FSL(N, C, F) NZ_LAUNCH((flow_stream_kernel<N, C, F>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned)
-#define NZ_FS(N)                                \
-    do {                                        \
-        if (NC == 1 && fast) NZ_FSL(N, 1, true);  \
-        else if (NC == 1) NZ_FSL(N, 1, false);    \
-        else if (fast) NZ_FSL(N, 2, true);        \
-        else NZ_FSL(N, 2, false);                 \
+#define NZ_FSL(N, F) NZ_LAUNCH((flow_stream_kernel<N, 2, F>), grid, dim3(64), 0, s, h, dst, g, S, nstrips, Se, nseg_e, nmin, nrange, aligned)
+#define NZ_FS(N)                     \
+    do {                             \
+        if (fast) NZ_FSL(N, true);   \
+        else NZ_FSL(N, false);       \
     } while (0)
     switch (n) {
         case 1: NZ_FS(1); break;

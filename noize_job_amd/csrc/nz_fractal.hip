@@ -1002,8 +1002,7 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
     // 4 rows per workgroup amortise the table staging on big grids (1 / 2 / 4 / 8 / 16 rows: 0.285 / 0.278 / 0.277 /
     // 0.281 / 0.292 ms for the metric's 4096^2 simplex plane); a small grid gets more, shorter workgroups (the launch
     // lasts as long as one workgroup's rows)
-    static const int rows_knob = getenv("NZ_NOISE_ROWS") ? atoi(getenv("NZ_NOISE_ROWS")) : 4;
-    p.rows_per_wg = rows_knob > 0 ? rows_knob : 4;
+    p.rows_per_wg = 4;
     {
         long long wg_per_row = (cols + 511) / 512;
         while (p.rows_per_wg > 1 && wg_per_row * ((rows + p.rows_per_wg - 1) / p.rows_per_wg) * count < 2048) p.rows_per_wg >>= 1;

@@ -73,13 +73,6 @@ struct nz_ctx {
     bool retry_sync_pending = false;
     bool handle_rides = false;    // this entry's handle may ride on its last kernel launch (nz_ctx_handle_rides)
     uint64_t armed_seq = 0;       // ... and this is the sequence number reserved for it (nz_ctx_arm_last_launch)
-    // striped pipeline (nz_terrain_pipeline): a second stream with its fork / join markers and the stripes' planes, all
-    // created on first use
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    float *pipe_work = nullptr;
-    size_t pipe_work_floats = 0;
-    int pipe_small_streak = 0;  // consecutive requests of less than a quarter of pipe_work (nz_ctx_pipe_state)
     // pool automaton, sparse form (nz_pool_job in nz_stages.cpp): {entries, done, -} in device memory, and in mapped host
     // memory what the last job that ran reported: job number << 32 | non-empty mask words it found
     int *pool_ctl = nullptr;
@@ -100,7 +93,6 @@ constexpr uint64_t NZ_HANDLE_SEQ_MASK = (1ull << NZ_HANDLE_SEQ_BITS) - 1;
 int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep);           // set device, order the stream after `dep`
 int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out);         // record the JobHandle marker
 int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out);
-int32_t nz_ctx_pipe_state(nz_ctx *ctx, size_t floats, float **work);  // aux stream, fork / join events, stripe planes
 
 // ---- kernel parameter blocks ----------------------------------------------------------------
 constexpr int NZ_MAX_KSIZE = 25;
@@ -145,9 +137,6 @@ struct nz_geom {
     // the kernels take the grid index from blockIdx.y
     int count = 1;
     size_t bstride = 0;
-    // the launch shares the chip with (chip_div - 1) launches like it on other streams: kernels that size their grid to
-    // one round of waves take 1 / chip_div of the chip
-    int chip_div = 1;
 };
 
 inline nz_geom nz_geom_batch(int res, int count) {

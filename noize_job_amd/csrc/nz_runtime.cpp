@@ -234,13 +234,6 @@ extern "C" int32_t nz_ctx_destroy(nz_ctx *ctx) {
     if (ctx->chain_flags) (void)hipFree(ctx->chain_flags);
     if (ctx->chain_err) (void)hipHostFree(ctx->chain_err);
     if (ctx->chain_err_epoch) (void)hipFree(ctx->chain_err_epoch);
-    if (ctx->aux) {
-        (void)hipStreamSynchronize(ctx->aux);
-        (void)hipStreamDestroy(ctx->aux);
-    }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->pipe_work) (void)hipFree(ctx->pipe_work);
     if (ctx->pool_ctl) (void)hipFree(ctx->pool_ctl);
     if (ctx->pool_hint) (void)hipHostFree(ctx->pool_hint);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -260,7 +253,6 @@ extern "C" int32_t nz_ctx_device(nz_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 static int32_t ctx_sync_all(nz_ctx *ctx) {
     NZ_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->aux) NZ_HIP(hipStreamSynchronize(ctx->aux));  // (its work is joined into `stream` before a call returns)
     return NZ_OK;
 }
 // ---- context registry: a handle value carries the id of the context that issued it ------------------------------
@@ -324,8 +316,7 @@ extern "C" int32_t nz_ctx_set_float_mode(nz_ctx *ctx, int32_t mode) {
 extern "C" int32_t nz_ctx_float_mode(nz_ctx *ctx) { return ctx ? ctx->float_mode : -1; }
 
 void nz_ctx_handle_rides(nz_ctx *ctx, bool wanted) {
-    static const bool enabled = [] { const char *e = getenv("NZ_HANDLE_ON_LAUNCH"); return !e || atoi(e) != 0; }();
-    ctx->handle_rides = wanted && enabled;
+    ctx->handle_rides = wanted;
 }
 
 void nz_ctx_arm_last_launch(nz_ctx *ctx) {
@@ -390,34 +381,6 @@ int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out) {
     NZ_HIP(hipEventRecord(*ev, ctx->stream));
     ctx->last_seq = q;
     *out = ((uint64_t)ctx->id << NZ_HANDLE_SEQ_BITS) | q;
-    return NZ_OK;
-}
-
-int32_t nz_ctx_pipe_state(nz_ctx *ctx, size_t floats, float **work) {
-    if (!ctx->aux) NZ_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
-    if (!ctx->ev_fork) NZ_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    if (!ctx->ev_join) NZ_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    // grown on demand; given back only after EIGHT consecutive requests of less than a quarter of it (the planes of a
-    // 16384^2 tile are 2 GB) -- a context that alternates tile sizes must not pay a stream drain and a hipFree / hipMalloc per
-    // call -- and never below 64 MB
-    const bool small = floats < ctx->pipe_work_floats / 4 && ctx->pipe_work_floats > ((size_t)16 << 20);
-    ctx->pipe_small_streak = small ? ctx->pipe_small_streak + 1 : 0;
-    if (floats > ctx->pipe_work_floats || ctx->pipe_small_streak >= 8) {
-        ctx->pipe_small_streak = 0;
-        if (ctx->pipe_work) {
-            NZ_TRY_(ctx_sync_all(ctx));
-            NZ_HIP(hipFree(ctx->pipe_work));
-            ctx->pipe_work = nullptr;
-            ctx->pipe_work_floats = 0;
-        }
-        hipError_t e = hipMalloc((void **)&ctx->pipe_work, floats * sizeof(float));
-        if (e != hipSuccess) {
-            nz_set_error("hipMalloc(%zu floats): %s", floats, hipGetErrorString(e));
-            return NZ_ERR_NOMEM;
-        }
-        ctx->pipe_work_floats = floats;
-    }
-    *work = ctx->pipe_work;
     return NZ_OK;
 }
 

@@ -183,7 +183,12 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     int cap = (t.ksize & 1) ? conv_tcap(t.ksize) : 0;
     // a small grid is served by one round of workgroups whatever the depth: one launch less beats the deeper halo
     // (512^2 tiles, READ / WRITE pair, 17 applications as 6 + 6 + 5 instead of 5 + 4 + 4 + 4: 11 100 -> 11 700 tiles/s)
-    if (t.ksize == 5 && cap == 5 && !getenv("NZ_CONV_TCAP") && nz_conv_small_grid(t.ksize, g)) cap = 6;
+    // ... and a grid of the reference's own tile sizes (256^2 .. 512^2: a hundred 64-row tiles whatever the depth, all resident
+    // at once) waits for the LATENCY of its dependent applications, not for throughput: nine applications per launch, 17 = 9 + 8
+    // in two launches instead of three (round 5: Gauss5 x17 at 256^2 / 512^2 52 -> 42 / 43 us, 13 100 -> 13 900 tiles/s one at a
+    // time; from 1024^2 on the deeper halo costs more than the launch it saves: 55 -> 59 us)
+    if (t.ksize == 5 && cap == 5 && !getenv("NZ_CONV_TCAP") && nz_conv_small_grid(t.ksize, g))
+        cap = (long long)g.cols * (g.or1 - g.or0) * g.count <= 600 * 1024 ? 9 : 6;
     if (nz_conv_has_wide(t.ksize)) {  // one launch per application, ping-pong, copy back after an odd count
         float *cur = src, *other = tmp;
         for (int i = 0; i < iterations; i++) {
@@ -1189,11 +1194,10 @@ extern "C" int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, floa
     NZ_REQUIRE(iterations >= 0, "iterations < 0");
     float t = (talus / 90.0f) * 3.14159f / 2.0f;                             // :131
     float maxDiff = (tanf(t) * meshHeightWidthRatio) / (float)resolution;   // :132
-    static const int pairs = [] { const char *e = getenv("NZ_THERMAL_PAIRS"); return e ? atoi(e) : 1; }();
     nz_ctx_handle_rides(ctx, out != nullptr);  // the handle rides on the last phase's launch
     for (int i = 0; i < iterations; i++) {
         const bool last = i == iterations - 1;
-        if (pairs && nz_thermal_pair_fits(resolution)) {  // two phases per pass over the plane
+        if (nz_thermal_pair_fits(resolution)) {  // two phases per pass over the plane (a row beyond the LDS strip: one launch per phase)
             NZ_TRY(nz_launch_thermal_pair(ctx->stream, src, resolution, 0, maxDiff, incrementRatio));
             if (last) nz_ctx_arm_last_launch(ctx);
             NZ_TRY(nz_launch_thermal_pair(ctx->stream, src, resolution, 1, maxDiff, incrementRatio));
@@ -1204,154 +1208,5 @@ extern "C" int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, floa
             }
         }
     }
-    return nz_ctx_finish(ctx, out);
-}
-
-// ---------------------------------------------------------------------------------------------
-// the stock stage list as one call: two independent row stripes on two streams (include/noize_hip.h)
-// ---------------------------------------------------------------------------------------------
-namespace {
-struct tp_launch {
-    int kind;  // 1 filter, 2 flow, 3 erosion
-    int n;     // applications / iterations fused in the launch
-    int up, down;  // rows it consumes above / below the rows it produces
-};
-
-// the launches after the noise, or an empty list if the fused form does not apply
-std::vector<tp_launch> tp_plan(const nz_terrain_params &p, nz_kernel_taps *taps) {
-    std::vector<tp_launch> v;
-    if (p.octaves < 0 || p.noiseSize == 0 || p.filterIterations < 0 || p.flowIterations < 0 || p.erosionIterations < 0) return {};
-    if (p.filterIterations > 0) {
-        if (filter_taps(p.filter, taps) != NZ_OK) return {};
-        const int cap = (taps->ksize & 1) ? conv_tcap(taps->ksize) : 0;
-        if (cap <= 0) return {};
-        const int O = (taps->ksize - 1) / 2, L = (p.filterIterations + cap - 1) / cap;
-        const int base = p.filterIterations / L, rem = p.filterIterations % L;
-        for (int i = 0; i < L; i++) {
-            const int T = base + (i < rem ? 1 : 0);
-            v.push_back({1, T, T * O, T * O});
-        }
-    }
-    if (p.flowIterations > 0) {
-        if (p.flowIterations > nz_flow_fused_max()) return {};  // several launches would need the ten state planes
-        v.push_back({2, p.flowIterations, 2 * p.flowIterations, 2 * p.flowIterations});
-    }
-    for (int left = p.erosionIterations; left > 0;) {
-        const int E = left < nz_erosion_max_fused() ? left : nz_erosion_max_fused();
-        v.push_back({3, E, E, 0});  // the min window reaches upwards only
-        left -= E;
-    }
-    return v;
-}
-
-int tp_stripes(const nz_terrain_params &p, int resolution, nz_kernel_taps *taps) {
-    static const int env = getenv("NZ_PIPELINE_STRIPES") ? atoi(getenv("NZ_PIPELINE_STRIPES")) : -1;
-    if (env == 0 || resolution < 1) return 0;
-    const int P = env > 0 ? env : 2;
-    if (P < 2 || P > 2) return 0;  // two streams per context
-    if (env < 0 && resolution < 2048) return 0;  // launches of half a small tile do not fill the chip
-    const std::vector<tp_launch> plan = tp_plan(p, taps);
-    if (plan.empty()) return 0;
-    int up = 0, down = 0;
-    for (const tp_launch &l : plan) { up += l.up; down += l.down; }
-    if (resolution / P < up + down + 1) return 0;
-    return P;
-}
-}  // namespace
-
-extern "C" int32_t nz_terrain_pipeline_stripes(const nz_terrain_params *p, int32_t resolution) {
-    nz_kernel_taps taps;
-    return p ? tp_stripes(*p, resolution, &taps) : 0;
-}
-
-extern "C" int32_t nz_terrain_pipeline(nz_ctx *ctx, float *data, int32_t resolution, int32_t xpos, int32_t zpos,
-                                       const nz_terrain_params *pp, nz_handle *marks, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
-    NZ_TRY(check_res(resolution));
-    NZ_REQUIRE(data && pp, "data/params is NULL");
-    const nz_terrain_params &p = *pp;
-    nz_kernel_taps taps;
-    const int P = tp_stripes(p, resolution, &taps);
-    NZ_REQUIRE(P == 2, "nz_terrain_pipeline does not apply to this stage list / resolution (nz_terrain_pipeline_stripes == 0)");
-    const std::vector<tp_launch> plan = tp_plan(p, &taps);
-    const int R = resolution;
-    int need_up = 0, need_down = 0;
-    for (const tp_launch &l : plan) { need_up += l.up; need_down += l.down; }
-    // stripe s owns global rows [g0, g1); its two planes hold rows [b0, b1) = the owned rows and every ghost row the
-    // launches downstream of the noise consume, clipped to the grid
-    struct stripe { int g0, g1, b0, b1; float *A, *B; hipStream_t st; };
-    stripe sp[2];
-    size_t floats = 0;
-    for (int s = 0; s < P; s++) {
-        sp[s].g0 = (int)((long long)R * s / P);
-        sp[s].g1 = (int)((long long)R * (s + 1) / P);
-        sp[s].b0 = sp[s].g0 - need_up > 0 ? sp[s].g0 - need_up : 0;
-        sp[s].b1 = sp[s].g1 + need_down < R ? sp[s].g1 + need_down : R;
-        floats += 2 * (size_t)(sp[s].b1 - sp[s].b0) * R;
-    }
-    float *work = nullptr;
-    NZ_TRY(nz_ctx_pipe_state(ctx, floats, &work));
-    for (int s = 0; s < P; s++) {
-        const size_t n = (size_t)(sp[s].b1 - sp[s].b0) * R;
-        sp[s].A = work; work += n;
-        sp[s].B = work; work += n;
-        sp[s].st = s == 0 ? ctx->stream : ctx->aux;
-    }
-    // everything that can be refused is refused before the second stream is involved
-    NZ_REQUIRE(p.noiseType >= 0 && p.noiseType <= NZ_NOISE_DOMAIN_ROTATED_SIMPLEX, "unknown noise type %d", p.noiseType);
-    NZ_REQUIRE(p.octaves >= 0 && p.noiseSize != 0, "octaves < 0 or noiseSize == 0");
-    // fork: the second stream starts behind everything this call is ordered after
-    NZ_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-    NZ_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-    auto mark = [&](int i) -> int32_t { return marks ? nz_ctx_finish(ctx, &marks[i]) : NZ_OK; };
-    auto geom = [&](const stripe &q, int up_left, int down_left) {
-        // rows still needed beyond the owned ones AFTER this launch decide what it produces (buffer coordinates)
-        nz_geom g{R, R, q.b1 - q.b0, 0, q.b1 - q.b0 - 1, 0, 0};
-        const int r0 = q.g0 - up_left > 0 ? q.g0 - up_left : 0, r1 = q.g1 + down_left < R ? q.g1 + down_left : R;
-        g.or0 = r0 - q.b0;
-        g.or1 = r1 - q.b0;
-        g.chip_div = P;
-        return g;
-    };
-    int kind = 0;
-    const int32_t rc = [&]() -> int32_t {  // whatever happens in here, the join below still orders the second stream
-        NZ_TRY(mark(0));
-        for (int s = 0; s < P; s++) {
-            const nz_geom g = geom(sp[s], need_up, need_down);
-            NZ_TRY(fractal_impl(ctx, sp[s].st, p.noiseType, sp[s].A + (size_t)g.or0 * R, g.or1 - g.or0, R, R, p.hurst,
-                                p.startingAmplitude, p.stepdown, p.detuneRate, p.octaves, xpos, zpos + sp[s].b0 + g.or0,
-                                p.noiseSize));
-        }
-        int up_left = need_up, down_left = need_down;
-        bool in_A[2] = {true, true};
-        for (size_t i = 0; i < plan.size(); i++) {
-            const tp_launch &l = plan[i];
-            while (kind < l.kind) NZ_TRY(mark(++kind));  // a stage left out: an empty interval
-            up_left -= l.up;
-            down_left -= l.down;
-            const bool last = i + 1 == plan.size();
-            for (int s = 0; s < P; s++) {
-                const stripe &q = sp[s];
-                const nz_geom g = geom(q, up_left, down_left);
-                const float *cur = in_A[s] ? q.A : q.B;
-                // the last launch stores its rows -- the stripe's own -- straight into the caller's plane: buffer row 0 is
-                // global row b0
-                float *nxt = last ? data + (size_t)q.b0 * R : (in_A[s] ? q.B : q.A);
-                if (l.kind == 1) NZ_TRY(nz_launch_conv_fused(q.st, cur, nxt, g, taps, l.n));
-                else if (l.kind == 2)
-                    NZ_TRY(nz_launch_flow_fused(q.st, cur, nullptr, nullptr, nxt, nullptr, g, l.n, 1, 1, p.normMin,
-                                                p.normMax - p.normMin));
-                else NZ_TRY(nz_launch_erosion_fused(q.st, cur, nxt, g, l.n));
-                in_A[s] = !in_A[s];
-            }
-        }
-        return NZ_OK;
-    }();
-    // join: whatever follows on the context's stream follows both stripes -- also when a launch above was refused
-    NZ_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
-    NZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-    if (rc) return rc;
-    for (int k = kind + 1; k <= 3; k++) NZ_TRY(mark(k));  // stages left out: empty intervals
-    NZ_TRY(mark(4));
     return nz_ctx_finish(ctx, out);
 }

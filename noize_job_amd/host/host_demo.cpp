@@ -43,10 +43,8 @@ int main(int argc, char **argv) {
     const bool rw = argc > 3 && std::strcmp(argv[3], "rw") == 0;
     const bool sharded = argc > 4 && std::strcmp(argv[3], "sharded") == 0;
     const bool sharded_rank = argc > 6 && std::strcmp(argv[3], "sharded-rank") == 0;
-    // `onecall`: BasePipeline.fuseStages -- the stock stage list as one nz_terrain_pipeline call (tiles of 2048^2 and more)
-    const bool onecall = argc > 3 && std::strcmp(argv[3], "onecall") == 0;
     const bool tiles = argc > 5 && std::strcmp(argv[3], "tiles") == 0;  // <res> <out> tiles <pipelines> <tiles>
-    if (rw || onecall) argc = 3;
+    if (rw) argc = 3;
     int G = argc > 3 ? std::atoi(argv[3]) : 17, F = argc > 4 ? std::atoi(argv[4]) : 5, E = argc > 5 ? std::atoi(argv[5]) : 5;
     try {
         nz_ctx *ctx = nullptr;
@@ -367,7 +365,6 @@ int main(int argc, char **argv) {
             ErosionStage erosion(ctx);
             erosion.iterations = E;
             BasePipeline pipe({&noise, &gauss, &flow, &erosion});
-            pipe.fuseStages = onecall;
             GeneratorData gd;
             gd.uuid = "host-demo";
             gd.data = &tile;
@@ -381,7 +378,6 @@ int main(int argc, char **argv) {
             pipe.Enqueue(&gd, nullptr, [&](StageIO *) { completed++; });
             pipe.RunToCompletion();
             if (completed != 1) throw std::runtime_error("completeAction did not fire");
-            if (onecall && !pipe.lastScheduleWasOneCall) throw std::runtime_error("the one-call form did not apply");
             std::vector<float> host((size_t)res * res);
             gd.data->CopyTo(host.data());  // with a pair, `data` is whichever plane the last stage left the result in
             FILE *f = std::fopen(argv[2], "wb");

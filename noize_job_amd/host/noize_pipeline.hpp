@@ -614,18 +614,11 @@ class BasePipeline {
                  std::function<void(StageIO *)> completeAction = nullptr, JobHandle dependency = JobHandle()) {
         queue.push_back(PipelineWorkItem{input, completeAction, scheduleAction, dependency, contextManager});
     }
-    // Opt-in: the stock stage list -- NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionStage], README.md:23-32
-    // -- on a tile big enough to split goes to the library as ONE call (nz_terrain_pipeline: two independent row stripes
-    // on two streams of the context, ghost rows recomputed; same plane, bit for bit).  Every stage still gets its
-    // jobHandle, TransformData and scheduled actions; it saves the WRITE plane and the stages' scratch planes.
-    bool fuseStages = false;
-    bool lastScheduleWasOneCall = false;
     void Schedule(PipelineWorkItem wi) {
         activeItem = std::move(wi);
         if (stage_instances.empty()) throw std::runtime_error("No stages in pipeline");
         pipelineBeingScheduled = true;
-        lastScheduleWasOneCall = fuseStages && ScheduleStockList();
-        if (!lastScheduleWasOneCall) stage_instances[0]->ReceiveHandledInput(activeItem, activeItem.dependency);
+        stage_instances[0]->ReceiveHandledInput(activeItem, activeItem.dependency);
     }
     bool WorkIsSchedulable(const PipelineWorkItem &item) {  // Pipeline.cs:256-265
         bool ready = true;
@@ -709,21 +702,13 @@ class BasePipeline {
 
   protected:
     bool RegeneratesItsTile() const;  // the first stage is the NoiseStage
-    // the stock list as one call; false: this list / work item / tile keeps the stage-by-stage hand-over
-    bool ScheduleStockList();
-    std::vector<size_t> chainLink;  // per stage: index of the hand-over to the next stage in its OnStageScheduledAction
     void Setup() {
         PipelineStage *previous = nullptr;
-        chainLink.assign(stage_instances.size(), (size_t)-1);
-        size_t i = 0;
         for (auto *stage : stage_instances) {
-            if (previous) {
-                chainLink[i - 1] = previous->OnStageScheduledAction.size();
+            if (previous)
                 previous->OnStageScheduledAction.push_back(
                     [stage](PipelineWorkItem &wi, JobHandle h) { stage->ReceiveHandledInput(wi, h); });
-            }
             previous = stage;
-            i++;
         }
         if (previous)
             previous->OnStageScheduledAction.push_back([this](PipelineWorkItem &wi, JobHandle h) {
@@ -875,7 +860,6 @@ class LiveErosion {
         jobHandle.Complete();
         if (particleQueue) nz_particle_queue_destroy(ctx, particleQueue);
         if (events) nz_erosive_events_destroy(ctx, events);
-        if (branchCtx) nz_ctx_destroy(branchCtx);
     }
 
     JobHandle TriggerQueuedBeyerMT(const std::vector<int> &seeds) {  // :378-436
@@ -906,34 +890,16 @@ class LiveErosion {
                                             &ep, &tm, EVENT_LIMIT, res, dep, link(false)), "nz_queued_beyer_cycle");
                 dep = h;
                 check(nz_process_beyer_erosive_events(ctx, heightMap->ptr, poolMap.ptr, streamMap.ptr, particleTrack.ptr, events, &ep,
-                                                      &tm, res, dep, link(parallelBranch)), "nz_process_beyer_erosive_events");
+                                                      &tm, res, dep, link(false)), "nz_process_beyer_erosive_events");
                 // CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all behind the event reduction
-                // (:408-412): the flow job runs on a stream of its own (a second context), beside the sediment job
-                if (parallelBranch) {
-                    if (!branchCtx) check(nz_ctx_create(nz_ctx_device(ctx), &branchCtx), "nz_ctx_create");  // the main context's device
-                    nz_handle flow = 0, both[2];
-                    check(nz_update_flow_from_track(branchCtx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
-                                                    ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, h, &flow), "nz_update_flow_from_track");
-                    dep = h;
-                    check(nz_clear_particle_queue(ctx, particleQueue, dep, link(false)), "nz_clear_particle_queue");
-                    dep = h;
-                    check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, dep, link(false)), "nz_erode_height_maps");
-                    if (all) {
-                        both[0] = h;
-                        both[1] = flow;
-                        check(nz_handle_combine(ctx, both, 2, &h), "nz_handle_combine");
-                    } else {
-                        h = flow;  // the automaton follows ErodeHeightMaps on this stream and waits for the branch
-                    }
-                } else {
-                    dep = h;
-                    check(nz_clear_particle_queue(ctx, particleQueue, dep, link(false)), "nz_clear_particle_queue");
-                    dep = h;
-                    check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, dep, link(false)), "nz_erode_height_maps");
-                    dep = h;
-                    check(nz_update_flow_from_track(ctx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
-                                                    ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, dep, link(false)), "nz_update_flow_from_track");
-                }
+                // (:408-412): one after the other on the context's stream
+                dep = h;
+                check(nz_clear_particle_queue(ctx, particleQueue, dep, link(false)), "nz_clear_particle_queue");
+                dep = h;
+                check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, dep, link(false)), "nz_erode_height_maps");
+                dep = h;
+                check(nz_update_flow_from_track(ctx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
+                                                ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, dep, link(false)), "nz_update_flow_from_track");
                 dep = h;
                 check(nz_pool_automata_job(ctx, poolMap.ptr, heightMap->ptr, particleQueue, &ep, &tm, es.WATER_STEPS, res,
                                            performErosion ? 1 : 0, dep, link(last)), "nz_pool_automata_job");
@@ -945,9 +911,7 @@ class LiveErosion {
     }
 
     nz_ctx *ctx;
-    bool parallelBranch = false;    // true: ErodeHeightMaps || UpdateFlowFromTrackJob on two streams, as in the reference's job graph (measured slower)
     bool fewHandles = true;         // false: a handle out of every job, as the reference schedules them (one event record each)
-    nz_ctx *branchCtx = nullptr;    // (created on first use; destroyed with the component)
     DeviceTile *heightMap;
     nz_tile_set_meta tileMeta;
     ErosionSettings erosionSettings;
@@ -961,7 +925,7 @@ class LiveErosion {
 
 
 // The stock stage list NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionStage] (README.md:23-32), all on one
-// context, as nz_terrain_params; false if the list is anything else.
+// context, as nz_terrain_params (what ShardedPipeline hands to nz_sharded_create); false if the list is anything else.
 inline bool stockListParams(const std::vector<PipelineStage *> &stages, nz_terrain_params *tp, NoiseStage **noise) {
     if (stages.empty()) return false;
     auto *n = dynamic_cast<NoiseStage *>(stages[0]);
@@ -992,26 +956,6 @@ inline bool stockListParams(const std::vector<PipelineStage *> &stages, nz_terra
 
 inline bool BasePipeline::RegeneratesItsTile() const {
     return !stage_instances.empty() && typeid(*stage_instances[0]) == typeid(NoiseStage);
-}
-
-inline bool BasePipeline::ScheduleStockList() {
-    auto *d = dynamic_cast<GeneratorData *>(activeItem.data);
-    if (!d || dynamic_cast<GeneratorDataBatch *>(d) || stage_instances.size() < 2) return false;
-    nz_terrain_params tp{};
-    NoiseStage *n = nullptr;
-    if (!stockListParams(stage_instances, &tp, &n)) return false;
-    if (nz_terrain_pipeline_stripes(&tp, d->resolution) <= 0) return false;
-    nz_handle h = 0;
-    check(nz_terrain_pipeline(n->ctx, d->data->ptr, d->resolution, d->xpos, d->zpos, &tp, nullptr, activeItem.dependency.id, &h),
-          "nz_terrain_pipeline");
-    for (size_t i = 0; i < stage_instances.size(); i++) {
-        PipelineStage *s = stage_instances[i];
-        s->jobHandle = JobHandle{n->ctx, h};
-        s->TransformData(activeItem);
-        for (size_t a = 0; a < s->OnStageScheduledAction.size(); a++)
-            if (a != chainLink[i]) s->OnStageScheduledAction[a](activeItem, s->jobHandle);  // the hand-over happened inside the call
-    }
-    return true;
 }
 
 // ---- one large grid over the GPUs of a node (new-framework feature; include/noize_hip.h, nz_comm.cpp) -------------------

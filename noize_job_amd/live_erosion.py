@@ -174,15 +174,11 @@ class LiveErosion:
         self.EVENT_LIMIT = 1500
         self.jobHandle = JobHandle()
         self.waterControl = self.textureControl = None
-        # ErodeHeightMaps and UpdateFlowFromTrackJob are siblings in the reference's job graph (CombineDependencies,
-        # :408-412).  parallelBranch = True runs the second on a stream of its own (a second context, created on first
-        # use) beside the first -- same planes, bit for bit; off by default: at 8192^2 the two cross-stream dependencies
-        # cost more than the overlap saves (2.71 against 2.54 ms per driver cycle)
-        self.parallelBranch = False
-        self._branchCtx = None
+        # ErodeHeightMaps and UpdateFlowFromTrackJob are siblings in the reference's job graph (CombineDependencies, :408-412);
+        # here they follow each other on the context's stream (rounds 3 and 4 could run the second on a stream of its own: at
+        # 8192^2 the two cross-stream dependencies cost more than the overlap saved, 2.71 against 2.54 ms per driver cycle)
         # The jobs of a cycle are links of ONE chain on this context's stream: only the handles somebody waits for are
-        # asked of the library (the event reduction's when the branch runs beside it, the branch's, the cycle chain's
-        # last) -- a handle is an event record, ~3 us of the stream.  False: one per job, as the reference
+        # asked of the library (the cycle chain's last) -- a handle is an event record, ~3 us of the stream.  False: one per job, as the reference
         # schedules them.
         self.fewHandles = True
 
@@ -215,32 +211,15 @@ class LiveErosion:
                                     self.particleTrack.ptr, self.particleQueue._h, self.events._h, epp, tmp_, self.EVENT_LIMIT,
                                     res, dep=handle, handle=False)
                 handle = self._call("nz_process_beyer_erosive_events", self.heightMap.ptr, self.poolMap.ptr, self.streamMap.ptr,
-                                    self.particleTrack.ptr, self.events._h, epp, tmp_, res, dep=handle,
-                                    handle=self.parallelBranch)  # the branch's stream waits for this one
+                                    self.particleTrack.ptr, self.events._h, epp, tmp_, res, dep=handle, handle=False)
                 # handle = CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all three behind the
                 # event reduction (:408-412)
-                reduced = handle
-                if self.parallelBranch:
-                    if self._branchCtx is None:
-                        from .runtime import Context
-                        self._branchCtx = Context(self.ctx.device)
-                    flow = self._branchCtx.call("nz_update_flow_from_track", self.poolMap.ptr, self.streamMap.ptr,
-                                                self.particleTrack.ptr, ep.FLOW_LOSS_RATE, ep.SURFACE_EVAPORATION_RATE,
-                                                float(tm.HEIGHT), res, dep=reduced)
-                    handle = self.particleQueue.Clear(dep=reduced, handle=not self.fewHandles)
-                    handle = self._call("nz_erode_height_maps", self.heightMap.ptr, self.events._h, epp, tmp_, res, dep=handle,
-                                        handle=False)
-                    if self.fewHandles:
-                        handle = flow  # the automaton follows ErodeHeightMaps on this stream and waits for the branch
-                    else:
-                        handle = JobHandle.CombineDependencies(self.ctx, handle, flow)
-                else:
-                    handle = self.particleQueue.Clear(dep=reduced, handle=not self.fewHandles)
-                    handle = self._call("nz_erode_height_maps", self.heightMap.ptr, self.events._h, epp, tmp_, res, dep=handle,
-                                        handle=False)
-                    handle = self._call("nz_update_flow_from_track", self.poolMap.ptr, self.streamMap.ptr, self.particleTrack.ptr,
-                                        ep.FLOW_LOSS_RATE, ep.SURFACE_EVAPORATION_RATE, float(tm.HEIGHT), res, dep=handle,
-                                        handle=False)
+                handle = self.particleQueue.Clear(dep=handle, handle=not self.fewHandles)
+                handle = self._call("nz_erode_height_maps", self.heightMap.ptr, self.events._h, epp, tmp_, res, dep=handle,
+                                    handle=False)
+                handle = self._call("nz_update_flow_from_track", self.poolMap.ptr, self.streamMap.ptr, self.particleTrack.ptr,
+                                    ep.FLOW_LOSS_RATE, ep.SURFACE_EVAPORATION_RATE, float(tm.HEIGHT), res, dep=handle,
+                                    handle=False)
                 handle = self._call("nz_pool_automata_job", self.poolMap.ptr, self.heightMap.ptr, self.particleQueue._h, epp,
                                     tmp_, es.WATER_STEPS, res, int(self.performErosion), dep=handle, handle=last)
         if self.waterControl is not None:  # the RGBA32 control textures (:418-430)
@@ -276,6 +255,3 @@ class LiveErosion:
                 t.Dispose()
         self.particleQueue.Dispose()
         self.events.Dispose()
-        if self._branchCtx is not None:
-            self._branchCtx.close()
-            self._branchCtx = None

@@ -641,62 +641,7 @@ class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
         if not self.stage_instances:
             raise Exception("No stages in pipeline")
         self.pipelineBeingScheduled = True
-        self.fusedMarks = None
-        plan = self._stock_stage_list(self.activeItem) if self.fuseStages else None
-        if plan is not None:
-            self._schedule_stock_list(self.activeItem, *plan)
-            return
         self.stage_instances[0].ReceiveHandledInput(self.activeItem, self.activeItem.dependency)
-
-    # The stock stage list -- NoiseStage -> [KernelFilterStage] -> [FlowMapStage] -> [ErosionStage], README.md:23-32 -- on
-    # a tile big enough to split is handed to the library as ONE call (nz_terrain_pipeline): the source is closed-form
-    # noise, so the library runs the tile as two independent row stripes on two streams.  Same kernels, same plane, bit
-    # for bit; every stage still gets its jobHandle, TransformData and scheduled actions.  Opt-in (fuseStages = True): it
-    # saves the WRITE plane, the stages' scratch planes and three host calls, but with the round-3 kernels the overlap of the
-    # two stripes buys no time (4096^2: 0.646 against 0.649 ms stage by stage), so the default stays the reference's
-    # stage-by-stage hand-over.
-    fuseStages = False
-
-    def _stock_stage_list(self, item):
-        st = self.stage_instances
-        d = item.data
-        if type(d) is not GeneratorData or not st or type(st[0]) is not NoiseStage or len(st) < 2:
-            return None
-        order = [KernelFilterStage, FlowMapStage, ErosionStage]
-        found, k = {}, 0
-        for s in st[1:]:
-            while k < len(order) and type(s) is not order[k]:
-                k += 1
-            if k == len(order) or s.ctx is not st[0].ctx:
-                return None
-            found[order[k]] = s
-            k += 1
-        n, f, w, e = st[0], found.get(KernelFilterStage), found.get(FlowMapStage), found.get(ErosionStage)
-        if f is not None and f.filter == KernelFilterType.Sobel3_2D:
-            return None
-        tp = N.TerrainParams(int(n.noiseType), n.hurst, n.startingAmplitude, n.stepdown, n.detuneRate, n.octaves,
-                             n.noiseSize, int(f.filter) if f else 0, f.iterations if f else 0,
-                             w.iterations if w else 0, w.normMin if w else 0.0, w.normMax if w else 0.0,
-                             e.iterations if e else 0)
-        if N.lib.nz_terrain_pipeline_stripes(C.byref(tp), d.resolution) <= 0:
-            return None
-        return tp, [n, f, w, e]
-
-    def _schedule_stock_list(self, item, tp, slots):
-        d, ctx = item.data, self.stage_instances[0].ctx
-        marks = (N.handle_t * 5)()
-        done = ctx.call("nz_terrain_pipeline", d.data.ptr, d.resolution, d.xpos, d.zpos, C.byref(tp), marks,
-                        dep=item.dependency)
-        self.fusedMarks = [JobHandle(ctx, m) for m in marks]  # noise / filter / flow / erosion begin (first stripe), end
-        chain = {s.ReceiveHandledInput for s in self.stage_instances}
-        for i, s in enumerate(slots):
-            if s is None:
-                continue
-            s.jobHandle = done  # covers both stripes; fusedMarks[i + 1] is where the first stripe left the stage
-            s.TransformData(item)
-            for action in s.OnStageScheduledAction:
-                if action not in chain:  # the hand-over to the next stage has happened inside the call
-                    action(item, s.jobHandle)
 
     def OnPipelineFullyScheduled(self, res, handle):  # :122-128
         self.pipelineHandle = handle

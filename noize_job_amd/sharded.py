@@ -131,20 +131,7 @@ def halo_rows_needed(ops, p):
     return max([max(r[2], r[3]) for r in radii] + [1])
 
 
-class PlaneWindow:
-    """A whole-grid plane seen through a stripe's geometry: `data_ptr()` is where buffer row 0 of the stripe would
-    lie inside the plane (possibly before its start for the top stripe: only owned rows are ever written through it).
-    Passed as `final` to pipeline_steps / run_pipeline, it makes the last launch store its owned rows straight into
-    the full plane."""
-
-    def __init__(self, plane_ptr, plan):
-        self._ptr = int(plane_ptr) + plan.grow0 * plan.cols * 4
-
-    def data_ptr(self):
-        return self._ptr
-
-
-def pipeline_steps(ops, plan, p, bufs, result, on_stage=None, final=None):
+def pipeline_steps(ops, plan, p, bufs, result, on_stage=None):
     """The sharded metric pipeline as a generator: yields (planes, up_rows, down_rows) wherever the
     ranks must exchange ghost rows (never in haloMode "recompute", once in "exchange_once"), runs the stripe
     kernels in between.
@@ -189,8 +176,6 @@ def pipeline_steps(ops, plan, p, bufs, result, on_stage=None, final=None):
             launch(win.rows_window(hi, win.own1))
 
     for i, (stage, n, up, down) in enumerate(radii):
-        if final is not None and i == len(radii) - 1:
-            nxt = final  # the last launch writes its owned rows into the caller's plane
         if stage != current:
             current = stage
             mark(current)
@@ -225,12 +210,12 @@ def pipeline_steps(ops, plan, p, bufs, result, on_stage=None, final=None):
     result.append(cur)
 
 
-def run_pipeline(ops, comm, plan, p, bufs, on_stage=None, final=None):
+def run_pipeline(ops, comm, plan, p, bufs, on_stage=None):
     """One pass of the sharded metric pipeline on this rank; returns the plane holding the result.
     A comm with begin() / finish() exchanges asynchronously: the launch that needs the ghost rows runs its interior
     rows while they travel (RCCL P2P on the process group's own stream) and its border rows after finish()."""
     result = []
-    gen = pipeline_steps(ops, plan, p, bufs, result, on_stage, final)
+    gen = pipeline_steps(ops, plan, p, bufs, result, on_stage)
     overlap = getattr(comm, "overlap", False)
     pending = None
     try:
@@ -278,35 +263,6 @@ def run_pipeline_lockstep(ops_list, plans, p, bufs_list, copy_rows):
                     q = plans[pl.down]
                     copy_rows(t, pl.own1, reqs[pl.down][0][i], q.own0, down_rows)
     return [r[0] for r in results]
-
-
-class StripedTile:
-    """ONE grid on ONE GPU as `nstripes` row stripes, each with its own context (HIP stream): the stripes are
-    independent (ghost rows recomputed from the closed-form noise, haloMode "recompute"), so the fp32-bound kernels of
-    one stripe overlap the HBM-bound kernels of the other.  Same kernels, same results (sharded == monolithic, bit
-    for bit), the result lands in the caller's full plane.  `alloc(rows, cols)` returns an object with data_ptr() (a
-    [rows, cols] fp32 plane; `alloc(5, rows, cols)` the flow state)."""
-
-    def __init__(self, contexts, plane_ptr, rows, cols, p, alloc):
-        assert p.haloMode == "recompute", "independent stripes need a closed-form source"
-        self.p, self.parts = p, []
-        for i, ctx in enumerate(contexts):
-            ops = HipStripeOps(ctx)
-            halo = halo_rows_needed(ops, p)
-            plan = StripePlan(i, len(contexts), rows, cols, halo, neighbours_own_halo=False)
-            bufs = (alloc(plan.rows, cols), alloc(plan.rows, cols), alloc(FLOW_PLANES, plan.rows, cols),
-                    alloc(FLOW_PLANES, plan.rows, cols))
-            self.parts.append((ops, plan, bufs, PlaneWindow(plane_ptr, plan)))
-
-    def run(self, on_stage=None):
-        """Enqueues one pass of the pipeline on every stripe's stream (no host synchronisation).  `on_stage(name)` is
-        called at the stage boundaries of stripe 0 (see pipeline_steps)."""
-        for i, (ops, plan, bufs, final) in enumerate(self.parts):
-            run_pipeline(ops, NoComm(), plan, self.p, bufs, on_stage=on_stage if i == 0 else None, final=final)
-
-    def synchronize(self):
-        for ops, _, _, _ in self.parts:
-            ops.ctx.synchronize()
 
 
 class HipStripeOps:

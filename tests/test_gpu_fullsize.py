@@ -17,32 +17,20 @@ f32 = np.float32
 R = 4096
 
 
-def _one_call_applies(nj, res, g_it, f_it, e_it, filt=None):
-    # what nz_terrain_pipeline_stripes says for this stage list (a tuning knob such as NZ_FLOW_NMAX may rule it out)
-    import ctypes as C
-    tp = nj._native.TerrainParams(3, 0.4, 1.0, 2.0, 0.0, 13, 1700, int(nj.KernelFilterType.Gauss5_S1 if filt is None else filt),
-                                  g_it, f_it, 0.0, 0.005, e_it)
-    return nj._native.lib.nz_terrain_pipeline_stripes(C.byref(tp), res) > 0
-
-
 def _run(nj, stage, d):
     stage.ReceiveHandledInput(nj.PipelineWorkItem(d), nj.JobHandle())
     stage.jobHandle.Complete()
 
 
-@pytest.mark.parametrize("fuse", [True, False], ids=["one-call", "stage-by-stage"])
-def test_metric_pipeline_4096_equals_oracle(nj, ctx, oracle, fuse):
-    # fuse: BasePipeline hands the stock stage list over as one call (nz_terrain_pipeline: two row stripes on two
-    # streams, what bench.py times) -- or schedules stage by stage as the reference does
+def test_metric_pipeline_4096_equals_oracle(nj, ctx, oracle):
+    # the stage list scheduled stage by stage as the reference does, one plane, the in-place entries
     data = ctx.alloc(R * R)
     stages = [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700),
               nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), nj.FlowMapStage(ctx, 5, 0.0, 0.005),
               nj.ErosionStage(ctx, 5)]
     pipe = nj.BasePipeline(stages, "config3")
-    pipe.fuseStages = fuse
     pipe.Enqueue(nj.GeneratorData("t", data, R, 0, 0))
     pipe.RunToCompletion()
-    assert (pipe.fusedMarks is not None) == (fuse and _one_call_applies(nj, R, 17, 5, 5))
     got = data.ToArray((R, R))
     want = oracle.pipeline(R, R)
     assert np.array_equal(got, want)
@@ -271,65 +259,3 @@ def test_degenerate_resolutions(nj, ctx, oracle, res):
         vtx, idx = oracle.mesh_heightmap(oracle.MESH_SQUARE, h, res, 0, 20.0, 10.0)
         assert np.array_equal(md.mesh.index_array(), idx)
         assert np.array_equal(md.mesh.vertices.ToArray().reshape(-1, 12), vtx)
-
-
-@pytest.mark.parametrize("res, noise, filt, g_it, f_it, e_it, pos", [
-    (2048, "Simplex", "Gauss5_S1", 17, 5, 5, (0, 0)),
-    (2048, "Perlin", "Gauss3_S1", 7, 3, 0, (4096, -2048)),
-    (2048, "Cellular", "Smooth3", 0, 5, 9, (0, 0)),       # no filter stage; erosion in two launches
-    (2560, "Simplex", "Gauss9_S2", 4, 0, 3, (17, 5)),      # no flow stage; a tile that does not split into equal tiles
-    (2048, "Simplex", "Gauss7_S1", 5, 0, 0, (0, 0)),       # filter only
-    (3000, "Sin", "Gauss5_S2", 6, 2, 1, (0, 0)),
-])
-def test_one_call_pipeline_equals_stage_by_stage(nj, ctx, res, noise, filt, g_it, f_it, e_it, pos):
-    # nz_terrain_pipeline (two independent row stripes, ghost rows recomputed, two streams) against the same stage list
-    # scheduled stage by stage on one stream: the same plane, bit for bit, whatever stages the list holds
-    def build():
-        st = [nj.NoiseStage(ctx, nj.FractalNoise[noise], 0.45, 1.5, 9, 2.0, 0.01, 900)]
-        if g_it:
-            st.append(nj.KernelFilterStage(ctx, nj.KernelFilterType[filt], g_it))
-        if f_it:
-            st.append(nj.FlowMapStage(ctx, f_it, -0.01, 0.02))
-        if e_it:
-            st.append(nj.ErosionStage(ctx, e_it))
-        return st
-    planes = []
-    for fuse in (True, False):
-        data = ctx.alloc(res * res)
-        pipe = nj.BasePipeline(build(), "variant")
-        pipe.fuseStages = fuse
-        seen = []
-        pipe.stage_instances[-1].OnStageScheduledAction.append(lambda item, h: seen.append(h))
-        pipe.Enqueue(nj.GeneratorData("t", data, res, *pos))
-        pipe.RunToCompletion()
-        applies = _one_call_applies(nj, res, g_it, f_it, e_it, nj.KernelFilterType[filt])
-        assert (pipe.fusedMarks is not None) == (fuse and applies) and len(seen) == 1
-        planes.append(data.ToArray((res, res)))
-        pipe.Destroy()
-        data.Dispose()
-    assert np.array_equal(planes[0], planes[1])
-
-
-def test_one_call_pipeline_does_not_apply_to_small_tiles_or_other_lists(nj, ctx):
-    N = nj._native
-    tp = N.TerrainParams(3, 0.4, 1.0, 2.0, 0.0, 13, 1700, int(nj.KernelFilterType.Gauss5_S1), 17, 5, 0.0, 0.005, 5)
-    import ctypes as C
-    if N.lib.nz_terrain_pipeline_stripes(C.byref(tp), 4096) == 0:
-        pytest.skip("the one-call form is ruled out by a tuning knob (NZ_FLOW_NMAX, NZ_PIPELINE_STRIPES)")
-    assert N.lib.nz_terrain_pipeline_stripes(C.byref(tp), 4096) == 2
-    assert N.lib.nz_terrain_pipeline_stripes(C.byref(tp), 512) == 0      # too small to split
-    tp.flowIterations = 12
-    assert N.lib.nz_terrain_pipeline_stripes(C.byref(tp), 4096) == 0     # more than one flow launch
-    tp.flowIterations, tp.filterIterations, tp.erosionIterations = 0, 0, 0
-    assert N.lib.nz_terrain_pipeline_stripes(C.byref(tp), 4096) == 0     # nothing but noise
-    # a list that is not the stock one keeps the stage-by-stage hand-over
-    data = ctx.alloc(2048 * 2048)
-    pipe = nj.BasePipeline([nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 4, 2.0, 0.0, 1700),
-                            nj.ConstantStage(ctx, nj.ConstantOperationType.MULTIPLY, 0.5),
-                            nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 2)], "other")
-    pipe.fuseStages = True
-    pipe.Enqueue(nj.GeneratorData("t", data, 2048, 0, 0))
-    pipe.RunToCompletion()
-    assert pipe.fusedMarks is None
-    pipe.Destroy()
-    data.Dispose()

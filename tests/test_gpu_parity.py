@@ -373,13 +373,6 @@ def test_cpp_host_mirror_runs_the_metric_pipeline(oracle, tmp_path):
     # the same pipeline on a READ / WRITE plane pair (nz_*_rw entries: SWAP_RWTILE as a pointer swap)
     subprocess.check_call([exe, "256", out, "rw"])
     assert np.array_equal(np.fromfile(out, dtype=np.float32).reshape(256, 256), got)
-    # BasePipeline.fuseStages of the C++ mirror: the stock list as one nz_terrain_pipeline call, at a size it applies to
-    import ctypes as C
-    import noize_job_amd as nj
-    tp = nj._native.TerrainParams(3, 0.4, 1.0, 2.0, 0.0, 13, 1700, int(nj.KernelFilterType.Gauss5_S1), 17, 5, 0.0, 0.005, 5)
-    if nj._native.lib.nz_terrain_pipeline_stripes(C.byref(tp), 2048) > 0:   # (a tuning knob may rule the one-call form out)
-        subprocess.check_call([exe, "2048", out, "onecall"])
-        assert np.array_equal(np.fromfile(out, dtype=np.float32).reshape(2048, 2048), oracle.pipeline(2048, 2048))
     # ReducePipeline of the C++ mirror: simplex (left) x cellular (right), MULTIPLY
     subprocess.check_call([exe, "200", out, "reduce"])
     got = np.fromfile(out, dtype=np.float32).reshape(200, 200)

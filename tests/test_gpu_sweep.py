@@ -219,37 +219,6 @@ def test_stripe_entry_points_random_geometry_and_pitch(nj, ctx, oracle, seed):
         src.Dispose(); dst.Dispose()
 
 
-@pytest.mark.parametrize("seed", range(3))
-def test_striped_tile_random_shapes(nj, ctx, oracle, seed):
-    # one grid as 2..4 independent stripes on their own streams, rectangular, columns not a multiple of 4 included
-    # (the last launch stores through an unaligned window into the caller's plane)
-    import torch
-    from noize_job_amd import sharded as sh
-    rng = np.random.default_rng(12000 + seed)
-    for _ in range(3):
-        n = int(rng.integers(2, 5))
-        rows, cols = int(rng.integers(4 * n, 700)), int(rng.integers(8, 600))
-        p = sh.PipelineParams(haloMode="recompute", xpos=int(rng.integers(-3000, 3000)), zpos=int(rng.integers(-3000, 3000)),
-                              gaussIterations=int(rng.integers(1, 19)), flowIterations=int(rng.integers(1, 8)),
-                              erosionIterations=int(rng.integers(1, 10)))
-        plane = torch.full((rows, cols), float("nan"), device="cuda")
-        torch.cuda.synchronize()
-        ctxs = [nj.Context(0) for _ in range(n)]
-        try:
-            tile = sh.StripedTile(ctxs, plane.data_ptr(), rows, cols, p,
-                                  lambda *shape: torch.full(shape, float("nan"), device="cuda"))
-            torch.cuda.synchronize()
-            tile.run()
-            tile.synchronize()
-            got = plane.cpu().numpy()
-        finally:
-            for c in ctxs:
-                c.close()
-        want = oracle.pipeline(rows, cols, xpos=p.xpos, zpos=p.zpos, gauss_iterations=p.gaussIterations,
-                               flow_iterations=p.flowIterations, erosion_iterations=p.erosionIterations)
-        assert np.array_equal(got, want), (n, rows, cols, vars(p))
-
-
 def test_chained_filter_launches_tolerate_a_straggling_tile(nj, ctx, oracle):
     # The launches of a filter stage run as ONE grid whose tiles wait for the previous launch's tiles they read -- and
     # overwrite the plane that launch read.  A tile held up before its loads (nz_debug_chain_delay: ~0.3 ms, several

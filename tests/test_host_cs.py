@@ -167,7 +167,7 @@ def test_the_cs_host_has_every_class_the_python_host_exports():
     renamed = {"Context": "GpuContext", "JobHandle": "GpuJobHandle", "NativeComm": "GpuComm", "ShardedGrid": "ShardedPipeline"}
     # Python-side plumbing with no counterpart in a compiled host: the mesh buffers are two members of MeshStageData, the
     # Python schedule of the sharded path (sharded.py) is nz_sharded_* behind the C ABI for a compiled host
-    python_only = {"MeshBuffers", "StripePlan", "PipelineParams", "PlaneWindow", "StripedTile", "HipStripeOps", "TorchComm", "NoComm"}
+    python_only = {"MeshBuffers", "StripePlan", "PipelineParams", "HipStripeOps", "TorchComm", "NoComm"}
     text = "\n".join(_cs_sources().values())
     missing = []
     for name in sorted(exported - python_only):

@@ -319,7 +319,6 @@ def test_live_erosion_soak_equals_oracle_at_ten_checkpoints(nj, ctx, oracle, res
     es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, CYCLES=per, WATER_STEPS=10)
     tm = nj.tile_set_meta(res, height=th, tile_size=2000, tile_res=res - 16, margin=8)
     G = nj.LiveErosion(ctx, ctx.from_host(h), tm, es)
-    G.parallelBranch = res == 512   # the smaller run also takes the reference's parallel branch (sediment || flow, two streams)
     L = oracle.LiveErosionOracle(h, _params(oracle, es), tile_height=th, patch_res=float(tm.PATCH_RES[0]))
     shape = (res, res)
     wet = []

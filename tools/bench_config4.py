@@ -29,10 +29,6 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--at", default="", help="comma-separated cycle counts of one long run at which the per-job times are taken")
     ap.add_argument("--skip-fresh", action="store_true", help="only the --at run")
-    ap.add_argument("--parallel-branch", action="store_true",
-                    help="driver figures with UpdateFlowFromTrackJob on a second context beside ErodeHeightMaps "
-                         "(LiveErosion.parallelBranch; off by default: the two cross-stream hand-overs cost more than the "
-                         "overlap saves, 1.64 against 1.55 ms per cycle)")
     a = ap.parse_args()
     res = a.res
     out = {"config": "%dx%d cellular-13oct base + live particle erosion, %d particles per cycle, WATER_STEPS %d" %
@@ -51,7 +47,6 @@ def main():
         es = nj.ErosionSettings(PARTICLES_PER_CYCLE=a.particles, CYCLES=1, WATER_STEPS=a.water_steps)
         tm = nj.tile_set_meta(res, height=1000, tile_size=res, tile_res=res - 16, margin=8)
         G = nj.LiveErosion(ctx, h, tm, es)
-        G.parallelBranch = a.parallel_branch
         ep = es.AsParameters()
         epp, tmp_ = C.byref(ep), C.byref(tm)
         jobs = [
@@ -165,7 +160,6 @@ def main():
         dt = updates()
         out["driver_cycles_per_s"] = round(3 * n_up / dt, 2)
         out["driver_cycle_ms"] = round(dt / (3 * n_up) * 1e3, 4)
-        out["driver_parallel_branch"] = bool(G.parallelBranch)
         out["driver_particle_steps_per_s"] = round(out["events_per_cycle"] * 3 * n_up / dt)
         G.OnDestroy()
     print(json.dumps(out, indent=1))

@@ -12,7 +12,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-extras --flush $FLUSH --schedule stages --float-mode $MODE"
+ARGS="--no-cpu-baseline --no-extras --flush $FLUSH --float-mode $MODE"
 P="$OUT/prof_$TAG"
 rm -rf "$P"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/stats" -o run -- python3 "$ROOT/bench.py" --steps 60 --warmup 20 $ARGS > "$OUT/${TAG}_stats.log" 2>&1

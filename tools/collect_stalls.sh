@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 P="$OUT/prof_stalls"
 rm -rf "$P"
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras --schedule stages --float-mode $MODE"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras --float-mode $MODE"
 i=0
 for GROUP in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVES" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT" \

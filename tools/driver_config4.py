@@ -15,7 +15,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--res", type=int, default=8192)
 ap.add_argument("--updates", type=int, default=20)
 ap.add_argument("--particles", type=int, default=10000)
-ap.add_argument("--parallel-branch", action="store_true")
 ap.add_argument("--one-handle-per-job", action="store_true")
 a = ap.parse_args()
 with nj.Context(0) as ctx:
@@ -27,7 +26,6 @@ with nj.Context(0) as ctx:
     es = nj.ErosionSettings(PARTICLES_PER_CYCLE=a.particles, CYCLES=3, WATER_STEPS=10)
     tm = nj.tile_set_meta(a.res, height=1000, tile_size=a.res, tile_res=a.res - 16, margin=8)
     G = nj.LiveErosion(ctx, h, tm, es)
-    G.parallelBranch = a.parallel_branch
     G.fewHandles = not a.one_handle_per_job
     G.TriggerQueuedBeyerMT([1, 2, 3]).Complete()
     t0 = time.perf_counter()
