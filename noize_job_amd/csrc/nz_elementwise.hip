@@ -91,10 +91,10 @@ __device__ __forceinline__ float flow_from_track_cell(float pv, float tv, float 
     return (1.0f - flowLossRate) * pv;
 }
 
-// Four cells per lane, 16-byte accesses.  The flow plane decays everywhere, but the track is zero wherever no particle
-// went this cycle and the pool wherever no water stands -- nearly everywhere -- and zeroing a zero or drying a dry cell
-// changes no bit: those stores are left out (a quad is stored when any of its four cells changes), 16 instead of 24
-// bytes per cell.
+// Four cells per lane, 16-byte accesses.  The flow plane decays wherever it is not zero, the track is zero wherever no
+// particle went this cycle and the pool wherever no water stands -- nearly everywhere -- and decaying a zero, zeroing a zero
+// or drying a dry cell changes no bit: those stores are left out (a quad is stored when any of its four cells changes),
+// 12 ... 16 instead of 24 bytes per cell.
 __global__ __launch_bounds__(CT) void flow_from_track_kernel(float *__restrict__ pool, float *__restrict__ flow,
                                                             float *__restrict__ track, size_t n, float flowLossRate,
                                                             float evaporation /* SURFACE_EVAPORATION_RATE / tm.HEIGHT */,
@@ -108,7 +108,11 @@ __global__ __launch_bounds__(CT) void flow_from_track_kernel(float *__restrict__
                                      flow_from_track_cell(pv.z, tv.z, po.z, flowLossRate), flow_from_track_cell(pv.w, tv.w, po.w, flowLossRate));
         const float4 pn = make_float4(fmaxf(po.x - evaporation, 0.0f), fmaxf(po.y - evaporation, 0.0f), fmaxf(po.z - evaporation, 0.0f),
                                       fmaxf(po.w - evaporation, 0.0f));
-        *reinterpret_cast<float4 *>(flow + i) = f;
+        // (flow that is zero stays zero where no particle went: (1 - loss) * 0 == 0, the same bits -- on a map that is mostly
+        // untouched the flow store of most quads is left out as well, 12 + a little instead of 16 bytes per cell; round 5)
+        const unsigned flow_diff = (__float_as_uint(f.x) ^ __float_as_uint(pv.x)) | (__float_as_uint(f.y) ^ __float_as_uint(pv.y)) |
+                                   (__float_as_uint(f.z) ^ __float_as_uint(pv.z)) | (__float_as_uint(f.w) ^ __float_as_uint(pv.w));
+        if (flow_diff) *reinterpret_cast<float4 *>(flow + i) = f;
         const unsigned track_bits = __float_as_uint(tv.x) | __float_as_uint(tv.y) | __float_as_uint(tv.z) | __float_as_uint(tv.w);
         if (track_bits) *reinterpret_cast<float4 *>(track + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         const unsigned pool_diff = (__float_as_uint(pn.x) ^ __float_as_uint(po.x)) | (__float_as_uint(pn.y) ^ __float_as_uint(po.y)) |

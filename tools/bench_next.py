@@ -2,7 +2,8 @@
 """Times the stages outside the metric pipeline (SURVEY.md 8a rows not in the metric, 8f "next" rows)
 on one device-resident tile: every noise basis, every KernelFilterType, wide Gaussian / box blurs,
 value erosion, the element-wise stages, thermal erosion and the mesh.  Back-to-back launches, HIP events.
-usage: bench_next.py [--res 4096] [--reps 10] [--json out.json]"""
+usage: bench_next.py [--res 4096] [--reps 10] [--json out.json] [--float-mode strict|fast|relaxed] [--only SUBSTRING]
+(tools/collect_next.sh runs it under rocprofv3 for the per-kernel counters, tools/next_counters_table.py prints them)"""
 import argparse
 import json
 import os
@@ -22,10 +23,13 @@ def main():
     ap.add_argument("--res", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--float-mode", choices=("strict", "fast", "relaxed"), default="strict")
+    ap.add_argument("--only", default="", help="only the rows whose name contains this")
     a = ap.parse_args()
     res, cells = a.res, a.res * a.res
     rows = []
     with nj.Context(0) as ctx:
+        ctx.float_mode = {"strict": 0, "fast": 1, "relaxed": 2}[a.float_mode]
         data, right = ctx.alloc(cells), ctx.alloc(cells)
         gd = nj.GeneratorData("b", data, res, 0, 0)
         rd = nj.ReduceData("b", data, right, res, 0, 0)
@@ -33,6 +37,9 @@ def main():
         seed = nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700)
 
         def run(name, stage, item, bytes_per_cell, note=""):
+            if a.only and a.only not in name:
+                stage.OnDestroy()
+                return
             wi = nj.PipelineWorkItem(item)
             for _ in range(2):
                 stage.Schedule(wi, nj.JobHandle())
@@ -122,6 +129,8 @@ def main():
                 ("live erosion: flow from track", lambda: ctx.call("nz_update_flow_from_track", pool.ptr, flow.ptr, track.ptr, 0.05, 0.1, 1000.0, res), 24, ""),
                 ("live erosion: pool automaton x1 (4 colour passes)", lambda: ctx.call("nz_pool_automata", pool.ptr, data.ptr, 1, res), 4 * 8,
                  "parallel runs of acting steps; 30 % of the cells under water")):
+            if a.only and a.only not in name:
+                continue
             fn()
             ctx.synchronize()
             h0 = ctx.record()
