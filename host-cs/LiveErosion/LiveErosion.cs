@@ -106,6 +106,7 @@ namespace xshazwar.noize.hip {
         }
 
         public bool fewHandles = true;           // false: a handle out of every job, as the reference schedules them (one event record each)
+        public bool fuseSiblings = true;         // ErodeHeightMaps + UpdateFlowFromTrackJob as one call (nz_erode_height_maps_and_flow)
 
         // TriggerQueuedBeyerMT :378-436.  seeds: one per cycle.
         public GpuJobHandle TriggerQueuedBeyerMT(int[] seeds) {
@@ -145,9 +146,15 @@ namespace xshazwar.noize.hip {
                     else { Native.Check(Native.nz_process_beyer_erosive_events(c, heightMap.Ptr, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, events.Handle,
                                                                                ref ep, ref tm, res, h, IntPtr.Zero), "nz_process_beyer_erosive_events"); h = 0; }
                     // CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all behind the event reduction
-                    // (:408-412): one after the other on the context's stream
+                    // (:408-412): the clear, then the two siblings as one call (the pile solver's launch carries the flow update's
+                    // workgroups); fuseSiblings = false: the two entries one after the other on the context's stream
                     h = particleQueue.Clear(ctx.Wrap(h), all).id;
-                    if (all) {
+                    if (fuseSiblings) {
+                        if (all) Native.Check(Native.nz_erode_height_maps_and_flow(c, heightMap.Ptr, events.Handle, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr,
+                                                                                   ref ep, ref tm, res, h, out h), "nz_erode_height_maps_and_flow");
+                        else { Native.Check(Native.nz_erode_height_maps_and_flow(c, heightMap.Ptr, events.Handle, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr,
+                                                                                 ref ep, ref tm, res, h, IntPtr.Zero), "nz_erode_height_maps_and_flow"); h = 0; }
+                    } else if (all) {
                         Native.Check(Native.nz_erode_height_maps(c, heightMap.Ptr, events.Handle, ref ep, ref tm, res, h, out h), "nz_erode_height_maps");
                         Native.Check(Native.nz_update_flow_from_track(c, poolMap.Ptr, streamMap.Ptr, particleTrack.Ptr, ep.FLOW_LOSS_RATE,
                                                                       ep.SURFACE_EVAPORATION_RATE, (float) tm.HEIGHT, res, h, out h), "nz_update_flow_from_track");

@@ -436,6 +436,15 @@ int32_t nz_process_beyer_erosive_events(nz_ctx *ctx, float *height, float *pool,
  * plane is then invalid */
 int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *events, const nz_erosion_params *ep,
                              const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out);
+/* ErodeHeightMaps and UpdateFlowFromTrackJob as ONE call.  The reference schedules the two on the same dependency and
+ * combines their handles (Component/LiveErosion.cs:408-412): siblings in its job graph, run side by side by the worker
+ * threads.  Here the pile solver's launch -- a few thousand waves that wait for memory and for each other on an otherwise idle
+ * chip -- carries the flow update's workgroups behind its own.  Results: exactly those of nz_erode_height_maps followed by
+ * nz_update_flow_from_track(pool, flow, track, ep->FLOW_LOSS_RATE, ep->SURFACE_EVAPORATION_RATE, tm->HEIGHT) -- the two jobs
+ * share no plane (pool / flow / track must not be `height`).  NZ_PILE_CARRY_FLOW=0: the two launches one after the other. */
+int32_t nz_erode_height_maps_and_flow(nz_ctx *ctx, float *height, nz_erosive_events *events, float *pool, float *flow,
+                                      float *track, const nz_erosion_params *ep, const nz_tile_set_meta *tm, int32_t res,
+                                      nz_handle dep, nz_handle *out);
 /* PoolAutomataJob.Schedule(pool, height, particleQueue, ep, tm, iterations, res, drainParticles, deps), :289-325:
  * with drainParticles != 0 a pool that finds a dry, lower neighbour leaves as one particle (pid 64000) in the queue */
 int32_t nz_pool_automata_job(nz_ctx *ctx, float *pool, const float *height, nz_particle_queue *particleQueue,

@@ -158,6 +158,7 @@ SIGNATURES = {
     "nz_queued_beyer_cycle": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, dev_ptr, C.c_void_p, C.c_void_p, ep_p, tm_p, _i, _i] + _tail),
     "nz_process_beyer_erosive_events": (_i, [ctx_p, dev_ptr, dev_ptr, dev_ptr, dev_ptr, C.c_void_p, ep_p, tm_p, _i] + _tail),
     "nz_erode_height_maps": (_i, [ctx_p, dev_ptr, C.c_void_p, ep_p, tm_p, _i] + _tail),
+    "nz_erode_height_maps_and_flow": (_i, [ctx_p, dev_ptr, C.c_void_p, dev_ptr, dev_ptr, dev_ptr, ep_p, tm_p, _i] + _tail),
     "nz_pool_automata_job": (_i, [ctx_p, dev_ptr, dev_ptr, C.c_void_p, ep_p, tm_p, _i, _i, _i] + _tail),
     "nz_curviture_map": (_i, [ctx_p, dev_ptr, dev_ptr, tm_p, _i, _i, _i] + _tail),
     "nz_set_rgba32": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i, _f] + _tail),

@@ -5,6 +5,7 @@
 // Pure streaming kernels: 16 B per lane, in place (the reference's tmp + flush copy is not needed for an
 // element-wise update); 8 or 12 B/cell.
 #include "nz_internal.hpp"
+#include "nz_flow_track.hpp"
 
 namespace {
 
@@ -83,18 +84,7 @@ __global__ __launch_bounds__(CT) void curve_kernel(float *data, size_t n, const 
 }
 
 // ---- live erosion: the deterministic grid jobs (planes indexed x * res + z, LiveErosionDataTypes.cs:608-610) -------
-// WorldTile.UpdateFlowMapFromTrack, LiveErosionDataTypes.cs:869-886 (UpdateFlowFromTrackJob)
-__device__ __forceinline__ float flow_from_track_cell(float pv, float tv, float poolV, float flowLossRate) {
-    const float MINFLOWPOOL = .00005f;
-    if (poolV > MINFLOWPOOL) return ((1.0f - 0.1f * flowLossRate) * pv);
-    if (tv > 0.0f) return ((1.0f - flowLossRate) * pv) + (flowLossRate * 50.0f * tv) / (1.0f + 50.0f * tv);
-    return (1.0f - flowLossRate) * pv;
-}
-
-// Four cells per lane, 16-byte accesses.  The flow plane decays wherever it is not zero, the track is zero wherever no
-// particle went this cycle and the pool wherever no water stands -- nearly everywhere -- and decaying a zero, zeroing a zero
-// or drying a dry cell changes no bit: those stores are left out (a quad is stored when any of its four cells changes),
-// 12 ... 16 instead of 24 bytes per cell.
+// WorldTile.UpdateFlowMapFromTrack, LiveErosionDataTypes.cs:869-886 (UpdateFlowFromTrackJob): nz_flow_track.hpp
 __global__ __launch_bounds__(CT) void flow_from_track_kernel(float *__restrict__ pool, float *__restrict__ flow,
                                                             float *__restrict__ track, size_t n, float flowLossRate,
                                                             float evaporation /* SURFACE_EVAPORATION_RATE / tm.HEIGHT */,
@@ -104,27 +94,9 @@ __global__ __launch_bounds__(CT) void flow_from_track_kernel(float *__restrict__
     if (aligned && i + 4 <= n) {
         const float4 pv = *reinterpret_cast<const float4 *>(flow + i), tv = *reinterpret_cast<const float4 *>(track + i),
                      po = *reinterpret_cast<const float4 *>(pool + i);
-        const float4 f = make_float4(flow_from_track_cell(pv.x, tv.x, po.x, flowLossRate), flow_from_track_cell(pv.y, tv.y, po.y, flowLossRate),
-                                     flow_from_track_cell(pv.z, tv.z, po.z, flowLossRate), flow_from_track_cell(pv.w, tv.w, po.w, flowLossRate));
-        const float4 pn = make_float4(fmaxf(po.x - evaporation, 0.0f), fmaxf(po.y - evaporation, 0.0f), fmaxf(po.z - evaporation, 0.0f),
-                                      fmaxf(po.w - evaporation, 0.0f));
-        // (flow that is zero stays zero where no particle went: (1 - loss) * 0 == 0, the same bits -- on a map that is mostly
-        // untouched the flow store of most quads is left out as well, 12 + a little instead of 16 bytes per cell; round 5)
-        const unsigned flow_diff = (__float_as_uint(f.x) ^ __float_as_uint(pv.x)) | (__float_as_uint(f.y) ^ __float_as_uint(pv.y)) |
-                                   (__float_as_uint(f.z) ^ __float_as_uint(pv.z)) | (__float_as_uint(f.w) ^ __float_as_uint(pv.w));
-        if (flow_diff) *reinterpret_cast<float4 *>(flow + i) = f;
-        const unsigned track_bits = __float_as_uint(tv.x) | __float_as_uint(tv.y) | __float_as_uint(tv.z) | __float_as_uint(tv.w);
-        if (track_bits) *reinterpret_cast<float4 *>(track + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const unsigned pool_diff = (__float_as_uint(pn.x) ^ __float_as_uint(po.x)) | (__float_as_uint(pn.y) ^ __float_as_uint(po.y)) |
-                                   (__float_as_uint(pn.z) ^ __float_as_uint(po.z)) | (__float_as_uint(pn.w) ^ __float_as_uint(po.w));
-        if (pool_diff) *reinterpret_cast<float4 *>(pool + i) = pn;
+        flow_from_track_quad(pool, flow, track, i, pv, tv, po, flowLossRate, evaporation);
     } else {
-        for (size_t k = i; k < n && k < i + 4; k++) {
-            const float pv = flow[k], tv = track[k], poolV = pool[k];
-            flow[k] = flow_from_track_cell(pv, tv, poolV, flowLossRate);
-            track[k] = 0.0f;
-            pool[k] = fmaxf(poolV - evaporation, 0.0f);
-        }
+        flow_from_track_cells(pool, flow, track, i, n < i + 4 ? n : i + 4, flowLossRate, evaporation);
     }
 }
 

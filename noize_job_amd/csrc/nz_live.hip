@@ -24,6 +24,7 @@
 #include <cstring>
 
 #include "nz_internal.hpp"
+#include "nz_flow_track.hpp"
 
 struct nz_particle_queue {  // device layout: header + particles
     int32_t *hdr = nullptr;  // {count, capacity, overflow, pad}
@@ -916,12 +917,29 @@ __global__ __launch_bounds__(1024) void pile_list_kernel(const int32_t *__restri
     if (busy) list[(size_t)c * cap + s_base[c] + mine] = b;
 }
 
-__global__ __launch_bounds__(64) void pile_ticket_kernel(float *height, const float *__restrict__ sediment, int32_t *blocks,
-                                                        const int32_t *__restrict__ list, int32_t *ctl, int cap,
-                                                        const short2 *__restrict__ ofs, int nverts, int res,
-                                                        int maxDistance, int B, int nb, float pileThreshold, float increment,
-                                                        unsigned *err_host) {
-    extern __shared__ unsigned char s_raw[];
+struct pile_ticket_args {
+    float *height;
+    const float *sediment;
+    int32_t *blocks;
+    const int32_t *list;
+    int32_t *ctl;
+    int cap;
+    const short2 *ofs;
+    int nverts, res, maxDistance, B, nb;
+    float pileThreshold, increment;
+    unsigned *err_host;
+};
+
+__device__ __forceinline__ void pile_ticket_wave(const pile_ticket_args &a, unsigned char *s_raw) {
+    float *height = a.height;
+    const float *__restrict__ sediment = a.sediment;
+    int32_t *blocks = a.blocks;
+    const int32_t *__restrict__ list = a.list;
+    int32_t *ctl = a.ctl;
+    const short2 *__restrict__ ofs = a.ofs;
+    const int cap = a.cap, nverts = a.nverts, res = a.res, maxDistance = a.maxDistance, B = a.B, nb = a.nb;
+    const float pileThreshold = a.pileThreshold, increment = a.increment;
+    unsigned *err_host = a.err_host;
     const pile_lds L = pile_carve(s_raw, nverts, B);
     const int lane = threadIdx.x;
     const int n0 = ctl[0], n1 = ctl[1], n2 = ctl[2], n3 = ctl[3];
@@ -961,6 +979,59 @@ __global__ __launch_bounds__(64) void pile_ticket_kernel(float *height, const fl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the block's stores have left
         __syncthreads();
         if (lane == 0) __hip_atomic_store(blocks + b, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(64) void pile_ticket_kernel(pile_ticket_args a) {
+    extern __shared__ unsigned char s_raw[];
+    pile_ticket_wave(a, s_raw);
+}
+
+// ErodeHeightMaps and UpdateFlowFromTrackJob are siblings in the reference's job graph (CombineDependencies,
+// Component/LiveErosion.cs:408-412): the pile solver touches height and the sediment events, the flow update pool, flow and
+// track.  The pile solver's launch is a couple of thousand waves that wait for memory and for each other (VALU issue 0.07,
+// HBM 0.04 of the chip); this form of it carries the flow update's workgroups BEHIND its own -- workgroups start in index
+// order, so every pile wave is resident before the first flow workgroup and no pile wave ever waits for a slot -- and the
+// flow update streams through the CUs the pile waves leave idle.  A flow workgroup: one wave, FLOW_UNROLL quads per lane,
+// all in flight at once (the launch's LDS -- the pile solver's, ~11 KB per workgroup -- caps a CU at 14 workgroups: few
+// waves, so each keeps more loads in flight than flow_from_track_kernel's do).  8192^2, cycle 100: the two jobs 0.294 + 0.192 ms
+// one after the other, 0.366-0.377 ms as one launch -- the pile waves' dependent loads take longer next to a streaming
+// kernel (alone 0.183 ms), so it is not max(0.29, 0.17); 2 ... 8 quads in flight and 1 ... 16 rounds per workgroup all land
+// within 0.366-0.387.
+constexpr int FLOW_UNROLL = 4;
+constexpr size_t FLOW_WG_CELLS = (size_t)64 * 4 * FLOW_UNROLL;
+struct flow_track_args {
+    float *pool, *flow, *track;
+    size_t n;
+    float flowLossRate, evaporation;
+    int aligned;
+};
+
+__global__ __launch_bounds__(64) void pile_ticket_flow_kernel(pile_ticket_args a, unsigned pile_grid, flow_track_args f) {
+    extern __shared__ unsigned char s_raw[];
+    if (blockIdx.x < pile_grid) {
+        pile_ticket_wave(a, s_raw);
+        return;
+    }
+    const size_t wg0 = (size_t)(blockIdx.x - pile_grid) * FLOW_WG_CELLS;
+    const size_t base = wg0 + (size_t)threadIdx.x * 4;
+    if (f.aligned && wg0 + FLOW_WG_CELLS <= f.n) {  // wave-uniform: the workgroup's cells are all inside
+        float4 pv[FLOW_UNROLL], tv[FLOW_UNROLL], po[FLOW_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FLOW_UNROLL; u++) {
+            const size_t i = base + (size_t)u * 256;
+            pv[u] = *reinterpret_cast<const float4 *>(f.flow + i);
+            tv[u] = *reinterpret_cast<const float4 *>(f.track + i);
+            po[u] = *reinterpret_cast<const float4 *>(f.pool + i);
+        }
+#pragma unroll
+        for (int u = 0; u < FLOW_UNROLL; u++)
+            flow_from_track_quad(f.pool, f.flow, f.track, base + (size_t)u * 256, pv[u], tv[u], po[u], f.flowLossRate, f.evaporation);
+    } else {
+        for (int u = 0; u < FLOW_UNROLL; u++) {
+            const size_t i = base + (size_t)u * 256;
+            if (i < f.n) flow_from_track_cells(f.pool, f.flow, f.track, i, f.n < i + 4 ? f.n : i + 4, f.flowLossRate, f.evaporation);
+        }
     }
 }
 
@@ -1210,12 +1281,15 @@ extern "C" int32_t nz_process_beyer_erosive_events(nz_ctx *ctx, float *height, f
     return nz_ctx_finish(ctx, out);
 }
 
-extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *events, const nz_erosion_params *ep,
-                                        const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out) {
+// ErodeHeightMaps; `fl` != NULL: and UpdateFlowFromTrackJob, its sibling (nz_erode_height_maps_and_flow)
+static int32_t erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *events, const nz_erosion_params *ep,
+                                 const nz_tile_set_meta *tm, int32_t res, const flow_track_args *fl, nz_handle dep, nz_handle *out) {
     NZ_BEGIN(ctx, dep);
     NZ_REQUIRE(height && events, "height / events is NULL");
     if (int32_t rc = check_live(ep, tm, res)) return rc;
     NZ_REQUIRE(events->res == res, "events were created for resolution %d", events->res);
+    NZ_REQUIRE(!fl || (fl->pool != height && fl->flow != height && fl->track != height),
+               "the flow update's planes must not be the height plane: the two jobs run side by side");
     NZ_REQUIRE(ep->PILING_RADIUS >= 0 && ep->PILING_RADIUS <= 50, "PILING_RADIUS %d out of range [0,50]", ep->PILING_RADIUS);
     const float thr = ep->PILE_THRESHOLD / (float)tm->HEIGHT;
     // the events ProcessBeyerErosiveEvents has just written are the cells of the list it filled (it flipped `cur` after)
@@ -1281,9 +1355,20 @@ extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_e
             // 2048 resident waves: 1024 leave blocks waiting for a wave (248 us), 3584 / 7168 fill the CUs with waves that
             // poll (239 / 279 us against 211)
             const unsigned grid = (unsigned)std::min<long long>((long long)nb * nb, 2048);
-            hipLaunchKernelGGL(pile_ticket_kernel, dim3(grid), dim3(64), lds, ctx->stream, height, events->sediment,
-                               events->pile_blocks, pile_list, pile_ctl, pile_cap, (const short2 *)events->pile_scratch, nverts,
-                               res, D, B, nb, thr, ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT, err_host);
+            const pile_ticket_args pa{height, events->sediment, events->pile_blocks, pile_list, pile_ctl, pile_cap,
+                                      (const short2 *)events->pile_scratch, nverts, res, D, B, nb, thr,
+                                      ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT, err_host};
+            static const bool carry = [] { const char *e = getenv("NZ_PILE_CARRY_FLOW"); return !e || atoi(e) != 0; }();
+            const size_t flow_wgs = fl ? (fl->n + FLOW_WG_CELLS - 1) / FLOW_WG_CELLS : 0;
+            if (fl && carry && flow_wgs + grid < 0x7fffffffull) {
+                if (lds > 64 * 1024)
+                    NZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pile_ticket_flow_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(pile_ticket_flow_kernel, dim3(grid + (unsigned)flow_wgs), dim3(64), lds, ctx->stream, pa, grid, *fl);
+                fl = nullptr;  // done
+            } else {
+                hipLaunchKernelGGL(pile_ticket_kernel, dim3(grid), dim3(64), lds, ctx->stream, pa);
+            }
             NZ_HIP(hipGetLastError());
         }
         for (int colour = 0; colour < 4 && !ticket; colour++) {
@@ -1296,7 +1381,27 @@ extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_e
             NZ_HIP(hipGetLastError());
         }
     }
+    // no pile solver launch to carry it (PILING_RADIUS 0, NZ_PILE_TICKET=0, NZ_PILE_CARRY_FLOW=0): the flow update by itself
+    if (fl) NZ_TRY_(nz_launch_flow_from_track(ctx->stream, fl->pool, fl->flow, fl->track, fl->n, fl->flowLossRate, fl->evaporation));
     return nz_ctx_finish(ctx, out);
+}
+
+extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *events, const nz_erosion_params *ep,
+                                        const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out) {
+    return erode_height_maps(ctx, height, events, ep, tm, res, nullptr, dep, out);
+}
+
+extern "C" int32_t nz_erode_height_maps_and_flow(nz_ctx *ctx, float *height, nz_erosive_events *events, float *pool, float *flow,
+                                                 float *track, const nz_erosion_params *ep, const nz_tile_set_meta *tm,
+                                                 int32_t res, nz_handle dep, nz_handle *out) {
+    if (!ctx) return NZ_ERR_INVALID;
+    if (!pool || !flow || !track || !ep || !tm || res < 1) {
+        nz_set_error("nz_erode_height_maps_and_flow: pool / flow / track / ep / tm is NULL");
+        return NZ_ERR_INVALID;
+    }
+    flow_track_args fl{pool, flow, track, (size_t)res * res, ep->FLOW_LOSS_RATE, ep->SURFACE_EVAPORATION_RATE / (float)tm->HEIGHT, 0};
+    fl.aligned = ((reinterpret_cast<uintptr_t>(pool) | reinterpret_cast<uintptr_t>(flow) | reinterpret_cast<uintptr_t>(track)) & 15) == 0;
+    return erode_height_maps(ctx, height, events, ep, tm, res, &fl, dep, out);
 }
 
 extern "C" int32_t nz_curviture_map(nz_ctx *ctx, uint8_t *texture, const float *height, const nz_tile_set_meta *tm,

@@ -892,14 +892,20 @@ class LiveErosion {
                 check(nz_process_beyer_erosive_events(ctx, heightMap->ptr, poolMap.ptr, streamMap.ptr, particleTrack.ptr, events, &ep,
                                                       &tm, res, dep, link(false)), "nz_process_beyer_erosive_events");
                 // CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all behind the event reduction
-                // (:408-412): one after the other on the context's stream
+                // (:408-412): the clear, then the two siblings as one call (the pile solver's launch carries the flow update's
+                // workgroups); fuseSiblings = false: the two entries one after the other on the context's stream
                 dep = h;
                 check(nz_clear_particle_queue(ctx, particleQueue, dep, link(false)), "nz_clear_particle_queue");
                 dep = h;
-                check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, dep, link(false)), "nz_erode_height_maps");
-                dep = h;
-                check(nz_update_flow_from_track(ctx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
-                                                ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, dep, link(false)), "nz_update_flow_from_track");
+                if (fuseSiblings) {
+                    check(nz_erode_height_maps_and_flow(ctx, heightMap->ptr, events, poolMap.ptr, streamMap.ptr, particleTrack.ptr, &ep,
+                                                        &tm, res, dep, link(false)), "nz_erode_height_maps_and_flow");
+                } else {
+                    check(nz_erode_height_maps(ctx, heightMap->ptr, events, &ep, &tm, res, dep, link(false)), "nz_erode_height_maps");
+                    dep = h;
+                    check(nz_update_flow_from_track(ctx, poolMap.ptr, streamMap.ptr, particleTrack.ptr, ep.FLOW_LOSS_RATE,
+                                                    ep.SURFACE_EVAPORATION_RATE, (float)tm.HEIGHT, res, dep, link(false)), "nz_update_flow_from_track");
+                }
                 dep = h;
                 check(nz_pool_automata_job(ctx, poolMap.ptr, heightMap->ptr, particleQueue, &ep, &tm, es.WATER_STEPS, res,
                                            performErosion ? 1 : 0, dep, link(last)), "nz_pool_automata_job");
@@ -912,6 +918,7 @@ class LiveErosion {
 
     nz_ctx *ctx;
     bool fewHandles = true;         // false: a handle out of every job, as the reference schedules them (one event record each)
+    bool fuseSiblings = true;       // ErodeHeightMaps + UpdateFlowFromTrackJob as one call (nz_erode_height_maps_and_flow)
     DeviceTile *heightMap;
     nz_tile_set_meta tileMeta;
     ErosionSettings erosionSettings;

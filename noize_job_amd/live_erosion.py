@@ -174,9 +174,11 @@ class LiveErosion:
         self.EVENT_LIMIT = 1500
         self.jobHandle = JobHandle()
         self.waterControl = self.textureControl = None
-        # ErodeHeightMaps and UpdateFlowFromTrackJob are siblings in the reference's job graph (CombineDependencies, :408-412);
-        # here they follow each other on the context's stream (rounds 3 and 4 could run the second on a stream of its own: at
-        # 8192^2 the two cross-stream dependencies cost more than the overlap saved, 2.71 against 2.54 ms per driver cycle)
+        # ErodeHeightMaps and UpdateFlowFromTrackJob are siblings in the reference's job graph (CombineDependencies, :408-412):
+        # one call, the pile solver's launch carries the flow update's workgroups (nz_erode_height_maps_and_flow).  False: the
+        # two entries one after the other on the context's stream.  (Rounds 3 and 4 could run the second on a stream of its own:
+        # at 8192^2 the two cross-stream dependencies cost more than the overlap saved, 2.71 against 2.54 ms per driver cycle.)
+        self.fuseSiblings = True
         # The jobs of a cycle are links of ONE chain on this context's stream: only the handles somebody waits for are
         # asked of the library (the cycle chain's last) -- a handle is an event record, ~3 us of the stream.  False: one per job, as the reference
         # schedules them.
@@ -215,11 +217,15 @@ class LiveErosion:
                 # handle = CombineDependencies(ClearQueueJob, ErodeHeightMaps, UpdateFlowFromTrackJob), all three behind the
                 # event reduction (:408-412)
                 handle = self.particleQueue.Clear(dep=handle, handle=not self.fewHandles)
-                handle = self._call("nz_erode_height_maps", self.heightMap.ptr, self.events._h, epp, tmp_, res, dep=handle,
-                                    handle=False)
-                handle = self._call("nz_update_flow_from_track", self.poolMap.ptr, self.streamMap.ptr, self.particleTrack.ptr,
-                                    ep.FLOW_LOSS_RATE, ep.SURFACE_EVAPORATION_RATE, float(tm.HEIGHT), res, dep=handle,
-                                    handle=False)
+                if self.fuseSiblings:
+                    handle = self._call("nz_erode_height_maps_and_flow", self.heightMap.ptr, self.events._h, self.poolMap.ptr,
+                                        self.streamMap.ptr, self.particleTrack.ptr, epp, tmp_, res, dep=handle, handle=False)
+                else:
+                    handle = self._call("nz_erode_height_maps", self.heightMap.ptr, self.events._h, epp, tmp_, res, dep=handle,
+                                        handle=False)
+                    handle = self._call("nz_update_flow_from_track", self.poolMap.ptr, self.streamMap.ptr, self.particleTrack.ptr,
+                                        ep.FLOW_LOSS_RATE, ep.SURFACE_EVAPORATION_RATE, float(tm.HEIGHT), res, dep=handle,
+                                        handle=False)
                 handle = self._call("nz_pool_automata_job", self.poolMap.ptr, self.heightMap.ptr, self.particleQueue._h, epp,
                                     tmp_, es.WATER_STEPS, res, int(self.performErosion), dep=handle, handle=last)
         if self.waterControl is not None:  # the RGBA32 control textures (:418-430)

@@ -82,13 +82,19 @@ def main():
                     why = "events"
                     break
                 G.particleQueue.Clear()
-                G.ctx.call("nz_erode_height_maps", G.heightMap.ptr, G.events._h, epp, tmp_, res)
+                one_call = bool(rng.integers(0, 2))  # the two siblings as one launch (nz_erode_height_maps_and_flow) or as two entries
+                if one_call:
+                    G.ctx.call("nz_erode_height_maps_and_flow", G.heightMap.ptr, G.events._h, G.poolMap.ptr, G.streamMap.ptr,
+                               G.particleTrack.ptr, epp, tmp_, res)
+                else:
+                    G.ctx.call("nz_erode_height_maps", G.heightMap.ptr, G.events._h, epp, tmp_, res)
                 L.erode_height_maps()
                 if not np.array_equal(G.heightMap.ToArray(shape), L.height):
-                    why = "sediment (disperse / piles)"
+                    why = "sediment (disperse / piles)" + (", one call" if one_call else "")
                     break
-                G.ctx.call("nz_update_flow_from_track", G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr, ep.FLOW_LOSS_RATE,
-                           ep.SURFACE_EVAPORATION_RATE, float(th), res)
+                if not one_call:
+                    G.ctx.call("nz_update_flow_from_track", G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr, ep.FLOW_LOSS_RATE,
+                               ep.SURFACE_EVAPORATION_RATE, float(th), res)
                 L.update_flow_from_track()
                 G.ctx.call("nz_pool_automata_job", G.poolMap.ptr, G.heightMap.ptr, G.particleQueue._h, epp, tmp_, 3, res, 1)
                 L.pool_automata(3, drain=True)

@@ -112,7 +112,8 @@ def test_hand_written_files_call_declared_entries_with_the_right_arity():
         assert "Native.%s(" % entry in sharded, entry
     live = _cs_sources()["LiveErosion/LiveErosion.cs"]
     for job in ("nz_thermal_erosion", "nz_fill_beyer_queue", "nz_queued_beyer_cycle", "nz_process_beyer_erosive_events",
-                "nz_clear_particle_queue", "nz_erode_height_maps", "nz_update_flow_from_track", "nz_pool_automata_job",
+                "nz_clear_particle_queue", "nz_erode_height_maps", "nz_update_flow_from_track", "nz_erode_height_maps_and_flow",
+                "nz_pool_automata_job",
                 "nz_set_rgba32", "nz_curviture_map"):
         assert "Native.%s(" % job in live, job
 

@@ -174,7 +174,10 @@ def test_spawn_jumps_ahead_in_the_workers_streams(nj, ctx, oracle, particles, wo
 @pytest.mark.gpu
 @pytest.mark.parametrize("res,particles,tile_height,patch", [(256, 3000, 1000, 1.0), (384, 6000, 500, 2.5),
                                                              (40, 600, 1000, 1.0)])  # 40: a third of the cells in the frame
-def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, tile_height, patch):
+@pytest.mark.parametrize("siblings", ["two-calls", "one-call"])
+def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, tile_height, patch, siblings):
+    """siblings = one-call: ErodeHeightMaps and UpdateFlowFromTrackJob through nz_erode_height_maps_and_flow (the pile
+    solver's launch carries the flow update's workgroups) -- the same planes as the two entries one after the other."""
     h = terrain(oracle, res)
     es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, PILE_THRESHOLD=0.4, PILING_RADIUS=7, MIN_PILE_INCREMENT=0.25)
     G = _gpu_state(nj, ctx, h, es, tile_height, patch)
@@ -203,7 +206,11 @@ def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, til
         assert np.array_equal(G.events.sediment(), L.sediment), cyc
         assert np.array_equal(G.poolMap.ToArray(shape), L.pool) and np.array_equal(G.particleTrack.ToArray(shape), L.track)
         G.particleQueue.Clear()
-        G.ctx.call("nz_erode_height_maps", G.heightMap.ptr, G.events._h, epp, tmp_, res)
+        if siblings == "one-call":
+            G.ctx.call("nz_erode_height_maps_and_flow", G.heightMap.ptr, G.events._h, G.poolMap.ptr, G.streamMap.ptr,
+                       G.particleTrack.ptr, epp, tmp_, res)
+        else:
+            G.ctx.call("nz_erode_height_maps", G.heightMap.ptr, G.events._h, epp, tmp_, res)
         L.erode_height_maps()
         piles = int(((L.sediment > f32(ep.PILE_THRESHOLD) / f32(tile_height))).sum())
         assert np.array_equal(G.heightMap.ToArray(shape), L.height), (cyc, piles)
@@ -212,9 +219,12 @@ def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, til
         if res < 256:  # events in the two-cell frame, where clamped taps of one source fold onto one target
             frame = np.ones(shape, bool); frame[2:-2, 2:-2] = False
             assert (L.sediment[frame] != 0).any()
-        G.ctx.call("nz_update_flow_from_track", G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr, ep.FLOW_LOSS_RATE,
-                   ep.SURFACE_EVAPORATION_RATE, float(tile_height), res)
+        if siblings != "one-call":
+            G.ctx.call("nz_update_flow_from_track", G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr, ep.FLOW_LOSS_RATE,
+                       ep.SURFACE_EVAPORATION_RATE, float(tile_height), res)
         L.update_flow_from_track()
+        assert np.array_equal(G.poolMap.ToArray(shape), L.pool) and np.array_equal(G.streamMap.ToArray(shape), L.flow)
+        assert not G.particleTrack.ToArray(shape).any()
         G.ctx.call("nz_pool_automata_job", G.poolMap.ptr, G.heightMap.ptr, G.particleQueue._h, epp, tmp_, 4, res, 1)
         L.pool_automata(4, drain=True)
         assert np.array_equal(G.poolMap.ToArray(shape), L.pool) and np.array_equal(G.streamMap.ToArray(shape), L.flow)

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--at", default="", help="comma-separated cycle counts of one long run at which the per-job times are taken")
     ap.add_argument("--skip-fresh", action="store_true", help="only the --at run")
+    ap.add_argument("--siblings", choices=("one-call", "two-calls"), default="one-call",
+                    help="ErodeHeightMaps and UpdateFlowFromTrackJob: nz_erode_height_maps_and_flow, or the two entries one after the other")
     a = ap.parse_args()
     res = a.res
     out = {"config": "%dx%d cellular-13oct base + live particle erosion, %d particles per cycle, WATER_STEPS %d" %
@@ -65,6 +67,13 @@ def main():
             ("pool_automata", lambda: ctx.call("nz_pool_automata_job", G.poolMap.ptr, h.ptr, G.particleQueue._h, epp, tmp_,
                                                a.water_steps, res, 1)),
         ]
+        if a.siblings == "one-call":
+            i = [n for n, _ in jobs].index("erode_height_maps")
+            jobs[i:i + 2] = [("erode_height_maps+flow_from_track",
+                              lambda: ctx.call("nz_erode_height_maps_and_flow", h.ptr, G.events._h, G.poolMap.ptr, G.streamMap.ptr,
+                                               G.particleTrack.ptr, epp, tmp_, res))]
+        G.fuseSiblings = a.siblings == "one-call"
+        out["siblings"] = a.siblings
         if a.at:
             # one long run; around every checkpoint the jobs of 10 cycles are bracketed with stream markers
             import numpy as np
