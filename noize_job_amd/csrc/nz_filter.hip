@@ -109,7 +109,7 @@ __device__ unsigned long long *nz_probe_buf = nullptr;  // [workgroup][24]
 #ifndef NZ_CONV5_WAVES
 #define NZ_CONV5_WAVES 6
 #endif
-constexpr int conv_waves(int ks, int nt) { return ks == 5 ? NZ_CONV5_WAVES : (nt >= 512 || ks >= 7) ? 4 : 6; }
+constexpr int conv_waves(int ks, int nt, int rbt) { return rbt < RB ? 4 : ks == 5 ? NZ_CONV5_WAVES : (nt >= 512 || ks >= 7) ? 4 : 6; }
 
 // 16-byte accesses that other XCDs can see / that see other XCDs' stores while the kernel runs: `sc1` buffer loads and
 // stores (they bypass the CU's L1; the stores write through and leave the XCD's L2), 4-byte ones as agent-scope relaxed
@@ -148,35 +148,36 @@ __device__ __forceinline__ float tap_acc(float total, float v, float k) {
     return FAST ? __builtin_fmaf(v, k, total) : total + v * k;
 }
 
-template <int KS, bool UNIT, int NT, bool SC1, bool FAST>
+template <int KS, bool UNIT, int NT, bool SC1, bool FAST, int RBT>
 __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *__restrict__ dst, const nz_geom &g,
                                           const nz_kernel_taps &taps, int T, int aligned, int ox0, int oz0,
                                           float4 *s_edge_raw NZ_PB_PARAM) {
     constexpr int O = (KS - 1) / 2;
     constexpr int WN = 4 + 2 * O;   // X window
-    constexpr int ZN = RB + 2 * O;  // Z window
-    constexpr int TH = NT / 32 * RB;  // tile rows: one 8-row block per 32 threads (shadows the file-level TH)
+    constexpr int ZN = RBT + 2 * O;  // Z window
+    constexpr int TH = NT / 32 * RBT;  // tile rows: one RBT-row block per 32 threads (shadows the file-level TH)
+    static_assert(O <= RBT, "a block's window reaches into the neighbouring blocks only");
     // boundary rows of every 8-row block: [parity][block][top|bottom][o][column group].  Double buffered
     // (one barrier per application) for the 3-tap kernel; the others keep one buffer and pay a second barrier
     // instead of giving up a resident workgroup (5 taps: 3 x 32 KB; 7/9 taps: 2 x 48/64 KB).
     constexpr int NBUF = (O == 2 && NZ_CONV5_NBUF == 2) ? 2 : (O >= 2 ? 1 : 2);
-    float4 (*s_edge)[TH / RB][2][O][TW / 4] = reinterpret_cast<float4 (*)[TH / RB][2][O][TW / 4]>(s_edge_raw);
+    float4 (*s_edge)[TH / RBT][2][O][TW / 4] = reinterpret_cast<float4 (*)[TH / RBT][2][O][TW / 4]>(s_edge_raw);
 
     const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
     const int H = T * O, HX = (H + 3) & ~3;
     const int OW = TW - 2 * HX, OH = TH - 2 * H;
     const int lx0 = ox0 - HX, lz0 = oz0 - H;
-    const int gx0 = lx0 + cg * 4, gzb = lz0 + rb * RB;
+    const int gx0 = lx0 + cg * 4, gzb = lz0 + rb * RBT;
     const bool inside = lx0 >= 0 && lx0 + TW <= g.cols && lz0 >= g.zc0 && lz0 + TH - 1 <= g.zc1;
     const bool fast = inside && aligned;
     NZ_PROBE_T(0);
     NZ_PROBE(14, (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)));   // HW_ID
     NZ_PROBE(15, (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)));  // XCC_ID
 
-    float v[RB][4];
+    float v[RBT][4];
     if (fast) {  // a real branch (the asm keeps the two forms from being merged into 4-byte accesses with selected addresses)
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
+        for (int r = 0; r < RBT; r++) {
             float4 t = SC1 ? load16_sc1(src, (size_t)(gzb + r) * g.pitch + gx0)
                            : *reinterpret_cast<const float4 *>(src + (size_t)(gzb + r) * g.pitch + gx0);
             v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
@@ -185,7 +186,7 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
     } else {
         asm volatile("; clamped 4-byte loads of an edge tile" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
+        for (int r = 0; r < RBT; r++) {
             size_t row = (size_t)clampi(gzb + r, g.zc0, g.zc1) * g.pitch;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -205,7 +206,7 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
     for (int t = 0; t < T; t++) {
         // ---- X pass (KernelSampleXOperator: taps k ascending), in place row by row
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
+        for (int r = 0; r < RBT; r++) {
             float w[WN];
 #pragma unroll
             for (int o = 0; o < O; o++) {
@@ -240,7 +241,7 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
 #pragma unroll
         for (int o = 0; o < O; o++) {
             s_edge[par][rb][0][o][cg] = make_float4(v[o][0], v[o][1], v[o][2], v[o][3]);
-            s_edge[par][rb][1][o][cg] = make_float4(v[RB - O + o][0], v[RB - O + o][1], v[RB - O + o][2], v[RB - O + o][3]);
+            s_edge[par][rb][1][o][cg] = make_float4(v[RBT - O + o][0], v[RBT - O + o][1], v[RBT - O + o][2], v[RBT - O + o][3]);
         }
         if (t == 0) NZ_PROBE_T(16);  // application 1: X pass done, edge rows written
         __syncthreads();
@@ -248,16 +249,16 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
         float z[ZN][4];
 #pragma unroll
         for (int o = 0; o < O; o++) {
-            // rows gzb-O+o (bottom rows of the block above) and gzb+RB+o (top rows of the block below)
+            // rows gzb-O+o (bottom rows of the block above) and gzb+RBT+o (top rows of the block below)
             float4 a = rb > 0 ? s_edge[par][rb - 1][1][o][cg] : make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
-            float4 b = rb < TH / RB - 1 ? s_edge[par][rb + 1][0][o][cg]
-                                        : make_float4(v[RB - 1][0], v[RB - 1][1], v[RB - 1][2], v[RB - 1][3]);
+            float4 b = rb < TH / RBT - 1 ? s_edge[par][rb + 1][0][o][cg]
+                                        : make_float4(v[RBT - 1][0], v[RBT - 1][1], v[RBT - 1][2], v[RBT - 1][3]);
             z[o][0] = a.x; z[o][1] = a.y; z[o][2] = a.z; z[o][3] = a.w;
-            z[RB + O + o][0] = b.x; z[RB + O + o][1] = b.y; z[RB + O + o][2] = b.z; z[RB + O + o][3] = b.w;
+            z[RBT + O + o][0] = b.x; z[RBT + O + o][1] = b.y; z[RBT + O + o][2] = b.z; z[RBT + O + o][3] = b.w;
         }
         if (NBUF == 1 && t + 1 < T) __syncthreads();  // everyone has read the edges before they are rewritten
 #pragma unroll
-        for (int r = 0; r < RB; r++)
+        for (int r = 0; r < RBT; r++)
 #pragma unroll
             for (int e = 0; e < 4; e++) z[O + r][e] = v[r][e];
         if (!inside) {
@@ -284,7 +285,7 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
         }
         // ---- Z pass (KernelSampleZOperator: k descending, Kernel[k_off - k])
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
+        for (int r = 0; r < RBT; r++) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 float total = z[r + 2 * O][e] * taps.kz[0];
@@ -299,8 +300,8 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
     // ---- store the interior
     if (fast) {  // whole tile inside the grid, 16-byte aligned rows: one 16-byte store per row
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
-            int lr = rb * RB + r, gz = gzb + r;
+        for (int r = 0; r < RBT; r++) {
+            int lr = rb * RBT + r, gz = gzb + r;
             bool in = lr >= H && lr < H + OH && cg * 4 >= HX && cg * 4 < HX + OW && gz < g.or1;
             if (in) {
                 if (SC1) store16_sc1(dst, (size_t)gz * g.pitch + gx0, make_float4(v[r][0], v[r][1], v[r][2], v[r][3]));
@@ -310,8 +311,8 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
     } else {
         asm volatile("; guarded stores of an edge tile" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
-            int lr = rb * RB + r, gz = gzb + r;
+        for (int r = 0; r < RBT; r++) {
+            int lr = rb * RBT + r, gz = gzb + r;
             bool in = lr >= H && lr < H + OH && cg * 4 >= HX && cg * 4 < HX + OW && gz < g.or1 && gx0 < g.cols;
             if (in) {
 #pragma unroll
@@ -326,20 +327,20 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
     NZ_PROBE_T(12);
 }
 
-template <int KS, bool UNIT, int NT, bool FAST>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(KS, NT)))) void conv_reg_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
+template <int KS, bool UNIT, int NT, bool FAST, int RBT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(KS, NT, RBT)))) void conv_reg_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
                                                      nz_kernel_taps taps, int T, int aligned) {
     constexpr int O = (KS - 1) / 2;
-    constexpr int TH = NT / 32 * RB;
+    constexpr int TH = NT / 32 * RBT;
     constexpr int NBUF = (O == 2 && NZ_CONV5_NBUF == 2) ? 2 : (O >= 2 ? 1 : 2);
-    __shared__ float4 s_edge[NBUF][TH / RB][2][O][TW / 4];
+    __shared__ float4 s_edge[NBUF][TH / RBT][2][O][TW / 4];
     const int H = T * O, HX = (H + 3) & ~3;
     src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
     dst += blockIdx.y * g.bstride;
     int ox0, oz0;
     tile_origin(g, TW - 2 * HX, TH - 2 * H, ox0, oz0);
     NZ_PB_INIT;
-    conv_tile<KS, UNIT, NT, false, FAST>(src, dst, g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0] NZ_PB_ARG);
+    conv_tile<KS, UNIT, NT, false, FAST, RBT>(src, dst, g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0] NZ_PB_ARG);
 }
 
 // ---- the launches of a stage as ONE grid with tile-level dependencies -------------------------------------------------
@@ -383,13 +384,13 @@ struct nz_chain {
 
 __host__ __device__ __forceinline__ int chain_class_count(int n, int c) { return n > c ? (n - c + 7) >> 3 : 0; }  // #{vb < n : vb % 8 == c}
 
-template <int KS, bool UNIT, int NT, bool FAST>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(KS, NT)))) void conv_chain_kernel(nz_geom g, nz_kernel_taps taps,
-                                                                                                                  nz_chain ch, int aligned) {
+template <int KS, bool UNIT, int NT, bool FAST, int RBT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(KS, NT, RBT)))) void conv_chain_kernel(nz_geom g, nz_kernel_taps taps,
+                                                                                                                       nz_chain ch, int aligned) {
     constexpr int O = (KS - 1) / 2;
-    constexpr int TH = NT / 32 * RB;
+    constexpr int TH = NT / 32 * RBT;
     constexpr int NBUF = (O == 2 && NZ_CONV5_NBUF == 2) ? 2 : (O >= 2 ? 1 : 2);
-    __shared__ float4 s_edge[NBUF][TH / RB][2][O][TW / 4];
+    __shared__ float4 s_edge[NBUF][TH / RBT][2][O][TW / 4];
     NZ_PB_INIT;
     NZ_PROBE_T(18);  // the workgroup's first instruction (after the kernel arguments' scalar loads)
     int l = 0, tile = 0;
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
     NZ_PROBE_T(8);  // the producers' flags are up
     if (ch.first[l] + tile == ch.delay_item)
         for (int i = 0; i < ch.delay_sleeps; i++) __builtin_amdgcn_s_sleep(127);  // 127 x 64 clocks ~ 3.4 us
-    conv_tile<KS, UNIT, NT, true, FAST>(ch.plane[l & 1], ch.plane[(l + 1) & 1], g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0] NZ_PB_ARG);
+    conv_tile<KS, UNIT, NT, true, FAST, RBT>(ch.plane[l & 1], ch.plane[(l + 1) & 1], g, taps, T, aligned, ox0, oz0, &s_edge[0][0][0][0][0] NZ_PB_ARG);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
     NZ_PROBE_T(10);  // wave 0's stores are acknowledged
     __syncthreads();
@@ -758,15 +759,28 @@ int32_t launch_wide(hipStream_t s, const float *src, float *dst, const nz_geom &
 #define NZ_CONV_NT_WIDE 512  // threads per workgroup for the 5-, 7- and 9-tap kernels: 128-row tiles (rows = NT / 4)
 #endif
 
-// Threads per workgroup = rows of the register tile / 4.  The 5-, 7- and 9-tap kernels use 128-row tiles (512 threads)
-// where throughput counts; a SMALL grid -- a tile of the reference's own sizes (256 ... 1024^2), a stripe's ghost-row
-// window -- cannot fill the chip whatever the tile, and what it waits for is the latency of one workgroup's dependent
-// applications: 64-row tiles (256 threads: one wave per SIMD instead of two) run an application in half the time.
+// Threads per workgroup = rows of the register tile / 4 at eight rows per thread.  The 5-, 7- and 9-tap kernels use 128-row
+// tiles (512 threads) where throughput counts; a SMALL grid -- a tile of the reference's own sizes (256 ... 1024^2), a stripe's
+// ghost-row window -- cannot fill the chip whatever the tile, and what it waits for is the latency of one workgroup's dependent
+// applications: 64-row tiles hold half the cells per CU, and FOUR rows per thread (512 threads, two waves per SIMD: a lone
+// wave issues a VALU instruction every ~6.6 cycles, two between them every ~4) instead of eight (256 threads, rounds 4 - 5)
+// take another fifth off an application: Gauss5 x17 at 512^2 42.0 -> 33.4 us, 1024^2 53.0 -> 45.5, 2048^2 95.9 -> 87.1.
 // Such a grid also runs its fused launches one after the other, not as a chained grid: with a few dozen tiles per launch
 // the polls and the sc1 accesses of the chain cost more than the launch boundaries it saves.  Gauss5 x17, one tile at a
 // time, 128-row tiles chained -> 64-row tiles in four launches: 256^2 80 -> 52 us, 512^2 81 -> 52, 1024^2 89 -> 54, 1536^2
 // 98 -> 74, 2048^2 110 -> 97, 2560^2 126 -> 117; 2816^2 127 against 131 and 3072^2 134 against 151: from 7 M cells on the
 // big tiles and the chain stay.
+#ifndef NZ_CONV_SMALL_NT
+#define NZ_CONV_SMALL_NT 512  // the 64-row tile of a small grid: NZ_CONV_SMALL_NT threads x NZ_CONV_SMALL_RB rows each
+#define NZ_CONV_SMALL_RB 4
+#endif
+static_assert(NZ_CONV_SMALL_NT / 32 * NZ_CONV_SMALL_RB == 64, "the hosts size a small grid's tiles as 64 rows");
+// A TINY grid -- a tile of 256^2 ... 768^2 cells, at most a workgroup per CU -- goes one step further with the 5-tap kernel
+// (whose window needs two rows of a neighbouring block at most): 1024 threads x 2 rows, four waves per SIMD.  Gauss5 x17,
+// one 512^2 tile at a time: 256 x 8 rows 42.0 us, 512 x 4 rows 33.4 us, 1024 x 2 rows 30.9 us; at 2048^2 (several workgroups per
+// CU) 95.9 / 87.1 / 116 us.
+constexpr long long NZ_CONV_TINY_CELLS = 600 * 1024;
+static inline bool conv_tiny_grid(const nz_geom &g) { return (long long)g.cols * (g.or1 - g.or0) * g.count <= NZ_CONV_TINY_CELLS; }
 #ifndef NZ_CONV_SMALL_CELLS
 #define NZ_CONV_SMALL_CELLS (7 * 1024 * 1024)
 #endif
@@ -778,15 +792,15 @@ static inline bool conv_small_grid(int ksize, const nz_geom &g) {
     return (long long)g.cols * (g.or1 - g.or0) * g.count < (long long)NZ_CONV_SMALL_CELLS;
 }
 
-template <int KS, int NT>
+template <int KS, int NT, int RBT = RB>
 int32_t launch_fused_nt(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T) {
-    constexpr int O = (KS - 1) / 2, RTH = NT / 32 * RB;  // register tile: RTH rows x 128 columns
+    constexpr int O = (KS - 1) / 2, RTH = NT / 32 * RBT;  // register tile: RTH rows x 128 columns
     int H = T * O, HX = (H + 3) & ~3;
     int OW = TW - 2 * HX, OH = RTH - 2 * H;
     long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
     int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
     const bool fast = nz_tls_float_mode >= NZ_FLOAT_FAST;
-#define NZ_CR(U, F) NZ_LAUNCH((conv_reg_kernel<KS, U, NT, F>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned)
+#define NZ_CR(U, F) NZ_LAUNCH((conv_reg_kernel<KS, U, NT, F, RBT>), dim3((unsigned)blocks, g.count), dim3(NT), 0, s, src, dst, g, k, T, aligned)
     if (k.factor == 1.0f) {
         if (fast) NZ_CR(true, true); else NZ_CR(true, false);
     } else {
@@ -799,18 +813,22 @@ int32_t launch_fused_nt(hipStream_t s, const float *src, float *dst, const nz_ge
 
 template <int KS>
 int32_t launch_fused(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T) {
-    if (KS >= 5 && conv_small_grid(KS, g)) return launch_fused_nt<KS, 256>(s, src, dst, g, k, T);
+    if (KS >= 5 && conv_small_grid(KS, g)) {
+        if constexpr (KS == 5)
+            if (conv_tiny_grid(g)) return launch_fused_nt<KS, 1024, 2>(s, src, dst, g, k, T);
+        return launch_fused_nt<KS, NZ_CONV_SMALL_NT, NZ_CONV_SMALL_RB>(s, src, dst, g, k, T);
+    }
     return launch_fused_nt<KS, (KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT)>(s, src, dst, g, k, T);
 }
 
 int g_chain_delay_item = -1, g_chain_delay_sleeps = 0;  // nz_debug_chain_delay
 int g_chain_spin_limit = 1 << 21;                         // nz_debug_chain_poll_limit
 
-template <int KS, int NT>
+template <int KS, int NT, int RBT = RB>
 int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
                         int L, int *flags, unsigned epoch, unsigned *err_host, unsigned *err_epoch) {
     constexpr int O = (KS - 1) / 2;
-    constexpr int RTH = NT / 32 * RB;
+    constexpr int RTH = NT / 32 * RBT;
     nz_chain ch{};
     ch.L = L;
     ch.first[0] = 0;
@@ -833,7 +851,7 @@ int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_ge
     ch.err_epoch = err_epoch;
     int aligned = ((reinterpret_cast<uintptr_t>(plane0) | reinterpret_cast<uintptr_t>(plane1) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
     const bool fast = nz_tls_float_mode >= NZ_FLOAT_FAST;
-#define NZ_CC(U, F) NZ_LAUNCH((conv_chain_kernel<KS, U, NT, F>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned)
+#define NZ_CC(U, F) NZ_LAUNCH((conv_chain_kernel<KS, U, NT, F, RBT>), dim3((unsigned)ch.total), dim3(NT), 0, s, g, k, ch, aligned)
     if (k.factor == 1.0f) {
         if (fast) NZ_CC(true, true); else NZ_CC(true, false);
     } else {
@@ -847,7 +865,11 @@ int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_ge
 template <int KS>
 int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k, const int *Ts,
                      int L, int *flags, unsigned epoch, unsigned *err_host, unsigned *err_epoch) {
-    if (KS >= 5 && conv_small_grid(KS, g)) return launch_chain_nt<KS, 256>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host, err_epoch);
+    if (KS >= 5 && conv_small_grid(KS, g)) {
+        if constexpr (KS == 5)
+            if (conv_tiny_grid(g)) return launch_chain_nt<KS, 1024, 2>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host, err_epoch);
+        return launch_chain_nt<KS, NZ_CONV_SMALL_NT, NZ_CONV_SMALL_RB>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host, err_epoch);
+    }
     return launch_chain_nt<KS, (KS >= 5 ? NZ_CONV_NT_WIDE : NZ_CONV_NT)>(s, plane0, plane1, g, k, Ts, L, flags, epoch, err_host, err_epoch);
 }
 
@@ -855,6 +877,8 @@ int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom 
 
 // a grid the 5-, 7- and 9-tap kernels serve with 64-row tiles and separate launches (see conv_small_grid)
 bool nz_conv_small_grid(int ksize, const nz_geom &g) { return conv_small_grid(ksize, g); }
+// ... and so small that a launch is at most a workgroup per CU (the 5-tap kernel then fuses nine applications, nz_stages.cpp)
+bool nz_conv_tiny_grid(int ksize, const nz_geom &g) { return conv_small_grid(ksize, g) && conv_tiny_grid(g); }
 
 // work items (= flags) the chained form of L launches needs on this geometry
 int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L) {

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(CT) void normalize_kernel(const float *src, float *
 #define NZ_FT_OCC 4
 #endif
 constexpr int FT_TH = 48, FT_TW = 128, FT_NT = NZ_FT_NT, FT_LP = FT_TW + 4;
-constexpr int FT_G = FT_TH * FT_TW / 4 / FT_NT;  // groups per thread = 3
+constexpr int FT_TH_TINY = 32;  // a tiny grid's tile: 32 rows, 1024 threads (nz_launch_flow_fused)
 // FT_MAX_N = 5 (nz_flow_common.hpp): 2n halo rows, n = 5 leaves a 28 x 104 interior
 
 // (bound_ctrl: the lane without a source reads 0, and no v_mov 0 has to initialise the destination first)
@@ -187,7 +187,7 @@ __device__ __forceinline__ void store_group(float *__restrict__ p, const nz_geom
     }
 }
 
-template <bool FIRST, bool LAST, bool EDGE, bool FAST>
+template <bool FIRST, bool LAST, bool EDGE, bool FAST, int FTH, int FNT>
 __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float *s_fs, int tile, const float *__restrict__ h, const float *__restrict__ w_in,
                                                           const float *__restrict__ fN_in, const float *__restrict__ fS_in,
                                                           const float *__restrict__ fE_in, const float *__restrict__ fW_in,
@@ -196,9 +196,11 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
                                                           float *__restrict__ fW_out, float *__restrict__ dst,
                                                           float *__restrict__ h_out, nz_geom g, int n, float nmin,
                                                           float nrange, int aligned) {
+    constexpr int FG = FTH * FT_TW / 4 / FNT;  // groups of four cells per thread
+    static_assert(FG * FNT * 4 == FTH * FT_TW, "the threads' groups tile the register tile");
     const int tid = threadIdx.x;
     const int H = 2 * n, HX = (H + 3) & ~3;
-    const int OW = FT_TW - 2 * HX, OH = FT_TH - 2 * H;
+    const int OW = FT_TW - 2 * HX, OH = FTH - 2 * H;
     const int tiles_x = (g.cols + OW - 1) / OW;
     const int by = tile / tiles_x, bx = tile - by * tiles_x;
     const int ox0 = bx * OW, oz0 = g.or0 + by * OH;
@@ -207,11 +209,11 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
     constexpr bool inner = !EDGE;
     const bool fast = inner && aligned;
 
-    float hh[FT_G][4], ww[FT_G][4], fW[FT_G][4], fE[FT_G][4], fS[FT_G][4], fN[FT_G][4];
-    int grow[FT_G], gcol[FT_G];
+    float hh[FG][4], ww[FG][4], fW[FG][4], fE[FG][4], fS[FG][4], fN[FG][4];
+    int grow[FG], gcol[FG];
 #pragma unroll
-    for (int j = 0; j < FT_G; j++) {
-        grow[j] = (tid >> 5) + j * (FT_NT / 32);
+    for (int j = 0; j < FG; j++) {
+        grow[j] = (tid >> 5) + j * (FNT / 32);
         gcol[j] = (tid & 31) * 4;
         int gx0 = lx0 + gcol[j], gz = lz0 + grow[j];
         load_group(h, g, gx0, gz, fast, hh[j]);
@@ -237,8 +239,8 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
         const int dead = EDGE ? 0 : 2 * it;
         // ---- 1. publish water + height
 #pragma unroll
-        for (int j = 0; j < FT_G; j++) {
-            if (grow[j] < dead || grow[j] >= FT_TH - dead) continue;
+        for (int j = 0; j < FG; j++) {
+            if (grow[j] < dead || grow[j] >= FTH - dead) continue;
             float tot[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) tot[e] = ww[j][e] + hh[j][e];
@@ -247,11 +249,11 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
         __syncthreads();
         // ---- 2. outflow (ComputeFlowStep), publish fN / fS
 #pragma unroll
-        for (int j = 0; j < FT_G; j++) {
+        for (int j = 0; j < FG; j++) {
             int r = grow[j];
-            if (r < dead || r >= FT_TH - dead) continue;
+            if (r < dead || r >= FTH - dead) continue;
             f4 tS = lds_load4(&s_tot[(r > 0 ? r - 1 : r) * FT_LP + gcol[j]]);
-            f4 tN = lds_load4(&s_tot[(r < FT_TH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);
+            f4 tN = lds_load4(&s_tot[(r < FTH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);
             float tot[4];  // recomputed rather than kept live across the barrier (same value)
 #pragma unroll
             for (int e = 0; e < 4; e++) tot[e] = ww[j][e] + hh[j][e];
@@ -279,11 +281,11 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
         if (LAST && it == n - 1) break;
         // ---- 3. water update (UpdateWaterStep)
 #pragma unroll
-        for (int j = 0; j < FT_G; j++) {
+        for (int j = 0; j < FG; j++) {
             int r = grow[j];
-            if (!EDGE && (r < dead + 2 || r >= FT_TH - dead - 2)) continue;  // the water of the next iteration's dead rows
+            if (!EDGE && (r < dead + 2 || r >= FTH - dead - 2)) continue;  // the water of the next iteration's dead rows
             f4 nS = lds_load4(&s_fn[(r > 0 ? r - 1 : r) * FT_LP + gcol[j]]);            // fN of row z-1
-            f4 sN = lds_load4(&s_fs[(r < FT_TH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);    // fS of row z+1
+            f4 sN = lds_load4(&s_fs[(r < FTH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);    // fS of row z+1
             float eW = wave_from_prev_lane(fE[j][3]), wE = wave_from_next_lane(fW[j][0]);
             int gx0 = lx0 + gcol[j], gz = lz0 + r;
 #pragma unroll
@@ -305,7 +307,7 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
     // ---- epilogue: interior groups only
     const float inv_range = FAST && LAST ? 1.0f / nrange : 0.0f;
 #pragma unroll
-    for (int j = 0; j < FT_G; j++) {
+    for (int j = 0; j < FG; j++) {
         int r = grow[j];
         int gx0 = lx0 + gcol[j], gz = lz0 + r;
         bool interior = r >= H && r < H + OH && gcol[j] >= HX && gcol[j] < HX + OW && gz < g.or1 && gx0 < g.cols;
@@ -313,7 +315,7 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
         if (LAST) {
             // CreateVelocityField + NormalizeMap, FlowMapComponents.cs:120-139,157-165
             f4 nS = lds_load4(&s_fn[(r > 0 ? r - 1 : r) * FT_LP + gcol[j]]);
-            f4 sN = lds_load4(&s_fs[(r < FT_TH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);
+            f4 sN = lds_load4(&s_fs[(r < FTH - 1 ? r + 1 : r) * FT_LP + gcol[j]]);
             float eW = wave_from_prev_lane(fE[j][3]), wE = wave_from_next_lane(fW[j][0]);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -351,8 +353,8 @@ __device__ __forceinline__ void flow_fused_body(float *s_tot, float *s_fn, float
 
 // The interior instantiation (tile strictly inside the grid) carries no border selects; the choice is
 // uniform per workgroup.
-template <bool FIRST, bool LAST, int OCC, bool FAST>
-__global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__restrict__ h, const float *__restrict__ w_in,
+template <bool FIRST, bool LAST, int OCC, bool FAST, int FTH, int FNT>
+__global__ __launch_bounds__(FNT, OCC) void flow_fused_kernel(const float *__restrict__ h, const float *__restrict__ w_in,
                                                                const float *__restrict__ fN_in, const float *__restrict__ fS_in,
                                                                const float *__restrict__ fE_in, const float *__restrict__ fW_in,
                                                                float *__restrict__ w_out, float *__restrict__ fN_out,
@@ -360,11 +362,11 @@ __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__r
                                                                float *__restrict__ fW_out, float *__restrict__ dst,
                                                                float *__restrict__ h_out, nz_geom g, int n, float nmin,
                                                                float nrange, int aligned) {
-    __shared__ __attribute__((aligned(16))) float s_tot[FT_TH * FT_LP];
-    __shared__ __attribute__((aligned(16))) float s_fn[FT_TH * FT_LP];
-    __shared__ __attribute__((aligned(16))) float s_fs[FT_TH * FT_LP];
+    __shared__ __attribute__((aligned(16))) float s_tot[FTH * FT_LP];
+    __shared__ __attribute__((aligned(16))) float s_fn[FTH * FT_LP];
+    __shared__ __attribute__((aligned(16))) float s_fs[FTH * FT_LP];
     const int H = 2 * n, HX = (H + 3) & ~3;
-    const int OW = FT_TW - 2 * HX, OH = FT_TH - 2 * H;
+    const int OW = FT_TW - 2 * HX, OH = FTH - 2 * H;
     const int tiles_x = (g.cols + OW - 1) / OW;
     // XCD-aware tile order (workgroups go round-robin to the 8 XCDs): XCD x takes the x-th contiguous eighth of
     // the tiles, so tiles that share halo rows / columns meet in one L2
@@ -375,17 +377,17 @@ __global__ __launch_bounds__(FT_NT, OCC) void flow_fused_kernel(const float *__r
     }
     const int by = tile / tiles_x, bx = tile - by * tiles_x;
     const int lx0 = bx * OW - HX, lz0 = g.or0 + by * OH - H;
-    const bool inner = lx0 > 0 && lx0 + FT_TW < g.cols && lz0 > g.zc0 && lz0 + FT_TH - 1 < g.zc1;
+    const bool inner = lx0 > 0 && lx0 + FT_TW < g.cols && lz0 > g.zc0 && lz0 + FTH - 1 < g.zc1;
     // batched launch: one independent grid per blockIdx.y, every plane shifted by the same stride
     const size_t off = blockIdx.y * g.bstride;
 #define NZ_SH(p) ((p) ? (p) + off : (p))
     if (inner)
-        flow_fused_body<FIRST, LAST, false, FAST>(s_tot, s_fn, s_fs, tile, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
+        flow_fused_body<FIRST, LAST, false, FAST, FTH, FNT>(s_tot, s_fn, s_fs, tile, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
                                             NZ_SH(fE_in), NZ_SH(fW_in), NZ_SH(w_out), NZ_SH(fN_out), NZ_SH(fS_out),
                                             NZ_SH(fE_out), NZ_SH(fW_out), NZ_SH(dst), NZ_SH(h_out), g, n, nmin, nrange,
                                             aligned);
     else
-        flow_fused_body<FIRST, LAST, true, FAST>(s_tot, s_fn, s_fs, tile, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
+        flow_fused_body<FIRST, LAST, true, FAST, FTH, FNT>(s_tot, s_fn, s_fs, tile, h + off, NZ_SH(w_in), NZ_SH(fN_in), NZ_SH(fS_in),
                                            NZ_SH(fE_in), NZ_SH(fW_in), NZ_SH(w_out), NZ_SH(fN_out), NZ_SH(fS_out),
                                            NZ_SH(fE_out), NZ_SH(fW_out), NZ_SH(dst), NZ_SH(h_out), g, n, nmin, nrange,
                                            aligned);
@@ -412,6 +414,15 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
     int H = 2 * n, HX = (H + 3) & ~3;
     int OW = FT_TW - 2 * HX, OH = FT_TH - 2 * H;
     long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
+    // A TINY grid (a tile of the reference's own sizes, 256^2 ... 512^2): at most a workgroup per CU whatever the tile, and what
+    // the launch waits for is the latency of one workgroup's dependent iterations.  32-row tiles of 1024 threads -- four cells
+    // per thread, four waves per SIMD -- run an iteration in ~0.6 of the time of the 48-row tile's twelve cells per thread (more
+    // workgroups, each with a third less work per SIMD): while they still fit one round of the CUs, they are used.
+    static const int tiny = getenv("NZ_FLOW_TINY") ? atoi(getenv("NZ_FLOW_TINY")) : 1;  // 0: never; 2: every size (test matrix)
+    const int OH_t = FT_TH_TINY - 2 * H;
+    const long long blocks_t = OH_t > 0 ? (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH_t - 1) / OH_t) : 0;
+    const bool use_tiny = OH_t >= 4 && (tiny == 2 || (tiny == 1 && blocks_t * g.count <= nz_cu_count()));
+    if (use_tiny) blocks = blocks_t;
     uintptr_t bits = reinterpret_cast<uintptr_t>(h) | (uintptr_t)(g.pitch * 4);
     if (!first)
         for (int i = 0; i < 5; i++) bits |= reinterpret_cast<uintptr_t>(in[i]);
@@ -428,9 +439,14 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
     // (the kernel is register-allocated for four waves per SIMD = two 512-thread workgroups per CU: one workgroup per CU with
     // the whole register file lost twice, 0.342 against 0.241 ms)
     const bool fast = nz_tls_float_mode >= NZ_FLOAT_RELAXED;
-#define NZ_FFL(F, L, M)                                                                                                             \
-    NZ_LAUNCH((flow_fused_kernel<F, L, NZ_FT_OCC, M>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, h, w_in, fN_in, fS_in, fE_in, \
-              fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n, nmin, nrange, aligned)
+#define NZ_FFA h, w_in, fN_in, fS_in, fE_in, fW_in, w_out, fN_out, fS_out, fE_out, fW_out, dst, h_out, g, n, nmin, nrange, aligned
+#define NZ_FFL(F, L, M)                                                                                                          \
+    do {                                                                                                                         \
+        if (use_tiny)                                                                                                            \
+            NZ_LAUNCH((flow_fused_kernel<F, L, 4, M, FT_TH_TINY, 1024>), dim3((unsigned)blocks, g.count), dim3(1024), 0, s, NZ_FFA); \
+        else                                                                                                                     \
+            NZ_LAUNCH((flow_fused_kernel<F, L, NZ_FT_OCC, M, FT_TH, FT_NT>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, NZ_FFA); \
+    } while (0)
 #define NZ_FF(F, L)                    \
     do {                               \
         if (fast) NZ_FFL(F, L, true);  \
@@ -442,6 +458,7 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
     else NZ_FF(false, false);
 #undef NZ_FF
 #undef NZ_FFL
+#undef NZ_FFA
     NZ_HIP(hipGetLastError());
     return NZ_OK;
 }

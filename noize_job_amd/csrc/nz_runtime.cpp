@@ -215,6 +215,16 @@ static int32_t ctx_create(int32_t device, hipStream_t stream, bool own, nz_ctx *
     return NZ_OK;
 }
 
+int nz_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            return 256;
+        return v;
+    }();
+    return n;
+}
+
 extern "C" int32_t nz_ctx_create(int32_t device, nz_ctx **out) { return ctx_create(device, nullptr, true, out); }
 
 extern "C" int32_t nz_ctx_create_on_stream(int32_t device, void *hip_stream, nz_ctx **out) {

@@ -188,7 +188,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     // in two launches instead of three (round 5: Gauss5 x17 at 256^2 / 512^2 52 -> 42 / 43 us, 13 100 -> 13 900 tiles/s one at a
     // time; from 1024^2 on the deeper halo costs more than the launch it saves: 55 -> 59 us)
     if (t.ksize == 5 && cap == 5 && !getenv("NZ_CONV_TCAP") && nz_conv_small_grid(t.ksize, g))
-        cap = (long long)g.cols * (g.or1 - g.or0) * g.count <= 600 * 1024 ? 9 : 6;
+        cap = nz_conv_tiny_grid(t.ksize, g) ? 9 : 6;
     if (nz_conv_has_wide(t.ksize)) {  // one launch per application, ping-pong, copy back after an odd count
         float *cur = src, *other = tmp;
         for (int i = 0; i < iterations; i++) {
