@@ -780,6 +780,8 @@ static_assert(NZ_CONV_SMALL_NT / 32 * NZ_CONV_SMALL_RB == 64, "the hosts size a 
 // one 512^2 tile at a time: 256 x 8 rows 42.0 us, 512 x 4 rows 33.4 us, 1024 x 2 rows 30.9 us; at 2048^2 (several workgroups per
 // CU) 95.9 / 87.1 / 116 us.
 constexpr long long NZ_CONV_TINY_CELLS = 600 * 1024;
+// (At 1024^2 the 1024-thread shape is faster by itself, 42.8 against 45.4 us, and slower in a tile's pipeline, 9 720 against 9 930
+// tiles/s: a 1024-thread workgroup cannot start beside the tail of the stage before.)
 static inline bool conv_tiny_grid(const nz_geom &g) { return (long long)g.cols * (g.or1 - g.or0) * g.count <= NZ_CONV_TINY_CELLS; }
 #ifndef NZ_CONV_SMALL_CELLS
 #define NZ_CONV_SMALL_CELLS (7 * 1024 * 1024)

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(CT) void normalize_kernel(const float *src, float *
 #define NZ_FT_OCC 4
 #endif
 constexpr int FT_TH = 48, FT_TW = 128, FT_NT = NZ_FT_NT, FT_LP = FT_TW + 4;
-constexpr int FT_TH_TINY = 32;  // a tiny grid's tile: 32 rows, 1024 threads (nz_launch_flow_fused)
+constexpr int FT_TH_TINY = 32, FT_TH_MID = 64;  // the tiles of grids that fit one round of the CUs: 1024 threads (nz_launch_flow_fused)
 // FT_MAX_N = 5 (nz_flow_common.hpp): 2n halo rows, n = 5 leaves a 28 x 104 interior
 
 // (bound_ctrl: the lane without a source reads 0, and no v_mov 0 has to initialise the destination first)
@@ -418,11 +418,19 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
     // the launch waits for is the latency of one workgroup's dependent iterations.  32-row tiles of 1024 threads -- four cells
     // per thread, four waves per SIMD -- run an iteration in ~0.6 of the time of the 48-row tile's twelve cells per thread (more
     // workgroups, each with a third less work per SIMD): while they still fit one round of the CUs, they are used.
-    static const int tiny = getenv("NZ_FLOW_TINY") ? atoi(getenv("NZ_FLOW_TINY")) : 1;  // 0: never; 2: every size (test matrix)
+    static const int tiny = getenv("NZ_FLOW_TINY") ? atoi(getenv("NZ_FLOW_TINY")) : 1;  // 0: never; 2 / 3: the 32- / 64-row tile at every size (test matrix)
     const int OH_t = FT_TH_TINY - 2 * H;
     const long long blocks_t = OH_t > 0 ? (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH_t - 1) / OH_t) : 0;
     const bool use_tiny = OH_t >= 4 && (tiny == 2 || (tiny == 1 && blocks_t * g.count <= nz_cu_count()));
+    // ... and the next size up (768^2 ... 1024^2): 64-row tiles of 1024 threads -- eight cells per thread, four waves per SIMD,
+    // 0.69 of the tile is interior at n = 5 instead of 0.58 -- while THEY fit one round (the 48-row tile's 370 workgroups at
+    // 1024^2 are one and a half per CU: the launch lasts as long as the CUs that hold two).  Flow x5: 512^2 20.3 -> 15.3 us
+    // (32-row tiles), 1024^2 30.6 -> 26.1 us (64-row tiles); 768^2 keeps the 48-row tile (224 workgroups: 21.4 against 24.5 us)
+    const int OH_m = FT_TH_MID - 2 * H;
+    const long long blocks_m = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH_m - 1) / OH_m);
+    const bool use_mid = !use_tiny && (tiny == 3 || (tiny == 1 && blocks * g.count > nz_cu_count() && blocks_m * g.count <= nz_cu_count()));
     if (use_tiny) blocks = blocks_t;
+    if (use_mid) blocks = blocks_m;
     uintptr_t bits = reinterpret_cast<uintptr_t>(h) | (uintptr_t)(g.pitch * 4);
     if (!first)
         for (int i = 0; i < 5; i++) bits |= reinterpret_cast<uintptr_t>(in[i]);
@@ -444,6 +452,8 @@ int32_t nz_launch_flow_fused(hipStream_t s, const float *h, const float *const i
     do {                                                                                                                         \
         if (use_tiny)                                                                                                            \
             NZ_LAUNCH((flow_fused_kernel<F, L, 4, M, FT_TH_TINY, 1024>), dim3((unsigned)blocks, g.count), dim3(1024), 0, s, NZ_FFA); \
+        else if (use_mid)                                                                                                        \
+            NZ_LAUNCH((flow_fused_kernel<F, L, 4, M, FT_TH_MID, 1024>), dim3((unsigned)blocks, g.count), dim3(1024), 0, s, NZ_FFA); \
         else                                                                                                                     \
             NZ_LAUNCH((flow_fused_kernel<F, L, NZ_FT_OCC, M, FT_TH, FT_NT>), dim3((unsigned)blocks, g.count), dim3(FT_NT), 0, s, NZ_FFA); \
     } while (0)

@@ -6,7 +6,7 @@ KNOBS=(NZ_POOL_RUNS=0 NZ_CONV_CHAIN=0 NZ_CONV_CHAIN=2 NZ_WIDE_BIG_FROM=11 NZ_NOI
        NZ_CONV_TCAP=2 NZ_CONV_TCAP=8 NZ_FLOW_NMAX=1 NZ_FLOW_NMAX=3 NZ_EROSION_EMAX=1 NZ_EROSION_EMAX=4
        NZ_EROSION_EMAX=5 NZ_FLOW_STREAM=0 NZ_FLOW_STREAM=2 NZ_CONV_STREAM=2 "NZ_FLOW_STREAM=2 NZ_FLOW_STREAM_WAVES=512"
        "NZ_CONV_STREAM=2 NZ_CONV_STREAM_WAVES=700" NZ_POOL_SPARSE=0 NZ_POOL_SPARSE=2 NZ_CONV_STREAM=0
-       NZ_CONV_SMALL=0 NZ_CONV_SMALL=2 "NZ_CONV_SMALL=2 NZ_CONV_CHAIN=2" NZ_PILE_TICKET=0 NZ_PILE_CARRY_FLOW=0 NZ_FLOW_TINY=0 NZ_FLOW_TINY=2)
+       NZ_CONV_SMALL=0 NZ_CONV_SMALL=2 "NZ_CONV_SMALL=2 NZ_CONV_CHAIN=2" NZ_PILE_TICKET=0 NZ_PILE_CARRY_FLOW=0 NZ_FLOW_TINY=0 NZ_FLOW_TINY=2 NZ_FLOW_TINY=3)
 first=${1:-0}; last=${2:-$((${#KNOBS[@]} - 1))}
 for ((i = first; i <= last && i < ${#KNOBS[@]}; i++)); do
   kv=${KNOBS[$i]}
