@@ -765,11 +765,11 @@ int32_t launch_wide(hipStream_t s, const float *src, float *dst, const nz_geom &
 // applications: 64-row tiles hold half the cells per CU, and FOUR rows per thread (512 threads, two waves per SIMD: a lone
 // wave issues a VALU instruction every ~6.6 cycles, two between them every ~4) instead of eight (256 threads, rounds 4 - 5)
 // take another fifth off an application: Gauss5 x17 at 512^2 42.0 -> 33.4 us, 1024^2 53.0 -> 45.5, 2048^2 95.9 -> 87.1.
-// Such a grid also runs its fused launches one after the other, not as a chained grid: with a few dozen tiles per launch
-// the polls and the sc1 accesses of the chain cost more than the launch boundaries it saves.  Gauss5 x17, one tile at a
-// time, 128-row tiles chained -> 64-row tiles in four launches: 256^2 80 -> 52 us, 512^2 81 -> 52, 1024^2 89 -> 54, 1536^2
-// 98 -> 74, 2048^2 110 -> 97, 2560^2 126 -> 117; 2816^2 127 against 131 and 3072^2 134 against 151: from 7 M cells on the
-// big tiles and the chain stay.
+// (Round 4, eight rows per thread, launches one after the other: Gauss5 x17 one tile at a time, 128-row tiles chained -> 64-row
+// tiles in four launches: 256^2 80 -> 52 us, 512^2 81 -> 52, 1024^2 89 -> 54, 1536^2 98 -> 74, 2048^2 110 -> 97, 2560^2 126 ->
+// 117; 2816^2 127 against 131 and 3072^2 134 against 151.  Round 5, four rows per thread, chained from two launches on
+// (nz_stages.cpp): 2048^2 68, 2560^2 95, 3072^2 133 against 124 with the big tiles, 4096^2 221 against 188: from 7 M cells on the
+// big tiles stay.)
 #ifndef NZ_CONV_SMALL_NT
 #define NZ_CONV_SMALL_NT 512  // the 64-row tile of a small grid: NZ_CONV_SMALL_NT threads x NZ_CONV_SMALL_RB rows each
 #define NZ_CONV_SMALL_RB 4
@@ -877,7 +877,7 @@ int32_t launch_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom 
 
 }  // namespace
 
-// a grid the 5-, 7- and 9-tap kernels serve with 64-row tiles and separate launches (see conv_small_grid)
+// a grid the 5-, 7- and 9-tap kernels serve with 64-row tiles (see conv_small_grid)
 bool nz_conv_small_grid(int ksize, const nz_geom &g) { return conv_small_grid(ksize, g); }
 // ... and so small that a launch is at most a workgroup per CU (the 5-tap kernel then fuses nine applications, nz_stages.cpp)
 bool nz_conv_tiny_grid(int ksize, const nz_geom &g) { return conv_small_grid(ksize, g) && conv_tiny_grid(g); }

@@ -220,7 +220,7 @@ int32_t nz_launch_conv_stream(hipStream_t s, const float *src, float *dst, const
 // L launches as one grid with tile-level dependencies; see nz_filter.hip
 int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L);
 int nz_cu_count();  // compute units of the current device (256 on MI355X): a launch of at most this many workgroups is one round
-bool nz_conv_small_grid(int ksize, const nz_geom &g);  // 64-row tiles, launches not chained
+bool nz_conv_small_grid(int ksize, const nz_geom &g);  // 64-row tiles
 bool nz_conv_tiny_grid(int ksize, const nz_geom &g);
 int32_t nz_launch_conv_chain(hipStream_t s, float *plane0, float *plane1, const nz_geom &g, const nz_kernel_taps &k,
                              const int *Ts, int L, int *flags, unsigned epoch, unsigned *err_host, unsigned *err_epoch);

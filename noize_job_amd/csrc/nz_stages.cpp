@@ -257,9 +257,12 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     static const int chain_mode = getenv("NZ_CONV_CHAIN") ? atoi(getenv("NZ_CONV_CHAIN")) : 1;
     // (where the row-streaming form of a launch applies -- big grids, 3 / 5 taps -- plain launches of it are faster still)
     const bool streamed = nz_conv_stream_wanted(g, t.ksize, base + (rem ? 1 : 0)) && nz_conv_stream_wanted(g, t.ksize, base);
-    // (a small grid -- fewer than ~7 M cells -- keeps separate launches: nz_filter.hip, conv_small_grid)
+    // (A small grid -- fewer than ~7 M cells, 64-row tiles -- chains from TWO launches on since round 5: with the ticket gone and
+    // four rows per thread the chained grid wins there too.  Gauss5 x17 2048^2 87.2 -> 67.9 us, 2560^2 110.9 -> 95.0; 1024^2 by
+    // itself 45.6 -> 47.3 us, in a tile's pipeline 10 550 -> 11 020 tiles/s (one launch to enqueue and to start instead of three);
+    // 512^2 18 000 -> 18 100.  Rounds 3 - 4 kept separate launches here: 512^2 55.7 against 51.7 us then.)
     const bool chain_on = !streamed && !ctx->chain_off &&
-                          (chain_mode == 2 ? L >= 2 : (chain_mode == 1 && L >= 3 && t.ksize >= 5 && !nz_conv_small_grid(t.ksize, g)));
+                          (chain_mode == 2 ? L >= 2 : (chain_mode == 1 && t.ksize >= 5 && L >= (nz_conv_small_grid(t.ksize, g) ? 2 : 3)));
     if (chain_on && L <= 8 && g.count == 1 && (size_t)g.rows * g.pitch * 4 < ((size_t)1 << 32) &&
         (swapped || !(L & 1))) {
         // T must not decrease along the chain: a tile of launch l + 1 waits for the launch-l tiles whose INTERIOR meets
