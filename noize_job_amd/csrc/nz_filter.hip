@@ -109,6 +109,9 @@ __device__ unsigned long long *nz_probe_buf = nullptr;  // [workgroup][24]
 #ifndef NZ_CONV5_WAVES
 #define NZ_CONV5_WAVES 6
 #endif
+// edge-row buffers: two (one barrier per application) for the 3-tap kernel, one (two barriers) for the others -- see conv_tile.
+// (The small grids' shapes with two: Gauss5 x17 512^2 30.1 -> 29.5 us, 1024^2 47.8 -> 48.8, 2048^2 67.9 -> 76.9: one it stays.)
+constexpr int conv_nbuf(int o) { return (o == 2 && NZ_CONV5_NBUF == 2) ? 2 : (o >= 2 ? 1 : 2); }
 constexpr int conv_waves(int ks, int nt, int rbt) { return rbt < RB ? 4 : ks == 5 ? NZ_CONV5_WAVES : (nt >= 512 || ks >= 7) ? 4 : 6; }
 
 // 16-byte accesses that other XCDs can see / that see other XCDs' stores while the kernel runs: `sc1` buffer loads and
@@ -160,7 +163,7 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
     // boundary rows of every 8-row block: [parity][block][top|bottom][o][column group].  Double buffered
     // (one barrier per application) for the 3-tap kernel; the others keep one buffer and pay a second barrier
     // instead of giving up a resident workgroup (5 taps: 3 x 32 KB; 7/9 taps: 2 x 48/64 KB).
-    constexpr int NBUF = (O == 2 && NZ_CONV5_NBUF == 2) ? 2 : (O >= 2 ? 1 : 2);
+    constexpr int NBUF = conv_nbuf(O);
     float4 (*s_edge)[TH / RBT][2][O][TW / 4] = reinterpret_cast<float4 (*)[TH / RBT][2][O][TW / 4]>(s_edge_raw);
 
     const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
                                                      nz_kernel_taps taps, int T, int aligned) {
     constexpr int O = (KS - 1) / 2;
     constexpr int TH = NT / 32 * RBT;
-    constexpr int NBUF = (O == 2 && NZ_CONV5_NBUF == 2) ? 2 : (O >= 2 ? 1 : 2);
+    constexpr int NBUF = conv_nbuf(O);
     __shared__ float4 s_edge[NBUF][TH / RBT][2][O][TW / 4];
     const int H = T * O, HX = (H + 3) & ~3;
     src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
                                                                                                                        nz_chain ch, int aligned) {
     constexpr int O = (KS - 1) / 2;
     constexpr int TH = NT / 32 * RBT;
-    constexpr int NBUF = (O == 2 && NZ_CONV5_NBUF == 2) ? 2 : (O >= 2 ? 1 : 2);
+    constexpr int NBUF = conv_nbuf(O);
     __shared__ float4 s_edge[NBUF][TH / RBT][2][O][TW / 4];
     NZ_PB_INIT;
     NZ_PROBE_T(18);  // the workgroup's first instruction (after the kernel arguments' scalar loads)
