@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times one stage of the metric pipeline in isolation (HIP events on the context's stream).
-usage: bench_stage.py {noise|gauss|flow|erosion|mesh|all} [--res 4096] [--reps 20]"""
+usage: bench_stage.py {noise|gauss|flow|erosion|mesh|all} [--res 4096] [--reps 20] [--pair]"""
 import argparse
 import os
 import sys
@@ -21,11 +21,12 @@ def main():
     ap.add_argument("--gauss", type=int, default=17)
     ap.add_argument("--flow", type=int, default=5)
     ap.add_argument("--erosion", type=int, default=5)
+    ap.add_argument("--pair", action="store_true", help="a READ / WRITE plane pair, as the tile pipelines use (no flush copies, free launch counts)")
     a = ap.parse_args()
     res = a.res
     with nj.Context(0) as ctx:
         data = ctx.alloc(res * res)
-        gd = nj.GeneratorData("b", data, res, 0, 0)
+        gd = nj.GeneratorData("b", data, res, 0, 0, write=ctx.alloc(res * res) if a.pair else None)
         stages = {"noise": nj.NoiseStage(ctx, nj.FractalNoise(a.basis), 0.4, 1.0, a.octaves, 2.0, 0.0, 1700),
                   "gauss": nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, a.gauss),
                   "flow": nj.FlowMapStage(ctx, a.flow, 0.0, 0.005),

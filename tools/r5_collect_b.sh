@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 evidence, part B (one GPU call): stalls, conv phase profile, next rows with counters, tiles, config 4, the rank rehearsal.
 #   tools/r5_collect_b.sh <tag> <commit>
-TAG=${1:-r05_v1}
+TAG=${1:-r05_v2}
 COMMIT=${2:-unknown}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
@@ -10,7 +10,8 @@ bash tools/collect_stalls.sh ${TAG} strict > gpurun_out/${TAG}_stalls.log 2>&1; 
 bash tools/collect_stalls.sh ${TAG}_fast fast > gpurun_out/${TAG}_fast_stalls.log 2>&1; echo "stalls fast done"
 bash tools/collect_next.sh ${TAG} $COMMIT strict > /dev/null 2>&1; echo "next rows strict done"
 python3 tools/bench_next.py --float-mode fast > gpurun_out/${TAG}_fast_next_rows.txt 2>&1; echo "next rows fast done"
-python3 tools/bench_tiles.py > gpurun_out/${TAG}_tiles.txt 2>&1; echo "tiles done"
+python3 tools/bench_tiles.py --res 256 512 768 1024 2048 --streams 1 2 4 > gpurun_out/${TAG}_tiles.txt 2>&1
+for r in 256 512 768 1024 2048; do python3 tools/bench_stage.py all --pair --res $r --reps 200 2>/dev/null | tail -5 >> gpurun_out/${TAG}_tiles.txt; done; echo "tiles done"
 python3 bench.py --as-rank 3 8 --halo recompute > gpurun_out/${TAG}_rank3of8_recompute.json 2>/dev/null
 python3 bench.py --as-rank 3 8 --halo exchange > gpurun_out/${TAG}_rank3of8_exchange_o0.json 2>/dev/null
 echo "rank rehearsal done"
