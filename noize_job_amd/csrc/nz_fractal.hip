@@ -178,7 +178,11 @@ __device__ __forceinline__ float fmod_lattice(float x, float per, float inv_lo) 
     return copysignf(r, x);
 }
 
-// noise.psrnoise(float2 pos, float2 per = (1010,102), rot), Appendix A.4
+// noise.psrnoise(float2 pos, float2 per = (1010,102), rot), Appendix A.4.
+// WX / WY = false: the caller has shown that no lattice coordinate of this sample reaches the period in x / y
+// (|p.x| <= |pos.x| + |pos.y| + 2.5 and |p.y| <= |pos.y| + 2 for the three corners), where fmod(x, per) == x bit for bit and
+// the wrap is left out: the first six octaves of a 4096^2 tile at the default scale wrap nowhere, the next three only in y.
+template <bool WX = true, bool WY = true>
 __device__ __forceinline__ float psrnoise2(float posx, float posy, const psr_tables &tab) {
     const float perx = 1010.0f, pery = 102.0f;
     posy += 0.001f;
@@ -195,9 +199,10 @@ __device__ __forceinline__ float psrnoise2(float posx, float posy, const psr_tab
     float d2x = posx - p2x, d2y = posy - p2y;
     constexpr float ipx = (1.0f / 1010.0f) * (1.0f - 0x1p-22f), ipy = (1.0f / 102.0f) * (1.0f - 0x1p-22f);
     float2 g0, g1, g2;
-    if (NZ_PSR_FMOD && fabsf(posx) < PSR_FAST_LIMIT && fabsf(posy) < PSR_FAST_LIMIT) {
-        float xw0 = fmod_lattice(p0x, perx, ipx), xw1 = fmod_lattice(p1x, perx, ipx), xw2 = fmod_lattice(p2x, perx, ipx);
-        float yw0 = fmod_lattice(p0y, pery, ipy), yw1 = fmod_lattice(p1y, pery, ipy), yw2 = fmod_lattice(p2y, pery, ipy);
+    if (!WX || !WY || (NZ_PSR_FMOD && fabsf(posx) < PSR_FAST_LIMIT && fabsf(posy) < PSR_FAST_LIMIT)) {
+        float xw0 = p0x, xw1 = p1x, xw2 = p2x, yw0 = p0y, yw1 = p1y, yw2 = p2y;
+        if (WX) { xw0 = fmod_lattice(p0x, perx, ipx); xw1 = fmod_lattice(p1x, perx, ipx); xw2 = fmod_lattice(p2x, perx, ipx); }
+        if (WY) { yw0 = fmod_lattice(p0y, pery, ipy); yw1 = fmod_lattice(p1y, pery, ipy); yw2 = fmod_lattice(p2y, pery, ipy); }
         g0 = rgrad2_tab(xw0 + 0.5f * yw0, yw0, tab);
         g1 = rgrad2_tab(xw1 + 0.5f * yw1, yw1, tab);
         g2 = rgrad2_tab(xw2 + 0.5f * yw2, yw2, tab);
@@ -934,6 +939,10 @@ __global__ __launch_bounds__(FR_THREADS) void fractal_kernel(float *__restrict__
     float xi[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; c++) xi[c] = ((float)(x0 + c) + p.posx) / p.noise_size;
+    // |xi| over the workgroup's columns (xi is monotonic in the column: the ends bound it)
+    const float xi_first = ((float)(bx * FR_THREADS * VEC) + p.posx) / p.noise_size;
+    const float xi_last = ((float)(min((bx + 1) * FR_THREADS * VEC, cols) - 1) + p.posx) / p.noise_size;
+    const float xreach = fmaxf(fabsf(xi_first), fabsf(xi_last));
     // p.rows_per_wg rows per workgroup: 8 amortise the table fill of the periodic bases on big grids
     int zend = min(rows, (by + 1) * p.rows_per_wg);
     for (int z = by * p.rows_per_wg; z < zend; z++) {
@@ -944,10 +953,27 @@ __global__ __launch_bounds__(FR_THREADS) void fractal_kernel(float *__restrict__
         float detune = 0.0f, f = 1.0f, a = p.amp;
         for (int i = 0; i < p.octaves; i++) {
             float zV = f * zi;
+            if constexpr (USES_TAB) {
+                // which coordinates of this octave can reach psrnoise's periods anywhere in the workgroup's cells (uniform:
+                // the bounds come from the workgroup's first and last column and the row)
+                const float zr = fabsf(zV) + 0.001f, xr = fabsf(f) * xreach;
+                const int nowrap = __builtin_amdgcn_readfirstlane((xr + zr + 3.5f < 1000.0f ? 1 : 0) | (zr + 3.0f < 100.0f ? 2 : 0));
+                if (nowrap == 3) {
 #pragma unroll
-            for (int c = 0; c < VEC; c++) {
-                float xV = f * xi[c];
-                t[c] += a * noise_value<BASIS>(xV, zV, tabs);
+                    for (int c = 0; c < VEC; c++) t[c] += a * rectify(psrnoise2<false, false>(f * xi[c], zV, tabs));
+                } else if (nowrap == 1) {
+#pragma unroll
+                    for (int c = 0; c < VEC; c++) t[c] += a * rectify(psrnoise2<false, true>(f * xi[c], zV, tabs));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < VEC; c++) t[c] += a * noise_value<BASIS>(f * xi[c], zV, tabs);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < VEC; c++) {
+                    float xV = f * xi[c];
+                    t[c] += a * noise_value<BASIS>(xV, zV, tabs);
+                }
             }
             detune += p.detune_rate;
             f *= (p.stepdown - detune);

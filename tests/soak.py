@@ -28,7 +28,6 @@ while time.time() < deadline:
     np.random.default_rng = lambda s=None, _k=seed: orig_rng(None if s is None else s * 7919 + _k)
     for name, fn, args in (("stencils", S.test_filters_erosion_flow_random_sizes, (nj, ctx, O, 1)),
                            ("pairs", S.test_rw_pair_random_stage_chains, (nj, ctx, O, 1)),
-                           ("striped", S.test_striped_tile_random_shapes, (nj, ctx, O, 1)),
                            ("mesh", S.test_mesh_random_shapes, (nj, ctx, O, 1)),
                            ("stripes", S.test_stripe_entry_points_random_geometry_and_pitch, (nj, ctx, O, 1)),
                            ("noise", S.test_noise_random_parameters, (nj, ctx, O, 1 + seed % 7)),

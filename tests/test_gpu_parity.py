@@ -77,6 +77,25 @@ def test_negative_lattice_cells_where_fp32_mod289_returns_289(nj, ctx, oracle, b
         d.data.Dispose()
 
 
+@pytest.mark.parametrize("basis", [2, 4], ids=[BASES[2], BASES[4]])
+def test_psrnoise_where_the_lattice_wraps_begin(nj, ctx, oracle, basis):
+    # the psrnoise kernels leave the wrap by the periods (1010, 102) out where no lattice coordinate of a workgroup's cells
+    # can reach them, per octave and per row: tiles whose octaves sit on either side of both thresholds, rows and columns
+    # that cross them inside the tile (coordinate = (cell + pos) / noiseSize * 2^octave), wider than one workgroup
+    for (res, octv, ns, xp, zp) in [(640, 8, 4, 0, 0),          # x reaches 160 * 2^o: wraps from octave 3; y: from octave 0 on
+                                    (300, 6, 3, 2400, -250),   # |x| in [800, 900]: at the x bound (1000 - |y| - 3.5) from octave 0
+                                    (300, 6, 3, -3290, 280),   # negative x just short of -1010, y just short of 102
+                                    (1100, 5, 11, -6000, -600),  # the thresholds cross the tile in both directions
+                                    (257, 13, 1700, 0, 0)]:    # the default scale: no wrap in the first octaves
+        st = nj.NoiseStage(ctx, nj.FractalNoise(basis), 0.5, 1.0, octv, 2.0, 0.0, ns)
+        d = gen(nj, ctx, res, xpos=xp, zpos=zp)
+        got = run(st, nj, d)
+        want = oracle.fractal(basis, res, res, 0.5, 1.0, 2.0, 0.0, octv, xp, zp, ns)
+        assert np.array_equal(got, want), "%s ns=%d pos=(%d,%d): %d cells differ" % (
+            BASES[basis], ns, xp, zp, int((got != want).sum()))
+        d.data.Dispose()
+
+
 def test_fractal_config1_plumbing(nj, ctx, oracle):
     # BASELINE config 1: 1024^2 Perlin, 8 octaves, hurst 0.5
     st = nj.NoiseStage(ctx, nj.FractalNoise.Perlin, 0.5, 1.0, 8, 2.0, 0.0, 1000)
