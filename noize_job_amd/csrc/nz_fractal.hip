@@ -434,6 +434,7 @@ constexpr int NZ_T1_N = 292, NZ_T2_N = 580;
 // limit (NaN included) take the direct evaluation, which follows the reference's arithmetic wherever it leads.
 constexpr float NZ_TAB_LIMIT = 1048576.0f;
 
+// (returns snoise / 2: see the end)
 __device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1, const float4 *s_t2) {
     const float Cx = 0.211324865405187f, Cy = 0.366025403784439f, Cz = -0.577350269189626f;
     float s = vx * Cy + vy * Cy;
@@ -471,8 +472,12 @@ __device__ __forceinline__ float snoise2_tab(float vx, float vy, const int *s_t1
     float q0 = g0.x * x0x + g0.y * x0y;
     float q1 = g1.x * x12x + g1.y * x12y;
     float q2 = g2.x * x12z + g2.y * x12w;
-    return 130.0f * (m0 * q0 + m1 * q1 + m2 * q2);
+    // rectify(130 n) = (1 + 130 n) / 2 = 0.5 + 65 n BIT FOR BIT: scaling by two commutes with rounding, so RN(130 n) / 2 ==
+    // RN(65 n) and RN(1 + v) / 2 == RN(0.5 + v / 2) (where v is small enough for a halving to lose a denormal bit, both
+    // forms return 0.5).  The caller adds the 0.5: one multiply and one add instead of two multiplies and an add.
+    return 65.0f * (m0 * q0 + m1 * q1 + m2 * q2);
 }
+__device__ __forceinline__ float rectify_half(float half_v) { return 0.5f + half_v; }  // rectify(v), given v / 2
 
 // ---- tolerance mode (NZ_FLOAT_FAST, nz_ctx_set_float_mode) ---------------------------------------------------------
 // The reference compiles FractalJob with FloatMode.Fast (Noise/Fractal/Fractal.cs:19): its own results move with the
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restr
 #pragma unroll
                 for (int c = 0; c < VEC; c++) {
                     float xV = f * xi[c];
-                    t[c] += a * rectify(snoise2_tab(xV, zV, s_t1, s_t2));
+                    t[c] += a * rectify_half(snoise2_tab(xV, zV, s_t1, s_t2));
                 }
                 detune += p.detune_rate;
                 f *= (p.stepdown - detune);
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(256) void fractal_simplex_tab_kernel(float *__restr
                 }
                 if (!FAST && big < NZ_TAB_LIMIT) {  // (tolerance mode: beyond the tables' range the strict direct form)
 #pragma unroll
-                    for (int c = 0; c < VEC; c++) t[c] += a * rectify(snoise2_tab(xV[c], zV, s_t1, s_t2));
+                    for (int c = 0; c < VEC; c++) t[c] += a * rectify_half(snoise2_tab(xV[c], zV, s_t1, s_t2));
                 } else {
                     asm volatile("; direct evaluation" ::: "memory");
 #pragma unroll
