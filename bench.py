@@ -53,10 +53,11 @@ STAGES = ["noise", "gauss", "flow", "erosion"]
 KERNEL_PREFIX = {"noise": ("fractal_simplex_tab_kernel",), "gauss": ("conv_chain_kernel<5", "conv_reg_kernel<5"),
                  "flow": ("flow_stream_kernel", "flow_fused_kernel"), "erosion": ("erosion_reg_kernel",)}
 # algorithmic fp32 lane-operations per cell (no FMA contraction anywhere, so a multiply-add is two): fBm 13
-# octaves x ~85; one 5-tap application = 2 passes x (5 mul + 4 add); one flow iteration ~40 + velocity / normalise ~15; one
+# octaves x 82 (the table form's octave-cell in the ISA: skew, two floors, unskew, two mod289, the table offsets, three corner
+# falloffs and dots, 0.5 + 65 n, the amplitude; "~85" until round 5 folded rectify); one 5-tap application = 2 passes x (5 mul + 4 add); one flow iteration ~40 + velocity / normalise ~15; one
 # value-erosion application = 2 min.  useful_valu_frac = this x cells / (SQ_INSTS_VALU x 64): what the halo recompute,
 # selects, moves and address arithmetic leave of the instructions executed
-ALGO_LANE_OPS = {"noise": 13 * 85.0, "gauss": G_IT * 18.0, "flow": F_IT * 40.0 + 15.0, "erosion": E_IT * 2.0}
+ALGO_LANE_OPS = {"noise": 13 * 82.0, "gauss": G_IT * 18.0, "flow": F_IT * 40.0 + 15.0, "erosion": E_IT * 2.0}
 # the same in lane-INSTRUCTIONS of the tolerance forms (an FMA is one): the fBm octave with its polynomial tail contracted
 # (64 per octave-cell in the ISA), a 5-tap application as 2 x (1 mul + 4 fma), a flow iteration with v_rcp_f32 for the division
 ALGO_LANE_OPS_MODE = {"strict": ALGO_LANE_OPS,

@@ -129,7 +129,7 @@ def test_reduce_pipeline_joins_two_contexts_on_the_device(nj, ctx, oracle):
 
 
 def test_contexts_report_their_device(nj):
-    # nz_ctx_device: what a host needs to put a second context (LiveErosion.parallelBranch) on the main context's device
+    # nz_ctx_device: what a host needs to put a second context (another pipeline, a tile server) on the first context's device
     n = nj.Context.device_count()
     for dev in range(min(n, 2)):
         with nj.Context(dev) as c:

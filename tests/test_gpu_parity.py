@@ -776,6 +776,27 @@ def test_rw_pair_pipeline_equals_the_in_place_pipeline(nj, ctx, oracle):
     assert np.array_equal(outs[0], oracle.constant(oracle.pipeline(res, res, xpos=40, zpos=-7), 0, 0.5))
 
 
+@pytest.mark.parametrize("res", [256, 280, 512, 768, 1000, 1024, 1536])
+def test_metric_pipeline_at_the_references_tile_sizes(nj, ctx, oracle, res):
+    """The reference's own tile sizes take launch shapes of their own (64-row filter tiles of 1024 x 2 or 512 x 4 rows, chained
+    from two launches on; 32-, 48- or 64-row flow tiles, whichever covers the grid in one round of the CUs): the stock stage
+    list on a single plane and on a READ / WRITE pair, bit for bit the oracle's tile."""
+    want = oracle.pipeline(res, res, xpos=3 * res, zpos=-res)
+    for pair in (False, True):
+        d = nj.GeneratorData("p", ctx.alloc(res * res), res, 3 * res, -res, write=ctx.alloc(res * res) if pair else None)
+        pipe = nj.BasePipeline([nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700),
+                                nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17),
+                                nj.FlowMapStage(ctx, 5, 0.0, 0.005), nj.ErosionStage(ctx, 5)])
+        seen = []
+        pipe.Enqueue(d, completeAction=lambda x: seen.append(x.data.ToArray((res, res))))
+        pipe.RunToCompletion()
+        pipe.Destroy()
+        assert np.array_equal(seen[0], want), (res, pair, int((seen[0] != want).sum()))
+        d.data.Dispose()
+        if pair:
+            d.write.Dispose()
+
+
 def test_rw_pair_batch_and_errors(nj, ctx, oracle):
     res, count = 96, 3
     b = nj.GeneratorDataBatch.create(ctx, "b", res, [(96 * k, -3 * k) for k in range(count)])
