@@ -446,24 +446,37 @@ def self_launch(argv, gpus):
     launcher's code."""
     import socket
     import subprocess
-    with socket.socket() as sk:  # a free port for the rendezvous
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import tempfile
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this pool
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
-          [a for a in argv if a != "--self-launch"]
-    print("bench.py: no launcher (WORLD_SIZE unset): starting %d rank(s): %s" % (gpus, " ".join(cmd)), file=sys.stderr)
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    last = None
-    for line in child.stdout:
-        if line.startswith("{"):
-            last = line
-        else:
-            sys.stderr.write(line)
-    rc = child.wait()
+    rc, last = 1, None
+    for attempt in range(3):
+        with socket.socket() as sk:  # a free port for the rendezvous
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+              [a for a in argv if a != "--self-launch"]
+        print("bench.py: no launcher (WORLD_SIZE unset): starting %d rank(s): %s" % (gpus, " ".join(cmd)), file=sys.stderr)
+        with tempfile.TemporaryFile("w+") as err:
+            child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=err, text=True)
+            last = None
+            for line in child.stdout:
+                if line.startswith("{"):
+                    last = line
+                else:
+                    sys.stderr.write(line)
+            rc = child.wait()
+            err.seek(0)
+            text = err.read()
+        sys.stderr.write(text)
+        # the port was free when it was probed and taken when the launcher's store bound it (another process of the box, a
+        # socket of an earlier run still closing): nothing has touched a GPU yet, take another port
+        if rc and last is None and "EADDRINUSE" in text and attempt < 2:
+            print("bench.py: port %d was taken before the rendezvous bound it; trying another" % port, file=sys.stderr)
+            continue
+        break
     if last is not None:
         sys.stdout.write(last)
         sys.stdout.flush()
