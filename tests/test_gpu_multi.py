@@ -18,6 +18,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _spawn(fn, world, make_args):
+    """mp.spawn on a rendezvous port probed as free; the port can be gone by the time rank 0 binds it (another process of
+    the box, a socket still closing): that one failure is retried on another port."""
+    import torch.multiprocessing as mp
+    for attempt in range(3):
+        try:
+            mp.spawn(fn, args=make_args(_free_port()), nprocs=world, join=True)
+            return
+        except Exception as e:  # ProcessRaisedException carries the rank's traceback as text
+            if attempt == 2 or not any(t in str(e) for t in ("EADDRINUSE", "address already in use", "Address already in use")):
+                raise
+
+
 def _worker(rank, world, port, grows, cols, pkw, out_path):
     import sys
     sys.path.insert(0, ROOT)
@@ -72,7 +85,7 @@ def test_nccl_sharded_equals_monolithic(oracle, tmp_path, mode):
     pkw = dict(octaves=8, noiseSize=300, gaussIterations=17, flowIterations=5, erosionIterations=5, xpos=100, zpos=900,
                haloMode=mode)
     out = str(tmp_path / "sharded.npy")
-    mp.spawn(_worker, args=(world, _free_port(), grows, cols, pkw, out), nprocs=world, join=True)
+    _spawn(_worker, world, lambda port: (world, port, grows, cols, pkw, out))
     want = oracle.pipeline(grows, cols, octaves=8, noise_size=300, xpos=100, zpos=900)
     assert np.array_equal(np.load(out), want)
     rng_want = oracle.get_map_range(want)

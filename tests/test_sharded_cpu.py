@@ -19,6 +19,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _spawn(fn, world, make_args):
+    """mp.spawn on a rendezvous port probed as free; the port can be gone by the time rank 0 binds it (another process of
+    the box, a socket still closing): that one failure is retried on another port."""
+    for attempt in range(3):
+        try:
+            mp.spawn(fn, args=make_args(_free_port()), nprocs=world, join=True)
+            return
+        except Exception as e:  # ProcessRaisedException carries the rank's traceback as text
+            if attempt == 2 or not any(t in str(e) for t in ("EADDRINUSE", "address already in use", "Address already in use")):
+                raise
+
+
 def _worker(rank, world, port, grows, cols, pkw, out_path, overlap=True):
     import sys
     sys.path.insert(0, ROOT)
@@ -57,7 +69,7 @@ def test_sharded_schedule_equals_monolithic(oracle, tmp_path, world, grows, cols
     pkw = dict(octaves=6, noiseSize=40, gaussIterations=7, flowIterations=3, erosionIterations=4, xpos=11, zpos=5,
                haloMode="exchange" if mode == "exchange_blocking" else mode)
     out = str(tmp_path / "sharded.npy")
-    mp.spawn(_worker, args=(world, _free_port(), grows, cols, pkw, out, overlap), nprocs=world, join=True)
+    _spawn(_worker, world, lambda port: (world, port, grows, cols, pkw, out, overlap))
     got = np.load(out)
     want = oracle.pipeline(grows, cols, octaves=6, noise_size=40, gauss_iterations=7, flow_iterations=3,
                            erosion_iterations=4, xpos=11, zpos=5)
@@ -108,7 +120,7 @@ def test_global_map_range_all_gather_equals_monolithic(oracle, tmp_path, world, 
     # ends with the monolithic {min, max, range} bit for bit and normalises its rows with it
     grows, cols = 30, 17
     out = str(tmp_path / "range.npz")
-    mp.spawn(_range_worker, args=(world, _free_port(), grows, cols, case, out), nprocs=world, join=True)
+    _spawn(_range_worker, world, lambda port: (world, port, grows, cols, case, out))
     got = np.load(out)
     a = _range_case(case, grows, cols)
     want = oracle.get_map_range(a, *_RANGE_LIMS[case])
