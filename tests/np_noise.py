@@ -51,14 +51,20 @@ def cnoise2(px, py):  # A.2
     return f(2.3) * lerp(nx0, nx1, fdy)
 
 
-def snoise2(vx, vy):  # A.3
+def snoise2(vx, vy, permute_mul=34.0, invert_i1=False, cy_scale=1.0):  # A.3
+    """The three keyword arguments are MUTATIONS for negative controls (tests/test_reference_screenshots.py): a hash
+    multiplier other than 34, the simplex corner select inverted, the skew constant C.y scaled.  Defaults = the spec."""
     vx, vy = np.asarray(vx, f), np.asarray(vy, f)
     Cx, Cy, Cz, Cw = f(0.211324865405187), f(0.366025403784439), f(-0.577350269189626), f(0.024390243902439)
+    Cy = f(Cy * f(cy_scale))
+
+    def permute(x):  # shadows the module's permute only when mutated
+        return mod289((f(permute_mul) * x + f(1.0)) * x)
     s = vx * Cy + vy * Cy                      # dot(v, C.yy)
     ix, iy = np.floor(vx + s), np.floor(vy + s)
     t = ix * Cx + iy * Cx                      # dot(i, C.xx)
     x0x, x0y = vx - ix + t, vy - iy + t
-    gt = x0x > x0y
+    gt = (x0x > x0y) != bool(invert_i1)
     i1x, i1y = np.where(gt, f(1.0), f(0.0)), np.where(gt, f(0.0), f(1.0))
     x12 = [x0x + Cx, x0y + Cx, x0x + Cz, x0y + Cz]
     x12[0] = x12[0] - i1x
