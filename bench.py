@@ -439,6 +439,40 @@ def cpu_baseline(res):
                       "read-write pass" % (CPU_PASSES, res, res, dt, flags)}, plane
 
 
+def stage_planes(res):
+    """The oracle's plane after every stage of the metric pipeline (the checker's intermediates; ~ one CPU pass)."""
+    import oracle as O
+    noise = O.fractal(O.SIMPLEX, res, res, 0.4, 1.0, 2.0, 0.0, 13, 0, 0, 1700)
+    gauss = O.kernel_filter(noise, O.GAUSS5_S1, G_IT)
+    flow = O.flowmap(gauss, F_IT, 0.0, 0.005)
+    return {"noise": noise, "gauss": gauss, "flow": flow, "erosion": O.erosion_min(flow, E_IT)}
+
+
+def stages_within_tolerance(np, nj, ctx, p, res, want):
+    """Every stage of the metric pipeline in the context's float mode, EACH FED THE ORACLE'S INPUT PLANE, against the oracle's
+    output plane: the per-stage contract of BASELINE.json (1e-5 relative, 1e-6 absolute floor), as tests/test_gpu_fast.py
+    checks it.  -> (all inside, {stage: {"max_rel", "max_abs", "cells_outside"}})."""
+    cells = res * res
+    inputs = {"noise": None, "gauss": want["noise"], "flow": want["gauss"], "erosion": want["flow"]}
+    detail, ok = {}, True
+    for name, st in zip(STAGES, make_stages(nj, ctx, p)):
+        t = ctx.alloc(cells) if inputs[name] is None else ctx.from_host(inputs[name])
+        w = ctx.alloc(cells)
+        gd = nj.GeneratorData("check-" + name, t, res, 0, 0, write=w)
+        st.ReceiveHandledInput(nj.PipelineWorkItem(gd), nj.JobHandle())
+        st.jobHandle.Complete()
+        got = gd.data.ToArray((res, res))
+        st.OnDestroy()
+        t.Dispose()
+        w.Dispose()
+        d = np.abs(got.astype(np.float64) - want[name])
+        bad = int((d > 1e-5 * np.abs(want[name]) + 1e-6).sum())
+        detail[name] = {"max_rel": float((d / np.maximum(np.abs(want[name]), 0.1)).max()), "max_abs": float(d.max()),
+                        "cells_outside": bad}
+        ok = ok and bad == 0
+    return ok, detail
+
+
 def self_launch(argv, gpus):
     """`python bench.py --gpus N` as the driver runs N = 1, with no launcher around it: start the N ranks as children
     (python -m torch.distributed.run, rendezvous on 127.0.0.1) BEFORE this process has touched the GPU -- a process that
@@ -928,6 +962,9 @@ def main():
             src = gd.data
             nj._native.check(nj._native.lib.nz_tile_download(ctx._h, src.ptr, got.ctypes.data, cells, 0, None), "download")
             fence()
+            if os.environ.get("NZ_BENCH_FLIP_CELL"):   # debug hook (tests/test_gpu_bench.py): a wrong run must fail
+                got[cells // 2] += np.float32(1.0)
+                out["debug_flipped_cell"] = cells // 2
             same = bool(np.array_equal(got.reshape(res, res), plane))
             out["verified"] = same
             if not same:
@@ -953,6 +990,7 @@ def main():
         # the other float modes beside the headline: the same step on the same planes, 100 timed steps after 30 untimed ones,
         # then 40 marked steps for the stage times; the plane each mode leaves is compared with the oracle's
         modes_out = {}
+        want_stages = stage_planes(res) if plane_oracle is not None else None
         for mode in FLOAT_MODES:
             gc.collect()
             ctx.float_mode = FLOAT_MODES[mode]
@@ -983,6 +1021,8 @@ def main():
                 d = np.abs(got - plane_oracle)
                 e["end_to_end_vs_oracle"] = {"bit_equal": bool(np.array_equal(got, plane_oracle)), "max_abs": float(d.max()),
                                              "cells_within_1e-5_rel_1e-6_abs": round(float(np.mean(d <= 1e-5 * np.abs(plane_oracle) + 1e-6)), 6)}
+                # the per-stage contract, each stage fed the oracle's input plane (strict: bit-equal, so inside by definition)
+                e["stages_within_1e-5"], e["stages_vs_oracle"] = stages_within_tolerance(np, nj, ctx, p, res, want_stages)
             modes_out[mode] = e
         del marks[:]
         ctx.float_mode = FLOAT_MODES[args.float_mode]
@@ -1009,7 +1049,7 @@ def main():
                 line = dict(out)
                 line["extras"] = "skipped: an informational measurement did not return within 240 s"
                 os.write(real_stdout, (json.dumps(line) + "\n").encode())
-                os._exit(0)
+                os._exit(3)   # the line is out, but a measurement hung: never a clean exit
         watchdog = threading.Timer(240.0, bail)
         watchdog.daemon = True
         watchdog.start()
@@ -1055,6 +1095,34 @@ def main():
     if out is not None:
         with out_lock:
             print(json.dumps(out), flush=True)
+        failed = failed_checks(out)
+        if failed:
+            print("bench.py: the line is printed, but these checks against the oracle FAILED: %s" % ", ".join(failed),
+                  file=sys.stderr, flush=True)
+            sys.exit(4)
+
+
+def failed_checks(out):
+    """Every verdict the line carries that says a computed plane is not the oracle's: `verified` (headline and grid, any
+    schedule), strict end to end not bit-equal, strict / fast per-stage contract broken.  (relaxed is reported only: its
+    flow stage is documented to leave the band.)"""
+    bad = []
+
+    def walk(d, path):
+        for k, v in d.items():
+            if k == "verified" and v is False:
+                bad.append("/".join(path + [k]))
+            elif isinstance(v, dict):
+                walk(v, path + [k])
+    walk(out, [])
+    fm = out.get("float_modes") or {}
+    for mode in ("strict", "fast"):
+        e = fm.get(mode) or {}
+        if e.get("stages_within_1e-5") is False:
+            bad.append("float_modes/%s/stages_within_1e-5" % mode)
+    if (fm.get("strict") or {}).get("end_to_end_vs_oracle", {}).get("bit_equal") is False and out.get("debug_flipped_cell") is None:
+        bad.append("float_modes/strict/end_to_end_vs_oracle/bit_equal")
+    return bad
 
 
 if __name__ == "__main__":

@@ -61,6 +61,27 @@ def test_single_gpu_line():
     assert fm["strict"]["end_to_end_vs_oracle"]["bit_equal"] is True
     assert fm["fast"]["end_to_end_vs_oracle"]["bit_equal"] is False and fm["fast"]["end_to_end_vs_oracle"]["max_abs"] < 2e-3
     assert fm["fast"]["ms_per_step"] > 0 and set(fm["relaxed"]["stages_ms"]) == {"noise", "gauss", "flow", "erosion"}
+    # ... and the tolerance mode verifies itself the way the contract is stated: per stage, each fed the oracle's input
+    assert fm["strict"]["stages_within_1e-5"] is True and fm["fast"]["stages_within_1e-5"] is True
+    assert set(fm["fast"]["stages_vs_oracle"]) == {"noise", "gauss", "flow", "erosion"}
+    assert all(v["cells_outside"] == 0 for v in fm["fast"]["stages_vs_oracle"].values())
+
+
+def test_a_wrong_plane_fails_the_run():
+    # debug hook: one cell of the downloaded plane is changed before it is compared with the oracle's -> the line is still
+    # printed (verified: false, with the count), and the process does NOT exit 0
+    env = dict(os.environ, NZ_BENCH_FLIP_CELL="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--res", "512",
+                          "--grid", "0", "--no-extras"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["verified"] is False and d["verified_detail"]["cells_outside_1e-5_rel"] == 1
+    assert out.returncode not in (0, None) and "FAILED" in out.stderr
+    # the same command without the hook is clean
+    ok = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--res", "512",
+                         "--grid", "0", "--no-extras"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert ok.returncode == 0 and json.loads(ok.stdout.strip())["verified"] is True
 
 
 def test_stripe_rehearsal_line():
