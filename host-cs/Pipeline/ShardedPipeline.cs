@@ -33,8 +33,12 @@ namespace xshazwar.noize.hip {
         }
         public int Rank => Native.nz_comm_rank(Handle);
         public int World => Native.nz_comm_world(Handle);
+        // The library refuses while ShardedPipelines still hold the communicator (dispose them first): the status is thrown
+        // and the handle KEPT, so that a later Dispose() still reaches ncclCommDestroy.
         public void Dispose() {
-            if (Handle != IntPtr.Zero) { Native.nz_comm_destroy(Handle); Handle = IntPtr.Zero; }
+            if (Handle == IntPtr.Zero) return;
+            Native.Check(Native.nz_comm_destroy(Handle), "nz_comm_destroy");
+            Handle = IntPtr.Zero;
         }
     }
 

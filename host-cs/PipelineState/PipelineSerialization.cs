@@ -84,7 +84,8 @@ namespace xshazwar.noize.hip {
             return sb.Append('"').ToString();
         }
 
-        // the three fields of the file above, in any order and spacing (a hand-rolled reader keeps the host free of a JSON package)
+        // the three fields of the file above, in any order and spacing (a hand-rolled reader keeps the host free of a JSON
+        // package).  Like the reference's JsonUtility.FromJson, fields it does not know are skipped, not refused.
         void Parse(string text) {
             int i = 0;
             files.Clear();
@@ -107,7 +108,7 @@ namespace xshazwar.noize.hip {
                                 if (k == "id") f.id = ReadString(text, ref i);
                                 else if (k == "type") f.type = ReadString(text, ref i);
                                 else if (k == "size") f.size = ReadInt(text, ref i);
-                                else throw new FormatException($"files.json: unknown field {k}");
+                                else SkipValue(text, ref i);
                                 if (Peek(text, ref i) == ',') { i++; continue; }
                                 Expect(text, ref i, '}');
                                 break;
@@ -118,7 +119,7 @@ namespace xshazwar.noize.hip {
                             break;
                         }
                     }
-                } else throw new FormatException($"files.json: unknown field {key}");
+                } else SkipValue(text, ref i);
                 if (Peek(text, ref i) == ',') { i++; continue; }
                 Expect(text, ref i, '}');
                 break;
@@ -132,6 +133,26 @@ namespace xshazwar.noize.hip {
             while (i < t.Length && (char.IsDigit(t[i]) || t[i] == '-')) i++;
             return int.Parse(t.Substring(s, i - s));
         }
+        // any JSON value, read and discarded: string, number / true / false / null, object, array (nested as deep as it goes)
+        static void SkipValue(string t, ref int i) {
+            char c = Peek(t, ref i);
+            if (c == '"') { ReadString(t, ref i); return; }
+            if (c == '{' || c == '[') {
+                char close = c == '{' ? '}' : ']';
+                i++;
+                if (Peek(t, ref i) == close) { i++; return; }
+                while (true) {
+                    if (c == '{') { ReadString(t, ref i); Expect(t, ref i, ':'); }
+                    SkipValue(t, ref i);
+                    if (Peek(t, ref i) == ',') { i++; continue; }
+                    Expect(t, ref i, close);
+                    return;
+                }
+            }
+            int s = i;
+            while (i < t.Length && t[i] != ',' && t[i] != '}' && t[i] != ']' && !char.IsWhiteSpace(t[i])) i++;
+            if (i == s) throw new FormatException($"files.json: a value expected at {i}");
+        }
         static string ReadString(string t, ref int i) {
             Expect(t, ref i, '"');
             StringBuilder sb = new StringBuilder();
@@ -139,7 +160,10 @@ namespace xshazwar.noize.hip {
                 if (t[i] == '\\') {
                     i++;
                     if (t[i] == 'u') { sb.Append((char) Convert.ToInt32(t.Substring(i + 1, 4), 16)); i += 4; }
-                    else sb.Append(t[i] == 'n' ? '\n' : t[i] == 't' ? '\t' : t[i]);
+                    else {
+                        char e = t[i];   // \" \\ \/ stand for themselves
+                        sb.Append(e == 'n' ? '\n' : e == 't' ? '\t' : e == 'r' ? '\r' : e == 'b' ? '\b' : e == 'f' ? '\f' : e);
+                    }
                 } else sb.Append(t[i]);
                 i++;
             }

@@ -9,8 +9,7 @@
  *     (Pipeline/Tiles/TileData.cs:72-77).
  *   - `JobHandle dependency` -> `nz_handle dep` (0 = default(JobHandle)); the returned JobHandle ->
  *     `nz_handle* out` (may be NULL: no handle, stream order only).  Work is enqueued asynchronously on the ctx's HIP stream;
- *     where an entry ends in a kernel launch its handle is that launch's completion event (no event record of its own;
- *     NZ_HANDLE_ON_LAUNCH=0: a recorded event everywhere).
+ *     where an entry ends in a kernel launch its handle is that launch's completion event (no event record of its own).
  *   - exceptions -> negative `int32` status; `nz_last_error()` gives the message.
  *   - scalar argument order is the delegate's.
  * One nz_ctx is driven by one host thread at a time (the reference schedules everything from the

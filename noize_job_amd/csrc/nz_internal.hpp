@@ -64,13 +64,14 @@ struct nz_ctx {
     // Which work a chained launch's time-out belongs to: a failing tile lowers *chain_err_epoch (device memory, atomicMin) to
     // its launch's epoch before it raises the flag; the host remembers the handle sequence number each of its last chained
     // launches was issued at.  Once seen, the failure is reported (NZ_ERR_RETRY) by every wait on a handle in [retry_lo,
-    // retry_hi] -- issued at or after the failing launch and before the host noticed -- and by the next nz_ctx_synchronize;
-    // a wait on an older handle (another pipeline's, a fence recorded before the stage) completes clean.
+    // retry_hi] -- issued at or after the failing launch and before the failure was first REPORTED (retry_open: the window's
+    // upper end follows last_seq until then) -- and by the next nz_ctx_synchronize; a wait on an older handle (another
+    // pipeline's, a fence recorded before the stage) completes clean.
     unsigned *chain_err_epoch = nullptr;
     struct chain_mark { unsigned epoch; uint64_t seq; };
     chain_mark chain_marks[64] = {};
     uint64_t retry_lo = 0, retry_hi = 0;
-    bool retry_sync_pending = false;
+    bool retry_sync_pending = false, retry_open = false;
     bool handle_rides = false;    // this entry's handle may ride on its last kernel launch (nz_ctx_handle_rides)
     uint64_t armed_seq = 0;       // ... and this is the sequence number reserved for it (nz_ctx_arm_last_launch)
     // pool automaton, sparse form (nz_pool_job in nz_stages.cpp): {entries, done, -} in device memory, and in mapped host
@@ -172,7 +173,6 @@ inline nz_geom nz_geom_tile(int res) { return nz_geom{res, res, res, 0, res - 1,
 // helper says so (nz_ctx_handle_rides); the helper arms the launch it knows to be its last (nz_ctx_arm_last_launch); that
 // launch -- NZ_LAUNCH instead of hipLaunchKernelGGL -- takes the event; nz_ctx_finish hands out the handle, or records an
 // event the old way when nothing took it.  nz_ctx_begin disarms whatever an entry that failed left behind.
-// NZ_HANDLE_ON_LAUNCH=0: always the old way.
 extern thread_local hipEvent_t nz_tls_stop_event;
 // the float mode of the context whose entry this thread is running (set by nz_ctx_begin: every launcher runs behind one)
 extern thread_local int nz_tls_float_mode;

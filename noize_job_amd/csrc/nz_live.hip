@@ -1360,7 +1360,10 @@ static int32_t erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *
                                       ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT, err_host};
             static const bool carry = [] { const char *e = getenv("NZ_PILE_CARRY_FLOW"); return !e || atoi(e) != 0; }();
             const size_t flow_wgs = fl ? (fl->n + FLOW_WG_CELLS - 1) / FLOW_WG_CELLS : 0;
-            if (fl && carry && flow_wgs + grid < 0x7fffffffull) {
+            // the flow workgroups of the one-call form are launched under the pile solver's dynamic LDS size: a few KB at the
+            // default radius, ~110 KB at PILING_RADIUS 50 -- where each of the res^2 / 1024 flow workgroups would hold a CU
+            // alone with one wave.  Beyond 16 KB the flow update is its own launch again (nz_launch_flow_from_track below)
+            if (fl && carry && lds <= 16 * 1024 && flow_wgs + grid < 0x7fffffffull) {
                 if (lds > 64 * 1024)
                     NZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pile_ticket_flow_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

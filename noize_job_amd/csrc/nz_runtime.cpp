@@ -496,9 +496,15 @@ static int32_t ctx_chain_check(nz_ctx *ctx, uint64_t waited_seq) {
             ctx->retry_lo = lo;
             ctx->retry_hi = ctx->last_seq > lo ? ctx->last_seq : lo;
             ctx->retry_sync_pending = true;
+            // The host may notice on a wait that is NOT for the failed work (an older handle: clean, below).  Until the
+            // failure has actually been REPORTED, whatever it enqueues -- a stage that takes an in-window handle as its
+            // dependency, a pipeline on the same plane -- is computed from the invalid plane too: the window stays open
+            // (its upper end follows last_seq) until the first report.
+            ctx->retry_open = true;
         }
     }
     if (!ctx->retry_hi) return NZ_OK;
+    if (ctx->retry_open && ctx->last_seq > ctx->retry_hi) ctx->retry_hi = ctx->last_seq;
     bool hit;
     if (waited_seq == NZ_WAIT_ALL) {
         hit = ctx->retry_sync_pending;
@@ -507,6 +513,7 @@ static int32_t ctx_chain_check(nz_ctx *ctx, uint64_t waited_seq) {
         hit = waited_seq >= ctx->retry_lo && waited_seq <= ctx->retry_hi;
         if (hit) ctx->retry_sync_pending = false;
     }
+    if (hit) ctx->retry_open = false;  // the host knows now: handles it issues from here on are its own decision
     if (!hit) return NZ_OK;
     nz_set_error("a chained kernel-filter launch timed out waiting for a producer tile: the plane that stage left (and whatever was "
                  "computed from it) is invalid; this context now runs filter stages as separate launches -- schedule the work item "

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdio>
 #include <deque>
 #include <functional>
 #include <map>
@@ -979,7 +980,17 @@ class Comm {  // nz_comm: ncclCommInitRank on the context's device + the exchang
     Comm(nz_ctx *ctx, const std::array<uint8_t, NZ_COMM_ID_BYTES> &id, int rank, int world) {
         check(nz_comm_init(ctx, id.data(), rank, world, &h), "nz_comm_init");
     }
-    ~Comm() { nz_comm_destroy(h); }
+    // nz_comm_destroy refuses while ShardedPipelines still hold the communicator (destroy them first -- objects declared
+    // after the Comm are, by the language's order).  Close() reports that; the destructor can only say so.
+    void Close() {
+        if (!h) return;
+        check(nz_comm_destroy(h), "nz_comm_destroy");
+        h = nullptr;
+    }
+    ~Comm() {
+        if (h && nz_comm_destroy(h) != NZ_OK)
+            std::fprintf(stderr, "noize::Comm: communicator leaked (%s)\n", nz_last_error());
+    }
     Comm(const Comm &) = delete;
     Comm &operator=(const Comm &) = delete;
     int Rank() const { return nz_comm_rank(h); }

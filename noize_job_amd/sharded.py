@@ -422,8 +422,10 @@ class NativeComm:
         self.rank, self.world = rank, world
 
     def close(self):
+        """nz_comm_destroy.  The library refuses while nz_sharded grids still hold the communicator (close them first):
+        the status is raised and the handle KEPT, so that a later close() can still reach ncclCommDestroy."""
         if self._h:
-            N.lib.nz_comm_destroy(self._h)
+            N.check(N.lib.nz_comm_destroy(self._h), "nz_comm_destroy")
             self._h = None
 
     # the TorchComm interface on top of nz_halo_exchange (one stripe per rank): lets run_pipeline drive the Python schedule

@@ -335,6 +335,34 @@ def test_a_chained_launch_that_times_out_is_reported_and_the_pipeline_runs_again
             lib.nz_debug_chain_delay(-1, 0)
         for st in stages:
             st.OnDestroy()
+    # (a') The host first notices on a wait for an OLDER handle (clean), has not been told yet, and schedules a dependent of the
+    # failed stage: that handle -- issued after the notice -- reports the failure too (the window closes at the first report).
+    with nj.Context(0) as c:
+        data, write = c.alloc(res * res), c.alloc(res * res)
+        stages = [nj.NoiseStage(c, nj.FractalNoise.Simplex, 0.4, 1.0, 6, 2.0, 0.0, 300),
+                  nj.KernelFilterStage(c, nj.KernelFilterType.Gauss5_S1, 17)]
+        ero = nj.ErosionStage(c, 2)
+        try:
+            assert lib.nz_debug_chain_poll_limit(8) == 0 and lib.nz_debug_chain_delay(3, 500) == 0
+            before = c.record()
+            gd = nj.GeneratorData("t", data, res, 0, 0, write=write)
+            h = nj.JobHandle()
+            for st in stages:
+                st.Schedule(nj.PipelineWorkItem(gd), h)
+                h = st.jobHandle
+            time.sleep(0.05)
+            before.Complete()                            # the notice: clean, nothing reported
+            ero.Schedule(nj.PipelineWorkItem(gd), h)     # a dependent of the invalid plane, issued after the notice
+            with pytest.raises(nj.NoizeError) as e:
+                ero.jobHandle.Complete()
+            assert e.value.status == nj._native.NZ_ERR_RETRY
+            later = c.record()                           # issued after the report: clean
+            later.Complete()
+        finally:
+            lib.nz_debug_chain_poll_limit(0)
+            lib.nz_debug_chain_delay(-1, 0)
+        for st in stages + [ero]:
+            st.OnDestroy()
     with nj.Context(0) as c:
         data, write = c.alloc(res * res), c.alloc(res * res)
         pipe = nj.BasePipeline([nj.NoiseStage(c, nj.FractalNoise.Simplex, 0.4, 1.0, 6, 2.0, 0.0, 300),

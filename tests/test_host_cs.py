@@ -192,3 +192,16 @@ def test_the_cs_host_has_every_class_the_python_host_exports():
     ctxs = _cs_sources()["Stages/ContextStages.cs"]
     assert ctxs.count("Native.nz_flush_write_slice(") == 2 and "Native.nz_handle_record(" in ctxs
     assert "stageManager" in _cs_sources()["Pipeline/Pipeline.cs"] and "nz_ctx_set_float_mode" in _cs_sources()["Runtime.cs"]
+
+
+def test_the_cs_index_reader_skips_unknown_fields_and_decodes_every_escape():
+    # the reference reads files.json with JsonUtility.FromJson (unknown fields ignored, full JSON escapes); the hand-rolled
+    # C# reader must not be stricter (tests/test_persistence.py holds the same fixture for the Python host)
+    src = open(os.path.join(ROOT, "host-cs", "PipelineState", "PipelineSerialization.cs")).read()
+    assert "unknown field" not in src and src.count("SkipValue(text, ref i)") == 2
+    body = src[src.index("static void SkipValue"):src.index("static string ReadString")]
+    for needle in ("ReadString(t, ref i)", "c == '{' || c == '['", "SkipValue(t, ref i)", "Expect(t, ref i, close)"):
+        assert needle in body, needle
+    rs = src[src.index("static string ReadString"):]
+    for esc in ("'n'", "'t'", "'r'", "'b'", "'f'", "'u'"):
+        assert "== " + esc in rs, esc

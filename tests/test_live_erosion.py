@@ -172,14 +172,17 @@ def test_spawn_jumps_ahead_in_the_workers_streams(nj, ctx, oracle, particles, wo
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("res,particles,tile_height,patch", [(256, 3000, 1000, 1.0), (384, 6000, 500, 2.5),
-                                                             (40, 600, 1000, 1.0)])  # 40: a third of the cells in the frame
+@pytest.mark.parametrize("res,particles,tile_height,patch,radius",
+                         [(256, 3000, 1000, 1.0, 7), (384, 6000, 500, 2.5, 7),
+                          (40, 600, 1000, 1.0, 7),        # 40: a third of the cells in the frame
+                          (256, 3000, 1000, 1.0, 30)])    # a pile solver with > 16 KB of LDS: the one-call form launches the
+                                                          # flow update on its own again (nz_live.hip, pile_ticket_flow_kernel)
 @pytest.mark.parametrize("siblings", ["two-calls", "one-call"])
-def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, tile_height, patch, siblings):
+def test_cycle_jobs_match_oracle_one_by_one(nj, ctx, oracle, res, particles, tile_height, patch, radius, siblings):
     """siblings = one-call: ErodeHeightMaps and UpdateFlowFromTrackJob through nz_erode_height_maps_and_flow (the pile
     solver's launch carries the flow update's workgroups) -- the same planes as the two entries one after the other."""
     h = terrain(oracle, res)
-    es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, PILE_THRESHOLD=0.4, PILING_RADIUS=7, MIN_PILE_INCREMENT=0.25)
+    es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, PILE_THRESHOLD=0.4, PILING_RADIUS=radius, MIN_PILE_INCREMENT=0.25)
     G = _gpu_state(nj, ctx, h, es, tile_height, patch)
     L = oracle.LiveErosionOracle(h, _params(oracle, es), tile_height=tile_height, patch_res=patch)
     ep, tm = es.AsParameters(), G.tileMeta

@@ -47,6 +47,22 @@ def test_reads_an_index_written_by_the_reference_and_by_version_1(tmp_path):
     assert np.array_equal(m.ReadData("a"), plane)
 
 
+def test_an_index_touched_by_another_tool_still_loads(tmp_path):
+    # JsonUtility.FromJson ignores fields it does not know and decodes every JSON escape; so do the hosts (the C# reader is
+    # hand-rolled: host-cs/PipelineState/PipelineSerialization.cs SkipValue / ReadString, checked in tests/test_host_cs.py)
+    from noize_job_amd.persistence import PipelineSerdeManager
+    base = tmp_path / "save__terrain"
+    (base / "data").mkdir(parents=True)
+    np.arange(4, dtype="<f4").tofile(base / "data" / "a.data")
+    (base / "files.json").write_text(
+        '{ "alias": "terrain", "tool": {"name": "x", "tags": [1, 2, {"k": null}]}, "version": "v1",\n'
+        '  "files": [ {"id": "a", "checksum": "ab\\/cd", "type": "NativeArray`1", "size": 4, "dirty": false},\n'
+        '             {"id": "tab\\there\\r\\b\\f\\u0041", "type": "NativeArray`1", "size": 9} ], "saved": 1.5e3 }')
+    m = PipelineSerdeManager(str(tmp_path), "terrain", "v1")
+    assert m.CachedSize("a") == 4 and np.array_equal(m.ReadData("a"), np.arange(4, dtype=np.float32))
+    assert m.CachedSize("tab\there\r\b\fA") == 9
+
+
 @pytest.mark.gpu
 def test_device_tile_round_trip(nj, ctx, tmp_path):
     from noize_job_amd.persistence import PipelineSerdeManager
