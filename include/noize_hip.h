@@ -500,26 +500,6 @@ typedef struct nz_terrain_params {
     int32_t erosionIterations;    /* ErosionKernelJob applications, 0 = none */
 } nz_terrain_params;
 
-/* ---- the stock stage list as a replayable graph: one tile request = one graph launch -------------------------------
- * The reference serves a tile request with BasePipeline.Schedule on one GeneratorData (Scripts/MeshTileGenerator.cs:181-211,
- * Pipeline/Executable/Pipeline.cs:104-128; PipelineStage.ReceiveHandledInput per stage, Pipeline/Stage/PipelineStage.cs:41-59)
- * at 256^2 .. 1024^2 cells, where the stage kernels last 5-40 us each and the request is bound by what lies between them.
- * nz_pipeline_graph_launch runs NoiseStage -> KernelFilterStage -> FlowMapStage -> erosion (nz_terrain_params; a stage with
- * 0 iterations is left out) on the READ / WRITE pair `tile` exactly as the four `_rw` stage entries would -- same kernels, same
- * order, the same plane holding the result, `tile` swapped the same way on return -- but as ONE replay of a HIP graph captured
- * the first time a (read, write) pair is seen (that first request runs eagerly).  Per request only the tile's world position
- * changes (and the epoch of a chained filter launch): both are patched into the graph's kernel nodes before the launch;
- * replays already enqueued keep theirs.  512^2: 55 -> 47 us per tile, 1024^2: 91 -> 77 us.
- * The object keeps the flow stage's ten state planes; it belongs to `ctx` (one host thread at a time, like every entry);
- * a change of the context's float mode, or a chained filter launch having timed out on it, makes the next launch capture
- * again.  count must be 1 (batches have their own entries). */
-typedef struct nz_pipeline_graph nz_pipeline_graph;
-int32_t nz_pipeline_graph_create(nz_ctx *ctx, const nz_terrain_params *params, int32_t resolution, nz_pipeline_graph **out);
-int32_t nz_pipeline_graph_launch(nz_ctx *ctx, nz_pipeline_graph *graph, nz_rw_tile *tile, int32_t xpos, int32_t zpos,
-                                 nz_handle dep, nz_handle *out);
-int32_t nz_pipeline_graph_captures(const nz_pipeline_graph *graph); /* captures so far (diagnostics / tests) */
-int32_t nz_pipeline_graph_destroy(nz_ctx *ctx, nz_pipeline_graph *graph); /* waits for the context's stream first */
-
 /* ---- one large grid over the GPUs of a node: row stripes + RCCL neighbour halo exchange (new-framework feature,
  * SURVEY.md 8e; the reference only has independent clamped tiles, Scripts/MeshTileGenerator.cs:166-192, which a host
  * requests one by one through BasePipeline.Schedule, Pipeline/Executable/Pipeline.cs:104-128).  One process per GPU;

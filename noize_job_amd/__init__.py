@@ -9,10 +9,10 @@ from ._native import NoizeError, Stripe
 from .runtime import Context, DeviceTile, JobHandle
 from .pipeline import (BasePipeline, BlurHelper, ConstantOperationType, ConstantStage, CropStage, CurveStage, DownsampleData, ErosionStage, FlowMapStage, FractalNoise, GaussSigma,
                        GeneratorData, GeneratorDataBatch, KernelFilterStage, KernelFilterType, MeshBuffers, MeshStageData,
-                       MeshTileStage, MeshType, NoiseStage, PipelineGraph, PipelineJoint, PipelineStage, PipelineWorkItem, ReduceData,
+                       MeshTileStage, MeshType, NoiseStage, PipelineJoint, PipelineStage, PipelineWorkItem, ReduceData,
                        ReducePipeline, ReduceStage, Upstream,
                        ReductionType, StageGaussianBlur, StageThermalErosion,
-                       StageIO, StageSmoothBlur, stock_list_params)
+                       StageIO, StageSmoothBlur)
 
 from .pipeline_state import (HandleLock, MeshTileReferenceDataStage, PipelineStateManager, ReadGeneratorContextStage,
                              WriteGeneratorContextStage)

@@ -195,10 +195,6 @@ SIGNATURES = {
     "nz_halo_exchange_finish": (_i, [ctx_p, C.c_void_p, handle_p]),
     "nz_halo_exchange": (_i, [ctx_p, C.c_void_p, C.POINTER(dev_ptr), _i, stripe_p, _i, _i] + _tail),
     "nz_comm_allgather_range": (_i, [ctx_p, C.c_void_p, dev_ptr, _sz, dev_ptr, _f, _f] + _tail),
-    "nz_pipeline_graph_create": (_i, [ctx_p, tp_p, _i, C.POINTER(C.c_void_p)]),
-    "nz_pipeline_graph_launch": (_i, [ctx_p, C.c_void_p, rw_tile_p, _i, _i] + _tail),
-    "nz_pipeline_graph_captures": (_i, [C.c_void_p]),
-    "nz_pipeline_graph_destroy": (_i, [ctx_p, C.c_void_p]),
     "nz_sharded_create": (_i, [ctx_p, C.c_void_p, sd_p, tp_p, C.POINTER(C.c_void_p)]),
     "nz_sharded_destroy": (_i, [C.c_void_p]),
     "nz_sharded_local_stripes": (_i, [C.c_void_p]),

@@ -43,9 +43,6 @@ struct nz_ctx {
     // another context's handle becomes a hipStreamWaitEvent (JobHandle dependencies across pipelines,
     // Pipeline/Executable/ReducePipeline.cs:82-148).  `hmx` guards the ring against a foreign context's lookup.
     std::vector<hipEvent_t> events;
-    // ... unless alias[q % size] is set: the handle then lives in an event somebody else owns and has recorded behind the work
-    // (a replayed graph's own marker, nz_ctx_finish_alias); cleared when the slot is taken again
-    std::vector<hipEvent_t> alias;
     uint64_t last_seq = 0;
     uint32_t id = 0;
     std::mutex hmx;
@@ -59,11 +56,6 @@ struct nz_ctx {
     // chained launches (nz_launch_conv_chain): tile flags (grown on demand, never cleared: they carry an epoch)
     int *chain_flags = nullptr;
     size_t chain_flags_n = 0;
-    size_t chain_last_items = 0;  // the flags the last chained launch asked for
-    // set while a replayable graph captures its launches: the chained grid then takes the GRAPH's own flags (the capture bakes
-    // the address in; the context's array may move when a bigger grid comes along)
-    int *chain_flags_override = nullptr;
-    size_t chain_flags_override_n = 0;
     // the error words in mapped host memory ([0]: a chained filter launch gave up waiting, [1]: the pile solver's ticket launch
     // did -- one word per kind, so neither overwrites the other), and their device address
     unsigned *chain_err = nullptr, *chain_err_dev = nullptr;
@@ -99,8 +91,6 @@ int32_t nz_ctx_pool_state(nz_ctx *ctx);  // allocates the three on first use
 
 constexpr int NZ_HANDLE_SEQ_BITS = 40;
 constexpr uint64_t NZ_HANDLE_SEQ_MASK = (1ull << NZ_HANDLE_SEQ_BITS) - 1;
-int32_t nz_ctx_finish_alias(nz_ctx *ctx, nz_handle *out, hipEvent_t recorded);  // the handle = an event already recorded
-void nz_ctx_chain_mark(nz_ctx *ctx, unsigned epoch);  // a captured chained launch with this epoch is about to be replayed
 int32_t nz_ctx_begin(nz_ctx *ctx, nz_handle dep);           // set device, order the stream after `dep`
 int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out);         // record the JobHandle marker
 int32_t nz_ctx_scratch(nz_ctx *ctx, size_t floats, float **out);

@@ -291,11 +291,6 @@ static inline uint32_t handle_ctx_id(nz_handle h) { return (uint32_t)(h >> NZ_HA
 static inline uint64_t handle_seq(nz_handle h) { return h & NZ_HANDLE_SEQ_MASK; }
 
 static bool seq_live(nz_ctx *c, uint64_t q) { return q != 0 && q <= c->last_seq && q + NZ_EVENT_RING > c->last_seq; }
-// the event that holds live sequence number q: the ring's own, or the one nz_ctx_finish_alias put in its place
-static hipEvent_t ring_event(nz_ctx *c, uint64_t q) {
-    const size_t i = q % NZ_EVENT_RING;
-    return (!c->alias.empty() && c->alias[i]) ? c->alias[i] : c->events[i];
-}
 
 // Runs fn(owner, seq) with the registry locked (the owner cannot be destroyed meanwhile) and the owner's ring
 // locked.  owner == nullptr: the issuing context no longer exists -- nz_ctx_destroy synchronised its stream, so
@@ -315,8 +310,8 @@ static int32_t with_owner(nz_handle h, F fn) {
 // The event that stands for `q` of `owner`: its own while it is in the ring, otherwise the owner's newest marker
 // (later in stream order, so waiting on it implies `q`).
 static hipEvent_t event_for(nz_ctx *owner, uint64_t q) {
-    if (seq_live(owner, q)) return ring_event(owner, q);
-    return owner->last_seq ? ring_event(owner, owner->last_seq) : nullptr;
+    if (seq_live(owner, q)) return owner->events[q % NZ_EVENT_RING];
+    return owner->last_seq ? owner->events[owner->last_seq % NZ_EVENT_RING] : nullptr;
 }
 
 thread_local hipEvent_t nz_tls_stop_event = nullptr;
@@ -345,7 +340,6 @@ void nz_ctx_arm_last_launch(nz_ctx *ctx) {
         *ev = nullptr;
         return;  // nz_ctx_finish records the old way and reports what fails
     }
-    if (!ctx->alias.empty()) ctx->alias[q % NZ_EVENT_RING] = nullptr;
     nz_tls_stop_event = *ev;
     ctx->armed_seq = q;
 }
@@ -394,28 +388,7 @@ int32_t nz_ctx_finish(nz_ctx *ctx, nz_handle *out) {
     NZ_REQUIRE(q < NZ_HANDLE_SEQ_MASK, "handle sequence exhausted");
     hipEvent_t *ev = &ctx->events[q % NZ_EVENT_RING];
     if (!*ev) NZ_HIP(hipEventCreate(ev));
-    if (!ctx->alias.empty()) ctx->alias[q % NZ_EVENT_RING] = nullptr;
     NZ_HIP(hipEventRecord(*ev, ctx->stream));
-    ctx->last_seq = q;
-    *out = ((uint64_t)ctx->id << NZ_HANDLE_SEQ_BITS) | q;
-    return NZ_OK;
-}
-
-// The entry's work is already followed by an event its caller owns and has recorded on the context's stream (a replayed
-// graph's marker): the handle is that event -- no second record (~5 us of the stream behind a graph launch).  The owner keeps
-// the event alive while the context lives, and re-records it only behind LATER work of this stream (a wait on the old handle is
-// then late, never early: the ring's own policy for expired handles).
-int32_t nz_ctx_finish_alias(nz_ctx *ctx, nz_handle *out, hipEvent_t recorded) {
-    nz_tls_stop_event = nullptr;
-    ctx->armed_seq = 0;
-    ctx->handle_rides = false;
-    if (!out) return NZ_OK;
-    std::lock_guard<std::mutex> lk(ctx->hmx);
-    if (ctx->events.empty()) ctx->events.assign(NZ_EVENT_RING, nullptr);
-    if (ctx->alias.empty()) ctx->alias.assign(NZ_EVENT_RING, nullptr);
-    uint64_t q = ctx->last_seq + 1;
-    NZ_REQUIRE(q < NZ_HANDLE_SEQ_MASK, "handle sequence exhausted");
-    ctx->alias[q % NZ_EVENT_RING] = recorded;
     ctx->last_seq = q;
     *out = ((uint64_t)ctx->id << NZ_HANDLE_SEQ_BITS) | q;
     return NZ_OK;
@@ -474,10 +447,7 @@ int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned *epo
         NZ_HIP(hipMalloc((void **)&ctx->chain_err_epoch, 4));
         NZ_HIP(hipMemsetAsync(ctx->chain_err_epoch, 0xff, 4, ctx->stream));
     }
-    if (ctx->chain_flags_override) {
-        NZ_REQUIRE(items <= ctx->chain_flags_override_n, "internal: a captured chained launch needs %zu flags, its graph holds %zu",
-                   items, ctx->chain_flags_override_n);
-    } else if (items > ctx->chain_flags_n) {
+    if (items > ctx->chain_flags_n) {
         if (ctx->chain_flags) {
             NZ_TRY_(ctx_sync_all(ctx));
             NZ_HIP(hipFree(ctx->chain_flags));
@@ -489,21 +459,15 @@ int32_t nz_ctx_chain_state(nz_ctx *ctx, size_t items, int **flags, unsigned *epo
         NZ_HIP(hipMemsetAsync(ctx->chain_flags, 0, n * sizeof(int), ctx->stream));
         ctx->chain_flags_n = n;
     }
-    ctx->chain_last_items = items;
     if (++ctx->chain_epoch == 0) ctx->chain_epoch = 1;  // 0 is what a fresh flag holds
     // the handle sequence number this launch is issued at: the next handle of the context is the launching entry's own or a
     // later one
     ctx->chain_marks[ctx->chain_epoch % 64] = {ctx->chain_epoch, ctx->last_seq + 1};
-    *flags = ctx->chain_flags_override ? ctx->chain_flags_override : ctx->chain_flags;
+    *flags = ctx->chain_flags;
     *epoch = ctx->chain_epoch;
     *err_epoch = ctx->chain_err_epoch;
     return NZ_OK;
 }
-
-// A captured chained launch is replayed with the epoch it was captured with (on flags of its own: nobody else writes them, and two
-// captures that alternate never meet their own epoch in them).  Should it time out, the failure belongs to the handles issued
-// from here on.
-void nz_ctx_chain_mark(nz_ctx *ctx, unsigned epoch) { ctx->chain_marks[epoch % 64] = {epoch, ctx->last_seq + 1}; }
 
 // A kernel whose bounded wait gave up has raised one of the context's error words (mapped host memory: no device-to-host
 // copy on the host's wait path): reported wherever the host waits for work the failure can have touched.  `waited_seq`: the
@@ -588,7 +552,7 @@ extern "C" int32_t nz_handle_query(nz_ctx *ctx, nz_handle h, int32_t *is_complet
         }
         NZ_REQUIRE(q <= owner->last_seq, "unknown handle");
         NZ_HIP(hipSetDevice(owner->device));
-        hipError_t e = seq_live(owner, q) ? hipEventQuery(ring_event(owner, q)) : hipStreamQuery(owner->stream);
+        hipError_t e = seq_live(owner, q) ? hipEventQuery(owner->events[q % NZ_EVENT_RING]) : hipStreamQuery(owner->stream);
         if (e == hipSuccess) {
             *is_completed = 1;
         } else if (e == hipErrorNotReady) {
@@ -629,7 +593,8 @@ extern "C" int32_t nz_handle_elapsed_ms(nz_ctx *ctx, nz_handle start, nz_handle 
     NZ_REQUIRE(handle_ctx_id(start) == ctx->id && handle_ctx_id(stop) == ctx->id, "handles of another context");
     NZ_REQUIRE(seq_live(ctx, handle_seq(start)) && seq_live(ctx, handle_seq(stop)), "handle expired or unknown");
     NZ_HIP(hipSetDevice(ctx->device));
-    NZ_HIP(hipEventElapsedTime(ms, ring_event(ctx, handle_seq(start)), ring_event(ctx, handle_seq(stop))));
+    NZ_HIP(hipEventElapsedTime(ms, ctx->events[handle_seq(start) % NZ_EVENT_RING],
+                               ctx->events[handle_seq(stop) % NZ_EVENT_RING]));
     return NZ_OK;
 }
 

@@ -904,10 +904,12 @@ extern "C" size_t nz_flowmap_stage_rw_work_floats(int32_t resolution, int32_t co
     return resolution > 0 && count > 0 ? (size_t)10 * resolution * resolution * count : 0;
 }
 
-// the launches of FlowMapStage on a READ / WRITE pair (tile->read holds the heights; the result lands in tile->write, the caller
-// swaps): shared by the stage entry and the replayable graph of the stock list
-static int32_t flowmap_rw_launches(nz_ctx *ctx, const nz_rw_tile *tile, float *work, int32_t iterations, float normMin,
-                                   float normMax, bool handle_wanted) {
+extern "C" int32_t nz_flowmap_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, float *work, int32_t iterations, float normMin,
+                                       float normMax, nz_handle dep, nz_handle *out) {
+    NZ_BEGIN(ctx, dep);
+    NZ_TRY(check_rw(tile));
+    NZ_REQUIRE(work, "work is NULL");
+    NZ_REQUIRE(iterations >= 1, "iterations < 1");
     size_t n = (size_t)tile->resolution * tile->resolution * tile->count;
     nz_geom g = rw_geom(tile);
     float *A[5], *B[5];  // {water, fN, fS, fE, fW} x {READ, WRITE}, FlowMapStage.cs:52-62
@@ -924,7 +926,7 @@ static int32_t flowmap_rw_launches(nz_ctx *ctx, const nz_rw_tile *tile, float *w
         int nit = base + (i < rem ? 1 : 0);
         int first = i == 0, last = i == launches - 1;
         if (last) {  // the stage's last operation: its handle rides on this launch
-            nz_ctx_handle_rides(ctx, handle_wanted);
+            nz_ctx_handle_rides(ctx, out != nullptr);
             nz_ctx_arm_last_launch(ctx);
         }
         NZ_TRY(launch_on_ctx(ctx, g, [&](hipStream_t st, const nz_geom &gb) {
@@ -934,16 +936,6 @@ static int32_t flowmap_rw_launches(nz_ctx *ctx, const nz_rw_tile *tile, float *w
         }));
         float **s = cur; cur = nxt; nxt = s;
     }
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_flowmap_stage_rw(nz_ctx *ctx, nz_rw_tile *tile, float *work, int32_t iterations, float normMin,
-                                       float normMax, nz_handle dep, nz_handle *out) {
-    NZ_BEGIN(ctx, dep);
-    NZ_TRY(check_rw(tile));
-    NZ_REQUIRE(work, "work is NULL");
-    NZ_REQUIRE(iterations >= 1, "iterations < 1");
-    NZ_TRY(flowmap_rw_launches(ctx, tile, work, iterations, normMin, normMax, out != nullptr));
     rw_swap(tile, true);
     return nz_ctx_finish(ctx, out);
 }
@@ -1220,252 +1212,4 @@ extern "C" int32_t nz_thermal_erosion(nz_ctx *ctx, float *src, float talus, floa
         }
     }
     return nz_ctx_finish(ctx, out);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The stock stage list as a replayable HIP graph (include/noize_hip.h, "one tile request = one graph launch").
-// A tile request of the reference is BasePipeline.Schedule on one GeneratorData (Scripts/MeshTileGenerator.cs:181-211,
-// Pipeline/Executable/Pipeline.cs:104-128): at its tile sizes (256^2 .. 1024^2) the stage kernels last 5-40 us each and
-// the request is bound by what lies between them.  The launches of NoiseStage -> KernelFilterStage -> FlowMapStage ->
-// erosion on a READ / WRITE pair are captured once and replayed per request: same kernels, same order as the stage entries,
-// bit-equal by construction.
-//
-// What differs between two requests must reach the kernels WITHOUT touching the instantiated graph: on this runtime a
-// hipGraphExecKernelNodeSetParams costs the next launch ~13 us on the GPU (512^2: 59.8 us per replay against 46.6 untouched and
-// 55.0 stage by stage; tools/probe_graph_native.py, round 6) -- the first version of this file did that and lost.  So:
-//  * the tile's world position travels through a MAILBOX in mapped host memory: the noise kernel reads {xpos, zpos} through its
-//    `positions` pointer (the batched launch's mechanism, a batch of one) -- +1.2 us (tools/microbench/graph_event.hip);
-//  * a chained filter grid keeps the epoch it was captured with, on flags that belong to the graph alone; two captures (slots)
-//    alternate, so a replay never finds its own epoch in the flags (its consumers wait for its own producers);
-//  * the same two slots double-buffer the mailbox: a slot is written again only after the replay that read it has finished
-//    (its marker event is queried, and waited for if a host runs further ahead than two requests).
-// The marker recorded behind a replay IS the request's handle (nz_ctx_finish_alias): an event node captured INTO the graph
-// costs nothing but reads as complete to the host before the replay has run (same probe), so it cannot be.
-// ---------------------------------------------------------------------------------------------
-// mailbox slots = how many requests a host may run ahead before a launch waits for an earlier replay (the wait itself is an
-// event wait of the host: ~60 us to wake up on this runtime, so it must stay the exception)
-constexpr int NZ_GRAPH_SLOTS = 4;
-
-struct nz_graph_variant {
-    float *read = nullptr, *write = nullptr;  // the pair as the request hands it over
-    int slot = 0;
-    float *result = nullptr;                  // the plane that holds the result (= tile->read after the launch)
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    int32_t *box = nullptr, *box_dev = nullptr;  // the mailbox {xpos, zpos} (mapped host memory) and its device address
-    hipEvent_t marker = nullptr;                 // recorded behind every replay of this variant
-    bool in_flight = false;
-    bool chained = false;
-    unsigned epoch = 0;
-    int float_mode = 0;
-    uint64_t used = 0;
-};
-
-struct nz_pipeline_graph {
-    nz_ctx *ctx = nullptr;
-    nz_terrain_params p{};
-    int32_t resolution = 0;
-    float *work = nullptr;  // the flow stage's state planes (nz_flowmap_stage_rw_work_floats)
-    int *flags = nullptr;   // a chained filter grid's tile flags: the graph's own (the capture bakes the address in)
-    size_t flags_n = 0;
-    std::vector<nz_graph_variant> variants;
-    uint64_t clock = 0;
-    int next_slot = 0;
-    int32_t captures = 0;
-};
-
-static void graph_variant_release(nz_ctx *ctx, nz_graph_variant &v) {
-    if (v.exec) (void)hipGraphExecDestroy(v.exec);
-    if (v.graph) (void)hipGraphDestroy(v.graph);
-    if (v.marker) {
-        std::lock_guard<std::mutex> lk(ctx->hmx);
-        for (auto &a : ctx->alias)  // (the stream has been waited for: a handle that named the marker reads as complete)
-            if (a == v.marker) a = nullptr;
-        (void)hipEventDestroy(v.marker);
-    }
-    if (v.box) (void)hipHostFree(v.box);
-    v = nz_graph_variant{};
-}
-
-// the stage list's launches on the context's stream (eager, or into an open capture).  positions != nullptr: the noise kernel
-// takes the tile's position from there (device-visible int32 {xpos, zpos}) instead of its arguments
-static int32_t graph_sequence(nz_pipeline_graph *G, float *read, float *write, int xpos, int zpos, const int32_t *positions,
-                              bool *chained, float **result) {
-    nz_ctx *ctx = G->ctx;
-    const nz_terrain_params &p = G->p;
-    const int res = G->resolution;
-    nz_rw_tile tile{read, write, res, 1};
-    const nz_geom g = nz_geom_tile(res);
-    NZ_TRY(fractal_impl(ctx, ctx->stream, p.noiseType, tile.read, res, res, res, p.hurst, p.startingAmplitude, p.stepdown,
-                        p.detuneRate, p.octaves, xpos, zpos, p.noiseSize, 1, 0, positions));
-    *chained = false;
-    if (p.filterIterations > 0) {
-        nz_kernel_taps t;
-        NZ_TRY(filter_taps(p.filter, &t));
-        bool swapped = false;
-        const unsigned e0 = ctx->chain_epoch;
-        NZ_TRY(conv_iterations(ctx, tile.read, tile.write, g, t, p.filterIterations, &swapped));
-        *chained = ctx->chain_epoch != e0;  // the stage ran as ONE chained grid: its launch carries an epoch and the flags' address
-        rw_swap(&tile, swapped);
-    }
-    if (p.flowIterations > 0) {
-        NZ_TRY(flowmap_rw_launches(ctx, &tile, G->work, p.flowIterations, p.normMin, p.normMax, false));
-        rw_swap(&tile, true);
-    }
-    if (p.erosionIterations > 0) {
-        bool swapped = false;
-        NZ_TRY(erosion_iterations(ctx, tile.read, tile.write, g, p.erosionIterations, &swapped));
-        rw_swap(&tile, swapped);
-    }
-    *result = tile.read;
-    return NZ_OK;
-}
-
-static int32_t graph_capture(nz_pipeline_graph *G, nz_graph_variant &v, float *read, float *write, int slot, int xpos, int zpos) {
-    nz_ctx *ctx = G->ctx;
-    bool chained = false;
-    float *result = nullptr;
-    // one eager pass first: every buffer a launcher keeps on the context (scratch planes, the noise tables) exists before the
-    // capture opens, and the request that causes the capture is served by it
-    NZ_TRY(graph_sequence(G, read, write, xpos, zpos, nullptr, &chained, &result));
-    if (chained && ctx->chain_last_items > G->flags_n) {
-        NZ_REQUIRE(!G->flags, "internal: the chained grid of one graph changed its size");
-        NZ_HIP(hipMalloc((void **)&G->flags, ctx->chain_last_items * sizeof(int)));
-        NZ_HIP(hipMemsetAsync(G->flags, 0, ctx->chain_last_items * sizeof(int), ctx->stream));
-        G->flags_n = ctx->chain_last_items;
-    }
-    NZ_HIP(hipHostMalloc((void **)&v.box, 64, hipHostMallocMapped));
-    NZ_HIP(hipHostGetDevicePointer((void **)&v.box_dev, v.box, 0));
-    v.box[0] = xpos;
-    v.box[1] = zpos;
-    NZ_HIP(hipEventCreate(&v.marker));
-    NZ_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-    ctx->chain_flags_override = G->flags;
-    ctx->chain_flags_override_n = G->flags_n;
-    int32_t rc = graph_sequence(G, read, write, xpos, zpos, v.box_dev, &chained, &result);
-    ctx->chain_flags_override = nullptr;
-    ctx->chain_flags_override_n = 0;
-    hipGraph_t graph = nullptr;
-    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-    v.graph = graph;
-    if (rc) return rc;
-    NZ_HIP(e);
-    v.read = read;
-    v.write = write;
-    v.slot = slot;
-    v.result = result;
-    v.float_mode = ctx->float_mode;
-    v.chained = chained;
-    v.epoch = ctx->chain_epoch;  // (the capture's nz_ctx_chain_state drew it: nobody else on this context ever holds it)
-    NZ_HIP(hipGraphInstantiate(&v.exec, graph, nullptr, nullptr, 0));
-    G->captures++;
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_pipeline_graph_create(nz_ctx *ctx, const nz_terrain_params *params, int32_t resolution,
-                                            nz_pipeline_graph **out) {
-    NZ_REQUIRE(ctx && params && out, "ctx/params/out is NULL");
-    NZ_TRY(check_res(resolution));
-    NZ_REQUIRE(params->noiseType >= 0 && params->noiseType <= NZ_NOISE_DOMAIN_ROTATED_SIMPLEX, "unknown noise type %d",
-               params->noiseType);
-    NZ_REQUIRE(params->octaves >= 0 && params->noiseSize != 0, "octaves < 0 or noiseSize == 0");
-    NZ_REQUIRE(params->filterIterations >= 0 && params->flowIterations >= 0 && params->erosionIterations >= 0, "iterations < 0");
-    NZ_REQUIRE(params->filterIterations == 0 || params->filter != NZ_SOBEL3_2D, "Sobel3_2D keeps a third plane: not in the stock list");
-    if (params->filterIterations > 0) {
-        nz_kernel_taps t;
-        NZ_TRY(filter_taps(params->filter, &t));
-    }
-    NZ_HIP(hipSetDevice(ctx->device));
-    nz_pipeline_graph *G = new nz_pipeline_graph();
-    G->ctx = ctx;
-    G->p = *params;
-    G->resolution = resolution;
-    if (params->flowIterations > 0) {
-        hipError_t e = hipMalloc((void **)&G->work, nz_flowmap_stage_rw_work_floats(resolution, 1) * sizeof(float));
-        if (e != hipSuccess) {
-            delete G;
-            nz_set_error("hipMalloc(flow state planes): %s", hipGetErrorString(e));
-            return NZ_ERR_NOMEM;
-        }
-    }
-    *out = G;
-    return NZ_OK;
-}
-
-extern "C" int32_t nz_pipeline_graph_launch(nz_ctx *ctx, nz_pipeline_graph *G, nz_rw_tile *tile, int32_t xpos, int32_t zpos,
-                                            nz_handle dep, nz_handle *out) {
-    NZ_REQUIRE(G, "graph is NULL");
-    NZ_REQUIRE(ctx == G->ctx, "the graph belongs to another context");
-    NZ_BEGIN(ctx, dep);
-    NZ_TRY(check_rw(tile));
-    NZ_REQUIRE(tile->resolution == G->resolution && tile->count == 1, "the graph was created for one %d^2 tile", G->resolution);
-    const int slot = G->next_slot;
-    G->next_slot = (slot + 1) % NZ_GRAPH_SLOTS;
-    nz_graph_variant *v = nullptr;
-    for (auto &c : G->variants)
-        if (c.read == tile->read && c.write == tile->write && c.slot == slot) v = &c;
-    // a capture holds kernels chosen for one float mode, and a chained filter grid only while the context still runs them
-    // (after a time-out it does not: nz_runtime.cpp, ctx_chain_check): otherwise capture again
-    if (v && (v->float_mode != ctx->float_mode || (v->chained && ctx->chain_off))) {
-        if (v->in_flight) NZ_HIP(hipEventSynchronize(v->marker));
-        graph_variant_release(ctx, *v);
-    }
-    if (!v || !v->exec) {
-        if (!v) {
-            if (G->variants.size() >= 4 * NZ_GRAPH_SLOTS) {  // (one pair = two orientations x the slots; two pairs is a generous cache)
-                size_t lru = 0;
-                for (size_t i = 1; i < G->variants.size(); i++)
-                    if (G->variants[i].used < G->variants[lru].used) lru = i;
-                if (G->variants[lru].in_flight) NZ_HIP(hipEventSynchronize(G->variants[lru].marker));
-                graph_variant_release(ctx, G->variants[lru]);
-                v = &G->variants[lru];
-            } else {
-                G->variants.emplace_back();
-                v = &G->variants.back();
-            }
-        }
-        int32_t rc = graph_capture(G, *v, tile->read, tile->write, slot, xpos, zpos);  // (its eager pass serves this request)
-        if (rc) {
-            graph_variant_release(ctx, *v);
-            return rc;
-        }
-        v->used = ++G->clock;
-        tile->write = v->result == tile->read ? tile->write : tile->read;
-        tile->read = v->result;
-        return nz_ctx_finish(ctx, out);
-    }
-    v->used = ++G->clock;
-    if (v->in_flight) {  // the replay before last read this slot's mailbox: finished by now, unless the host runs far ahead
-        hipError_t q = hipEventQuery(v->marker);
-        if (q == hipErrorNotReady) {
-            (void)hipGetLastError();
-            NZ_HIP(hipEventSynchronize(v->marker));
-        } else {
-            NZ_HIP(q);
-        }
-    }
-    v->box[0] = xpos;  // SetPosition, Fractal.cs:109-112: (float) of these is what fractal_impl hands the kernel
-    v->box[1] = zpos;
-    __atomic_thread_fence(__ATOMIC_RELEASE);
-    if (v->chained) nz_ctx_chain_mark(ctx, v->epoch);
-    NZ_HIP(hipGraphLaunch(v->exec, ctx->stream));
-    NZ_HIP(hipEventRecord(v->marker, ctx->stream));
-    v->in_flight = true;
-    tile->write = v->result == tile->read ? tile->write : tile->read;
-    tile->read = v->result;
-    return nz_ctx_finish_alias(ctx, out, v->marker);
-}
-
-extern "C" int32_t nz_pipeline_graph_captures(const nz_pipeline_graph *G) { return G ? G->captures : -1; }
-
-extern "C" int32_t nz_pipeline_graph_destroy(nz_ctx *ctx, nz_pipeline_graph *G) {
-    if (!G) return NZ_OK;
-    NZ_REQUIRE(ctx == G->ctx, "the graph belongs to another context");
-    NZ_HIP(hipSetDevice(ctx->device));
-    NZ_HIP(hipStreamSynchronize(ctx->stream));  // replays in flight read the state planes, the flags and the mailboxes
-    for (auto &v : G->variants) graph_variant_release(ctx, v);
-    if (G->work) (void)hipFree(G->work);
-    if (G->flags) (void)hipFree(G->flags);
-    delete G;
-    return NZ_OK;
 }

@@ -128,12 +128,10 @@ def _tiles_of(d):
     return [d.data]
 
 
-def _call_rw(ctx, name, d, *args, dep=None, first=None):
-    """Runs an nz_*_rw entry on the payload's READ / WRITE pair and adopts the pair as the call left it.  `first`: an
-    argument in front of the tile (nz_pipeline_graph_launch's graph)."""
+def _call_rw(ctx, name, d, *args, dep=None):
+    """Runs an nz_*_rw entry on the payload's READ / WRITE pair and adopts the pair as the call left it."""
     t = N.RWTile(d.data.ptr, d.write.ptr, d.resolution, getattr(d, "count", 1))
-    lead = () if first is None else (first,)
-    handle = ctx.call(name, *lead, C.byref(t), *args, dep=dep)
+    handle = ctx.call(name, C.byref(t), *args, dep=dep)
     if t.read != d.data.ptr:
         d.data, d.write = d.write, d.data
     return handle
@@ -608,61 +606,8 @@ class MeshTileStage(PipelineStage):  # Mesh/Stage/MeshTileStage.cs:28-61
 
 
 # ---- BasePipeline -------------------------------------------------------------------------------
-def stock_list_params(stages):
-    """nz_terrain_params of a stage list, when it IS the stock list -- NoiseStage, then at most one KernelFilterStage, one
-    FlowMapStage and one ErosionStage in that order, nothing else -- else None.  (The C++ and C# hosts: stockListParams /
-    BasePipeline.StockListParams.)"""
-    if not stages or type(stages[0]) is not NoiseStage:
-        return None
-    n = stages[0]
-    tp = N.TerrainParams(int(n.noiseType), n.hurst, n.startingAmplitude, n.stepdown, n.detuneRate, n.octaves, n.noiseSize,
-                         0, 0, 0, 0.0, 0.0, 0)
-    order = 0
-    for st in stages[1:]:
-        if type(st) is KernelFilterStage and order < 1 and st.filter != KernelFilterType.Sobel3_2D and st.iterations >= 1:
-            tp.filter, tp.filterIterations, order = int(st.filter), st.iterations, 1
-        elif type(st) is FlowMapStage and order < 2 and st.iterations >= 1:
-            tp.flowIterations, tp.normMin, tp.normMax, order = st.iterations, st.normMin, st.normMax, 2
-        elif type(st) is ErosionStage and order < 3 and st.iterations >= 1:
-            tp.erosionIterations, order = st.iterations, 3
-        else:
-            return None
-    return tp
-
-
-class PipelineGraph:
-    """nz_pipeline_graph: the stock stage list on a READ / WRITE pair as ONE replayed HIP graph per tile request
-    (include/noize_hip.h).  Same kernels, same order, same result plane as the four stage entries."""
-
-    def __init__(self, ctx, stages_or_params, resolution):
-        tp = stages_or_params if isinstance(stages_or_params, N.TerrainParams) else stock_list_params(stages_or_params)
-        if tp is None:
-            raise Exception("PipelineGraph: not the stock stage list")
-        self.ctx, self.tp, self.resolution = ctx, tp, resolution
-        h = C.c_void_p()
-        N.check(N.lib.nz_pipeline_graph_create(ctx._h, C.byref(tp), resolution, C.byref(h)), "nz_pipeline_graph_create")
-        self._h = h
-
-    @property
-    def captures(self):
-        return N.lib.nz_pipeline_graph_captures(self._h)
-
-    def Launch(self, d, dependency=None):
-        """One request: d is a GeneratorData with `write`; returns the JobHandle, `d.data` is the plane with the result."""
-        return _call_rw(self.ctx, "nz_pipeline_graph_launch", d, d.xpos, d.zpos, dep=dependency, first=self._h)
-
-    def Destroy(self):
-        if self._h:
-            N.check(N.lib.nz_pipeline_graph_destroy(self.ctx._h, self._h), "nz_pipeline_graph_destroy")
-            self._h = None
-
-
 class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
-    def __init__(self, stages, alias="Unnamed Pipeline", contextManager=None, replay=False):
-        # replay (new-framework): a tile request on a READ / WRITE pair runs as ONE replayed graph of the stage list instead of
-        # stage by stage, when the list is the stock one and nobody listens to the stages individually (see _replayable)
-        self.replay = replay
-        self._graphs = {}
+    def __init__(self, stages, alias="Unnamed Pipeline", contextManager=None):
         self.alias = alias
         self.contextManager = contextManager  # PipelineStateManager handed to every work item (:76-104)
         self.queue = collections.deque()  # ConcurrentQueue: deque.append is thread-safe
@@ -696,28 +641,7 @@ class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
         if not self.stage_instances:
             raise Exception("No stages in pipeline")
         self.pipelineBeingScheduled = True
-        if self.replay and self._replayable(self.activeItem):
-            d = self.activeItem.data
-            g = self._graphs.get(d.resolution)
-            if g is None:
-                g = self._graphs[d.resolution] = PipelineGraph(self.stage_instances[0].ctx, self.stage_instances, d.resolution)
-            handle = g.Launch(d, self.activeItem.dependency)
-            for st in self.stage_instances:   # every stage's work is behind this handle
-                st.jobHandle = handle
-            self.OnPipelineFullyScheduled(self.activeItem, handle)
-            return
         self.stage_instances[0].ReceiveHandledInput(self.activeItem, self.activeItem.dependency)
-
-    def _replayable(self, item):
-        """The request can run as one graph launch: a single tile with its WRITE plane, the stock stage list, and no listener on
-        an individual stage (a joint, a downstream pipeline's OnScheduledUpstream: those want the stage's own handle)."""
-        d = item.data
-        if type(d) is not GeneratorData or d.write is None:
-            return False
-        own = {s.ReceiveHandledInput for s in self.stage_instances} | {self.OnPipelineFullyScheduled}
-        if not all(a in own for s in self.stage_instances for a in s.OnStageScheduledAction):
-            return False
-        return stock_list_params(self.stage_instances) is not None
 
     def OnPipelineFullyScheduled(self, res, handle):  # :122-128
         self.pipelineHandle = handle
@@ -805,9 +729,6 @@ class BasePipeline:  # Pipeline/Executable/Pipeline.cs:19-287
         return [self]
 
     def Destroy(self):  # :244-254,267-274
-        for g in self._graphs.values():
-            g.Destroy()
-        self._graphs = {}
         for stage in self.stage_instances:
             stage.OnDestroy()
 

@@ -15,11 +15,11 @@ import noize_job_amd as nj  # noqa: E402
 gc.disable()  # a full collection pass of the host (tens of ms with a big heap) must not land in a timed loop
 
 
-def make(ctx, res, replay=False):
+def make(ctx, res):
     stages = [nj.NoiseStage(ctx, nj.FractalNoise.Simplex, 0.4, 1.0, 13, 2.0, 0.0, 1700),
               nj.KernelFilterStage(ctx, nj.KernelFilterType.Gauss5_S1, 17), nj.FlowMapStage(ctx, 5, 0.0, 0.005),
               nj.ErosionStage(ctx, 5)]
-    pipe = nj.BasePipeline(stages, "tile", replay=replay)   # replay: one graph launch per request (nz_pipeline_graph)
+    pipe = nj.BasePipeline(stages, "tile")
     gd = nj.GeneratorData("t", ctx.alloc(res * res), res, 0, 0, write=ctx.alloc(res * res))  # READ / WRITE pair
     return pipe, gd
 
@@ -30,7 +30,6 @@ def main():
     ap.add_argument("--streams", type=int, nargs="+", default=[1, 2, 4])
     ap.add_argument("--tiles", type=int, default=256)
     ap.add_argument("--batch", type=int, nargs="*", default=[4, 16, 64])
-    ap.add_argument("--replay", type=int, nargs="*", default=[0, 1], help="0: stage by stage; 1: BasePipeline(replay=True)")
     a = ap.parse_args()
     for res in a.res:
         for B in a.batch:
@@ -58,9 +57,9 @@ def main():
                 batch.data.Dispose()
                 batch.write.Dispose()
                 batch.positions.Dispose()
-        for S, replay in [(S, r) for S in a.streams for r in a.replay]:
+        for S in a.streams:
             ctxs = [nj.Context(0) for _ in range(S)]
-            pipes = [make(c, res, bool(replay)) for c in ctxs]
+            pipes = [make(c, res) for c in ctxs]
             for _ in range(3):
                 for i, (p, gd) in enumerate(pipes):
                     gd.xpos = 7 * i
@@ -78,8 +77,8 @@ def main():
             for c in ctxs:
                 c.synchronize()
             dt = time.perf_counter() - t0
-            print("res %5d  streams %d %s: %8.1f tiles/s  %9.0f Mcells/s  (%.3f ms per tile, host enqueue %.3f ms per tile)" % (
-                res, S, "replay" if replay else "stages", a.tiles / dt, a.tiles * res * res / dt / 1e6, dt / a.tiles * 1e3, t_host / a.tiles * 1e3))
+            print("res %5d  streams %d: %8.1f tiles/s  %9.0f Mcells/s  (%.3f ms per tile, host enqueue %.3f ms per tile)" % (
+                res, S, a.tiles / dt, a.tiles * res * res / dt / 1e6, dt / a.tiles * 1e3, t_host / a.tiles * 1e3))
             for p, gd in pipes:
                 p.Destroy()
                 gd.data.Dispose()
