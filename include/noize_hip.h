@@ -440,7 +440,8 @@ int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *even
  * threads.  Here the pile solver's launch -- a few thousand waves that wait for memory and for each other on an otherwise idle
  * chip -- carries the flow update's workgroups behind its own.  Results: exactly those of nz_erode_height_maps followed by
  * nz_update_flow_from_track(pool, flow, track, ep->FLOW_LOSS_RATE, ep->SURFACE_EVAPORATION_RATE, tm->HEIGHT) -- the two jobs
- * share no plane (pool / flow / track must not be `height`).  NZ_PILE_CARRY_FLOW=0: the two launches one after the other. */
+ * share no plane (pool / flow / track must not be `height`).  (A pile solver with more than 16 KB of
+ * LDS -- PILING_RADIUS beyond ~18 -- runs the two launches one after the other.) */
 int32_t nz_erode_height_maps_and_flow(nz_ctx *ctx, float *height, nz_erosive_events *events, float *pool, float *flow,
                                       float *track, const nz_erosion_params *ep, const nz_tile_set_meta *tm, int32_t res,
                                       nz_handle dep, nz_handle *out);

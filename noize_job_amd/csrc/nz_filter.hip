@@ -746,13 +746,12 @@ int32_t launch_wide_nt(hipStream_t s, const float *src, float *dst, const nz_geo
     return NZ_OK;
 }
 
-// 32-row tiles (256 threads) up to NZ_WIDE_BIG_FROM taps, 64-row tiles (512 threads) beyond: the taller tile stages
+// 32-row tiles (256 threads) below 17 taps, 64-row tiles (512 threads) from there on: the taller tile stages
 // fewer halo rows per output row, which pays once the halo (kernelSize - 1 rows) is a large part of the tile
 template <int O>
 int32_t launch_wide(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k) {
-    static const int big_from = getenv("NZ_WIDE_BIG_FROM") ? atoi(getenv("NZ_WIDE_BIG_FROM")) : 17;
-    if (2 * O + 1 >= big_from) return launch_wide_nt<O, 512>(s, src, dst, g, k);
-    return launch_wide_nt<O, 256>(s, src, dst, g, k);
+    if constexpr (2 * O + 1 >= 17) return launch_wide_nt<O, 512>(s, src, dst, g, k);
+    else return launch_wide_nt<O, 256>(s, src, dst, g, k);
 }
 
 #ifndef NZ_CONV_NT

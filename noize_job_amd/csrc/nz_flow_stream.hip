@@ -396,7 +396,7 @@ void flow_stream_kernel(const float *__restrict__ h, float *__restrict__ dst, nz
 }  // namespace
 
 // The whole stage (first && last) in its row-streaming form.  A segment of S rows per wave: S is chosen so that the grid
-// is about one round of waves for the chip (NZ_FLOW_STREAM_WAVES resident waves; longer segments waste less on the pipeline
+// is about one round of waves for the chip (one round of resident waves; longer segments waste less on the pipeline
 // fill, but a second, partial round of waves would cost more), never below 16 rows.
 bool nz_flow_stream_wanted(const nz_geom &g, int n) {
     static const int mode = getenv("NZ_FLOW_STREAM") ? atoi(getenv("NZ_FLOW_STREAM")) : 1;
@@ -411,8 +411,7 @@ int32_t nz_launch_flow_stream(hipStream_t s, const float *h, float *dst, const n
     // two columns per lane: a 128-column strip per wave (one column per lane -- 64-column strips, five waves per SIMD -- was built
     // in round 4 and lost: 0.174 against 0.148 ms, 1.22x the halo columns; removed in round 5)
     constexpr int NC = 2;
-    static const int waves_env = getenv("NZ_FLOW_STREAM_WAVES") ? atoi(getenv("NZ_FLOW_STREAM_WAVES")) : 0;
-    const int waves = waves_env > 0 ? waves_env : 1024 * NZ_FS_WPE;  // one round of resident waves
+    const int waves = 1024 * NZ_FS_WPE;  // one round of resident waves
     const int H = 2 * n, OW = 64 * NC - 2 * H;
     const int nstrips = (g.cols + OW - 1) / OW, rows = g.or1 - g.or0;
     const long long per = (long long)nstrips * g.count;

@@ -1038,7 +1038,7 @@ int32_t nz_launch_fractal(hipStream_t s, int noiseType, float *dst, int rows, in
         long long wg_per_row = (cols + 511) / 512;
         while (p.rows_per_wg > 1 && wg_per_row * ((rows + p.rows_per_wg - 1) / p.rows_per_wg) * count < 2048) p.rows_per_wg >>= 1;
     }
-    static const int use_tab = getenv("NZ_NOISE_TAB") ? atoi(getenv("NZ_NOISE_TAB")) : 1;
+    constexpr int use_tab = 1;  // (the direct kernels below serve Sin / psrnoise and every basis beyond its tables' range)
     if (noiseType == NZ_NOISE_SIMPLEX && use_tab && d_simplex) {
 #ifndef NZ_FT_VEC
 #define NZ_FT_VEC 2

@@ -1358,7 +1358,7 @@ static int32_t erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *
             const pile_ticket_args pa{height, events->sediment, events->pile_blocks, pile_list, pile_ctl, pile_cap,
                                       (const short2 *)events->pile_scratch, nverts, res, D, B, nb, thr,
                                       ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT, err_host};
-            static const bool carry = [] { const char *e = getenv("NZ_PILE_CARRY_FLOW"); return !e || atoi(e) != 0; }();
+            const bool carry = true;
             const size_t flow_wgs = fl ? (fl->n + FLOW_WG_CELLS - 1) / FLOW_WG_CELLS : 0;
             // the flow workgroups of the one-call form are launched under the pile solver's dynamic LDS size: a few KB at the
             // default radius, ~110 KB at PILING_RADIUS 50 -- where each of the res^2 / 1024 flow workgroups would hold a CU
@@ -1384,7 +1384,7 @@ static int32_t erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *
             NZ_HIP(hipGetLastError());
         }
     }
-    // no pile solver launch to carry it (PILING_RADIUS 0, NZ_PILE_TICKET=0, NZ_PILE_CARRY_FLOW=0): the flow update by itself
+    // no pile solver launch to carry it (PILING_RADIUS 0, NZ_PILE_TICKET=0, a solver with more than 16 KB of LDS): the flow update by itself
     if (fl) NZ_TRY_(nz_launch_flow_from_track(ctx->stream, fl->pool, fl->flow, fl->track, fl->n, fl->flowLossRate, fl->evaporation));
     return nz_ctx_finish(ctx, out);
 }

@@ -156,17 +156,12 @@ static int32_t smooth_taps(int32_t width, nz_kernel_taps *t) {
 static int conv_tcap(int ksize) {
     int hw = nz_conv_max_fused(ksize);
     if (hw == 0) return 0;
-    static const char *env = getenv("NZ_CONV_TCAP");
     int cap;
-    if (env && atoi(env) > 0) {
-        cap = atoi(env);
-    } else {
-        switch (ksize) {  // default fusion depth per launch (tuned on MI355X)
-            case 3: cap = 6; break;
-            case 5: cap = 5; break;
-            case 7: cap = 3; break;
-            default: cap = 3; break;
-        }
+    switch (ksize) {  // fusion depth per launch (tuned on MI355X; other depths lost every measurement, HISTORY.md)
+        case 3: cap = 6; break;
+        case 5: cap = 5; break;
+        case 7: cap = 3; break;
+        default: cap = 3; break;
     }
     return cap < hw ? cap : hw;
 }
@@ -187,7 +182,7 @@ static int32_t conv_iterations(nz_ctx *ctx, float *src, float *tmp, const nz_geo
     // at once) waits for the LATENCY of its dependent applications, not for throughput: nine applications per launch, 17 = 9 + 8
     // in two launches instead of three (round 5: Gauss5 x17 at 256^2 / 512^2 52 -> 42 / 43 us, 13 100 -> 13 900 tiles/s one at a
     // time; from 1024^2 on the deeper halo costs more than the launch it saves: 55 -> 59 us)
-    if (t.ksize == 5 && cap == 5 && !getenv("NZ_CONV_TCAP") && nz_conv_small_grid(t.ksize, g))
+    if (t.ksize == 5 && cap == 5 && nz_conv_small_grid(t.ksize, g))
         cap = nz_conv_tiny_grid(t.ksize, g) ? 9 : 6;
     if (nz_conv_has_wide(t.ksize)) {  // one launch per application, ping-pong, copy back after an odd count
         float *cur = src, *other = tmp;

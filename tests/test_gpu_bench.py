@@ -144,7 +144,7 @@ def test_bench_starts_its_own_ranks_one_rank():
     assert c["ranks"][0]["native_comm"] == {"rank": 0, "world": 1} and c["ranks"][0]["owned_rows"] == [0, 384]
     assert c["backend"] == "nccl" and c["world"] == 1 and c["halo"] == "exchange" and c["overlapped"] is False
     # one exchange per stencil launch: 4 filter launches + flow + erosion unless a fusion-depth knob regroups them
-    regrouped = any(os.environ.get(k) for k in ("NZ_CONV_TCAP", "NZ_FLOW_NMAX", "NZ_EROSION_EMAX"))
+    regrouped = any(os.environ.get(k) for k in ("NZ_FLOW_NMAX", "NZ_EROSION_EMAX"))
     assert c["impl"].startswith("native") and (c["exchanges_per_step"] == 6 or regrouped) and c["host_enqueue_ms_idle_queue"] > 0.0
     assert c["exchange_ms_per_step"] is not None and c["exchange_ms_per_step"] >= 0.0 and c["rccl_version"]
     assert d["grid_1024"]["recompute"]["Mcells/s"] > 0

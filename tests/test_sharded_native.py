@@ -34,7 +34,7 @@ def _native_plan(sh, rank, world, grows, cols, p, overlap, stripes=None):
 
 def _exchanges_planned(sh, grows, cols, p, stripes, as_rank=(0, 1)):
     """Exchange batches per step of the native plan: one per filter launch + the flow launch + the erosion launch under the
-    default fusion depths (6 for the metric list), more or fewer under the NZ_CONV_TCAP / NZ_FLOW_NMAX / NZ_EROSION_EMAX
+    default fusion depths (6 for the metric list), more or fewer under the NZ_FLOW_NMAX / NZ_EROSION_EMAX
     knobs of tools/run_knob_matrix.sh -- the rows sent do not depend on how the applications are grouped."""
     g = sh.ShardedGrid(None, None, grows, cols, p, stripes=stripes, overlap=0, as_rank=as_rank)
     try:
@@ -44,7 +44,7 @@ def _exchanges_planned(sh, grows, cols, p, stripes, as_rank=(0, 1)):
 
 
 def _default_fusion():
-    return not any(os.environ.get(k) for k in ("NZ_CONV_TCAP", "NZ_FLOW_NMAX", "NZ_EROSION_EMAX"))
+    return not any(os.environ.get(k) for k in ("NZ_FLOW_NMAX", "NZ_EROSION_EMAX"))
 
 
 PARAM_SETS = [

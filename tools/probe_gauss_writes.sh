@@ -28,7 +28,6 @@ PY
 }
 ARGS="--res 4096 --gauss 17" run "4096 x17 chain" X=1
 ARGS="--res 4096 --gauss 17" run "4096 x17 separate" NZ_CONV_CHAIN=0
-ARGS="--res 4096 --gauss 16" run "4096 x16 T4 chain" NZ_CONV_TCAP=4
-ARGS="--res 4032 --gauss 16" run "4032 x16 T4 chain" NZ_CONV_TCAP=4
-ARGS="--res 4032 --gauss 16" run "4032 x16 T4 separate" NZ_CONV_TCAP=4 NZ_CONV_CHAIN=0
+ARGS="--res 4032 --gauss 17" run "4032 x17 chain" X=1
+ARGS="--res 4032 --gauss 17" run "4032 x17 separate" NZ_CONV_CHAIN=0
 cat "$OUT/gauss_writes.txt"
