@@ -85,6 +85,11 @@ namespace xshazwar.noize.hip {
         public int particleGenerationID = 0, EVENT_LIMIT = 1500, QUEUE_SIZE;
         public GpuJobHandle jobHandle;
 
+        // nz_ctx_set_pile_safe: ErodeHeightMaps keeps a copy of the height plane, waits for the pile solver's one-launch form and runs
+        // itself again colour by colour should a block of it ever give up (a property of the context)
+        public bool Safe { set { Native.Check(Native.nz_ctx_set_pile_safe(ctx.Handle, value ? 1 : 0), "nz_ctx_set_pile_safe"); } }
+        public int PileRetries => Native.nz_ctx_pile_retries(ctx.Handle);
+
         public LiveErosion(GpuContext ctx, DeviceTile heightMap, NzTileSetMeta tileMeta, ErosionSettings settings, bool performErosion = true) {
             this.ctx = ctx; this.tileMeta = tileMeta; this.heightMap = heightMap; erosionSettings = settings; this.performErosion = performErosion;
             res = tileMeta.GENERATOR_RES_x;

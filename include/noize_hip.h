@@ -431,8 +431,15 @@ int32_t nz_process_beyer_erosive_events(nz_ctx *ctx, float *height, float *pool,
 /* ErodeHeightMaps.ScheduleRun(height, erosions, ep, tm, res, deps), :459-479: applies the events of the LAST
  * nz_process_beyer_erosive_events on `events` (in place on `height`).  The PileSolver events of all four block colours run as
  * ONE launch whose busy blocks wait for their lower-coloured busy neighbours (NZ_PILE_TICKET=0: a launch per colour); that
- * wait is bounded -- a block that gives up makes the context's next wait / synchronisation return NZ_ERR_HIP, the height
- * plane is then invalid */
+ * wait is bounded.  A block that gives up (never, while resident waves hold the lower tickets) makes the context's next wait /
+ * synchronisation return NZ_ERR_HIP -- the height plane is then invalid, and the context runs a launch per colour from then on.
+ * SAFE MODE, nz_ctx_set_pile_safe(ctx, 1): the job keeps a copy of `height` as it found it (one plane copy per call), waits for
+ * its ticket launch, and, should a block have given up, puts the plane back and runs itself again colour by colour: the caller
+ * sees a job that succeeded (nz_ctx_pile_retries counts them).  The three hosts expose it as LiveErosion's `safe` option. */
+int32_t nz_ctx_set_pile_safe(nz_ctx *ctx, int32_t on);
+int32_t nz_ctx_pile_retries(nz_ctx *ctx);
+/* test hook: polls after which a block of the ticket launch gives up; <= 0: the default (2^22, seconds) */
+int32_t nz_debug_pile_poll_limit(int32_t polls);
 int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *events, const nz_erosion_params *ep,
                              const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out);
 /* ErodeHeightMaps and UpdateFlowFromTrackJob as ONE call.  The reference schedules the two on the same dependency and

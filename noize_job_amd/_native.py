@@ -122,6 +122,9 @@ SIGNATURES = {
     "nz_smooth_blur_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i, _i] + _tail),
     "nz_erosion_stage": (_i, [ctx_p, dev_ptr, dev_ptr, _i, _i] + _tail),
     "nz_debug_chain_delay": (_i, [_i, _i]),
+    "nz_ctx_set_pile_safe": (_i, [ctx_p, _i]),
+    "nz_ctx_pile_retries": (_i, [ctx_p]),
+    "nz_debug_pile_poll_limit": (_i, [_i]),
     "nz_kernel_filter_halo_rows": (_i, [_i, _i]),
     "nz_kernel_filter_max_fused": (_i, [_i]),
     "nz_erosion_max_fused_iterations": (_i, []),

@@ -72,6 +72,10 @@ struct nz_ctx {
     chain_mark chain_marks[64] = {};
     uint64_t retry_lo = 0, retry_hi = 0;
     bool retry_sync_pending = false, retry_open = false;
+    // live erosion, the pile solver's ticket launch (nz_live.hip): safe mode (nz_ctx_set_pile_safe) waits for it and runs the job
+    // again colour by colour should it ever give up -- for good on this context (pile_ticket_off)
+    bool pile_safe = false, pile_ticket_off = false;
+    int pile_retries = 0;
     bool handle_rides = false;    // this entry's handle may ride on its last kernel launch (nz_ctx_handle_rides)
     uint64_t armed_seq = 0;       // ... and this is the sequence number reserved for it (nz_ctx_arm_last_launch)
     // pool automaton, sparse form (nz_pool_job in nz_stages.cpp): {entries, done, -} in device memory, and in mapped host

@@ -46,6 +46,7 @@ struct nz_erosive_events {
     // control words {busy blocks of colour 0..3, ticket}, then the busy blocks listed per colour ((nb + 1)^2 / 4 each)
     int32_t *pile_blocks = nullptr;
     size_t pile_blocks_n = 0;
+    float *height_snapshot = nullptr;   // [res^2], safe mode only (nz_ctx_set_pile_safe): the plane as ErodeHeightMaps found it
 };
 
 namespace {
@@ -888,6 +889,7 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
 // raised.  ctl: {items of colour 0..3, ticket}.  A wait is bounded all the same (err_host, mapped host memory: the context
 // reports an internal error at its next synchronisation instead of hanging).
 constexpr int PILE_CTL = 8;
+int g_pile_spin_limit = 1 << 22;  // nz_debug_pile_poll_limit
 // the blocks disperse_list_kernel flagged, listed under their colour (a colour's blocks are independent: any order).  A
 // thread per flag; a wave numbers its blocks with a ballot per colour, the workgroup's waves share LDS counters, and ONE
 // increment per colour and workgroup reaches memory (7 000 returning atomics on four words took 75 us).
@@ -928,6 +930,7 @@ struct pile_ticket_args {
     int nverts, res, maxDistance, B, nb;
     float pileThreshold, increment;
     unsigned *err_host;
+    int spin_limit;  // polls of a neighbour's flag before a block gives up (2^22: seconds; nz_debug_pile_poll_limit)
 };
 
 __device__ __forceinline__ void pile_ticket_wave(const pile_ticket_args &a, unsigned char *s_raw) {
@@ -940,6 +943,7 @@ __device__ __forceinline__ void pile_ticket_wave(const pile_ticket_args &a, unsi
     const int cap = a.cap, nverts = a.nverts, res = a.res, maxDistance = a.maxDistance, B = a.B, nb = a.nb;
     const float pileThreshold = a.pileThreshold, increment = a.increment;
     unsigned *err_host = a.err_host;
+    const int spin_limit = a.spin_limit;
     const pile_lds L = pile_carve(s_raw, nverts, B);
     const int lane = threadIdx.x;
     const int n0 = ctl[0], n1 = ctl[1], n2 = ctl[2], n3 = ctl[3];
@@ -967,7 +971,7 @@ __device__ __forceinline__ void pile_ticket_wave(const pile_ticket_args &a, unsi
                 int spins = 0;
                 while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) {
                     __builtin_amdgcn_s_sleep(16);
-                    if (++spins > (1 << 22)) {  // seconds: never, unless the protocol is broken
+                    if (++spins > spin_limit) {  // seconds by default: never, unless the protocol is broken
                         __hip_atomic_store(err_host + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // word [1]: the pile solver's
                         break;
                     }
@@ -1192,7 +1196,8 @@ extern "C" int32_t nz_erosive_events_destroy(nz_ctx *ctx, nz_erosive_events *ev)
     if (!ev) return NZ_OK;
     NZ_HIP(hipSetDevice(ctx->device));
     NZ_HIP(hipStreamSynchronize(ctx->stream));
-    void *ps[] = {ev->acc, ev->touched, ev->list[0], ev->list[1], ev->counters, ev->sediment, ev->pile_scratch, ev->pile_blocks};
+    void *ps[] = {ev->acc, ev->touched, ev->list[0], ev->list[1], ev->counters, ev->sediment, ev->pile_scratch, ev->pile_blocks,
+                  ev->height_snapshot};
     for (void *p : ps)
         if (p) (void)hipFree(p);
     delete ev;
@@ -1310,14 +1315,23 @@ static int32_t erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *
     }
     int32_t *pile_ctl = D >= 1 ? events->pile_blocks + (size_t)nb * nb : nullptr;
     int32_t *pile_list = D >= 1 ? pile_ctl + PILE_CTL : nullptr;
-    hipLaunchKernelGGL(disperse_list_kernel, dim3(2048), dim3(CT), 0, ctx->stream, height, events->sediment, events->list[slot],
-                       events->counters, slot, res, thr, D >= 1 ? events->pile_blocks : nullptr, B, nb);
-    {
+    // safe mode keeps the plane as the job found it (one plane copy per cycle, ~25 us at 8192^2)
+    static const bool ticket_wanted = [] { const char *e = getenv("NZ_PILE_TICKET"); return !e || atoi(e) != 0; }();
+    const bool safe = ctx->pile_safe && D >= 1 && ticket_wanted && !ctx->pile_ticket_off;
+    if (safe) {
+        if (!events->height_snapshot) NZ_HIP(hipMalloc((void **)&events->height_snapshot, (size_t)res * res * sizeof(float)));
+        NZ_HIP(hipMemcpyAsync(events->height_snapshot, height, (size_t)res * res * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    auto disperse = [&]() -> int32_t {
+        hipLaunchKernelGGL(disperse_list_kernel, dim3(2048), dim3(CT), 0, ctx->stream, height, events->sediment, events->list[slot],
+                           events->counters, slot, res, thr, D >= 1 ? events->pile_blocks : nullptr, B, nb);
         const long long frame = (long long)std::min(res, 4) * res + (long long)std::max(res - 4, 0) * 4;
         hipLaunchKernelGGL(disperse_frame_kernel, dim3((unsigned)((frame + CT - 1) / CT)), dim3(CT), 0, ctx->stream, height,
                            events->sediment, res, thr);
-    }
-    NZ_HIP(hipGetLastError());
+        NZ_HIP(hipGetLastError());
+        return NZ_OK;
+    };
+    NZ_TRY_(disperse());
     // PileSolver.Init :1058-1098: vertex offsets (host), GetOffset = dist * dirA + i * (dirB - dirA)
     if (D >= 1) {
         std::vector<short2> ofs;
@@ -1342,8 +1356,21 @@ static int32_t erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *
         if (lds > 64 * 1024)
             NZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // NZ_PILE_TICKET (1): all colours in one launch, the busy blocks handed out by ticket (pile_ticket_kernel); 0: one
-        // launch per colour over every block of it
-        static const bool ticket = [] { const char *e = getenv("NZ_PILE_TICKET"); return !e || atoi(e) != 0; }();
+        // launch per colour over every block of it -- also what a context does for good after a ticket launch of its gave up
+        static const bool ticket_env = [] { const char *e = getenv("NZ_PILE_TICKET"); return !e || atoi(e) != 0; }();
+        const bool ticket = ticket_env && !ctx->pile_ticket_off;
+        const float incr = ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT;
+        auto colour_launches = [&]() -> int32_t {
+            for (int colour = 0; colour < 4; colour++) {
+                const int cx = colour & 1, cz = colour >> 1;
+                const int bxn = (nb - cx + 1) / 2, bzn = (nb - cz + 1) / 2;
+                if (bxn <= 0 || bzn <= 0) continue;
+                hipLaunchKernelGGL(pile_kernel, dim3((unsigned)(bxn * bzn)), dim3(64), lds, ctx->stream, height, events->sediment,
+                                   events->pile_blocks, (const short2 *)events->pile_scratch, nverts, res, D, B, nb, cx, cz, thr, incr);
+                NZ_HIP(hipGetLastError());
+            }
+            return NZ_OK;
+        };
         if (ticket) {
             unsigned *err_host = nullptr;
             NZ_TRY_(nz_ctx_error_word(ctx, &err_host));
@@ -1356,38 +1383,59 @@ static int32_t erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *
             // poll (239 / 279 us against 211)
             const unsigned grid = (unsigned)std::min<long long>((long long)nb * nb, 2048);
             const pile_ticket_args pa{height, events->sediment, events->pile_blocks, pile_list, pile_ctl, pile_cap,
-                                      (const short2 *)events->pile_scratch, nverts, res, D, B, nb, thr,
-                                      ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT, err_host};
-            const bool carry = true;
+                                      (const short2 *)events->pile_scratch, nverts, res, D, B, nb, thr, incr, err_host,
+                                      g_pile_spin_limit};
             const size_t flow_wgs = fl ? (fl->n + FLOW_WG_CELLS - 1) / FLOW_WG_CELLS : 0;
             // the flow workgroups of the one-call form are launched under the pile solver's dynamic LDS size: a few KB at the
             // default radius, ~110 KB at PILING_RADIUS 50 -- where each of the res^2 / 1024 flow workgroups would hold a CU
-            // alone with one wave.  Beyond 16 KB the flow update is its own launch again (nz_launch_flow_from_track below)
-            if (fl && carry && lds <= 16 * 1024 && flow_wgs + grid < 0x7fffffffull) {
-                if (lds > 64 * 1024)
-                    NZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pile_ticket_flow_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            // alone with one wave.  Beyond 16 KB the flow update is its own launch again (nz_launch_flow_from_track below);
+            // so it is in safe mode, whose retry runs the pile solver alone
+            if (fl && !safe && lds <= 16 * 1024 && flow_wgs + grid < 0x7fffffffull) {
                 hipLaunchKernelGGL(pile_ticket_flow_kernel, dim3(grid + (unsigned)flow_wgs), dim3(64), lds, ctx->stream, pa, grid, *fl);
                 fl = nullptr;  // done
             } else {
                 hipLaunchKernelGGL(pile_ticket_kernel, dim3(grid), dim3(64), lds, ctx->stream, pa);
             }
             NZ_HIP(hipGetLastError());
-        }
-        for (int colour = 0; colour < 4 && !ticket; colour++) {
-            const int cx = colour & 1, cz = colour >> 1;
-            const int bxn = (nb - cx + 1) / 2, bzn = (nb - cz + 1) / 2;
-            if (bxn <= 0 || bzn <= 0) continue;
-            hipLaunchKernelGGL(pile_kernel, dim3((unsigned)(bxn * bzn)), dim3(64), lds, ctx->stream, height, events->sediment,
-                               events->pile_blocks, (const short2 *)events->pile_scratch, nverts, res, D, B, nb, cx, cz, thr,
-                               ep->MIN_PILE_INCREMENT / (float)tm->HEIGHT);
-            NZ_HIP(hipGetLastError());
+            if (safe) {
+                // Safe mode (nz_ctx_set_pile_safe): the ticket launch is waited for here.  Its bounded wait never gives up while
+                // the protocol holds (a block waits only for lower tickets, which resident waves hold) -- should it, the plane it
+                // left is invalid: put back what the job found, and run the whole job again the way that cannot wait, a launch
+                // per colour, on this context from now on.  The caller sees a job that succeeded.
+                NZ_HIP(hipStreamSynchronize(ctx->stream));
+                volatile unsigned *w = reinterpret_cast<volatile unsigned *>(ctx->chain_err);
+                if (w && w[1]) {
+                    w[1] = 0;
+                    ctx->pile_ticket_off = true;
+                    ctx->pile_retries++;
+                    NZ_HIP(hipMemcpyAsync(height, events->height_snapshot, (size_t)res * res * sizeof(float), hipMemcpyDeviceToDevice,
+                                          ctx->stream));
+                    NZ_HIP(hipMemsetAsync(events->pile_blocks, 0, ((size_t)nb * nb + PILE_CTL) * 4, ctx->stream));
+                    NZ_TRY_(disperse());
+                    NZ_TRY_(colour_launches());
+                }
+            }
+        } else {
+            NZ_TRY_(colour_launches());
         }
     }
     // no pile solver launch to carry it (PILING_RADIUS 0, NZ_PILE_TICKET=0, a solver with more than 16 KB of LDS): the flow update by itself
     if (fl) NZ_TRY_(nz_launch_flow_from_track(ctx->stream, fl->pool, fl->flow, fl->track, fl->n, fl->flowLossRate, fl->evaporation));
     return nz_ctx_finish(ctx, out);
 }
+
+// Test hook: polls of a lower-coloured neighbour's flag after which a block of the pile solver's ticket launch gives up (<= 0: the
+// default, 2^22 = seconds).  With a limit of 1 every block that has to wait at all gives up: the time-out path runs.
+extern "C" int32_t nz_debug_pile_poll_limit(int32_t polls) {
+    g_pile_spin_limit = polls > 0 ? polls : 1 << 22;
+    return NZ_OK;
+}
+extern "C" int32_t nz_ctx_set_pile_safe(nz_ctx *ctx, int32_t on) {
+    NZ_REQUIRE(ctx, "ctx is NULL");
+    ctx->pile_safe = on != 0;
+    return NZ_OK;
+}
+extern "C" int32_t nz_ctx_pile_retries(nz_ctx *ctx) { return ctx ? ctx->pile_retries : -1; }
 
 extern "C" int32_t nz_erode_height_maps(nz_ctx *ctx, float *height, nz_erosive_events *events, const nz_erosion_params *ep,
                                         const nz_tile_set_meta *tm, int32_t res, nz_handle dep, nz_handle *out) {

@@ -477,8 +477,10 @@ static int32_t ctx_chain_check(nz_ctx *ctx, uint64_t waited_seq) {
     volatile unsigned *w = reinterpret_cast<volatile unsigned *>(ctx->chain_err);
     if (w[1]) {
         w[1] = 0;
+        ctx->pile_ticket_off = true;  // this context runs a launch per colour from now on
         nz_set_error("internal: a block of the pile solver gave up waiting for a neighbouring block (nz_erode_height_maps); the "
-                     "height plane is invalid.  NZ_PILE_TICKET=0 runs the four colour launches instead");
+                     "height plane is invalid.  The context runs the four colour launches from now on; nz_ctx_set_pile_safe(ctx, 1) "
+                     "makes the job keep a copy of the plane and run again by itself");
         return NZ_ERR_HIP;
     }
     if (w[0]) {

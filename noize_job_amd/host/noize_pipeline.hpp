@@ -857,6 +857,10 @@ class LiveErosion {
         check(nz_erosive_events_create(ctx, res, &events), "nz_erosive_events_create");
     }
     LiveErosion(const LiveErosion &) = delete;
+    // nz_ctx_set_pile_safe: ErodeHeightMaps keeps a copy of the height plane, waits for the pile solver's one-launch form and runs
+    // itself again colour by colour should a block of it ever give up (a property of the context)
+    void SetSafe(bool on) { check(nz_ctx_set_pile_safe(ctx, on ? 1 : 0), "nz_ctx_set_pile_safe"); }
+    int PileRetries() const { return nz_ctx_pile_retries(ctx); }
     ~LiveErosion() {
         jobHandle.Complete();
         if (particleQueue) nz_particle_queue_destroy(ctx, particleQueue);

@@ -184,6 +184,21 @@ class LiveErosion:
         # schedules them.
         self.fewHandles = True
 
+    @property
+    def safe(self):
+        """nz_ctx_set_pile_safe: ErodeHeightMaps keeps a copy of the height plane, waits for the pile solver's one-launch form and
+        runs itself again colour by colour should a block of it ever give up (include/noize_hip.h).  A property of the CONTEXT."""
+        return getattr(self.ctx, "_pile_safe", False)
+
+    @safe.setter
+    def safe(self, on):
+        N.check(N.lib.nz_ctx_set_pile_safe(self.ctx._h, int(bool(on))), "nz_ctx_set_pile_safe")
+        self.ctx._pile_safe = bool(on)
+
+    @property
+    def pileRetries(self):
+        return N.lib.nz_ctx_pile_retries(self.ctx._h)
+
     def _call(self, name, *args, dep=None, handle=True):
         return self.ctx.call(name, *args, dep=dep, handle=handle or not self.fewHandles)
 

@@ -3,6 +3,7 @@ bit for bit on the GPU (same seeds, same planes), plus the invariants that tie t
 intent (Geologic/ParticleErosion/*)."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -383,3 +384,64 @@ def test_config4_full_size_is_deterministic_and_keeps_its_invariants(nj, ctx, or
     assert pool.min() >= 0 and track.max() == 0 and flow.min() >= 0 and flow.max() < 1 and 0 <= height.min() and height.max() <= 1
     assert a[4] > particles   # events of the last cycle: every particle leaves at least its death event
     base.data.Dispose()
+
+
+@pytest.mark.gpu
+def test_safe_mode_runs_a_timed_out_pile_launch_again_colour_by_colour(nj, oracle):
+    """nz_ctx_set_pile_safe: with a poll limit of 1 every block of the ticket launch that has to wait for a neighbour at all gives
+    up -- the height plane it leaves is invalid.  In safe mode ErodeHeightMaps notices, puts the plane back and runs itself again
+    with a launch per colour: the caller sees the oracle's plane, the retry counter says the path ran, and the context stays
+    on the colour launches.  Without safe mode the same time-out is an error at the next wait."""
+    lib = nj._native.lib
+    res, particles, th = 256, 4000, 1000
+    h = terrain(oracle, res)
+    es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, PILE_THRESHOLD=0.2, PILING_RADIUS=7, MIN_PILE_INCREMENT=0.25)
+    if os.environ.get("NZ_PILE_TICKET") == "0":
+        pytest.skip("knob matrix: no ticket launch")
+
+    def cycles(ctx, safe, n=3):
+        G = _gpu_state(nj, ctx, h, es, th, 1.0)
+        G.safe = safe
+        L = oracle.LiveErosionOracle(h, _params(oracle, es), tile_height=th, patch_res=1.0)
+        ep, tm = es.AsParameters(), G.tileMeta
+        epp, tmp_ = C.byref(ep), C.byref(tm)
+        for cyc in range(n):
+            seed = 77 + cyc
+            G.ctx.call("nz_fill_beyer_queue", G.particleQueue._h, epp, tmp_, cyc % 4, res, particles, seed, 10)
+            L.fill_queue(cyc % 4, particles, seed, 10)
+            G.ctx.call("nz_queued_beyer_cycle", G.heightMap.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
+                       G.particleQueue._h, G.events._h, epp, tmp_, 1500, res)
+            L.descend()
+            G.ctx.call("nz_process_beyer_erosive_events", G.heightMap.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
+                       G.events._h, epp, tmp_, res)
+            L.process_events()
+            G.particleQueue.Clear()
+            G.ctx.call("nz_erode_height_maps_and_flow", G.heightMap.ptr, G.events._h, G.poolMap.ptr, G.streamMap.ptr,
+                       G.particleTrack.ptr, epp, tmp_, res)
+            L.erode_height_maps()
+            L.update_flow_from_track()
+            got = G.heightMap.ToArray((res, res))       # (waits for the context)
+            assert np.array_equal(got, L.height), cyc
+            assert np.array_equal(G.poolMap.ToArray((res, res)), L.pool) and np.array_equal(G.streamMap.ToArray((res, res)), L.flow)
+        return G
+
+    try:
+        assert lib.nz_debug_pile_poll_limit(1) == 0
+        with nj.Context(0) as c:
+            G = cycles(c, True)
+            assert G.pileRetries >= 1, "the forced time-out did not happen: the test has no power"
+            first = G.pileRetries
+            G.OnDestroy()
+            G = cycles(c, True, n=1)                     # the context stays on the colour launches: nothing to retry any more
+            assert G.pileRetries == first
+            G.OnDestroy()
+        with nj.Context(0) as c:                         # without safe mode: the error reaches the caller's wait
+            with pytest.raises(nj.NoizeError) as e:
+                cycles(c, False)
+            assert e.value.status == nj._native.NZ_ERR_HIP
+    finally:
+        lib.nz_debug_pile_poll_limit(0)
+    with nj.Context(0) as c:                             # and with the default limit nothing ever times out
+        G = cycles(c, True)
+        assert G.pileRetries == 0
+        G.OnDestroy()
