@@ -648,6 +648,36 @@ __device__ __forceinline__ void map_range_take(map_range_part &p, float v, long 
         if (__builtin_signbit(v)) p.last_nz = i; else p.last_pz = i;  // i ascends within a thread
     }
 }
+// The streaming form of the same fold, for the kernel that reads the plane: v_min_f32 / v_max_f32 (IEEE minNum / maxNum: a NaN
+// operand is skipped, like math.min / math.max) -- the sign of a zero result is whatever the instruction picks, which does not
+// matter: a zero minimum (maximum) takes its sign from the LAST zero of the plane (map_range_finish), kept here as ONE key per
+// lane, position << 1 | sign, overwritten in ascending order.  7 VALU instructions per cell instead of 28.
+struct map_range_lane {
+    float mn, mx;
+    unsigned long long key;  // 0: no zero met
+};
+__device__ __forceinline__ void map_range_take4(map_range_lane &p, const float4 &t, unsigned long long b) {
+    p.mn = __builtin_fminf(__builtin_fminf(p.mn, t.x), __builtin_fminf(t.y, __builtin_fminf(t.z, t.w)));
+    p.mx = __builtin_fmaxf(__builtin_fmaxf(p.mx, t.x), __builtin_fmaxf(t.y, __builtin_fmaxf(t.z, t.w)));
+    // a lane's four cells are consecutive: the last zero among them
+    const unsigned bx = __float_as_uint(t.x), by = __float_as_uint(t.y), bz = __float_as_uint(t.z), bw = __float_as_uint(t.w);
+    if (((bx << 1) == 0) | ((by << 1) == 0) | ((bz << 1) == 0) | ((bw << 1) == 0)) {   // rare: a zero among the four
+        unsigned long long k = p.key;
+        if ((bx << 1) == 0) k = ((b + 1) << 1) | (bx >> 31);
+        if ((by << 1) == 0) k = ((b + 2) << 1) | (by >> 31);
+        if ((bz << 1) == 0) k = ((b + 3) << 1) | (bz >> 31);
+        if ((bw << 1) == 0) k = ((b + 4) << 1) | (bw >> 31);
+        p.key = k;   // (positions are stored + 1, so that 0 means none)
+    }
+}
+__device__ __forceinline__ map_range_part map_range_from_lane(const map_range_lane &l) {
+    map_range_part p{l.mn, l.mx, -2, -2};
+    if (l.key) {
+        const long long pos = (long long)(l.key >> 1) - 1;
+        if (l.key & 1) p.last_nz = pos; else p.last_pz = pos;
+    }
+    return p;
+}
 __device__ __forceinline__ void map_range_merge(map_range_part &a, const map_range_part &b) {
     a.mn = umin(a.mn, b.mn);
     a.mx = umax(a.mx, b.mx);
@@ -695,23 +725,29 @@ __global__ __launch_bounds__(CT) void map_range_partial_kernel(const float *__re
     const size_t stride = (size_t)gridDim.x * CT;
     if (vec) {
         const size_t n4 = n / 4;
-        constexpr int U = 4;  // loads in flight per thread
+#ifndef NZ_MAP_RANGE_U
+#define NZ_MAP_RANGE_U 4
+#endif
+        constexpr int U = NZ_MAP_RANGE_U;  // 16-byte loads in flight per thread (rocprofv3, 4096^2: 4 -> 13.2 us, 8 -> 14.3; round 5's 28-instruction fold: 16.7)
+        map_range_lane l{__builtin_inff(), -__builtin_inff(), 0ull};
         for (size_t i0 = (size_t)blockIdx.x * CT + threadIdx.x; i0 < n4; i0 += U * stride) {
             float4 t[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const size_t i = i0 + u * stride;
-                t[u] = i < n4 ? reinterpret_cast<const float4 *>(map)[i] : make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                if (i < n4) {  // read once, by one workgroup: non-temporal (no line of the plane is worth keeping in the L2)
+                    const f4v q = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(map) + i);
+                    t[u] = make_float4(q.x, q.y, q.z, q.w);
+                } else {
+                    t[u] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                }
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) {  // ascending indices: the last zero a thread meets is its highest
-                const long long b = (long long)(4 * (i0 + u * stride));
-                map_range_take(p, t[u].x, b);
-                map_range_take(p, t[u].y, b + 1);
-                map_range_take(p, t[u].z, b + 2);
-                map_range_take(p, t[u].w, b + 3);
-            }
+            for (int u = 0; u < U; u++)  // ascending indices: the last zero a lane meets is its highest
+                map_range_take4(l, t[u], (unsigned long long)(4 * (i0 + u * stride)));
         }
+        p = map_range_from_lane(l);
         for (size_t i = n4 * 4 + (size_t)blockIdx.x * CT + threadIdx.x; i < n; i += stride) map_range_take(p, map[i], (long long)i);
     } else {
         for (size_t i = (size_t)blockIdx.x * CT + threadIdx.x; i < n; i += stride) map_range_take(p, map[i], (long long)i);
