@@ -24,6 +24,11 @@ namespace {
 
 constexpr int CT = 256;      // threads per workgroup
 constexpr int TW = 128;      // LDS tile width, cells
+// columns of x halo a fused tile carries on each side for H = T * O applications' worth of reach: a multiple of four (16-byte
+// loads).  (Round 6 tried 16 wherever that is enough, so that the interior a tile STORES is 96 columns = whole 128-byte lines --
+// 104 columns are 416 bytes at offsets that are multiples of 416, every row of a tile's store ends in partial lines, which is
+// where WRITE_SIZE = 5.18 planes for four launches comes from -- and lost: 8 % more tiles, Gauss5 x17 0.189 -> 0.207 ms.)
+__host__ __device__ constexpr int conv_hx(int H) { return (H + 3) & ~3; }
 constexpr int TH = 64;       // LDS tile height, rows
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -167,7 +172,7 @@ __device__ __forceinline__ void conv_tile(const float *__restrict__ src, float *
     float4 (*s_edge)[TH / RBT][2][O][TW / 4] = reinterpret_cast<float4 (*)[TH / RBT][2][O][TW / 4]>(s_edge_raw);
 
     const int tid = threadIdx.x, cg = tid & 31, rb = tid >> 5;
-    const int H = T * O, HX = (H + 3) & ~3;
+    const int H = T * O, HX = conv_hx(H);
     const int OW = TW - 2 * HX, OH = TH - 2 * H;
     const int lx0 = ox0 - HX, lz0 = oz0 - H;
     const int gx0 = lx0 + cg * 4, gzb = lz0 + rb * RBT;
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
     constexpr int TH = NT / 32 * RBT;
     constexpr int NBUF = conv_nbuf(O);
     __shared__ float4 s_edge[NBUF][TH / RBT][2][O][TW / 4];
-    const int H = T * O, HX = (H + 3) & ~3;
+    const int H = T * O, HX = conv_hx(H);
     src += blockIdx.y * g.bstride;  // batched launch: one independent grid per blockIdx.y
     dst += blockIdx.y * g.bstride;
     int ox0, oz0;
@@ -420,12 +425,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(conv_waves(K
     }
     NZ_PROBE_T(7);  // the ticket is back
     NZ_PROBE(13, ((unsigned long long)l << 32) | (unsigned)tile);
-    const int T = ch.T[l], H = T * O, HX = (H + 3) & ~3;
+    const int T = ch.T[l], H = T * O, HX = conv_hx(H);
     const int OW = TW - 2 * HX, OH = TH - 2 * H;
     const int by = tile / ch.tiles_x[l], bx = tile - by * ch.tiles_x[l];
     const int ox0 = bx * OW, oz0 = g.or0 + by * OH;
     if (l > 0) {
-        const int Tp = ch.T[l - 1], Hp = Tp * O, HXp = (Hp + 3) & ~3;
+        const int Tp = ch.T[l - 1], Hp = Tp * O, HXp = conv_hx(Hp);
         const int OWp = TW - 2 * HXp, OHp = TH - 2 * Hp;
         // Awaited: the launch-(l-1) tiles whose interior meets this tile's input window (their stores are read here) or
         // lies within THEIR halo of this tile's interior (they read the cells this tile overwrites: the ping-pong plane
@@ -799,7 +804,7 @@ static inline bool conv_small_grid(int ksize, const nz_geom &g) {
 template <int KS, int NT, int RBT = RB>
 int32_t launch_fused_nt(hipStream_t s, const float *src, float *dst, const nz_geom &g, const nz_kernel_taps &k, int T) {
     constexpr int O = (KS - 1) / 2, RTH = NT / 32 * RBT;  // register tile: RTH rows x 128 columns
-    int H = T * O, HX = (H + 3) & ~3;
+    int H = T * O, HX = conv_hx(H);
     int OW = TW - 2 * HX, OH = RTH - 2 * H;
     long long blocks = (long long)((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
     int aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(g.pitch * 4)) & 15) == 0;
@@ -837,7 +842,7 @@ int32_t launch_chain_nt(hipStream_t s, float *plane0, float *plane1, const nz_ge
     ch.L = L;
     ch.first[0] = 0;
     for (int l = 0; l < L; l++) {
-        int H = Ts[l] * O, HX = (H + 3) & ~3;
+        int H = Ts[l] * O, HX = conv_hx(H);
         int OW = TW - 2 * HX, OH = RTH - 2 * H;
         ch.T[l] = Ts[l];
         ch.tiles_x[l] = (g.cols + OW - 1) / OW;
@@ -890,7 +895,7 @@ int nz_conv_chain_items(int ksize, const nz_geom &g, const int *Ts, int L) {
     const int RTH = (ksize >= 5 ? (conv_small_grid(ksize, g) ? 256 : NZ_CONV_NT_WIDE) : NZ_CONV_NT) / 32 * RB;
     int n = 0;
     for (int l = 0; l < L; l++) {
-        int H = Ts[l] * O, HX = (H + 3) & ~3;
+        int H = Ts[l] * O, HX = conv_hx(H);
         int OW = TW - 2 * HX, OH = RTH - 2 * H;
         n += ((g.cols + OW - 1) / OW) * ((g.or1 - g.or0 + OH - 1) / OH);
     }
