@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libnoize_oracle.so")
+# NZO_LIB: another build of the same sources (tools/oracle_sanitize.sh loads the AddressSanitizer / UBSan one)
+_SO = os.environ.get("NZO_LIB") or os.path.join(_HERE, "libnoize_oracle.so")
 _lib = None
 
 f32p = C.POINTER(C.c_float)
