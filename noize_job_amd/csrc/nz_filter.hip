@@ -623,12 +623,12 @@ __global__ __launch_bounds__(CT) void conv_pass_z_kernel(const float *__restrict
 // ---- wide separable kernels (odd kernelSize 11..25): both passes of one application in one launch -----
 // Used by the Gaussian / box blur stages (StageGaussianBlur / StageSmoothBlur, width <= 25,
 // Filter/Kernel/Blur/BlurJob.cs:11-52).  A workgroup of NT threads produces an (NT/8) x 128 output tile.  Source rows
-// [z0-O, z0+32+O) x columns [x0-16, x0+144), clamped to the grid (RWTileData.GetData), are staged in LDS
-// as 160-float rows: 16-byte loads, five whole 128-byte lines per row.  The X pass runs on all 32+2O rows
+// [z0-O, z0+32+O) x columns [x0-16, x0+144) (x0-12 .. x0+140 for the 64-row tiles of 23 / 25 taps), clamped to the grid
+// (RWTileData.GetData), are staged in LDS as 160-float (152-float) rows: 16-byte loads.  The X pass runs on all 32+2O rows
 // in place (see s_a), 8 consecutive outputs per thread from one register window; the Z pass reads
 // those columns row after row, 4 columns x 4 rows per thread, and stores 16 bytes per lane.  Clamped source
 // rows give the X-pass value of the clamped row, which is what the reference's Z pass reads after the flush.
-constexpr int WD_W = 128, WD_XH = 16, WD_AP = WD_W + 2 * WD_XH;
+constexpr int WD_W = 128;
 
 template <int O, bool UNIT, int WD_NT, bool FAST>
 __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restrict__ src, float *__restrict__ dst, nz_geom g,
@@ -636,9 +636,16 @@ __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restric
     constexpr int KS = 2 * O + 1;
     constexpr int WD_H = WD_NT / 8;           // output rows: 4 per 32 threads
     constexpr int NR = WD_H + 2 * O;          // staged rows
+    // x halo staged on each side: 16 columns (five whole 128-byte lines per row) -- except for the 64-row tiles of 23 and 25
+    // taps, whose 86 / 88 staged rows of 160 floats are 55 / 56 KB: two workgroups per CU.  With 12 columns a row is 152
+    // floats and THREE workgroups fit the CU's 160 KB (round 6, together with the 8 x 2 Z pass below, which brings the
+    // 512-thread kernels from 95-124 to <= 85 VGPRs: six waves per SIMD)
+    constexpr int WD_XH = (WD_NT == 512 && O >= 11) ? 12 : 16;
+    constexpr int WD_AP = WD_W + 2 * WD_XH;
     constexpr int OFF = WD_XH - O;            // first window column of output column 0
     constexpr int OFA = OFF & ~3, SH = OFF & 3;
     constexpr int NF = (SH + 8 + 2 * O + 3) / 4;  // float4s per X window
+    static_assert(OFA + 8 * 15 + 4 * NF <= WD_AP, "the last thread's X window leaves the staged row");
     // One LDS plane: the X pass writes a row's results back over that row's source columns [WD_XH, WD_XH + 128).
     // The 16 threads of a row are lanes of one wave, whose LDS loads of the row all precede its stores in program
     // order, so no lane reads a column another lane has already replaced; half the LDS lets twice the workgroups
@@ -699,7 +706,42 @@ __global__ __launch_bounds__(WD_NT) void conv_wide_kernel(const float *__restric
     __syncthreads();
 
     // ---- Z pass (KernelSampleZOperator: taps k descending, first term is row z+o with K[0])
-    {
+    if constexpr (WD_NT == 512) {
+        // 8 rows x 2 columns per thread: a window of 8 + 2 O rows of two floats (64 registers at 25 taps; 4 x 4 holds
+        // 28 rows of four = 112), 8-byte LDS reads (57 % of the 4 x 4 form's bytes), 8-byte stores (a wave writes 512
+        // contiguous bytes of a row)
+        const int cg = tid & 63, rg = tid >> 6;
+        float v[8 + 2 * O][2];
+        const float2 *col = reinterpret_cast<const float2 *>(s_a) + ((rg * 8) * WD_AP + WD_XH) / 2 + cg;
+#pragma unroll
+        for (int i = 0; i < 8 + 2 * O; i++) {
+            float2 t = col[i * (WD_AP / 2)];
+            v[i][0] = t.x; v[i][1] = t.y;
+        }
+        const int gx = x0 + 2 * cg;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float o[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                float total = v[j + 2 * O][e] * taps.kz[0];
+#pragma unroll
+                for (int kk = 1; kk < KS; kk++) total = tap_acc<FAST>(total, v[j + 2 * O - kk][e], taps.kz[kk]);
+                o[e] = UNIT ? total : total * taps.factor;
+            }
+            int gz = z0 + rg * 8 + j;
+            if (gz < g.or1 && gx < g.cols) {
+                float *out = dst + (size_t)gz * g.pitch + gx;
+                if (aligned && gx + 2 <= g.cols) {
+                    *reinterpret_cast<float2 *>(out) = make_float2(o[0], o[1]);
+                    asm volatile("; 8-byte store" ::: "memory");
+                } else {
+                    out[0] = o[0];
+                    if (gx + 1 < g.cols) out[1] = o[1];
+                }
+            }
+        }
+    } else {
         const int cg = tid & 31, rg = tid >> 5;
         float v[4 + 2 * O][4];
 #pragma unroll
