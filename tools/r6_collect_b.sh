@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-5 evidence, part B (one GPU call): stalls, conv phase profile, next rows with counters, tiles, config 4, the rank rehearsal.
-#   tools/r5_collect_b.sh <tag> <commit>
-TAG=${1:-r05_v2}
+# Round-6 evidence, part B (one GPU call): stalls, conv phase profile, next rows with counters, tiles, config 4, the rank rehearsal.
+#   tools/r6_collect_b.sh <tag> <commit>
+TAG=${1:-r06_v1}
 COMMIT=${2:-unknown}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
