@@ -1,6 +1,7 @@
 """ctypes wrapper around oracle/libnoize_oracle.so -- the CPU restatement of the reference.
 
-TEST INFRASTRUCTURE ONLY (parity unpinned, see noize_oracle.h).  Only tests/,
+TEST INFRASTRUCTURE ONLY (parity pinned at image level only -- the reference's README screenshots --, numerically unpinned: see
+noize_oracle.h).  Only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
 package (noize_job_amd) never does.
 """

@@ -1,6 +1,7 @@
 /*
  * noize_oracle.c -- CPU restatement of noize-job's per-cell terrain hot path.
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED -- see noize_oracle.h for the full statement.
+ * TEST INFRASTRUCTURE ONLY; parity pinned at image level only (the reference's screenshots), numerically unpinned -- see
+ * noize_oracle.h for the full statement.
  *
  * Each function cites the reference file:line it follows (paths relative to
  * /root/reference).  Pass structure is the reference's: row-parallel pass into `tmp`, then

@@ -5,13 +5,19 @@
  * "CPU restatement of the Burst path" baseline.  Only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg may load it; nothing under noize_job_amd/ does.
  *
- * PARITY UNPINNED: the reference (C# / Unity Burst) ships no tests, golden vectors or
- * fixtures for this path and cannot be compiled or run here (no .NET / Unity toolchain).
- * The noise bases live in com.unity.mathematics 1.2.1 (package.json:17), which is not in the
- * reference tree; they are restated from the published webgl-noise algorithm (SURVEY.md
- * Appendix A).  The only reference-held numbers this oracle is pinned against are the
- * Gaussian coefficient literals (Filter/Kernel/KernelJob.cs:97-105, Filter/Kernel/Blur/
- * BlurKernels.cs:59-318), see tests/golden/gauss_tables.json.
+ * PARITY PINNED AT IMAGE LEVEL ONLY (round 6); NUMERICALLY UNPINNED.  The reference (C# / Unity Burst)
+ * ships no tests, golden vectors or fixtures for this path and cannot be compiled or run here (no
+ * .NET / Unity toolchain).  The noise bases live in com.unity.mathematics 1.2.1 (package.json:17), which
+ * is not in the reference tree; they are restated from the published webgl-noise algorithm (SURVEY.md
+ * Appendix A).  What this oracle IS checked against:
+ *   - the reference's README screenshots (README.md:23-40, docs~/0-6.jpg: its own output with every
+ *     parameter readable beside it): simplex and cellular fBm, Gauss5 x17, the flow map -- Pearson r
+ *     0.94 ... 0.9999 with negative controls, tests/test_reference_screenshots.py.  An image pin (JPEG,
+ *     8 bit, a display mapping), not the 1e-5 bar;
+ *   - the reference's Gaussian coefficient literals (Filter/Kernel/KernelJob.cs:97-105, Filter/Kernel/
+ *     Blur/BlurKernels.cs:59-318), bit for bit: tests/golden/gauss_tables.json.
+ * Without any reference-held output: cnoise, psrnoise, the 3-D bases, Sin, the min filter, the mesh, the
+ * live erosion.
  *
  * Floating-point model: strict IEEE-754 binary32, operations in the order the C# source
  * writes them, no contraction (build with -ffp-contract=off, no -ffast-math); libm

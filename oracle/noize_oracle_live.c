@@ -1,6 +1,6 @@
 /*
  * noize_oracle_live.c -- CPU restatement of the PARTICLE half of noize-job's live erosion (BASELINE config 4).
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED -- see noize_oracle.h.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (nothing the reference holds shows the live erosion's output) -- see noize_oracle.h.
  *
  * The reference (Geologic/ParticleErosion/) is deterministic per particle but not per run: particle positions come
  * from UnityEngine.Random seeds (MultiThreadErosionJob.cs:50), events meet in a parallel multi-hash-map and are summed
