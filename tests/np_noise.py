@@ -112,9 +112,13 @@ def psrnoise2_parts(posx, posy, perx=1010.0, pery=102.0):  # A.4 up to the gradi
     return iu, yw, d
 
 
-def cellular2(Px, Py):  # A.5
+def cellular2(Px, Py, permute_mul=34.0, jitter=1.0):  # A.5
+    """The keyword arguments are MUTATIONS for negative controls (tests/test_reference_screenshots.py).  Defaults = the spec."""
     Px, Py = np.asarray(Px, f), np.asarray(Py, f)
-    K, Ko, jitter = f(0.142857142857), f(0.428571428571), f(1.0)
+    K, Ko, jitter = f(0.142857142857), f(0.428571428571), f(jitter)
+
+    def permute(x):  # shadows the module's permute only when mutated
+        return mod289((f(permute_mul) * x + f(1.0)) * x)
     Pix, Piy = mod289(np.floor(Px)), mod289(np.floor(Py))
     Pfx, Pfy = frac(Px), frac(Py)
     oi = [f(-1.0), f(0.0), f(1.0)]

@@ -228,6 +228,27 @@ def test_cellular_fbm_is_the_picture(planes, shots, oracle):
     assert match(display(planes["simplex"]), img["L0"]) < 0.7   # a smooth picture: chance alone gives 0.5
 
 
+def test_cellular_negative_controls_fall_below_the_bar(planes, shots):
+    """The recalled `cellular` mutated in one constant: measured r 0.9947 for the spec, 0.689 with a hash
+    multiplier of 33, 0.966 with jitter 0.8 (0.9885 with 0.9: the picture at hurst 1 is smooth, its power against small changes
+    of this basis is limited) (rectified F1 * F2 per octave, Fractal.cs:263-278)."""
+    import np_noise as N
+    img, meta = shots
+    c = meta["0"]
+    args = (c["hurst"], c["octaves"], c["xpos"], c["zpos"], c["noiseSize"])
+
+    def rectified(**mut):
+        def basis(x, z):
+            F1, F2 = N.cellular2(x, z, **mut)
+            return ((f32(1.0) + F1) / f32(2.0)) * ((f32(1.0) + F2) / f32(2.0))
+        return basis
+    true_np = np_fractal(rectified(), *args)
+    assert np.abs(true_np - planes["cellular"]).max() <= 2e-6
+    assert match(display(true_np), img["L0"]) >= 0.99
+    assert match(display(np_fractal(rectified(permute_mul=33.0), *args)), img["L0"]) < 0.8
+    assert match(display(np_fractal(rectified(jitter=0.8), *args)), img["L0"]) < 0.99
+
+
 def test_gauss5_x17_is_the_picture(planes, shots, oracle):
     img, _ = shots
     for basis, before, after in (("simplex", "L3", "L4"), ("cellular", "L0", "L1")):
