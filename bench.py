@@ -921,10 +921,15 @@ def main():
                                "traffic": s["hbm_bytes_per_launch"]}
         elif s.get("bound") == "valu-fp32":
             ach = s["valu_insts_per_launch"] * 64 / (s["avg_launch_ms"] * 1e-3) / 1e12
+            # `achieved` counts EXECUTED instructions; `algorithmic` the lane-operations of SURVEY.md 8(d) only
+            # (ALGO_LANE_OPS x the cells one launch produces), over the same launch time and the same peak
+            alg = ALGO_LANE_OPS_MODE[mode][dom] * rcells / launches[dom] / (s["avg_launch_ms"] * 1e-3) / 1e12
             res_["roofline"] = {"kernel": s["kernel"], "bound": "valu-fp32", "achieved": round(ach, 2),
                                "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tlane-op/s",
                                "frac": round(ach / VALU_PEAK_TOPS, 4), "traffic": s["hbm_bytes_per_launch"],
-                               "hbm_traffic_frac": s["hbm_traffic_frac"]}
+                               "hbm_traffic_frac": s["hbm_traffic_frac"],
+                               "algorithmic": {"achieved": round(alg, 2), "frac": round(alg / VALU_PEAK_TOPS, 4),
+                                               "lane_ops_per_cell": ALGO_LANE_OPS_MODE[mode][dom]}}
         else:  # no counter summary of these kernels: the only figure this run can form itself
             ach = BYTES[dom] * rcells / launches[dom] / (s["avg_launch_ms"] * 1e-3) / 1e9
             res_["roofline"] = {"kernel": s["kernel"], "bound": "unknown", "achieved": None, "peak": HBM_PEAK_GBS,

@@ -39,6 +39,8 @@ def test_single_gpu_line():
     if d["counters_source"] is not None:   # a counter summary of these kernel sources is committed
         assert r["bound"] in ("hbm", "valu-fp32") and 0.0 < r["frac"] <= 1.0
         assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=2e-3)
+        if r["bound"] == "valu-fp32":   # ... and beside the executed-instruction rate, the algorithmic one (never above it)
+            assert 0.0 < r["algorithmic"]["frac"] <= r["frac"] + 1e-3
         for s in d["stages"].values():
             assert 0.0 < s["valu_issue_frac"] <= 1.0 and 0.0 < s["hbm_traffic_frac"] <= 1.0
             assert s["bound"] == ("valu-fp32" if s["valu_issue_frac"] >= s["hbm_traffic_frac"] else "hbm")
