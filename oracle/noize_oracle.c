@@ -703,7 +703,10 @@ void nzo_flow_step(const float *height, const float *water, float *fN, float *fN
             float sum_ = (flW + flE) + (flS + flN); /* math.csum(float4) = (x.x + x.y) + (x.z + x.w), Unity.Mathematics 1.2.1 */
             if (sum_ > 0.0f) {
                 float K = water_0 / (sum_ * TIMESTEP);
-                K = K < 0.0f ? 0.0f : (K > 1.0f ? 1.0f : K); /* clamp(K,0,1) = max(0,min(1,K)) */
+                /* math.clamp(K, 0, 1) = max(0, min(1, K)) with Unity.Mathematics' min / max (a NaN SECOND operand is skipped):
+                 * K is NaN when water_0 is 0 and sum_ * TIMESTEP underflows to 0 (sum_ a denormal): min(1, NaN) = 1.  (A ternary
+                 * clamp, which rounds 1-5 carried here, passes the NaN on: found by round 6's soak, seed 62067.) */
+                K = maxf_(0.0f, minf_(1.0f, K));
                 fW_buf[c] = flW * K;
                 fE_buf[c] = flE * K;
                 fS_buf[c] = flS * K;
@@ -1140,7 +1143,7 @@ int nzo_curve(float *src, float *tmp, const float *curve, int curveSize, int row
         for (int x = 0; x < cols; x++) {
             int c = tile_idx(x, z, rows, cols);
             float v = src[c];
-            float cl = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); /* clamp(v,0,1) = max(0,min(1,v)) */
+            float cl = maxf_(0.0f, minf_(1.0f, v)); /* math.clamp(v, 0, 1) = max(0, min(1, v)): a NaN cell reads as 1 */
             float rect = cl * (float)curveSize;
             float lowerIdx = minf_(floorf(rect), (float)(curveSize - 2));
             float left = curve[(int)lowerIdx], right = curve[(int)lowerIdx + 1];

@@ -131,6 +131,20 @@ def test_non_finite_cells_propagate_like_the_oracle(nj, ctx, oracle, seed):
             assert eq(got, oracle.flowmap(t, it, 0.0, 0.005)), ("flow", res, it)
         got = _run(nj, nj.StageThermalErosion(ctx, 2, 45, 0.5, 0.75), nj.GeneratorData("t", ctx.from_host(t), res))
         assert eq(got, oracle.thermal_erosion(t, 45.0, 0.5, 0.75, 2)), ("thermal", res)
+        # math.clamp on a NaN (max(0, min(1, NaN)) = 1): the curve's input clamp, and the flow map's outflow scale where a cell
+        # without water faces a flux sum that underflows (round 6: the soak's seed 62067 -- sparse impulses on a plane of zeros,
+        # twelve iterations: the water differences that drive the flow there are denormal)
+        sq = lambda u: u * u  # noqa: E731
+        got = _run(nj, nj.CurveStage(ctx, sq, 9), nj.GeneratorData("c", ctx.from_host(t), res))
+        assert eq(got, oracle.curve(t, np.array([sq(f32(i) / f32(9)) for i in range(9)], f32))), ("curve", res)
+        z = np.zeros((res, res), f32)
+        z[0, 0] = z[-1, -1] = z[0, -1] = 1.0
+        z[res // 3, 4] = -2.0
+        z[res // 2, res // 2] = 1e-45
+        for it in (3, 12):
+            got = _run(nj, nj.FlowMapStage(ctx, it, 0.0, 0.005), nj.GeneratorData("f", ctx.from_host(z), res))
+            want = oracle.flowmap(z, it, 0.0, 0.005)
+            assert eq(got, want) and np.isfinite(want).all(), ("flow on impulses", res, it)
 
 
 @pytest.mark.parametrize("basis", range(1, 8))

@@ -518,3 +518,33 @@ def test_get_map_range_known_answers(oracle):
     assert r[0] == 0 and not np.signbit(r[0])
     r = oracle.get_map_range(np.array([-3, 0.0, -0.0, -1], f))                 # ... and of a maximum that is zero
     assert r[1] == 0 and np.signbit(r[1]) and r[0] == -3
+
+
+# ---- Unity.Mathematics' clamp on a NaN (round 6: the soak's seed 62067) -----------------------------------------------------
+def test_flow_scale_of_zero_water_over_a_flux_sum_that_underflows_is_one(oracle):
+    # ComputeFlowStep (FlowMapComponents.cs:52-56): K = clamp(water_0 / (sum_ * TIMESTEP), 0, 1) under `if (sum_ > 0)`.  With no
+    # water on the cell and a flux sum so small that sum_ * 0.2 underflows to 0 -- a denormal height difference -- K is 0 / 0 = NaN,
+    # and math.clamp = max(0, min(1, K)) with Unity.Mathematics' min / max (float.IsNaN(y) || x < y ? x : y: a NaN second operand
+    # is skipped) gives 1: the fluxes stay what they were, nothing turns NaN.
+    tiny = np.float32(1e-45)                      # the smallest denormal
+    h = np.full((3, 3), tiny, f32)
+    h[1, 2] = 0.0                                 # [z][x]: the cell EAST of the centre is one denormal lower
+    water = np.zeros((3, 3), f32)
+    z = np.zeros((3, 3), f32)
+    fN, fS, fE, fW = oracle.flow_step(h, water, z, z, z, z)
+    for fl in (fN, fS, fE, fW):
+        assert np.isfinite(fl).all()
+    # centre cell: flow = (0, 1e-45, 0, 0), sum_ = 1e-45 > 0, sum_ * 0.2 rounds to 0, K = 0 / 0 -> clamp -> 1
+    assert fE[1, 1] == tiny and fW[1, 1] == 0 and fN[1, 1] == 0 and fS[1, 1] == 0
+    # ... and the whole stage stays finite on such a plane
+    big = np.zeros((40, 40), f32)
+    big[7, 9] = tiny
+    assert np.isfinite(oracle.flowmap(big, 3, 0.0, 0.005)).all()
+
+
+def test_curve_reads_a_nan_cell_as_one(oracle):
+    # CurveOperator.Apply (Filter/Curve/CurveJob.cs:56-89): rect = clamp(v, 0, 1) * N; clamp(NaN, 0, 1) = max(0, min(1, NaN)) = 1
+    samples = np.linspace(0.0, 1.0, 5, dtype=f32) ** 2
+    a = np.array([[np.nan, 1.0], [0.25, 2.0]], f32)
+    got = oracle.curve(a, samples)
+    assert got[0, 0] == got[0, 1] == got[1, 1] and np.isfinite(got).all()
