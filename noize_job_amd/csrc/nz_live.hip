@@ -709,7 +709,8 @@ __device__ __forceinline__ void pile_load_offsets(const pile_lds &L, const short
 template <bool COH>
 __device__ __forceinline__ void pile_block(const pile_lds &L, float *height, const float *__restrict__ sediment, int nverts,
                                            int res, int maxDistance, int B, int bx, int bz, float pileThreshold,
-                                           float increment) {
+                                           float increment, int32_t *beat = nullptr) {
+    int beats = 0;  // (ticket launch) piles started: the block's flag carries 1 + 2 * beats while it is busy, see pile_ticket_wave
     float *s_val = L.val;
     int *s_idx = L.idx;
     unsigned char *s_flag = L.flag;
@@ -771,6 +772,7 @@ __device__ __forceinline__ void pile_block(const pile_lds &L, float *height, con
                 todo &= todo - 1;
                 px = xb + src_lane;
                 pz = z;
+                if (beat && lane == 0) __hip_atomic_store(beat, 1 + 2 * (++beats & 0x3fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const float amount = __shfl(val, src_lane);
                 // SetPile, as far as the pile will look: a round r only examines the vertices of the rings dist < r
                 // (2 r (r + 3) of them), and most piles are a few increments that the first rounds place -- the first
@@ -797,6 +799,9 @@ __device__ __forceinline__ void pile_block(const pile_lds &L, float *height, con
                     float remaining = amount;
                     int cmax = -1;
                     for (int guard = 0; remaining > 0.0f && increment > 0.0f && guard < 4096; guard++) {
+                        // (a pile of a million increments is seconds of one wave, ~0.8 ms a pass: a sign of life every 8 passes)
+                        if (beat && (guard & 7) == 7 && lane == 0)
+                            __hip_atomic_store(beat, 1 + 2 * (++beats & 0x3fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const float amt = remaining;
                         float deposited = 0.0f, rem = amt;
                         bool done = false;
@@ -884,8 +889,8 @@ __global__ __launch_bounds__(64) void pile_kernel(float *height, const float *__
 // tails.  Here the busy blocks (disperse_list_kernel lists them per colour) are work items in colour-major order, handed
 // out by an atomic ticket; a block waits only for the busy ones among its eight neighbours that have a LOWER colour --
 // the blocks whose piles the canonical order puts before its own -- i.e. for items with a lower ticket, which a resident
-// workgroup holds or has finished: progress does not depend on how the hardware dispatches workgroups.  blocks[b]: 1 = busy,
-// 2 = done.  Heights travel between CUs with agent-scope accesses, a block's stores have left (vmcnt 0) before its flag is
+// workgroup holds or has finished: progress does not depend on how the hardware dispatches workgroups.  blocks[b]: odd = busy
+// (1 when listed, 1 + 2 k once its k-th pile has started: the heartbeat a waiting neighbour's bound watches), 2 = done.  Heights travel between CUs with agent-scope accesses, a block's stores have left (vmcnt 0) before its flag is
 // raised.  ctl: {items of colour 0..3, ticket}.  A wait is bounded all the same (err_host, mapped host memory: the context
 // reports an internal error at its next synchronisation instead of hanging).
 constexpr int PILE_CTL = 8;
@@ -968,10 +973,22 @@ __device__ __forceinline__ void pile_ticket_wave(const pile_ticket_args &a, unsi
             const int qc = (qx & 1) | ((qz & 1) << 1);
             if (qx >= 0 && qz >= 0 && qx < nb && qz < nb && qc < c) {
                 const int32_t *f = blocks + (size_t)qx * nb + qz;
-                int spins = 0;
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) {
+                // busy = an ODD flag: 1 when listed, then 1 + 2 k as the block starts its k-th pile (a heartbeat: a block of a
+                // plane buried in sediment works for seconds -- 5 000 droplets on 89^2 cells, increments of a 60 000th of the
+                // sediment: round 6's soak, seed 707 case 7457 -- and the bound below is on polls WITHOUT progress, not on time)
+                // A block that WAITS passes the sign of life on: whenever the flag it watches moves, it moves its own, so that a block
+                // waiting for a block that waits for a busy block does not run out of patience either.
+                int spins = 0, last = 1, passed = 0;
+                for (;;) {
+                    const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(v & 1)) break;
+                    if (v != last) {
+                        last = v;
+                        spins = 0;
+                        __hip_atomic_store(blocks + b, 1 + 2 * ((++passed << 3 | lane) & 0x3fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     __builtin_amdgcn_s_sleep(16);
-                    if (++spins > spin_limit) {  // seconds by default: never, unless the protocol is broken
+                    if (++spins > spin_limit) {  // seconds without a sign of life: never, unless the protocol is broken
                         __hip_atomic_store(err_host + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // word [1]: the pile solver's
                         break;
                     }
@@ -979,7 +996,7 @@ __device__ __forceinline__ void pile_ticket_wave(const pile_ticket_args &a, unsi
             }
         }
         __syncthreads();
-        pile_block<true>(L, height, sediment, nverts, res, maxDistance, B, bx, bz, pileThreshold, increment);
+        pile_block<true>(L, height, sediment, nverts, res, maxDistance, B, bx, bz, pileThreshold, increment, blocks + b);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the block's stores have left
         __syncthreads();
         if (lane == 0) __hip_atomic_store(blocks + b, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

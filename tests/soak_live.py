@@ -18,6 +18,54 @@ import oracle  # noqa: E402  (the checker: tools and tests only)
 f32 = np.float32
 
 
+def one_case(rng, nj, oracle, G, L, ep, epp, tmp_, res, particles, th, workers, shape, stats):
+    why = None
+    for cyc in range(2):
+        seed = int(rng.integers(1, 2 ** 31 - 1))
+        G.ctx.call("nz_fill_beyer_queue", G.particleQueue._h, epp, tmp_, cyc, res, particles, seed, workers)
+        L.fill_queue(cyc, particles, seed, workers)
+        G.ctx.call("nz_queued_beyer_cycle", G.heightMap.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
+                   G.particleQueue._h, G.events._h, epp, tmp_, 1500, res)
+        n = L.descend()
+        if G.events.Count != n:
+            why = "event count"
+            break
+        G.ctx.call("nz_process_beyer_erosive_events", G.heightMap.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
+                   G.events._h, epp, tmp_, res)
+        L.process_events()
+        stats[0] += n
+        thr = f32(ep.PILE_THRESHOLD) / f32(th)
+        stats[1] += int((L.sediment > thr).sum())
+        stats[2] += int(((L.sediment != 0) & ~(L.sediment > thr)).sum())
+        if not (np.array_equal(G.events.sediment(), L.sediment) and np.array_equal(G.poolMap.ToArray(shape), L.pool)
+                and np.array_equal(G.particleTrack.ToArray(shape), L.track)):
+            why = "events"
+            break
+        G.particleQueue.Clear()
+        one_call = bool(rng.integers(0, 2))  # the two siblings as one launch (nz_erode_height_maps_and_flow) or as two entries
+        if one_call:
+            G.ctx.call("nz_erode_height_maps_and_flow", G.heightMap.ptr, G.events._h, G.poolMap.ptr, G.streamMap.ptr,
+                       G.particleTrack.ptr, epp, tmp_, res)
+        else:
+            G.ctx.call("nz_erode_height_maps", G.heightMap.ptr, G.events._h, epp, tmp_, res)
+        L.erode_height_maps()
+        if not np.array_equal(G.heightMap.ToArray(shape), L.height):
+            why = "sediment (disperse / piles)" + (", one call" if one_call else "")
+            break
+        if not one_call:
+            G.ctx.call("nz_update_flow_from_track", G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr, ep.FLOW_LOSS_RATE,
+                       ep.SURFACE_EVAPORATION_RATE, float(th), res)
+        L.update_flow_from_track()
+        G.ctx.call("nz_pool_automata_job", G.poolMap.ptr, G.heightMap.ptr, G.particleQueue._h, epp, tmp_, 3, res, 1)
+        L.pool_automata(3, drain=True)
+        stats[3] += int(L.count.value)
+        if not (np.array_equal(G.poolMap.ToArray(shape), L.pool) and np.array_equal(G.streamMap.ToArray(shape), L.flow)
+                and np.array_equal(G.particleTrack.ToArray(shape), L.track)):
+            why = "flow from track / automaton"
+            break
+    return why
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=3.0)
@@ -27,7 +75,7 @@ def main():
     oracle.lib()
     t_end = time.time() + 60 * a.minutes
     cases = bad = 0
-    events = piles = dispersed = drained = 0
+    stats = [0, 0, 0, 0]   # particle steps, cells piled, dispersed, particles drained
     with nj.Context(0) as ctx:
         while time.time() < t_end:
             res = int(rng.integers(40, 420))
@@ -60,49 +108,12 @@ def main():
             epp, tmp_ = C.byref(ep), C.byref(tm)
             shape = (res, res)
             why = None
-            for cyc in range(2):
-                seed = int(rng.integers(1, 2 ** 31 - 1))
-                G.ctx.call("nz_fill_beyer_queue", G.particleQueue._h, epp, tmp_, cyc, res, particles, seed, workers)
-                L.fill_queue(cyc, particles, seed, workers)
-                G.ctx.call("nz_queued_beyer_cycle", G.heightMap.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
-                           G.particleQueue._h, G.events._h, epp, tmp_, 1500, res)
-                n = L.descend()
-                if G.events.Count != n:
-                    why = "event count"
-                    break
-                G.ctx.call("nz_process_beyer_erosive_events", G.heightMap.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
-                           G.events._h, epp, tmp_, res)
-                L.process_events()
-                events += n
-                thr = f32(ep.PILE_THRESHOLD) / f32(th)
-                piles += int((L.sediment > thr).sum())
-                dispersed += int(((L.sediment != 0) & ~(L.sediment > thr)).sum())
-                if not (np.array_equal(G.events.sediment(), L.sediment) and np.array_equal(G.poolMap.ToArray(shape), L.pool)
-                        and np.array_equal(G.particleTrack.ToArray(shape), L.track)):
-                    why = "events"
-                    break
-                G.particleQueue.Clear()
-                one_call = bool(rng.integers(0, 2))  # the two siblings as one launch (nz_erode_height_maps_and_flow) or as two entries
-                if one_call:
-                    G.ctx.call("nz_erode_height_maps_and_flow", G.heightMap.ptr, G.events._h, G.poolMap.ptr, G.streamMap.ptr,
-                               G.particleTrack.ptr, epp, tmp_, res)
-                else:
-                    G.ctx.call("nz_erode_height_maps", G.heightMap.ptr, G.events._h, epp, tmp_, res)
-                L.erode_height_maps()
-                if not np.array_equal(G.heightMap.ToArray(shape), L.height):
-                    why = "sediment (disperse / piles)" + (", one call" if one_call else "")
-                    break
-                if not one_call:
-                    G.ctx.call("nz_update_flow_from_track", G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr, ep.FLOW_LOSS_RATE,
-                               ep.SURFACE_EVAPORATION_RATE, float(th), res)
-                L.update_flow_from_track()
-                G.ctx.call("nz_pool_automata_job", G.poolMap.ptr, G.heightMap.ptr, G.particleQueue._h, epp, tmp_, 3, res, 1)
-                L.pool_automata(3, drain=True)
-                drained += int(L.count.value)
-                if not (np.array_equal(G.poolMap.ToArray(shape), L.pool) and np.array_equal(G.streamMap.ToArray(shape), L.flow)
-                        and np.array_equal(G.particleTrack.ToArray(shape), L.track)):
-                    why = "flow from track / automaton"
-                    break
+            try:
+                why = one_case(rng, nj, oracle, G, L, ep, epp, tmp_, res, particles, th, workers, shape, stats)
+            except nj.NoizeError as e:   # (an error out of the library: say which set-up, then let it end the run)
+                print("ERROR %s: case %d res %d particles %d height %d patch %g workers %d %s" % (
+                    e, cases, res, particles, th, patch, workers, {n: getattr(ep, n) for n, _ in ep._fields_}), flush=True)
+                raise
             cases += 1
             if why:
                 bad += 1
@@ -110,10 +121,10 @@ def main():
                     why, res, particles, th, patch, workers, {n: getattr(ep, n) for n, _ in ep._fields_}), flush=True)
             if cases % 200 == 0:
                 print("%d cases, %d differ (%d particle steps, %d cells piled, %d dispersed, %d particles drained from pools)" % (
-                    cases, bad, events, piles, dispersed, drained), flush=True)
+                    cases, bad, *stats), flush=True)
             G.OnDestroy()
     print("%d cases, %d differ (%d particle steps, %d cells piled, %d dispersed, %d particles drained from pools)" % (
-        cases, bad, events, piles, dispersed, drained))
+        cases, bad, *stats))
     sys.exit(1 if bad else 0)
 
 

@@ -445,3 +445,51 @@ def test_safe_mode_runs_a_timed_out_pile_launch_again_colour_by_colour(nj, oracl
         G = cycles(c, True)
         assert G.pileRetries == 0
         G.OnDestroy()
+
+
+@pytest.mark.gpu
+def test_a_block_that_works_for_seconds_is_not_a_time_out(nj, oracle):
+    """Round 6's soak (tests/soak_live.py --seed 707, case 7457): 5 000 droplets on an 89^2 plane, increments of a 60 000th of the
+    tile height -- one pile of 1.4 million increments keeps a block of the pile solver busy for seconds.  Its neighbours' bounded
+    wait counts polls WITHOUT a sign of life from the block they wait for (the flag carries a heartbeat), so it does not expire:
+    forced here with a bound of ~20 ms without progress, which the old bound on the waiting time itself could not survive."""
+    lib = nj._native.lib
+    if os.environ.get("NZ_PILE_TICKET") == "0":
+        pytest.skip("knob matrix: no ticket launch")
+    res, particles, th = 89, 5013, 3000
+    es = nj.ErosionSettings(PARTICLES_PER_CYCLE=particles, MAXAGE=70, PILING_RADIUS=10, PILE_THRESHOLD=0.05, MIN_PILE_INCREMENT=0.05,
+                            INERTIA=0.18391865, GRAVITY=18.4762, FRICTION=1.55434888, DRAG=0.00306747, EVAP=0.03214284,
+                            CAPACITY=7.83815, EROSION=0.85846327, DEPOSITION=0.23305014, FLOW_HEIGHT_CONTRIBUTION=17.42407852)
+    h = np.clip(terrain(oracle, res, octaves=5, size=200), 0, 1).astype(f32)
+    try:
+        assert lib.nz_debug_pile_poll_limit(20000) == 0
+        with nj.Context(0) as c:
+            G = _gpu_state(nj, c, h, es, th, 2.5, capacity=1 << 17)
+            L = oracle.LiveErosionOracle(h, _params(oracle, es), tile_height=th, patch_res=2.5, capacity=1 << 17)
+            ep, tm = es.AsParameters(), G.tileMeta
+            epp, tmp_ = C.byref(ep), C.byref(tm)
+            longest = 0.0
+            for cyc, seed in enumerate((476132161, 1146990835)):
+                G.ctx.call("nz_fill_beyer_queue", G.particleQueue._h, epp, tmp_, cyc, res, particles, seed, 64)
+                L.fill_queue(cyc, particles, seed, 64)
+                G.ctx.call("nz_queued_beyer_cycle", G.heightMap.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
+                           G.particleQueue._h, G.events._h, epp, tmp_, 1500, res)
+                L.descend()
+                G.ctx.call("nz_process_beyer_erosive_events", G.heightMap.ptr, G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr,
+                           G.events._h, epp, tmp_, res)
+                L.process_events()
+                longest = max(longest, float(L.sediment.max() / (f32(ep.MIN_PILE_INCREMENT) / f32(th))))
+                G.particleQueue.Clear()
+                G.ctx.call("nz_erode_height_maps", G.heightMap.ptr, G.events._h, epp, tmp_, res)
+                L.erode_height_maps()
+                assert np.array_equal(G.heightMap.ToArray((res, res)), L.height), cyc      # (the wait: no NZ_ERR_HIP)
+                G.ctx.call("nz_update_flow_from_track", G.poolMap.ptr, G.streamMap.ptr, G.particleTrack.ptr, ep.FLOW_LOSS_RATE,
+                           ep.SURFACE_EVAPORATION_RATE, float(th), res)
+                L.update_flow_from_track()
+                G.ctx.call("nz_pool_automata_job", G.poolMap.ptr, G.heightMap.ptr, G.particleQueue._h, epp, tmp_, 3, res, 1)
+                L.pool_automata(3, drain=True)
+            assert longest > 2e5, "no pile long enough to outlast the bound: the test has no power (%g increments)" % longest
+            assert G.pileRetries == 0
+            G.OnDestroy()
+    finally:
+        lib.nz_debug_pile_poll_limit(0)
