@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-6 evidence, part A (one GPU call): kernel stats + counters of the metric step in the three float modes, the bench lines.
 #   tools/r6_collect_a.sh <tag> <commit>
-TAG=${1:-r06_v1}
+TAG=${1:-r06_v2}
 COMMIT=${2:-unknown}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"

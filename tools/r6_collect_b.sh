@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-6 evidence, part B (one GPU call): stalls, conv phase profile, next rows with counters, tiles, config 4, the rank rehearsal.
 #   tools/r6_collect_b.sh <tag> <commit>
-TAG=${1:-r06_v1}
+TAG=${1:-r06_v2}
 COMMIT=${2:-unknown}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
