@@ -1,6 +1,8 @@
+"""Replays the one mismatch of round 6's first soak (tests/soak.py, seed 62067): flow map x12 on a 300^2 plane of sparse impulses -- the
+oracle's ternary clamp passed a NaN on where Unity.Mathematics' clamp gives 1 (HISTORY.md).  40 repetitions per stage of the seed."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tools/repro/ -> the repository
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import noize_job_amd as nj
 import oracle as O
