@@ -2,7 +2,7 @@
 oracle's ternary clamp passed a NaN on where Unity.Mathematics' clamp gives 1 (HISTORY.md).  40 repetitions per stage of the seed."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tools/repro/ -> the repository
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/repro/ -> the repository (under tests/: these scripts drive the oracle, the checker)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import noize_job_amd as nj
 import oracle as O

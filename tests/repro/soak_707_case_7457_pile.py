@@ -1,7 +1,7 @@
 """Fast-forwards tests/soak_live.py --seed 707 to case 7457 (the draws only) and runs that case with timing."""
 import ctypes as C, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tools/repro/ -> the repository
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/repro/ -> the repository (under tests/: these scripts drive the oracle, the checker)
 sys.path.insert(0, ROOT)
 import noize_job_amd as nj
 import oracle
