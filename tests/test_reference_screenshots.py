@@ -332,3 +332,20 @@ def test_hip_path_is_the_pictures(nj, ctx, shots, planes):
     # and the planes the pictures were compared with are the oracle's, bit for bit (strict float mode)
     assert np.array_equal(hs["noise"], planes["simplex"]) and np.array_equal(hs["gauss"], planes["simplex_gauss"])
     assert np.array_equal(hs["flow"], planes["simplex_flow"]) and np.array_equal(hc["noise"], planes["cellular"])
+
+
+@pytest.mark.gpu
+def test_hip_path_in_fast_mode_is_the_pictures_too(nj, shots, planes):
+    """NZ_FLOAT_FAST (the reference's own FloatMode.Fast: contracted tails, every stage within 1e-5 of strict) against the same
+    pictures: the image pin does not depend on the strict build."""
+    img, meta = shots
+    s = meta["3"]
+    with nj.Context(0) as c:
+        c.float_mode = 1
+        hs = _hip_planes(nj, c, nj.FractalNoise.Simplex, s["hurst"], s["octaves"], s["xpos"], s["zpos"], s["noiseSize"],
+                         s["filterIterations"], s["flowIterations"])
+    assert match(display(hs["noise"]), img["L3"]) >= 0.9995
+    assert match(display(hs["gauss"]), img["L4"]) >= 0.999
+    assert match(flow_display(hs["flow"]), img["B5"]) >= 0.9
+    assert not np.array_equal(hs["noise"], planes["simplex"])           # (it IS the tolerance build)
+    assert np.abs(hs["noise"] - planes["simplex"]).max() <= 1e-5 * np.abs(planes["simplex"]).max() + 1e-6
