@@ -6,6 +6,8 @@ import importlib.util
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 spec = importlib.util.spec_from_file_location("gen_native_cs", os.path.join(ROOT, "tools", "gen_native_cs.py"))
@@ -205,3 +207,66 @@ def test_the_cs_index_reader_skips_unknown_fields_and_decodes_every_escape():
     rs = src[src.index("static string ReadString"):]
     for esc in ("'n'", "'t'", "'r'", "'b'", "'f'", "'u'"):
         assert "== " + esc in rs, esc
+
+
+def _cs_bracket_depths(src):
+    """A C# lexer as far as nesting goes: line / block comments, char literals, regular, verbatim (@) and interpolated ($) strings
+    are skipped; returns the final depth of { ( [ and raises when a closer comes before its opener or a literal does not end."""
+    i, n = 0, len(src)
+    depth = {"{": 0, "(": 0, "[": 0}
+    closers = {"}": "{", ")": "(", "]": "["}
+    while i < n:
+        c = src[i]
+        if src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i)
+            assert j >= 0, "block comment without an end"
+            i = j + 2
+        elif c == "'":
+            j = i + (3 if src[i + 1] == "\\" else 2)
+            assert src[j] == "'", "char literal without an end: %r" % src[i:i + 8]
+            i = j + 1
+        elif c == '"' or (c in "$@" and (src[i + 1:i + 2] == '"' or (src[i + 1:i + 2] in ("$", "@") and src[i + 2:i + 3] == '"'))):
+            verbatim = False
+            while src[i] in "$@":
+                verbatim |= src[i] == "@"
+                i += 1
+            i += 1
+            while True:
+                assert i < n, "string without an end"
+                if verbatim and src[i] == '"' and src[i + 1:i + 2] == '"':
+                    i += 2
+                elif not verbatim and src[i] == "\\":
+                    i += 2
+                elif src[i] == '"':
+                    i += 1
+                    break
+                else:
+                    i += 1
+        else:
+            if c in depth:
+                depth[c] += 1
+            elif c in closers:
+                depth[closers[c]] -= 1
+                assert depth[closers[c]] >= 0, "a %s before its opener near %r" % (c, src[max(0, i - 40):i + 1])
+            i += 1
+    return depth
+
+
+def test_every_cs_file_lexes_and_nests():
+    # no compiler has seen host-cs/ (no .NET in the image): the least a source file owes is literals that end and brackets that
+    # pair up -- checked with a small lexer, so that an edit which breaks a file's structure fails here
+    seen = 0
+    for d, _, files in os.walk(os.path.join(ROOT, "host-cs")):
+        for f in files:
+            if f.endswith(".cs"):
+                with open(os.path.join(d, f)) as fh:
+                    assert _cs_bracket_depths(fh.read()) == {"{": 0, "(": 0, "[": 0}, f
+                seen += 1
+    assert seen >= 10
+    assert _cs_bracket_depths("class A { void f() { if (x) { } }")["{"] == 1      # (the checker itself has power)
+    with pytest.raises(AssertionError):
+        _cs_bracket_depths("class A { } }")
+    assert _cs_bracket_depths('class A { string s = $"{{"; char c = \'}\'; /* { */ }') == {"{": 0, "(": 0, "[": 0}
